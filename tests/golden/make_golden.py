@@ -1,0 +1,327 @@
+#!/usr/bin/env python3
+"""Golden-vector generator (TEST INFRASTRUCTURE — runs only in the build container).
+
+Imports the *real* reference (``/root/reference``, read-only, CPU) and records the
+inputs/outputs of ``pi_mpc.mppi.MPPI.forward`` for the five shipped models into small
+``.npz`` fixtures under ``tests/golden/``.  Nothing from the reference (source,
+bytecode) is written into the fixtures: they hold arrays only.
+
+Usage (container only; the GPU box has no /root/reference):
+    python tests/golden/make_golden.py
+
+Recipe follows SURVEY.md Appendix C: stub the UI-only imports (moviepy, fire,
+gymnasium), run with cwd=/root/reference (racing_env.py:47-49 opens a relative CSV),
+extract the nested model closures of example/{pendulum,cartpole,mountaincar}.py with
+``ast`` and run them eagerly.
+"""
+from __future__ import annotations
+
+import ast
+import os
+import sys
+import textwrap
+import types
+
+import numpy as np
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def _import_reference():
+    sys.path[:0] = [f"{REF}/src", f"{REF}/example"]
+    for n in [
+        "moviepy",
+        "moviepy.video",
+        "moviepy.video.io",
+        "moviepy.video.io.ImageSequenceClip",
+        "fire",
+        "gymnasium",
+    ]:
+        sys.modules.setdefault(n, types.ModuleType(n))
+    sys.modules["moviepy.video.io.ImageSequenceClip"].ImageSequenceClip = object
+    sys.modules["fire"].Fire = lambda f: None
+    import matplotlib
+
+    matplotlib.use("Agg")
+    os.chdir(REF)
+
+
+def _extract_closures(path: str, names):
+    """Pull nested FunctionDefs out of ``main()`` of an example script (eager, no jit)."""
+    import torch
+
+    src = open(path).read()
+    tree = ast.parse(src)
+    ns = {"torch": torch}
+    # module-level angle_normalize (drop the jit decorator)
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name == "angle_normalize":
+            node.decorator_list = []
+            seg = ast.unparse(node)
+            exec(seg, ns)
+    main = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "main"][0]
+    out = {}
+    for node in main.body:
+        if isinstance(node, ast.FunctionDef) and node.name in names:
+            node.decorator_list = []
+            seg = textwrap.dedent(ast.unparse(node))
+            exec(seg, ns)
+            out[node.name] = ns[node.name]
+    return out
+
+
+def pack_bits(m: np.ndarray) -> np.ndarray:
+    return np.packbits((m != 0).astype(np.uint8).ravel())
+
+
+class Recorder:
+    """Wraps cost_func to capture the per-call costs the solver sums (mppi.py:307-336)."""
+
+    def __init__(self, fn):
+        self.fn = fn
+        self.calls = []
+
+    def __call__(self, state, action, info):
+        c = self.fn(state, action, info)
+        self.calls.append(c.detach().clone())
+        return c
+
+
+def run_case(name, make_solver, x0, K, next_state, keep_S, before_solve=None):
+    """Run K closed-loop solves and dump everything the parity tests need."""
+    import torch
+
+    solver, rec, extra = make_solver()
+    N, T = solver._num_samples, solver._horizon
+    d = dict(extra)
+    d["ctor_eps"] = solver._action_noises.numpy().copy()  # Q2: ctor consumes one draw
+    state = torch.as_tensor(np.asarray(x0), dtype=torch.float32)
+    for k in range(K):
+        if before_solve is not None:
+            for kk, vv in before_solve(state, k).items():
+                d[f"{kk}_{k}"] = vv
+        rec.calls.clear()
+        mean_in = solver._previous_action_seq.detach().clone().numpy()
+        hist_in = solver._actions_history_for_sg.detach().clone().numpy()
+        a, s = solver.forward(state=state.clone())
+        calls = list(rec.calls)
+        # first T+1 calls belong to the N-sample pass; (no cost calls in the B=1 rollout)
+        stage = torch.stack(calls[:T], dim=1)
+        terminal = calls[T]
+        costs = torch.sum(stage, dim=1) + terminal  # exactly mppi.py:333-334
+        d[f"x0_{k}"] = state.numpy().copy()
+        d[f"mean_in_{k}"] = mean_in
+        d[f"sg_hist_in_{k}"] = hist_in
+        d[f"eps_{k}"] = solver._action_noises.numpy().copy()
+        d[f"costs_{k}"] = costs.numpy().copy()
+        d[f"stage_costs_{k}"] = stage.numpy().copy() if keep_S else np.zeros(0, np.float32)
+        d[f"lambda_{k}"] = np.float64(solver._lambda)
+        d[f"weights_{k}"] = solver._weights.detach().numpy().copy()
+        d[f"action_seq_{k}"] = a.detach().numpy().copy()
+        d[f"state_seq_{k}"] = s.detach().numpy().copy()
+        if keep_S:
+            d[f"U_{k}"] = solver._perturbed_action_seqs.numpy().copy()
+            d[f"S_{k}"] = solver._state_seq_batch.numpy().copy()
+        if k == 0 and N >= 8:
+            ts, tw = solver.get_top_samples(8)
+            d["top8_states_0"] = ts.numpy().copy()
+            d["top8_weights_0"] = tw.detach().numpy().copy()
+        state = next_state(state, a, s)
+    d["K"] = np.int64(K)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **d)
+    print(f"wrote {path}  ({os.path.getsize(path)/1024:.0f} KiB)")
+
+
+def main():
+    _import_reference()
+    import torch
+
+    torch.set_num_threads(1)
+    from pi_mpc.mppi import MPPI
+
+    cpu = torch.device("cpu")
+
+    def pred_next(state, a, s):
+        # closed loop without a simulator: apply the predicted next state.
+        return s[0, 1].detach().clone()
+
+    # ------------------------------------------------------------ classic control
+    def classic(example, dyn_name, cost_name, **kw):
+        fns = _extract_closures(f"{REF}/example/{example}.py", [dyn_name, cost_name])
+
+        def make():
+            rec = Recorder(fns[cost_name])
+            solver = MPPI(dynamics=fns[dyn_name], cost_func=rec, device=cpu, **kw)
+            return solver, rec, {}
+
+        return make
+
+    pend = dict(dim_state=2, dim_control=1, u_min=torch.tensor([-2.0]), u_max=torch.tensor([2.0]),
+                sigmas=torch.tensor([1.0]))
+    x0_pend = [np.pi, 0.0]
+    run_case("pendulum_T50_N1000_essps",
+             classic("pendulum", "dynamics", "cost_function", horizon=50, num_samples=1000,
+                     lambda_="ESSPS", **pend), x0_pend, 3, pred_next, keep_S=False)
+    run_case("pendulum_T15_N256_fixed",
+             classic("pendulum", "dynamics", "cost_function", horizon=15, num_samples=256,
+                     lambda_=1.0, **pend), x0_pend, 3, pred_next, keep_S=True)
+    run_case("pendulum_T15_N256_lbps",
+             classic("pendulum", "dynamics", "cost_function", horizon=15, num_samples=256,
+                     lambda_="LBPS", **pend), x0_pend, 3, pred_next, keep_S=False)
+    run_case("pendulum_T15_N256_mpo",
+             classic("pendulum", "dynamics", "cost_function", horizon=15, num_samples=256,
+                     lambda_="MPO", **pend), x0_pend, 3, pred_next, keep_S=False)
+    run_case("pendulum_T15_N200_explore",
+             classic("pendulum", "dynamics", "cost_function", horizon=15, num_samples=200,
+                     lambda_=0.5, exploration=0.25, **pend), x0_pend, 3, pred_next, keep_S=True)
+
+    cart = dict(dim_state=4, dim_control=1, u_min=torch.tensor([-3.0]), u_max=torch.tensor([3.0]),
+                sigmas=torch.tensor([1.0]))
+    x0_cart = [0.01, 0.0, 0.02, 0.0]
+    run_case("cartpole_T64_N1024_essps_sg",
+             classic("cartpole", "dynamics", "stage_cost", horizon=64, num_samples=1024,
+                     lambda_="ESSPS", use_sg_filter=True, **cart), x0_cart, 3, pred_next, keep_S=False)
+    run_case("cartpole_T10_N100_fixed",
+             classic("cartpole", "dynamics", "stage_cost", horizon=10, num_samples=100,
+                     lambda_=0.001, **cart), x0_cart, 3, pred_next, keep_S=True)
+
+    mc = dict(dim_state=2, dim_control=1, u_min=torch.tensor([-1.0]), u_max=torch.tensor([1.0]),
+              sigmas=torch.tensor([1.0]))
+    run_case("mountaincar_T100_N256_fixed",
+             classic("mountaincar", "dynamics", "cost_func", horizon=100, num_samples=256,
+                     lambda_=0.1, **mc), [-0.5, 0.0], 3, pred_next, keep_S=True)
+
+    # ------------------------------------------------------------ navigation 2d
+    from envs.navigation_2d import Navigation2DEnv
+
+    nav_env = Navigation2DEnv(device=cpu)
+    nav_map = nav_env._obstacle_map._map
+    nav_extra = {
+        "map_bits": pack_bits(nav_map),
+        "map_shape": np.array(nav_map.shape, np.int64),
+        "cell_size": np.float64(nav_env._obstacle_map._cell_size),
+        "origin": np.array(nav_env._obstacle_map._cell_map_origin, np.int64),
+        "x_lim": np.array(nav_env._obstacle_map.x_lim, np.float64),
+        "y_lim": np.array(nav_env._obstacle_map.y_lim, np.float64),
+        "circles": np.array([[c.center[0], c.center[1], c.radius]
+                             for c in nav_env._obstacle_map.circle_obs_list], np.float64),
+        "rects": np.array([[r.center[0], r.center[1], r.width, r.height]
+                           for r in nav_env._obstacle_map.rectangle_obs_list], np.float64),
+        "goal": nav_env._goal_pos.numpy().copy(),
+        "start_state": nav_env._robot_state.numpy().copy(),
+    }
+
+    def nav(**kw):
+        def make():
+            rec = Recorder(nav_env.cost_function)
+            solver = MPPI(dim_state=3, dim_control=2, dynamics=nav_env.dynamics, cost_func=rec,
+                          u_min=nav_env.u_min, u_max=nav_env.u_max,
+                          sigmas=torch.tensor([0.5, 0.5]), device=cpu, **kw)
+            return solver, rec, {}
+
+        return make
+
+    np.savez_compressed(os.path.join(OUT, "nav2d_env.npz"), **nav_extra)
+
+    x0_nav = nav_env._robot_state.numpy().copy()
+    run_case("nav2d_T50_N512_essps", nav(horizon=50, num_samples=512, lambda_="ESSPS"),
+             x0_nav, 3, pred_next, keep_S=False)
+    run_case("nav2d_T30_N256_fixed_explore", nav(horizon=30, num_samples=256, lambda_=1.0,
+                                                 exploration=0.25),
+             x0_nav, 3, pred_next, keep_S=True)
+
+    # ------------------------------------------------------------ racing
+    import racing as racing_example  # example/racing.py (fire stubbed)
+    from envs.racing_env import RacingEnv
+
+    env = RacingEnv(device=cpu)
+    obst = env._obstacle_map._map
+    lane = env._lane_map._map
+    racing_extra = {
+        "center_path": env.racing_center_path.numpy().copy(),  # [3678,3] f32
+        "center_path_f64": None,
+        "obst_bits": pack_bits(obst),
+        "lane_bits": pack_bits(lane),
+        "map_shape": np.array(obst.shape, np.int64),
+        "cell_size": np.float64(env.cell_size),
+        "origin": np.array(env._obstacle_map._cell_map_origin, np.int64),
+        "lane_origin": np.array(env._lane_map._cell_map_origin, np.int64),
+        "x_lim": np.array(env._obstacle_map.x_lim, np.float64),
+        "y_lim": np.array(env._obstacle_map.y_lim, np.float64),
+        "circles": np.array([[c.center[0], c.center[1], c.radius]
+                             for c in env._obstacle_map.circle_obs_list], np.float64),
+        "start_state": env._robot_state.numpy().copy(),
+        "lane_width": np.float64(env.line_width * 0.8),
+    }
+    # float64 centre path as produced by the circuit generator (LaneMap input)
+    from envs.circuit_generator.path_generate import make_csv_paths
+
+    cp64, _, _ = make_csv_paths("src/envs/circuit_generator/circuit.csv")
+    racing_extra["center_path_f64"] = cp64
+    np.savez_compressed(os.path.join(OUT, "racing_env.npz"), **racing_extra)
+
+    def racing_case(name, T, N, K, keep_S):
+        ctrl_box = {}
+
+        def make():
+            ctrl = racing_example.racing_controller(env, debug=False, device=cpu)
+            ctrl.set_cost_map(env._obstacle_map, env._lane_map)
+            rec = Recorder(ctrl.cost_function)
+            ctrl.solver = MPPI(horizon=T, num_samples=N, dim_state=4, dim_control=2,
+                               dynamics=env.dynamics, cost_func=rec, u_min=env.u_min,
+                               u_max=env.u_max, sigmas=torch.tensor([0.5, 0.1]), lambda_=1.0,
+                               device=cpu)
+            ctrl_box["c"] = ctrl
+            return ctrl.solver, rec, {}
+
+        def before(state, k):
+            ctrl = ctrl_box["c"]
+            cind_in = ctrl.current_path_index
+            ref, ind = ctrl.calc_ref_trajectory(state, env.racing_center_path, cind_in,
+                                                ctrl.solver._horizon, DL=0.1,
+                                                lookahead_distance=3,
+                                                reference_path_interval=0.85)
+            ctrl.reference_path, ctrl.current_path_index = ref, ind
+            return {"ref_path": ref.numpy().copy(), "cind_in": np.int64(cind_in),
+                    "cind_out": np.int64(ind)}
+
+        def nxt(state, a, s):
+            u = torch.clamp(a[0], env.u_min, env.u_max)
+            return env.dynamics(state.unsqueeze(0), u.unsqueeze(0)).squeeze(0).detach().clone()
+
+        run_case(name, make, env._robot_state.numpy().copy(), K, nxt, keep_S, before_solve=before)
+
+    racing_case("racing_T50_N512_fixed", 50, 512, 3, keep_S=False)
+    racing_case("racing_T25_N256_fixed", 25, 256, 3, keep_S=True)
+
+    # ------------------------------------------------------------ torch-CPU RNG stream
+    rng = {}
+    for seed in (0, 42):
+        for n in (1000, 15000):
+            torch.manual_seed(seed)
+            rng[f"randn_seed{seed}_n{n}_a"] = torch.randn(n).numpy().copy()
+            rng[f"randn_seed{seed}_n{n}_b"] = torch.randn(n).numpy().copy()  # consecutive draw
+    np.savez_compressed(os.path.join(OUT, "torch_cpu_randn.npz"), **rng)
+
+    # ------------------------------------------------------------ model-level pins
+    # angle_normalize / map lookup on random inputs (Appendix A pins)
+    g = torch.Generator().manual_seed(7)
+    xs = (torch.rand(20000, generator=g) - 0.5) * 40.0
+    from envs.racing_env import angle_normalize
+
+    pins = {"an_in": xs.numpy().copy(), "an_out": angle_normalize(xs).numpy().copy()}
+    pts = (torch.rand(20000, 1, 2, generator=g) - 0.5) * 90.0
+    pins["occ_pts"] = pts.numpy().copy()
+    pins["occ_obst"] = env._obstacle_map.compute_cost(pts).numpy().copy()
+    pins["occ_lane"] = env._lane_map.compute_cost(pts).numpy().copy()
+    pts2 = (torch.rand(20000, 1, 2, generator=g) - 0.5) * 22.0
+    pins["occ_nav_pts"] = pts2.numpy().copy()
+    pins["occ_nav"] = nav_env._obstacle_map.compute_cost(pts2).numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "model_pins.npz"), **pins)
+    print("done")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,95 @@
+"""Shared test helpers: golden-fixture loading and oracle problem construction."""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle import oracle as orc  # noqa: E402
+
+# case name -> (model, ctor kwargs as used by tests/golden/make_golden.py)
+CASES = {
+    "pendulum_T50_N1000_essps": dict(model="pendulum", T=50, N=1000, lambda_="ESSPS"),
+    "pendulum_T15_N256_fixed": dict(model="pendulum", T=15, N=256, lambda_=1.0),
+    "pendulum_T15_N256_lbps": dict(model="pendulum", T=15, N=256, lambda_="LBPS"),
+    "pendulum_T15_N256_mpo": dict(model="pendulum", T=15, N=256, lambda_="MPO"),
+    "pendulum_T15_N200_explore": dict(model="pendulum", T=15, N=200, lambda_=0.5, exploration=0.25),
+    "cartpole_T64_N1024_essps_sg": dict(model="cartpole", T=64, N=1024, lambda_="ESSPS", use_sg_filter=True),
+    "cartpole_T10_N100_fixed": dict(model="cartpole", T=10, N=100, lambda_=0.001),
+    "mountaincar_T100_N256_fixed": dict(model="mountaincar", T=100, N=256, lambda_=0.1),
+    "nav2d_T50_N512_essps": dict(model="nav2d", T=50, N=512, lambda_="ESSPS"),
+    "nav2d_T30_N256_fixed_explore": dict(model="nav2d", T=30, N=256, lambda_=1.0, exploration=0.25),
+    "racing_T50_N512_fixed": dict(model="racing", T=50, N=512, lambda_=1.0),
+    "racing_T25_N256_fixed": dict(model="racing", T=25, N=256, lambda_=1.0),
+}
+
+MODEL_CFG = {
+    "pendulum": dict(u_min=[-2.0], u_max=[2.0], sigmas=[1.0]),
+    "cartpole": dict(u_min=[-3.0], u_max=[3.0], sigmas=[1.0]),
+    "mountaincar": dict(u_min=[-1.0], u_max=[1.0], sigmas=[1.0]),
+    "nav2d": dict(u_min=[0.0, -1.0], u_max=[2.0, 1.0], sigmas=[0.5, 0.5]),
+    "racing": dict(u_min=[-2.0, -0.25], u_max=[2.0, 0.25], sigmas=[0.5, 0.1]),
+}
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def unpack_bits(bits, shape):
+    n = int(shape[0]) * int(shape[1])
+    return np.unpackbits(bits)[:n].reshape(int(shape[0]), int(shape[1])).astype(np.uint8)
+
+
+_env_cache = {}
+
+
+def racing_env_fixture():
+    if "racing" not in _env_cache:
+        e = load("racing_env")
+        shape = e["map_shape"]
+        _env_cache["racing"] = dict(
+            obst=unpack_bits(e["obst_bits"], shape), lane=unpack_bits(e["lane_bits"], shape),
+            cell=float(e["cell_size"]), origin=e["origin"].astype(np.float64),
+            center_path=e["center_path"], center_path_f64=e["center_path_f64"], circles=e["circles"],
+            start_state=e["start_state"], x_lim=e["x_lim"], y_lim=e["y_lim"],
+            lane_width=float(e["lane_width"]))
+    return _env_cache["racing"]
+
+
+def nav2d_env_fixture():
+    if "nav2d" not in _env_cache:
+        e = load("nav2d_env")
+        _env_cache["nav2d"] = dict(
+            map=unpack_bits(e["map_bits"], e["map_shape"]), cell=float(e["cell_size"]),
+            origin=e["origin"].astype(np.float64), circles=e["circles"], rects=e["rects"],
+            goal=e["goal"], start_state=e["start_state"], x_lim=e["x_lim"], y_lim=e["y_lim"])
+    return _env_cache["nav2d"]
+
+
+def oracle_problem(model, N, T, exploration=0.0, ref_path=None):
+    cfg = MODEL_CFG[model]
+    params, maps = (), ()
+    if model == "racing":
+        e = racing_env_fixture()
+        params = orc.racing_params()
+        maps = [(e["obst"], e["cell"], e["origin"]), (e["lane"], e["cell"], e["origin"])]
+    elif model == "nav2d":
+        e = nav2d_env_fixture()
+        params = orc.nav2d_params()
+        maps = [(e["map"], e["cell"], e["origin"])]
+    return orc.Problem(model, N, T, cfg["u_min"], cfg["u_max"], exploration=exploration, params=params,
+                       maps=maps, ref_path=ref_path)
+
+
+def rel_err(a, b):
+    """max |a-b| relative to max |b| (the tolerance convention of SURVEY Appendix D)."""
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-30))
