@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""bench.py — MPPI hot-path throughput on MI355X (BASELINE.json metric).
+
+Workload (config.workload): racing kinematic-bicycle, horizon T=50, num_samples N=1,048,576 per GPU,
+lambda=1.0 (BASELINE configs[2] = C3; with --gpus G it is C4: G*N samples sharded over G ranks, weak
+scaling, one all_gather of 4+T*dc floats per solve).  A "step" is one MPPI solve = one pass of the hot
+path: sample -> rollout+cost -> weights+reduce -> finalize, with every input resident in HBM.
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \\
+        --master-port 29500 bench.py --gpus 8 --steps 50 --warmup 10
+
+Prints ONE JSON line on rank 0.  `value` = sample-steps/s (N_total * T * solves/s), whole job.
+`roofline` is for the dominant kernel (rollout_cost_kernel), measured with HIP events on the launch
+stream inside the timed region; `cpu_baseline` is the oracle (C restatement of the reference
+algorithm, OpenMP over samples) timed on this host, rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured copy
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--samples", type=int, default=1 << 20, help="samples per GPU")
+    ap.add_argument("--horizon", type=int, default=50)
+    ap.add_argument("--math", type=int, default=1, help="1 = fast-path math (default), 0 = library math")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import mppi_playground_amd  # noqa: F401
+    from envs.racing_controller import racing_controller
+    from envs.racing_env import RacingEnv
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 or world > 1:
+        assert world == args.gpus, f"launch with torch.distributed.run --nproc-per-node {args.gpus}"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+
+    N_local, T = args.samples, args.horizon
+    N_total = N_local * world
+    env = RacingEnv()
+    ctrl = racing_controller(env, horizon=T, num_samples=N_total, lambda_=1.0, shard_samples=world > 1)
+    ctrl.set_cost_map(env._obstacle_map, env._lane_map)
+    solver = ctrl.solver
+    solver.set_option("math", args.math)
+    state = env.reset()
+    ref, _ = ctrl.calc_ref_trajectory(state, env.racing_center_path, 0, T, DL=0.1, lookahead_distance=3,
+                                      reference_path_interval=0.85)
+    ctrl.set_reference(ref)
+    x0 = state.clone()
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        solver.forward(x0)
+    sync()
+    solver.set_option("timing", 1)
+    solver.stage_times_ms()  # drain
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        a, s = solver.forward(x0)
+    sync()
+    dt = time.perf_counter() - t0
+    stages = solver.stage_times_ms()
+    solver.set_option("timing", 0)
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert torch.isfinite(a).all() and torch.isfinite(s).all()
+
+    ms_per_step = dt / args.steps * 1e3
+    solves_per_s = args.steps / dt
+    value = N_total * T * solves_per_s
+
+    if rank == 0:
+        dc = 2
+        # algorithmic bytes: per sample-step 4*dc B noise written by the sampler, read by the
+        # rollout, read again by the weighted reduction, + 8 B/sample of costs -> per solve and per GPU:
+        b_alg_solve = 3 * 4 * dc * N_local * T + 8 * N_local
+        # dominant kernel = rollout_cost_kernel: reads the noise once, writes costs once
+        b_alg_rollout = 4 * dc * N_local * T + 4 * N_local
+        t_roll = stages["rollout_cost"] * 1e-3
+        achieved = b_alg_rollout / t_roll / 1e9
+        dev_solve_ms = sum(stages[k] for k in ("sample", "rollout_cost", "weights_reduce", "finalize"))
+        out = {
+            "metric": "sample_steps_per_sec", "value": value, "unit": "sample-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "racing kinematic-bicycle MPPI solve (BASELINE configs[2]/[3])",
+                       "num_samples_per_gpu": N_local, "num_samples_total": N_total, "horizon": T,
+                       "lambda": 1.0, "noise": "device philox4x32-10", "math": "fast" if args.math else "library",
+                       "sharding": f"num_samples x{world}" if world > 1 else "none"},
+            "solves_per_sec": solves_per_s,
+            "roofline": {"bound": "hbm", "kernel": "rollout_cost_kernel<racing>", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "algorithmic_bytes_per_launch": b_alg_rollout,
+                         "kernel_ms": stages["rollout_cost"]},
+            "solve_roofline": {"algorithmic_bytes_per_solve": b_alg_solve, "device_ms_per_solve": dev_solve_ms,
+                               "achieved_GBps": b_alg_solve / (dev_solve_ms * 1e-3) / 1e9,
+                               "frac_of_8TBps": b_alg_solve / (dev_solve_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "stages_ms": {k: stages[k] for k in ("sample", "rollout_cost", "weights_reduce", "finalize")},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(np, T, ref.numpy(), x0.cpu().numpy())
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(np, T, ref, x0):
+    """The oracle (oracle/mppi_oracle.c: C restatement of the reference algorithm, OpenMP over the
+    samples) on this host: racing T=50, two solves of N=262,144 samples each (bounded sample of the
+    same workload), rollout+costs+softmax+weighted mean; reported in the metric's unit."""
+    from helpers import oracle_problem, orc
+
+    n = 262144
+    P = oracle_problem("racing", n, T, ref_path=ref)
+    eps = orc.philox_normal(42, 1, 0, n, T, 2, [0.5, 0.1])
+    mean = np.zeros((T, 2), np.float32)
+    P.rollout_cost(x0, mean, eps[:4096].copy() if False else eps)  # warm the caches / page in
+    t0 = time.perf_counter()
+    reps = 2
+    for _ in range(reps):
+        r = P.rollout_cost(x0, mean, eps)
+        w, _ = orc.softmax_weights(r["costs"], 1.0)
+        P.weighted_actions(w, mean, eps)
+    dt = time.perf_counter() - t0
+    return {"value": reps * n * T / dt, "unit": "sample-steps/s", "cores": orc.num_threads(), "kind": "port",
+            "sample": f"{reps} solves of racing N={n} T={T} (oracle C port, OpenMP over samples; noise "
+                      "generation excluded)", "solves_per_sec_at_1M": (reps * n * T / dt) / ((1 << 20) * T)}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,171 @@
+/*
+ * mppi_hip.h — C ABI of libmppi_hip.so: the MI355X (gfx950) implementation of the
+ * pi_mpc.mppi.MPPI.forward() hot path of kohonda/mppi_playground.
+ *
+ * The reference is pure Python/PyTorch, so the "FFI" a maintainer would add is a ctypes
+ * binding inside src/pi_mpc/mppi.py (shown in INTEGRATION.md).  Every entry point below
+ * names the reference code it replaces (file:line relative to the reference repo).
+ *
+ * Conventions
+ *   - plain C: opaque handle, POD structs, raw pointers and sizes; no torch/HIP types.
+ *   - every function returns 0 on success or a negative MPPI_E_* code; the message of the
+ *     last failure on a handle is available from mppi_last_error().  Nothing throws.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  All device work
+ *     is enqueued asynchronously on it; only the functions documented "synchronises" block.
+ *   - pointers named *_dev are device pointers (HBM), *_host are host pointers.
+ *   - all arithmetic is fp32 (reference dtype, mppi.py:45).
+ *
+ * Data layout in HBM (owned by the handle)
+ *   noise   lane-major tiles: for tile b (samples 64b..64b+63) and float4 group r
+ *           (flat horizon index 4r..4r+3 of the [T*dc] row) lane l's float4 lives at
+ *           ((b*R + r)*64 + l), R = ceil(T*dc/4).  A wavefront therefore reads or writes one
+ *           contiguous 1 KiB segment per instruction.  This is the storage of the reference's
+ *           `_action_noises` [N,T,dc] (mppi.py:261-263); mppi_export_noise() converts.
+ *   costs   float[N]                                    (`costs`, mppi.py:333-336)
+ *   summary float[MPPI_SUMMARY_HEAD + T*dc] per shard   (see mppi_weights_reduce)
+ */
+#ifndef MPPI_HIP_H
+#define MPPI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct MppiSolver* mppi_handle_t;
+
+enum {
+    MPPI_OK = 0,
+    MPPI_E_INVALID = -1,   /* bad argument / unsupported configuration */
+    MPPI_E_HIP = -2,       /* a HIP runtime call failed                */
+    MPPI_E_STATE = -3,     /* call sequence error (e.g. no map uploaded) */
+    MPPI_E_NODEVICE = -4   /* no gfx950 device visible                 */
+};
+
+/* Native model plugins = the five shipped dynamics/cost pairs. */
+enum {
+    MPPI_MODEL_PENDULUM = 0,    /* example/pendulum.py:17-47                                  */
+    MPPI_MODEL_CARTPOLE = 1,    /* example/cartpole.py:17-81                                  */
+    MPPI_MODEL_MOUNTAINCAR = 2, /* example/mountaincar.py:17-55                               */
+    MPPI_MODEL_NAV2D = 3,       /* src/envs/navigation_2d.py:218-279                          */
+    MPPI_MODEL_RACING = 4       /* src/envs/racing_env.py:327-372 + example/racing.py:110-159 */
+};
+
+/* Racing parameter vector (mppi_set_model_params), racing_env.py:37-42,341-370, racing.py:41-46 */
+enum { MPPI_RP_AMIN = 0, MPPI_RP_AMAX, MPPI_RP_SMIN, MPPI_RP_SMAX, MPPI_RP_L, MPPI_RP_VMAX, MPPI_RP_DT,
+       MPPI_RP_XLO, MPPI_RP_XHI, MPPI_RP_YLO, MPPI_RP_YHI, MPPI_RP_QC, MPPI_RP_QL, MPPI_RP_QV, MPPI_RP_QO,
+       MPPI_RP_QIN, MPPI_RP_QDIN, MPPI_RP_COUNT };
+/* Navigation2D parameter vector, navigation_2d.py:54-72,218-279 */
+enum { MPPI_NP_VMIN = 0, MPPI_NP_VMAX, MPPI_NP_WMIN, MPPI_NP_WMAX, MPPI_NP_DT, MPPI_NP_XLO, MPPI_NP_XHI,
+       MPPI_NP_YLO, MPPI_NP_YHI, MPPI_NP_GX, MPPI_NP_GY, MPPI_NP_QO, MPPI_NP_COUNT };
+
+#define MPPI_MAX_PARAMS 32
+#define MPPI_MAX_DIM_STATE 4
+#define MPPI_MAX_DIM_CONTROL 2
+#define MPPI_SUMMARY_HEAD 4 /* {min cost, sum e, sum e^2, sum e*c} */
+
+/* Constructor arguments that reach the device path (MPPI.__init__, mppi.py:24-47,109-121). */
+typedef struct MppiConfig {
+    int32_t model;          /* MPPI_MODEL_*                                                     */
+    int32_t horizon;        /* T                                                                */
+    int32_t dim_state;      /* must match the model                                             */
+    int32_t dim_control;    /* must match the model                                             */
+    int64_t num_samples;    /* N held by THIS handle (= the local shard when sharded)           */
+    int64_t sample_offset;  /* global index of local sample 0 (0 when not sharded)              */
+    int64_t inherit_count;  /* global threshold int(N_global*(1-exploration)), mppi.py:266      */
+    float u_min[MPPI_MAX_DIM_CONTROL];
+    float u_max[MPPI_MAX_DIM_CONTROL];
+    float sigmas[MPPI_MAX_DIM_CONTROL];
+    uint64_t seed;          /* Philox key (mppi.py:46,93 `seed`)                                */
+    int32_t device;         /* HIP device ordinal                                               */
+    int32_t reserved;
+} MppiConfig;
+
+/* Library / build information ("gfx950", version). */
+const char* mppi_version(void);
+/* Number of visible HIP devices (0 => the product cannot run; callers must fail loudly). */
+int mppi_device_count(void);
+const char* mppi_last_error(mppi_handle_t h);
+
+/* MPPI.__init__ buffers (mppi.py:143-180): allocates noise tiles, costs, warm start (zeroed,
+ * mppi.py:157), partials.  Does NOT draw the constructor sample (mppi.py:146-148 is only an
+ * RNG-stream side effect; callers that mirror the torch CPU stream draw it themselves). */
+int mppi_create(const MppiConfig* cfg, mppi_handle_t* out);
+int mppi_destroy(mppi_handle_t h);
+
+/* Model constants (closures' Python constants / env attributes).  params: MPPI_RP_* or MPPI_NP_*
+ * layout; models without parameters accept n == 0. */
+int mppi_set_model_params(mppi_handle_t h, const float* params_host, int n);
+/* ObstacleMap.convert_to_torch / LaneMap._map_torch (obstacle_map_2d.py:164-166,
+ * lane_map_2d.py:85-88): occupancy grid cells[nx][ny] (0/1), first index = x.
+ * slot 0 = obstacle map (nav2d, racing), slot 1 = lane map (racing).  Synchronises. */
+int mppi_upload_map(mppi_handle_t h, int slot, const uint8_t* cells_host, int nx, int ny, float cell_size,
+                    float origin_x, float origin_y);
+/* racing_controller.reference_path = calc_ref_trajectory(...) (example/racing.py:73-81):
+ * ref [rows][4] = (x, y, yaw, v_target), rows >= T (the cost reads rows 0..T-1). */
+int mppi_set_reference(mppi_handle_t h, const float* ref_host, int rows, void* stream);
+
+/* `_previous_action_seq` (mppi.py:157,255,452).  on_device != 0: pointer is a device pointer. */
+int mppi_set_mean(mppi_handle_t h, const float* mean, int on_device, void* stream);
+int mppi_get_mean(mppi_handle_t h, float* mean_out, int on_device, void* stream);
+/* forward(state) argument (mppi.py:247-253), dim_state floats. */
+int mppi_set_state(mppi_handle_t h, const float* x0, int on_device, void* stream);
+
+/* Step 1 — `_noise_distribution.rsample` (mppi.py:261-263): eps ~ N(0, diag(sigma^2)) from the
+ * device Philox4x32-10 stream, counter = (global sample index, float4 group, solve_idx): results
+ * do not depend on how num_samples is sharded. */
+int mppi_sample(mppi_handle_t h, uint32_t solve_idx, void* stream);
+/* Parity mode: load externally drawn noise eps[N][T][dc] (reference layout, device pointer)
+ * into the tiled buffer (replaces mppi_sample for that solve). */
+int mppi_inject_noise(mppi_handle_t h, const float* eps_dev, void* stream);
+/* `_action_noises` / `_perturbed_action_seqs` attributes (mppi.py:261-275) in the reference
+ * layout [N][T][dc]; either output may be NULL. */
+int mppi_export_noise(mppi_handle_t h, float* eps_out_dev, float* actions_out_dev, void* stream);
+
+/* Steps 1b-3 — clamp(mean + eps) (mppi.py:266-275), the N x T dynamics rollout
+ * (mppi.py:280-286) and stage + terminal costs (mppi.py:291-336), fused; writes costs[N] and the
+ * shard's minimum cost. */
+int mppi_rollout_cost(mppi_handle_t h, void* stream);
+/* `costs` (mppi.py:333-336) -> dst[N] (device or host).  Host copies synchronise. */
+int mppi_get_costs(mppi_handle_t h, float* dst, int on_device, void* stream);
+/* Overwrite costs[N] (used by tests and by the generic-callable path). */
+int mppi_set_costs(mppi_handle_t h, const float* src, int on_device, void* stream);
+
+/* Steps 5-6 — softmax(-costs/lambda) and sum_i w_i U_i (mppi.py:376-384), un-normalised:
+ * writes the shard summary {min c, sum e, sum e^2, sum e*c, A[T*dc] = sum e_i*U_i} with
+ * e_i = exp((-c_i)/lambda - max_j (-c_j)/lambda) over THIS shard.  summary_out_dev may be NULL
+ * (the handle keeps its own copy). */
+int mppi_weights_reduce(mppi_handle_t h, float lambda, float* summary_out_dev, void* stream);
+/* Combine `num_shards` summaries (device array [num_shards][MPPI_SUMMARY_HEAD + T*dc]; NULL = this
+ * handle's own, num_shards = 1), form action_seq = A / sum e (mppi.py:381-385), optionally store it
+ * as the next warm start (mppi.py:452), and roll it out with batch 1 (mppi.py:448-449,508-524).
+ * action_out_dev [T][dc], state_seq_out_dev [T+1][ds], stats_out_dev [4] = {min c, sum e, sum e^2,
+ * sum e*c} (global); any output may be NULL. */
+int mppi_finalize(mppi_handle_t h, const float* summaries_dev, int num_shards, float lambda, int store_mean,
+                  float* action_out_dev, float* state_seq_out_dev, float* stats_out_dev, void* stream);
+
+/* `_weights` (mppi.py:376) for this shard given the GLOBAL {min c, sum e}: w_out_dev[N]. */
+int mppi_weights(mppi_handle_t h, float lambda, float cmin_global, float sum_e_global, float* w_out_dev,
+                 void* stream);
+/* `_states_prediction` (mppi.py:508-524) for k action sequences actions_dev[k][T][dc] ->
+ * states_out_dev[k][T+1][ds] (step 8 after host-side smoothing; get_samples_from_posterior). */
+int mppi_rollout_actions(mppi_handle_t h, const float* actions_dev, int k, float* states_out_dev, void* stream);
+/* `_state_seq_batch[top_indices]` (mppi.py:481): re-roll the k local samples idx_dev[k] from the
+ * resident noise instead of materialising S[N][T+1][ds] -> states_out_dev[k][T+1][ds]. */
+int mppi_rollout_samples(mppi_handle_t h, const int64_t* idx_dev, int k, float* states_out_dev, void* stream);
+
+/* Tuning knobs (not in the reference): "math" 0 = library sin/cos/tan/fmod/div, 1 = range-checked
+ * fast paths (default); "reduce_blocks" grid of the weighted reduction. */
+int mppi_set_option(mppi_handle_t h, const char* key, int64_t value);
+/* Device time per stage from HIP event pairs recorded on the caller's stream around every stage call
+ * since the last drain (no host synchronisation while recording): out[0..3] = mean ms of
+ * {sample, rollout_cost, weights_reduce, finalize}, out[4..7] = number of calls averaged.
+ * Enabled by mppi_set_option(h, "timing", 1).  Synchronises and clears the recorded pairs. */
+int mppi_get_timing(mppi_handle_t h, float* out_ms8);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPPI_HIP_H */

@@ -1,0 +1,118 @@
+"""ctypes binding of include/mppi_hip.h (libmppi_hip.so).  Thin: no compute happens here.
+
+The library is required: there is no CPU or PyTorch fallback for the hot path.  Importing this module
+without the built extension, or creating a solver without a visible MI355X, raises immediately.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmppi_hip.so")
+
+MODEL_IDS = {"pendulum": 0, "cartpole": 1, "mountaincar": 2, "nav2d": 3, "racing": 4}
+MODEL_DIMS = {"pendulum": (2, 1), "cartpole": (4, 1), "mountaincar": (2, 1), "nav2d": (3, 2), "racing": (4, 2)}
+SUMMARY_HEAD = 4
+
+# every symbol include/mppi_hip.h declares
+SYMBOLS = [
+    "mppi_version", "mppi_device_count", "mppi_last_error", "mppi_create", "mppi_destroy",
+    "mppi_set_model_params", "mppi_upload_map", "mppi_set_reference", "mppi_set_mean", "mppi_get_mean",
+    "mppi_set_state", "mppi_sample", "mppi_inject_noise", "mppi_export_noise", "mppi_rollout_cost",
+    "mppi_get_costs", "mppi_set_costs", "mppi_weights_reduce", "mppi_finalize", "mppi_weights",
+    "mppi_rollout_actions", "mppi_rollout_samples", "mppi_set_option", "mppi_get_timing",
+]
+
+
+class MppiConfig(C.Structure):
+    _fields_ = [
+        ("model", C.c_int32), ("horizon", C.c_int32), ("dim_state", C.c_int32), ("dim_control", C.c_int32),
+        ("num_samples", C.c_int64), ("sample_offset", C.c_int64), ("inherit_count", C.c_int64),
+        ("u_min", C.c_float * 2), ("u_max", C.c_float * 2), ("sigmas", C.c_float * 2),
+        ("seed", C.c_uint64), ("device", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class MppiError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """dlopen the in-tree extension; raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MppiError(
+            f"HIP extension missing: {LIB_PATH}. Build it with `python -m mppi_playground_amd._build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the MPPI hot path.")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64, u32, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_uint32, C.c_float
+    lib.mppi_version.restype = C.c_char_p
+    lib.mppi_last_error.restype = C.c_char_p
+    lib.mppi_last_error.argtypes = [vp]
+    lib.mppi_create.argtypes = [C.POINTER(MppiConfig), C.POINTER(vp)]
+    lib.mppi_destroy.argtypes = [vp]
+    lib.mppi_set_model_params.argtypes = [vp, vp, i32]
+    lib.mppi_upload_map.argtypes = [vp, i32, vp, i32, i32, f32, f32, f32]
+    lib.mppi_set_reference.argtypes = [vp, vp, i32, vp]
+    lib.mppi_set_mean.argtypes = [vp, vp, i32, vp]
+    lib.mppi_get_mean.argtypes = [vp, vp, i32, vp]
+    lib.mppi_set_state.argtypes = [vp, vp, i32, vp]
+    lib.mppi_sample.argtypes = [vp, u32, vp]
+    lib.mppi_inject_noise.argtypes = [vp, vp, vp]
+    lib.mppi_export_noise.argtypes = [vp, vp, vp, vp]
+    lib.mppi_rollout_cost.argtypes = [vp, vp]
+    lib.mppi_get_costs.argtypes = [vp, vp, i32, vp]
+    lib.mppi_set_costs.argtypes = [vp, vp, i32, vp]
+    lib.mppi_weights_reduce.argtypes = [vp, f32, vp, vp]
+    lib.mppi_finalize.argtypes = [vp, vp, i32, f32, i32, vp, vp, vp, vp]
+    lib.mppi_weights.argtypes = [vp, f32, f32, f32, vp, vp]
+    lib.mppi_rollout_actions.argtypes = [vp, vp, i32, vp, vp]
+    lib.mppi_rollout_samples.argtypes = [vp, vp, i32, vp, vp]
+    lib.mppi_set_option.argtypes = [vp, C.c_char_p, i64]
+    lib.mppi_get_timing.argtypes = [vp, vp]
+    for name in SYMBOLS:
+        fn = getattr(lib, name)  # AttributeError if the .so does not export what the header declares
+        if name not in ("mppi_version", "mppi_last_error"):
+            fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+class Handle:
+    """RAII wrapper of mppi_handle_t; every call checks the return code and raises MppiError."""
+
+    def __init__(self, cfg: MppiConfig):
+        self.lib = load()
+        if self.lib.mppi_device_count() <= 0:
+            raise MppiError("no HIP device visible: the MPPI hot path needs an MI355X (gfx950); "
+                            "there is no CPU fallback")
+        self.h = C.c_void_p()
+        rc = self.lib.mppi_create(C.byref(cfg), C.byref(self.h))
+        if rc != 0:
+            msg = self.lib.mppi_last_error(self.h).decode() if self.h else f"code {rc}"
+            if self.h:
+                self.lib.mppi_destroy(self.h)
+                self.h = C.c_void_p()
+            raise MppiError(f"mppi_create failed ({rc}): {msg}")
+
+    def call(self, name, *args):
+        rc = getattr(self.lib, name)(self.h, *args)
+        if rc != 0:
+            raise MppiError(f"{name} failed ({rc}): {self.lib.mppi_last_error(self.h).decode()}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mppi_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

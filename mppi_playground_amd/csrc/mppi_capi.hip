@@ -1,0 +1,474 @@
+// mppi_capi.hip — C ABI (include/mppi_hip.h) over the gfx950 kernels in mppi_kernels.hpp.
+// Host-side state only: buffers, model context, launch geometry.  No torch, no exceptions across
+// the boundary.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/mppi_hip.h"
+#include "mppi_kernels.hpp"
+
+using namespace mppi;
+
+struct MppiSolver {
+    MppiConfig cfg{};
+    Dims d{};
+    int ds = 0, dc = 0;
+    // device buffers
+    float4* noise = nullptr;
+    float* costs = nullptr;
+    unsigned* min_key = nullptr;
+    float* x0 = nullptr;
+    float* mean = nullptr;
+    float* ref = nullptr;
+    int ref_cap = 0;
+    float* partials = nullptr;
+    float* heads = nullptr;
+    float* summary = nullptr;
+    uint8_t* map_cells[2] = {nullptr, nullptr};
+    uint8_t* map_fused = nullptr;
+    std::vector<uint8_t> map_host[2];
+    ModelCtx ctx{};
+    // options
+    int math_fast = 1;
+    int reduce_blocks = 512;
+    int timing = 0;
+    std::vector<hipEvent_t> ev_pool[4];  // per stage: start0, stop0, start1, stop1, ...
+    size_t ev_used[4] = {0, 0, 0, 0};
+    int CH = 32, nchunks = 1, colsp = 128;
+    std::string err;
+};
+
+namespace {
+
+int fail(mppi_handle_t h, int code, const std::string& msg) {
+    if (h) h->err = msg;
+    return code;
+}
+#define HIP_TRY(h, expr)                                                                              \
+    do {                                                                                              \
+        hipError_t _e = (expr);                                                                       \
+        if (_e != hipSuccess)                                                                         \
+            return fail(h, MPPI_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));            \
+    } while (0)
+
+struct ModelDims { int ds, dc; };
+bool model_dims(int model, ModelDims& md) {
+    switch (model) {
+    case MPPI_MODEL_PENDULUM: md = {2, 1}; return true;
+    case MPPI_MODEL_CARTPOLE: md = {4, 1}; return true;
+    case MPPI_MODEL_MOUNTAINCAR: md = {2, 1}; return true;
+    case MPPI_MODEL_NAV2D: md = {3, 2}; return true;
+    case MPPI_MODEL_RACING: md = {4, 2}; return true;
+    }
+    return false;
+}
+
+// Brackets one stage with a pair of HIP events on the caller's stream (no host synchronisation);
+// pairs accumulate until mppi_get_timing() drains them.
+struct StageTimer {
+    mppi_handle_t h; int stage; hipStream_t s; hipEvent_t stop = nullptr;
+    static hipEvent_t next(mppi_handle_t h, int stage) {
+        auto& pool = h->ev_pool[stage];
+        if (h->ev_used[stage] == pool.size()) {
+            if (pool.size() >= 16384) return nullptr;
+            hipEvent_t e = nullptr;
+            if (hipEventCreate(&e) != hipSuccess) return nullptr;
+            pool.push_back(e);
+        }
+        return pool[h->ev_used[stage]++];
+    }
+    StageTimer(mppi_handle_t h_, int stage_, hipStream_t s_) : h(h_), stage(stage_), s(s_) {
+        if (!h->timing) return;
+        hipEvent_t start = next(h, stage);
+        stop = start ? next(h, stage) : nullptr;
+        if (start && stop) (void)hipEventRecord(start, s);
+        else if (start) { --h->ev_used[stage]; }
+    }
+    ~StageTimer() {
+        if (stop) (void)hipEventRecord(stop, s);
+    }
+};
+
+bool use_fast(mppi_handle_t h);
+// dispatch on (model, math variant)
+#define MPPI_DISPATCH(h, CALL)                                                                        \
+    do {                                                                                              \
+        const bool fast_ = use_fast(h);                                                               \
+        switch ((h)->cfg.model) {                                                                     \
+        case MPPI_MODEL_PENDULUM: if (fast_) { CALL(MPPI_MODEL_PENDULUM, true); } else { CALL(MPPI_MODEL_PENDULUM, false); } break; \
+        case MPPI_MODEL_CARTPOLE: if (fast_) { CALL(MPPI_MODEL_CARTPOLE, true); } else { CALL(MPPI_MODEL_CARTPOLE, false); } break; \
+        case MPPI_MODEL_MOUNTAINCAR: if (fast_) { CALL(MPPI_MODEL_MOUNTAINCAR, true); } else { CALL(MPPI_MODEL_MOUNTAINCAR, false); } break; \
+        case MPPI_MODEL_NAV2D: if (fast_) { CALL(MPPI_MODEL_NAV2D, true); } else { CALL(MPPI_MODEL_NAV2D, false); } break; \
+        case MPPI_MODEL_RACING: if (fast_) { CALL(MPPI_MODEL_RACING, true); } else { CALL(MPPI_MODEL_RACING, false); } break; \
+        }                                                                                             \
+    } while (0)
+
+// FAST kernels assume launch-uniform preconditions (see mppi_models.hpp); otherwise use FAST=false.
+bool use_fast(mppi_handle_t h) {
+    if (!h->math_fast) return false;
+    const int m = h->cfg.model;
+    if (m == MPPI_MODEL_NAV2D) return h->ctx.maps[0].inv_cell != 0.0f;
+    if (m == MPPI_MODEL_RACING)
+        return h->ctx.maps[0].inv_cell != 0.0f && h->ctx.fused != nullptr && h->ctx.tan_small != 0 && h->ctx.inv_L != 0.0f;
+    return true;
+}
+
+int check_ready(mppi_handle_t h) {
+    const int m = h->cfg.model;
+    if ((m == MPPI_MODEL_NAV2D || m == MPPI_MODEL_RACING) && !h->map_cells[0])
+        return fail(h, MPPI_E_STATE, "obstacle map (slot 0) not uploaded");
+    if (m == MPPI_MODEL_RACING && !h->map_cells[1]) return fail(h, MPPI_E_STATE, "lane map (slot 1) not uploaded");
+    if (m == MPPI_MODEL_RACING && (!h->ctx.ref || h->ctx.ref_rows < h->d.T))
+        return fail(h, MPPI_E_STATE, "reference path not set or shorter than the horizon");
+    return MPPI_OK;
+}
+
+void refresh_fused(mppi_handle_t h) {
+    h->ctx.fused = nullptr;
+    if (h->cfg.model != MPPI_MODEL_RACING) return;
+    const MapView &a = h->ctx.maps[0], &b = h->ctx.maps[1];
+    if (!h->map_cells[0] || !h->map_cells[1]) return;
+    if (a.nx != b.nx || a.ny != b.ny || a.cell != b.cell || a.ox != b.ox || a.oy != b.oy) return;
+    const size_t n = (size_t)a.nx * a.ny;
+    std::vector<uint8_t> f(n);
+    for (size_t i = 0; i < n; ++i) f[i] = (uint8_t)(h->map_host[0][i] + h->map_host[1][i]);
+    if (h->map_fused) (void)hipFree(h->map_fused);
+    h->map_fused = nullptr;
+    if (hipMalloc(&h->map_fused, n) != hipSuccess) return;
+    if (hipMemcpy(h->map_fused, f.data(), n, hipMemcpyHostToDevice) != hipSuccess) return;
+    h->ctx.fused = h->map_fused;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* mppi_version(void) { return "mppi_hip 0.1.0 (gfx950, wave64, lane-per-trajectory)"; }
+
+int mppi_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* mppi_last_error(mppi_handle_t h) { return h ? h->err.c_str() : "null handle"; }
+
+int mppi_create(const MppiConfig* cfg, mppi_handle_t* out) {
+    if (!cfg || !out) return MPPI_E_INVALID;
+    *out = nullptr;
+    ModelDims md{};
+    if (!model_dims(cfg->model, md)) return MPPI_E_INVALID;
+    if (cfg->dim_state != md.ds || cfg->dim_control != md.dc) return MPPI_E_INVALID;
+    if (cfg->horizon < 1 || cfg->num_samples < 1) return MPPI_E_INVALID;
+    if (mppi_device_count() <= 0) return MPPI_E_NODEVICE;
+    MppiSolver* h = new (std::nothrow) MppiSolver();
+    if (!h) return MPPI_E_INVALID;
+    h->cfg = *cfg;
+    h->ds = md.ds; h->dc = md.dc;
+    Dims& d = h->d;
+    d.N = cfg->num_samples;
+    d.tiles = (d.N + 63) / 64;
+    d.sample_offset = cfg->sample_offset;
+    d.inherit_count = cfg->inherit_count;
+    d.T = cfg->horizon;
+    d.row = d.T * md.dc;
+    d.R = (d.row + 3) / 4;
+    for (int k = 0; k < MPPI_MAX_DIM_CONTROL; ++k) {
+        d.u_min[k] = cfg->u_min[k]; d.u_max[k] = cfg->u_max[k]; d.sigma[k] = cfg->sigmas[k];
+    }
+    h->CH = d.R <= 8 ? 8 : 32;
+    h->nchunks = (d.R + h->CH - 1) / h->CH;
+    h->colsp = h->nchunks * h->CH * 4;
+    *out = h;  // so that the caller can read the error and destroy on failure
+    HIP_TRY(h, hipSetDevice(cfg->device));
+    const size_t noise_bytes = (size_t)d.tiles * d.R * 64 * sizeof(float4);
+    HIP_TRY(h, hipMalloc(&h->noise, noise_bytes));
+    HIP_TRY(h, hipMemset(h->noise, 0, noise_bytes));
+    HIP_TRY(h, hipMalloc(&h->costs, sizeof(float) * (size_t)d.N));
+    HIP_TRY(h, hipMalloc(&h->min_key, sizeof(unsigned)));
+    HIP_TRY(h, hipMalloc(&h->x0, sizeof(float) * MPPI_MAX_DIM_STATE));
+    HIP_TRY(h, hipMemset(h->x0, 0, sizeof(float) * MPPI_MAX_DIM_STATE));
+    HIP_TRY(h, hipMalloc(&h->mean, sizeof(float) * (size_t)d.row));
+    HIP_TRY(h, hipMemset(h->mean, 0, sizeof(float) * (size_t)d.row));  // mppi.py:157
+    const int max_blocks = 2048;
+    HIP_TRY(h, hipMalloc(&h->partials, sizeof(float) * (size_t)max_blocks * h->colsp));
+    HIP_TRY(h, hipMalloc(&h->heads, sizeof(float) * (size_t)max_blocks * 4));
+    HIP_TRY(h, hipMalloc(&h->summary, sizeof(float) * (size_t)(MPPI_SUMMARY_HEAD + d.row)));
+    std::memset(&h->ctx, 0, sizeof(h->ctx));
+    HIP_TRY(h, hipDeviceSynchronize());
+    return MPPI_OK;
+}
+
+int mppi_destroy(mppi_handle_t h) {
+    if (!h) return MPPI_E_INVALID;
+    (void)hipFree(h->noise); (void)hipFree(h->costs); (void)hipFree(h->min_key); (void)hipFree(h->x0);
+    (void)hipFree(h->mean); (void)hipFree(h->ref); (void)hipFree(h->partials); (void)hipFree(h->heads);
+    (void)hipFree(h->summary); (void)hipFree(h->map_cells[0]); (void)hipFree(h->map_cells[1]);
+    (void)hipFree(h->map_fused);
+    for (auto& pool : h->ev_pool) for (auto& e : pool) if (e) (void)hipEventDestroy(e);
+    delete h;
+    return MPPI_OK;
+}
+
+int mppi_set_model_params(mppi_handle_t h, const float* p, int n) {
+    if (!h || n < 0 || n > MPPI_MAX_PARAMS || (n > 0 && !p)) return fail(h, MPPI_E_INVALID, "bad params");
+    const int need = h->cfg.model == MPPI_MODEL_RACING ? MPPI_RP_COUNT : h->cfg.model == MPPI_MODEL_NAV2D ? MPPI_NP_COUNT : 0;
+    if (n != need) return fail(h, MPPI_E_INVALID, "parameter count does not match the model");
+    for (int i = 0; i < n; ++i) h->ctx.P[i] = p[i];
+    if (h->cfg.model == MPPI_MODEL_RACING) {
+        h->ctx.tan_small = (std::fabs(p[MPPI_RP_SMIN]) <= 0.25f && std::fabs(p[MPPI_RP_SMAX]) <= 0.25f) ? 1 : 0;
+        const float L = p[MPPI_RP_L];
+        uint32_t bits; std::memcpy(&bits, &L, 4);
+        h->ctx.inv_L = (L > 0.0f && (bits & 0x7fffffu) != 0x7fffffu) ? 1.0f / L : 0.0f;
+    }
+    return MPPI_OK;
+}
+
+int mppi_upload_map(mppi_handle_t h, int slot, const uint8_t* cells, int nx, int ny, float cell, float ox, float oy) {
+    if (!h || slot < 0 || slot > 1 || !cells || nx < 1 || ny < 1 || !(cell > 0.0f))
+        return fail(h, MPPI_E_INVALID, "bad map");
+    const size_t n = (size_t)nx * ny;
+    for (size_t i = 0; i < n; ++i)
+        if (cells[i] > 1) return fail(h, MPPI_E_INVALID, "map cells must be 0/1 occupancy");
+    if (h->map_cells[slot]) { (void)hipFree(h->map_cells[slot]); h->map_cells[slot] = nullptr; }
+    HIP_TRY(h, hipMalloc(&h->map_cells[slot], n));
+    HIP_TRY(h, hipMemcpy(h->map_cells[slot], cells, n, hipMemcpyHostToDevice));
+    h->map_host[slot].assign(cells, cells + n);
+    MapView& m = h->ctx.maps[slot];
+    m.cells = h->map_cells[slot];
+    m.nx = nx; m.ny = ny; m.cell = cell; m.ox = ox; m.oy = oy;
+    // Markstein division needs y = RN(1/cell) and a significand of cell that is not all ones.
+    uint32_t bits; std::memcpy(&bits, &cell, 4);
+    const bool all_ones = (bits & 0x7fffffu) == 0x7fffffu;
+    m.inv_cell = all_ones ? 0.0f : 1.0f / cell;  // host IEEE division: correctly rounded
+    refresh_fused(h);
+    return MPPI_OK;
+}
+
+int mppi_set_reference(mppi_handle_t h, const float* ref, int rows, void* stream) {
+    if (!h || !ref || rows < 1) return fail(h, MPPI_E_INVALID, "bad reference");
+    hipStream_t s = (hipStream_t)stream;
+    if (rows > h->ref_cap) {
+        if (h->ref) (void)hipFree(h->ref);
+        h->ref = nullptr;
+        HIP_TRY(h, hipMalloc(&h->ref, sizeof(float) * 8 * (size_t)rows));
+        h->ref_cap = rows;
+    }
+    std::vector<float> buf((size_t)rows * 8);
+    for (int i = 0; i < rows; ++i) {
+        float* o = &buf[(size_t)i * 8];
+        o[0] = ref[4 * i]; o[1] = ref[4 * i + 1]; o[2] = ref[4 * i + 2]; o[3] = ref[4 * i + 3];
+        o[4] = sinf(o[2]); o[5] = cosf(o[2]);  // torch.sin/cos of the fp32 scalar, racing.py:127-139
+        o[6] = o[7] = 0.0f;
+    }
+    HIP_TRY(h, hipMemcpyAsync(h->ref, buf.data(), sizeof(float) * buf.size(), hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipStreamSynchronize(s));  // buf is a stack-lifetime staging buffer
+    h->ctx.ref = h->ref;
+    h->ctx.ref_rows = rows;
+    return MPPI_OK;
+}
+
+static int copy_small(mppi_handle_t h, void* dst, const void* src, size_t bytes, bool dst_dev, bool src_dev, hipStream_t s) {
+    const hipMemcpyKind kind = dst_dev ? (src_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice)
+                                       : (src_dev ? hipMemcpyDeviceToHost : hipMemcpyHostToHost);
+    HIP_TRY(h, hipMemcpyAsync(dst, src, bytes, kind, s));
+    if (!dst_dev || !src_dev) HIP_TRY(h, hipStreamSynchronize(s));
+    return MPPI_OK;
+}
+
+int mppi_set_mean(mppi_handle_t h, const float* mean, int on_device, void* stream) {
+    if (!h || !mean) return fail(h, MPPI_E_INVALID, "null");
+    return copy_small(h, h->mean, mean, sizeof(float) * (size_t)h->d.row, true, on_device != 0, (hipStream_t)stream);
+}
+int mppi_get_mean(mppi_handle_t h, float* out, int on_device, void* stream) {
+    if (!h || !out) return fail(h, MPPI_E_INVALID, "null");
+    return copy_small(h, out, h->mean, sizeof(float) * (size_t)h->d.row, on_device != 0, true, (hipStream_t)stream);
+}
+int mppi_set_state(mppi_handle_t h, const float* x0, int on_device, void* stream) {
+    if (!h || !x0) return fail(h, MPPI_E_INVALID, "null");
+    return copy_small(h, h->x0, x0, sizeof(float) * (size_t)h->ds, true, on_device != 0, (hipStream_t)stream);
+}
+
+int mppi_sample(mppi_handle_t h, uint32_t solve_idx, void* stream) {
+    if (!h) return MPPI_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    StageTimer tm(h, 0, s);
+    const unsigned grid = (unsigned)((h->d.tiles + 3) / 4);
+    hipLaunchKernelGGL(sample_kernel, dim3(grid), dim3(BLOCK), 0, s, h->noise, h->d, (uint32_t)h->cfg.seed,
+                       (uint32_t)(h->cfg.seed >> 32), solve_idx);
+    HIP_TRY(h, hipGetLastError());
+    return MPPI_OK;
+}
+
+int mppi_inject_noise(mppi_handle_t h, const float* eps_dev, void* stream) {
+    if (!h || !eps_dev) return fail(h, MPPI_E_INVALID, "null");
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)h->d.tiles, (unsigned)((h->d.row + CONV_COLS - 1) / CONV_COLS));
+    hipLaunchKernelGGL(inject_kernel, grid, dim3(BLOCK), 0, s, eps_dev, h->noise, h->d);
+    HIP_TRY(h, hipGetLastError());
+    return MPPI_OK;
+}
+
+int mppi_export_noise(mppi_handle_t h, float* eps_out, float* act_out, void* stream) {
+    if (!h) return MPPI_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)h->d.tiles, (unsigned)((h->d.row + CONV_COLS - 1) / CONV_COLS));
+    hipLaunchKernelGGL(export_kernel, grid, dim3(BLOCK), 0, s, h->noise, h->mean, eps_out, act_out, h->d);
+    HIP_TRY(h, hipGetLastError());
+    return MPPI_OK;
+}
+
+int mppi_rollout_cost(mppi_handle_t h, void* stream) {
+    if (!h) return MPPI_E_INVALID;
+    if (int rc = check_ready(h)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    StageTimer tm(h, 1, s);
+    HIP_TRY(h, hipMemsetAsync(h->min_key, 0xFF, sizeof(unsigned), s));
+    const unsigned grid = (unsigned)((h->d.tiles + 3) / 4);
+#define CALL_ROLLOUT(MODEL, FASTV)                                                                    \
+    hipLaunchKernelGGL((rollout_cost_kernel<MODEL, FASTV>), dim3(grid), dim3(BLOCK), 0, s, h->noise, h->mean, \
+                       h->x0, h->costs, h->min_key, h->d, h->ctx)
+    MPPI_DISPATCH(h, CALL_ROLLOUT);
+#undef CALL_ROLLOUT
+    HIP_TRY(h, hipGetLastError());
+    return MPPI_OK;
+}
+
+int mppi_get_costs(mppi_handle_t h, float* dst, int on_device, void* stream) {
+    if (!h || !dst) return fail(h, MPPI_E_INVALID, "null");
+    return copy_small(h, dst, h->costs, sizeof(float) * (size_t)h->d.N, on_device != 0, true, (hipStream_t)stream);
+}
+
+__global__ void min_cost_kernel(const float* __restrict__ costs, int64_t N, unsigned* __restrict__ min_key) {
+    float m = INFINITY;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x)
+        m = fminf(m, costs[i]);
+    m = wave_min(m);
+    if ((threadIdx.x & 63) == 0 && m < INFINITY) atomicMin(min_key, float_to_key(m));
+}
+
+int mppi_set_costs(mppi_handle_t h, const float* src, int on_device, void* stream) {
+    if (!h || !src) return fail(h, MPPI_E_INVALID, "null");
+    hipStream_t s = (hipStream_t)stream;
+    if (int rc = copy_small(h, h->costs, src, sizeof(float) * (size_t)h->d.N, true, on_device != 0, s)) return rc;
+    HIP_TRY(h, hipMemsetAsync(h->min_key, 0xFF, sizeof(unsigned), s));
+    const unsigned grid = (unsigned)std::min<int64_t>((h->d.N + BLOCK - 1) / BLOCK, 1024);
+    hipLaunchKernelGGL(min_cost_kernel, dim3(grid), dim3(BLOCK), 0, s, h->costs, h->d.N, h->min_key);
+    HIP_TRY(h, hipGetLastError());
+    return MPPI_OK;
+}
+
+int mppi_weights_reduce(mppi_handle_t h, float lambda, float* summary_out_dev, void* stream) {
+    if (!h || !(lambda > 0.0f)) return fail(h, MPPI_E_INVALID, "lambda must be > 0");
+    hipStream_t s = (hipStream_t)stream;
+    StageTimer tm(h, 2, s);
+    int64_t blocks = std::min<int64_t>(h->reduce_blocks, (h->d.tiles + 3) / 4);
+    blocks = std::max<int64_t>(1, std::min<int64_t>(blocks, 2048));
+    const dim3 grid((unsigned)blocks, (unsigned)h->nchunks);
+    if (h->CH == 8)
+        hipLaunchKernelGGL((weights_reduce_kernel<8>), grid, dim3(BLOCK), 0, s, h->noise, h->mean, h->costs,
+                           h->min_key, h->partials, h->heads, h->d, lambda);
+    else
+        hipLaunchKernelGGL((weights_reduce_kernel<32>), grid, dim3(BLOCK), 0, s, h->noise, h->mean, h->costs,
+                           h->min_key, h->partials, h->heads, h->d, lambda);
+    HIP_TRY(h, hipGetLastError());
+    hipLaunchKernelGGL(summarize_kernel, dim3(1), dim3(BLOCK), 0, s, h->partials, h->heads, h->min_key, (int)blocks,
+                       h->colsp, h->d.row, h->summary);
+    HIP_TRY(h, hipGetLastError());
+    if (summary_out_dev)
+        HIP_TRY(h, hipMemcpyAsync(summary_out_dev, h->summary, sizeof(float) * (size_t)(MPPI_SUMMARY_HEAD + h->d.row),
+                                  hipMemcpyDeviceToDevice, s));
+    return MPPI_OK;
+}
+
+int mppi_finalize(mppi_handle_t h, const float* summaries_dev, int num_shards, float lambda, int store_mean,
+                  float* action_out, float* state_out, float* stats_out, void* stream) {
+    if (!h || !(lambda > 0.0f) || num_shards < 1) return fail(h, MPPI_E_INVALID, "bad finalize arguments");
+    if (int rc = check_ready(h)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    StageTimer tm(h, 3, s);
+    const float* sums = summaries_dev ? summaries_dev : h->summary;
+    if (!summaries_dev) num_shards = 1;
+    const size_t shmem = sizeof(float) * (size_t)h->d.row;
+#define CALL_FINALIZE(MODEL, FASTV)                                                                   \
+    hipLaunchKernelGGL((finalize_kernel<MODEL, FASTV>), dim3(1), dim3(BLOCK), shmem, s, sums, num_shards, lambda, \
+                       h->d.row, h->d.T, h->x0, store_mean ? h->mean : (float*)nullptr, action_out, state_out, \
+                       stats_out, h->ctx)
+    MPPI_DISPATCH(h, CALL_FINALIZE);
+#undef CALL_FINALIZE
+    HIP_TRY(h, hipGetLastError());
+    return MPPI_OK;
+}
+
+int mppi_weights(mppi_handle_t h, float lambda, float cmin, float sum_e, float* w_out, void* stream) {
+    if (!h || !w_out || !(lambda > 0.0f)) return fail(h, MPPI_E_INVALID, "bad weights arguments");
+    const unsigned grid = (unsigned)((h->d.N + BLOCK - 1) / BLOCK);
+    hipLaunchKernelGGL(weights_kernel, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, h->costs, h->d.N, lambda, cmin,
+                       sum_e, w_out);
+    HIP_TRY(h, hipGetLastError());
+    return MPPI_OK;
+}
+
+int mppi_rollout_actions(mppi_handle_t h, const float* actions_dev, int k, float* states_out, void* stream) {
+    if (!h || !actions_dev || !states_out || k < 1) return fail(h, MPPI_E_INVALID, "bad rollout_actions arguments");
+    if (int rc = check_ready(h)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned grid = (unsigned)((k + WAVE - 1) / WAVE);
+#define CALL_RA(MODEL, FASTV)                                                                         \
+    hipLaunchKernelGGL((rollout_actions_kernel<MODEL, FASTV>), dim3(grid), dim3(WAVE), 0, s, actions_dev, k, h->d.T, \
+                       h->x0, states_out, h->ctx)
+    MPPI_DISPATCH(h, CALL_RA);
+#undef CALL_RA
+    HIP_TRY(h, hipGetLastError());
+    return MPPI_OK;
+}
+
+int mppi_rollout_samples(mppi_handle_t h, const int64_t* idx_dev, int k, float* states_out, void* stream) {
+    if (!h || !idx_dev || !states_out || k < 1) return fail(h, MPPI_E_INVALID, "bad rollout_samples arguments");
+    if (int rc = check_ready(h)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned grid = (unsigned)((k + WAVE - 1) / WAVE);
+#define CALL_RS(MODEL, FASTV)                                                                         \
+    hipLaunchKernelGGL((rollout_samples_kernel<MODEL, FASTV>), dim3(grid), dim3(WAVE), 0, s, h->noise, h->mean, \
+                       idx_dev, k, h->x0, states_out, h->d, h->ctx)
+    MPPI_DISPATCH(h, CALL_RS);
+#undef CALL_RS
+    HIP_TRY(h, hipGetLastError());
+    return MPPI_OK;
+}
+
+int mppi_set_option(mppi_handle_t h, const char* key, int64_t value) {
+    if (!h || !key) return MPPI_E_INVALID;
+    const std::string k(key);
+    if (k == "math") { h->math_fast = value ? 1 : 0; return MPPI_OK; }
+    if (k == "reduce_blocks") { h->reduce_blocks = (int)std::max<int64_t>(1, std::min<int64_t>(value, 2048)); return MPPI_OK; }
+    if (k == "timing") { h->timing = value ? 1 : 0; return MPPI_OK; }
+    return fail(h, MPPI_E_INVALID, "unknown option " + k);
+}
+
+int mppi_get_timing(mppi_handle_t h, float* out) {
+    if (!h || !out) return MPPI_E_INVALID;
+    for (int i = 0; i < 4; ++i) {
+        out[i] = -1.0f;
+        out[4 + i] = 0.0f;
+        const size_t pairs = h->ev_used[i] / 2;
+        double sum = 0.0;
+        for (size_t p = 0; p < pairs; ++p) {
+            float ms = 0.0f;
+            HIP_TRY(h, hipEventSynchronize(h->ev_pool[i][2 * p + 1]));
+            HIP_TRY(h, hipEventElapsedTime(&ms, h->ev_pool[i][2 * p], h->ev_pool[i][2 * p + 1]));
+            sum += ms;
+        }
+        if (pairs) { out[i] = (float)(sum / (double)pairs); out[4 + i] = (float)pairs; }
+        h->ev_used[i] = 0;
+    }
+    return MPPI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,495 @@
+// mppi_kernels.hpp — gfx950 kernels of the MPPI.forward() hot path.
+//
+// Mapping (CDNA4, wave64): one LANE per trajectory, one WAVEFRONT per tile of 64 trajectories.
+// The horizon recurrence is serial in t, so the 64 lanes of a wave advance 64 independent
+// trajectories in lock-step; the noise is stored lane-major (see include/mppi_hip.h) so each
+// wave-level load/store is one contiguous 1 KiB segment, no LDS transpose is needed on the hot
+// path, and state stays in VGPRs for the whole horizon.  LDS is used only for the block-level
+// reductions and for the [N][T][dc] <-> tile layout conversions (inject/export).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "mppi_models.hpp"
+#include "philox.hpp"
+
+namespace mppi {
+
+constexpr int WAVE = 64;
+constexpr int BLOCK = 256;  // 4 waves
+
+struct Dims {
+    int64_t N;              // local samples
+    int64_t tiles;          // ceil(N/64)
+    int64_t sample_offset;  // global index of local sample 0
+    int64_t inherit_count;  // global threshold of mppi.py:266
+    int32_t T, R, row;      // horizon, float4 groups per trajectory, row = T*dc
+    float u_min[MPPI_MAX_DIM_CONTROL], u_max[MPPI_MAX_DIM_CONTROL], sigma[MPPI_MAX_DIM_CONTROL];
+};
+
+__device__ __forceinline__ unsigned float_to_key(float f) {  // order-preserving map for atomicMin
+    const unsigned b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float key_to_float(unsigned k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fminf(v, __shfl_xor(v, m));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// Step 1: eps ~ N(0, diag(sigma^2)) written as lane-major tiles.  HBM-write bound:
+// 16 B per lane per Philox call, one 1 KiB store per wave instruction.
+__global__ __launch_bounds__(BLOCK) void sample_kernel(float4* __restrict__ noise, Dims d, uint32_t seed_lo,
+                                                       uint32_t seed_hi, uint32_t solve_idx) {
+    const int lane = threadIdx.x & 63;
+    const int64_t tile = (int64_t)blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6);
+    if (tile >= d.tiles) return;
+    const uint64_t gi = (uint64_t)(d.sample_offset + tile * 64 + lane);
+    float4* out = noise + tile * d.R * 64 + lane;
+    const int dc = d.row / d.T;
+    for (int r = 0; r < d.R; ++r) {
+        const u32x4 x = philox4x32_10((uint32_t)gi, (uint32_t)(gi >> 32), (uint32_t)r, solve_idx, seed_lo, seed_hi);
+        float z[4];
+        box_muller(x.x, x.y, z[0], z[1]);
+        box_muller(x.z, x.w, z[2], z[3]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int f = 4 * r + j;
+            const float sg = (dc == 1) ? d.sigma[0] : d.sigma[f & 1];  // dc in {1, 2}
+            z[j] = (f < d.row) ? z[j] * sg : 0.0f;
+        }
+        out[(int64_t)r * 64] = make_float4(z[0], z[1], z[2], z[3]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Steps 1b-3 fused: U = clamp(mean + eps), rollout, stage + terminal cost (mppi.py:266-336).
+// Reads the noise once (16 B per lane per 4/dc steps), writes costs[N] and the shard minimum.
+//
+// trajectory_cost(): one lane walks one trajectory.  `np` points at the lane's first float4 of the
+// tile; consecutive groups are 64 float4 apart.
+template <int MODEL, bool FAST>
+__device__ __forceinline__ float trajectory_cost(const float4* __restrict__ np, const float* __restrict__ mean,
+                                                 const float* __restrict__ x0, const Dims& d, const ModelCtx& ctx,
+                                                 bool inherit, bool& bad) {
+    using M = Model<MODEL, FAST>;
+    constexpr int DS = M::DS, DC = M::DC, SPG = 4 / DC;
+    float s[DS], pu[DC], pl[DC];
+#pragma unroll
+    for (int j = 0; j < DS; ++j) s[j] = x0[j];
+#pragma unroll
+    for (int k = 0; k < DC; ++k) pu[k] = pl[k] = 0.0f;
+    float acc = 0.0f;
+    int t = 0;
+    float4 e = np[0];
+    for (int r = 0; r < d.R; ++r) {
+        const float4 en = (r + 1 < d.R) ? np[(int64_t)(r + 1) * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float ev[4] = {e.x, e.y, e.z, e.w};
+#pragma unroll
+        for (int g = 0; g < SPG; ++g) {
+            if (t < d.T) {
+                float u[DC];
+#pragma unroll
+                for (int k = 0; k < DC; ++k) {
+                    const float mv = mean[t * DC + k];  // uniform (scalar) load, unconditional
+                    const float m = inherit ? mv : 0.0f;
+                    u[k] = clampf(m + ev[g * DC + k], d.u_min[k], d.u_max[k]);
+                }
+                if (t == 0) {
+#pragma unroll
+                    for (int k = 0; k < DC; ++k) pu[k] = u[k];
+                }
+                float sn[DS], ss[DS];
+                M::step(ctx, s, u, sn, ss, bad);
+                acc += M::cost(ctx, ss, u, pu, t, bad);
+#pragma unroll
+                for (int k = 0; k < DC; ++k) { pl[k] = pu[k]; pu[k] = u[k]; }
+#pragma unroll
+                for (int j = 0; j < DS; ++j) s[j] = sn[j];
+                ++t;
+            }
+        }
+        e = en;
+    }
+    // terminal cost: zero action, stale prev_action U[:, max(T-2,0)] and stale t = T-1
+    // (mppi.py:318-328)
+    float zero[DC];
+#pragma unroll
+    for (int k = 0; k < DC; ++k) zero[k] = 0.0f;
+    const float term = M::cost(ctx, s, zero, pl, d.T - 1, bad);
+    return acc + term;
+}
+
+template <int MODEL, bool FAST>
+__global__ __launch_bounds__(BLOCK) void rollout_cost_kernel(const float4* __restrict__ noise,
+                                                             const float* __restrict__ mean,
+                                                             const float* __restrict__ x0,
+                                                             float* __restrict__ costs,
+                                                             unsigned* __restrict__ min_key, Dims d, ModelCtx ctx) {
+    __shared__ float s_min[BLOCK / WAVE];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int64_t tile = (int64_t)blockIdx.x * (BLOCK / WAVE) + wid;
+    float total = INFINITY;
+    if (tile < d.tiles) {
+        const int64_t i = tile * 64 + lane;
+        const bool inherit = (d.sample_offset + i) < d.inherit_count;
+        const float4* np = noise + tile * d.R * 64 + lane;
+        bool bad = false;
+        total = trajectory_cost<MODEL, FAST>(np, mean, x0, d, ctx, inherit, bad);
+        if (FAST) {
+            if (bad) {  // a fast path left its validity range: redo this lane with the library math
+                bool ignore = false;
+                total = trajectory_cost<MODEL, false>(np, mean, x0, d, ctx, inherit, ignore);
+            }
+        }
+        if (i < d.N) costs[i] = total;
+        else total = INFINITY;
+    }
+    const float wm = wave_min(total);
+    if (lane == 0) s_min[wid] = wm;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = s_min[0];
+#pragma unroll
+        for (int w = 1; w < BLOCK / WAVE; ++w) m = fminf(m, s_min[w]);
+        if (m < INFINITY) atomicMin(min_key, float_to_key(m));
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Steps 5-6: e_i = exp((-c_i)/lambda - max_j(-c_j)/lambda) and A = sum_i e_i * clamp(mean + eps_i)
+// (mppi.py:376-384, un-normalised).  Each lane accumulates its own trajectories over the tiles its
+// wave owns in NACC registers, then a butterfly reduce-scatter combines the 64 lanes with
+// NACC-1 (+ log) shuffles instead of 6*NACC.  Tiles whose 64 weights are all exactly zero are
+// skipped without touching their noise (exact: they contribute 0).
+template <int NACC>
+__device__ __forceinline__ void wave_reduce_scatter(float (&a)[NACC], int lane) {
+    int cur = NACC;
+#pragma unroll
+    for (int mask = 32; mask >= 1; mask >>= 1) {
+        if (cur > 1) {
+            const int half = cur >> 1;
+            const bool hi = (lane & mask) != 0;
+#pragma unroll
+            for (int j = 0; j < half; ++j) {
+                const float send = hi ? a[j] : a[j + half];
+                const float keep = hi ? a[j + half] : a[j];
+                a[j] = keep + __shfl_xor(send, mask);
+            }
+            cur = half;
+        } else {
+            a[0] += __shfl_xor(a[0], mask);
+        }
+    }
+}
+
+// partials layout: [gridDim.x][colsp] with colsp = gridDim.y * CH * 4; heads: [gridDim.x][4]
+template <int CH>  // float4 groups per column chunk (8 or 32)
+__global__ __launch_bounds__(BLOCK) void weights_reduce_kernel(const float4* __restrict__ noise,
+                                                               const float* __restrict__ mean,
+                                                               const float* __restrict__ costs,
+                                                               const unsigned* __restrict__ min_key,
+                                                               float* __restrict__ partials,
+                                                               float* __restrict__ heads, Dims d, float lambda) {
+    constexpr int NACC = CH * 4;
+    __shared__ float s_cols[BLOCK / WAVE][NACC];
+    __shared__ float s_head[BLOCK / WAVE][4];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * CH;  // first float4 group of this column chunk
+    const int nr = min(CH, d.R - r0);
+    const int dc = d.row / d.T;
+    const float cmin = key_to_float(*min_key);
+    const float xmax = (-cmin) / lambda;
+    float acc[NACC];
+#pragma unroll
+    for (int j = 0; j < NACC; ++j) acc[j] = 0.0f;
+    float se = 0.0f, se2 = 0.0f, sec = 0.0f;
+    const int64_t wave_id = (int64_t)blockIdx.x * (BLOCK / WAVE) + wid;
+    const int64_t nwaves = (int64_t)gridDim.x * (BLOCK / WAVE);
+    for (int64_t tile = wave_id; tile < d.tiles; tile += nwaves) {
+        const int64_t i = tile * 64 + lane;
+        float e = 0.0f, c = 0.0f;
+        if (i < d.N) {
+            c = costs[i];
+            e = expf((-c) / lambda - xmax);
+        }
+        if (__ballot(e != 0.0f) == 0ull) continue;  // wave-uniform skip
+        se += e;
+        se2 = fmaf(e, e, se2);
+        sec = fmaf(e, c, sec);
+        const bool inherit = (d.sample_offset + i) < d.inherit_count;
+        const float4* np = noise + (tile * d.R + r0) * 64 + lane;
+#pragma unroll
+        for (int r = 0; r < CH; ++r) {
+            if (r < nr) {
+                const float4 n4 = np[(int64_t)r * 64];
+                const float nv[4] = {n4.x, n4.y, n4.z, n4.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int f = 4 * (r0 + r) + j;
+                    if (f < d.row) {
+                        const int k = (dc == 1) ? 0 : (f & 1);
+                        const float m = inherit ? mean[f] : 0.0f;
+                        const float u = clampf(m + nv[j], d.u_min[k], d.u_max[k]);
+                        acc[4 * r + j] = fmaf(e, u, acc[4 * r + j]);
+                    }
+                }
+            }
+        }
+    }
+    wave_reduce_scatter<NACC>(acc, lane);
+    se = wave_sum(se);
+    se2 = wave_sum(se2);
+    sec = wave_sum(sec);
+    // after the butterfly lane l holds columns [l*NACC/64, (l+1)*NACC/64) when NACC >= 64, and
+    // column l >> (6 - log2 NACC) (replicated) when NACC < 64
+    if (NACC >= 64) {
+        constexpr int PER = NACC / 64 > 0 ? NACC / 64 : 1;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) s_cols[wid][lane * PER + j] = acc[j];
+    } else {
+        constexpr int REP = 64 / (NACC < 64 ? NACC : 64);
+        if ((lane % REP) == 0) s_cols[wid][lane / REP] = acc[0];
+    }
+    if (lane == 0) { s_head[wid][0] = se; s_head[wid][1] = se2; s_head[wid][2] = sec; s_head[wid][3] = 0.f; }
+    __syncthreads();
+    const int colsp = gridDim.y * NACC;
+    for (int cidx = threadIdx.x; cidx < NACC; cidx += BLOCK) {
+        float v = 0.0f;
+#pragma unroll
+        for (int w = 0; w < BLOCK / WAVE; ++w) v += s_cols[w][cidx];
+        partials[(int64_t)blockIdx.x * colsp + blockIdx.y * NACC + cidx] = v;
+    }
+    if (blockIdx.y == 0 && threadIdx.x < 4) {
+        float v = 0.0f;
+#pragma unroll
+        for (int w = 0; w < BLOCK / WAVE; ++w) v += s_head[w][threadIdx.x];
+        heads[(int64_t)blockIdx.x * 4 + threadIdx.x] = v;
+    }
+}
+
+// Sum the per-block partials into one shard summary {min c, sum e, sum e^2, sum e*c, A[row]}.
+__global__ __launch_bounds__(BLOCK) void summarize_kernel(const float* __restrict__ partials,
+                                                          const float* __restrict__ heads,
+                                                          const unsigned* __restrict__ min_key, int nblocks,
+                                                          int colsp, int row, float* __restrict__ summary) {
+    for (int cidx = threadIdx.x; cidx < row + 3; cidx += BLOCK) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        if (cidx < row) {
+            int b = 0;
+            for (; b + 4 <= nblocks; b += 4) {
+                a0 += partials[(int64_t)(b + 0) * colsp + cidx];
+                a1 += partials[(int64_t)(b + 1) * colsp + cidx];
+                a2 += partials[(int64_t)(b + 2) * colsp + cidx];
+                a3 += partials[(int64_t)(b + 3) * colsp + cidx];
+            }
+            for (; b < nblocks; ++b) a0 += partials[(int64_t)b * colsp + cidx];
+            summary[MPPI_SUMMARY_HEAD + cidx] = (a0 + a1) + (a2 + a3);
+        } else {
+            const int h = cidx - row;  // 0..2 -> sum e, sum e^2, sum e*c
+            for (int b = 0; b < nblocks; ++b) a0 += heads[(int64_t)b * 4 + h];
+            summary[1 + h] = a0;
+        }
+    }
+    if (threadIdx.x == 0) summary[0] = key_to_float(*min_key);
+}
+
+// One trajectory rolled out from explicit actions (reference layout row) or from noise, writing the
+// states the reference would leave in its state buffer.  GETU(t, u) fills the action of step t.
+template <int MODEL, bool FAST, class GETU>
+__device__ __forceinline__ bool rollout_states(const float* __restrict__ x0, int T, const ModelCtx& ctx,
+                                               float* __restrict__ out, GETU getu) {
+    using M = Model<MODEL, FAST>;
+    constexpr int DS = M::DS, DC = M::DC;
+    bool bad = false;
+    float s[DS];
+#pragma unroll
+    for (int j = 0; j < DS; ++j) s[j] = x0[j];
+    for (int t = 0; t < T; ++t) {
+        float u[DC], sn[DS], ss[DS];
+        getu(t, u);
+        M::step(ctx, s, u, sn, ss, bad);
+#pragma unroll
+        for (int j = 0; j < DS; ++j) { out[t * DS + j] = ss[j]; s[j] = sn[j]; }
+    }
+#pragma unroll
+    for (int j = 0; j < DS; ++j) out[T * DS + j] = s[j];
+    return bad;
+}
+template <int MODEL, bool FAST, class GETU>
+__device__ __forceinline__ void rollout_states_checked(const float* __restrict__ x0, int T, const ModelCtx& ctx,
+                                                       float* __restrict__ out, GETU getu) {
+    const bool bad = rollout_states<MODEL, FAST>(x0, T, ctx, out, getu);
+    if (FAST) {
+        if (bad) (void)rollout_states<MODEL, false>(x0, T, ctx, out, getu);
+    }
+}
+
+// Combine shard summaries, normalise, store the warm start, roll the result out with batch 1
+// (mppi.py:381-385,448-452,508-524).
+template <int MODEL, bool FAST>
+__global__ __launch_bounds__(BLOCK) void finalize_kernel(const float* __restrict__ summaries, int num_shards,
+                                                         float lambda, int row, int T,
+                                                         const float* __restrict__ x0, float* __restrict__ mean_store,
+                                                         float* __restrict__ action_out,
+                                                         float* __restrict__ state_out, float* __restrict__ stats_out,
+                                                         ModelCtx ctx) {
+    constexpr int DC = Model<MODEL, FAST>::DC;
+    extern __shared__ __attribute__((aligned(16))) float s_act[];  // [row]
+    const int stride = MPPI_SUMMARY_HEAD + row;
+    float xmax = -INFINITY, cmin = INFINITY;
+    for (int g = 0; g < num_shards; ++g) {
+        const float m = summaries[(int64_t)g * stride];
+        xmax = fmaxf(xmax, (-m) / lambda);
+        cmin = fminf(cmin, m);
+    }
+    float se = 0.f, se2 = 0.f, sec = 0.f;
+    for (int g = 0; g < num_shards; ++g) {
+        const float* sm = summaries + (int64_t)g * stride;
+        const float f = expf((-sm[0]) / lambda - xmax);
+        se = fmaf(f, sm[1], se);
+        se2 = fmaf(f * f, sm[2], se2);
+        sec = fmaf(f, sm[3], sec);
+    }
+    for (int cidx = threadIdx.x; cidx < row; cidx += BLOCK) {
+        float a = 0.f;
+        for (int g = 0; g < num_shards; ++g) {
+            const float* sm = summaries + (int64_t)g * stride;
+            const float f = expf((-sm[0]) / lambda - xmax);
+            a = fmaf(f, sm[MPPI_SUMMARY_HEAD + cidx], a);
+        }
+        a = a / se;
+        s_act[cidx] = a;
+        if (action_out) action_out[cidx] = a;
+        if (mean_store) mean_store[cidx] = a;
+    }
+    if (threadIdx.x == 0 && stats_out) {
+        stats_out[0] = cmin; stats_out[1] = se; stats_out[2] = se2; stats_out[3] = sec;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && state_out) {
+        rollout_states_checked<MODEL, FAST>(x0, T, ctx, state_out, [&](int t, float* u) {
+#pragma unroll
+            for (int k = 0; k < DC; ++k) u[k] = s_act[t * DC + k];
+        });
+    }
+}
+
+// `_weights` (mppi.py:376) given the global min cost and sum e.
+__global__ __launch_bounds__(BLOCK) void weights_kernel(const float* __restrict__ costs, int64_t N, float lambda,
+                                                        float cmin, float sum_e, float* __restrict__ w) {
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < N) w[i] = expf((-costs[i]) / lambda - (-cmin) / lambda) / sum_e;
+}
+
+// `_states_prediction` (mppi.py:508-524) for k action sequences in the reference layout.
+template <int MODEL, bool FAST>
+__global__ __launch_bounds__(WAVE) void rollout_actions_kernel(const float* __restrict__ actions, int k, int T,
+                                                               const float* __restrict__ x0,
+                                                               float* __restrict__ states, ModelCtx ctx) {
+    constexpr int DS = Model<MODEL, FAST>::DS, DC = Model<MODEL, FAST>::DC;
+    const int q = blockIdx.x * WAVE + threadIdx.x;
+    if (q >= k) return;
+    const float* a = actions + (int64_t)q * T * DC;
+    float* out = states + (int64_t)q * (T + 1) * DS;
+    rollout_states_checked<MODEL, FAST>(x0, T, ctx, out, [&](int t, float* u) {
+#pragma unroll
+        for (int kk = 0; kk < DC; ++kk) u[kk] = a[t * DC + kk];
+    });
+}
+
+// `_state_seq_batch[idx]` (mppi.py:481) re-rolled from the resident noise.
+template <int MODEL, bool FAST>
+__global__ __launch_bounds__(WAVE) void rollout_samples_kernel(const float4* __restrict__ noise,
+                                                               const float* __restrict__ mean,
+                                                               const int64_t* __restrict__ idx, int k,
+                                                               const float* __restrict__ x0,
+                                                               float* __restrict__ states, Dims d, ModelCtx ctx) {
+    constexpr int DS = Model<MODEL, FAST>::DS, DC = Model<MODEL, FAST>::DC;
+    const int q = blockIdx.x * WAVE + threadIdx.x;
+    if (q >= k) return;
+    const int64_t i = idx[q];
+    const bool inherit = (d.sample_offset + i) < d.inherit_count;
+    const float* np = reinterpret_cast<const float*>(noise + (i >> 6) * d.R * 64 + (i & 63));
+    float* out = states + (int64_t)q * (d.T + 1) * DS;
+    rollout_states_checked<MODEL, FAST>(x0, d.T, ctx, out, [&](int t, float* u) {
+#pragma unroll
+        for (int kk = 0; kk < DC; ++kk) {
+            const int f = t * DC + kk;
+            const float e = np[(int64_t)(f >> 2) * 256 + (f & 3)];
+            const float m = inherit ? mean[f] : 0.0f;
+            u[kk] = clampf(m + e, d.u_min[kk], d.u_max[kk]);
+        }
+    });
+}
+
+// ------------------------------------------------------------------------------------------
+// Layout conversions between the reference layout [N][T][dc] and the lane-major tiles, staged
+// through LDS so that both the global reads and the global writes are coalesced.
+// One block per (tile, 128-float column chunk); LDS row stride 129 floats (bank-conflict free).
+constexpr int CONV_COLS = 128;
+__global__ __launch_bounds__(BLOCK) void inject_kernel(const float* __restrict__ eps, float4* __restrict__ noise,
+                                                       Dims d) {
+    __shared__ float tilebuf[64][CONV_COLS + 1];
+    const int64_t tile = blockIdx.x;
+    const int c0 = blockIdx.y * CONV_COLS;
+    const int nc = min(CONV_COLS, d.row - c0);
+    for (int idx = threadIdx.x; idx < 64 * CONV_COLS; idx += BLOCK) {
+        const int l = idx / CONV_COLS, cc = idx % CONV_COLS;
+        const int64_t i = tile * 64 + l;
+        float v = 0.0f;
+        if (i < d.N && cc < nc) v = eps[i * d.row + c0 + cc];
+        tilebuf[l][cc] = v;
+    }
+    __syncthreads();
+    const int ngroups = (nc + 3) / 4;
+    for (int idx = threadIdx.x; idx < 64 * ngroups; idx += BLOCK) {
+        const int g = idx / 64, l = idx % 64;
+        const float4 v = make_float4(tilebuf[l][4 * g], tilebuf[l][4 * g + 1], tilebuf[l][4 * g + 2],
+                                     tilebuf[l][4 * g + 3]);
+        noise[(tile * d.R + (c0 / 4) + g) * 64 + l] = v;
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void export_kernel(const float4* __restrict__ noise,
+                                                       const float* __restrict__ mean, float* __restrict__ eps_out,
+                                                       float* __restrict__ act_out, Dims d) {
+    __shared__ float tilebuf[64][CONV_COLS + 1];
+    const int64_t tile = blockIdx.x;
+    const int c0 = blockIdx.y * CONV_COLS;
+    const int nc = min(CONV_COLS, d.row - c0);
+    const int ngroups = (nc + 3) / 4;
+    const int dc = d.row / d.T;
+    for (int idx = threadIdx.x; idx < 64 * ngroups; idx += BLOCK) {
+        const int g = idx / 64, l = idx % 64;
+        const float4 v = noise[(tile * d.R + (c0 / 4) + g) * 64 + l];
+        tilebuf[l][4 * g] = v.x; tilebuf[l][4 * g + 1] = v.y; tilebuf[l][4 * g + 2] = v.z; tilebuf[l][4 * g + 3] = v.w;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 64 * CONV_COLS; idx += BLOCK) {
+        const int l = idx / CONV_COLS, cc = idx % CONV_COLS;
+        const int64_t i = tile * 64 + l;
+        if (i < d.N && cc < nc) {
+            const float e = tilebuf[l][cc];
+            const int f = c0 + cc;
+            if (eps_out) eps_out[i * d.row + f] = e;
+            if (act_out) {
+                const bool inherit = (d.sample_offset + i) < d.inherit_count;
+                const int k = (dc == 1) ? 0 : (f & 1);
+                const float m = inherit ? mean[f] : 0.0f;
+                act_out[i * d.row + f] = clampf(m + e, d.u_min[k], d.u_max[k]);
+            }
+        }
+    }
+}
+
+}  // namespace mppi

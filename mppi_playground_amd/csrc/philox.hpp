@@ -1,0 +1,42 @@
+// philox.hpp — counter-based device RNG of the sampler (step 1 of MPPI.forward, mppi.py:261-263).
+//
+// Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11).
+// key     = (seed_lo, seed_hi)
+// counter = (global sample index lo, hi, float4 group r of the [T*dc] row, solve index)
+// The four 32-bit outputs become four normals through two Box-Muller pairs, so one call fills one
+// float4 of the lane-major noise tile and the value of eps[i][t][k] depends only on (seed, solve,
+// global i, t, k) — not on how num_samples is sharded across GPUs.
+#pragma once
+#include <stdint.h>
+
+namespace mppi {
+
+struct u32x4 {
+    uint32_t x, y, z, w;
+};
+
+__device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                               uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return {c0, c1, c2, c3};
+}
+
+// Box-Muller on (a, b): u1 = ((a>>8)+1) * 2^-24 in (0,1], u2 = (b>>8) * 2^-24 in [0,1).
+// Hardware transcendentals: v_log_f32 (log2), v_sqrt_f32, v_sin_f32 / v_cos_f32 (argument in
+// revolutions, so 2*pi*u2 needs no multiply).
+__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& z0, float& z1) {
+    const float u1 = (float)((a >> 8) + 1u) * (1.0f / 16777216.0f);
+    const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);
+    const float rad = __builtin_amdgcn_sqrtf(-1.38629436112f * __builtin_amdgcn_logf(u1));  // -2 ln2 log2(u1)
+    z0 = rad * __builtin_amdgcn_cosf(u2);
+    z1 = rad * __builtin_amdgcn_sinf(u2);
+}
+
+}  // namespace mppi

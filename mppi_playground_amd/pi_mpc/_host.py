@@ -1,0 +1,119 @@
+"""Host-side pieces of MPPI.forward() that the north star keeps on the CPU: automatic temperature
+tuning (ESSPS / LBPS / MPO) and Savitzky-Golay smoothing.  numpy/scipy only, fp32 where the reference
+computes in fp32.  Citations are relative to the reference repo.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+from scipy.optimize import brentq, minimize_scalar
+
+F32 = np.float32
+
+
+def softmax_weights(costs: np.ndarray, lam: float) -> np.ndarray:
+    """torch.softmax(-costs / lambda_, dim=0) in fp32 (src/pi_mpc/mppi.py:355,376,543,564)."""
+    x = (-costs) / F32(lam)
+    e = np.exp(x - x.max())
+    return e / e.sum(dtype=F32)
+
+
+def compute_ess(weights: np.ndarray) -> float:
+    """ESS = 1 / sum(w^2) (src/pi_mpc/mppi.py:526-532)."""
+    return 1.0 / float(np.sum(weights * weights, dtype=F32))
+
+
+def essps_lambda(costs: np.ndarray, target_ess: float, lam_min: float, lam_max: float) -> float:
+    """Effective-sample-size policy search (src/pi_mpc/mppi.py:351-370,559-566)."""
+    ess_at_min = compute_ess(softmax_weights(costs, lam_min))
+    ess_at_max = compute_ess(softmax_weights(costs, lam_max))
+    if target_ess <= ess_at_min:
+        return lam_min
+    if target_ess >= ess_at_max:
+        return lam_max
+    return brentq(lambda lam: compute_ess(softmax_weights(costs, lam)) - target_ess, lam_min, lam_max)
+
+
+def lbps_objective(lam: float, costs: np.ndarray, delta: float) -> float:
+    """Negative lower bound of the expected return (src/pi_mpc/mppi.py:534-557)."""
+    w = softmax_weights(costs, lam)
+    ess = compute_ess(w)
+    expected_return = -float(np.sum(w * costs, dtype=F32))
+    cost_range = float(costs.max() - costs.min())
+    penalty = cost_range * math.sqrt((1 - delta) / delta) / math.sqrt(ess)
+    return -(expected_return - penalty)
+
+
+def lbps_lambda(costs: np.ndarray, delta: float, lam_min: float, lam_max: float) -> float:
+    """Lower-bound policy search (src/pi_mpc/mppi.py:341-349)."""
+    res = minimize_scalar(lambda lam: lbps_objective(lam, costs, delta), bounds=(lam_min, lam_max),
+                          method="bounded")
+    return float(res.x)
+
+
+class MpoTemperature:
+    """MPO E-step dual on the temperature (src/pi_mpc/mppi.py:191-200,387-398): one Adam(lr=0.2) step
+    per solve on loss = softplus(logT) * (eps + logsumexp(-c / softplus(logT))), then
+    lambda = exp(logT).  The gradient is written out instead of using autograd:
+      dL/dT = eps + LSE + (sum_i w_i c_i) / T,   dT/dlogT = sigmoid(logT).
+    """
+
+    def __init__(self, lam0: float = 1.0, epsilon: float = 0.1, lr: float = 0.2):
+        self.log_temperature = F32(math.log(lam0))
+        self.epsilon = epsilon
+        self.lr, self.b1, self.b2, self.eps = lr, 0.9, 0.999, 1e-8
+        self.m = F32(0.0)
+        self.v = F32(0.0)
+        self.t = 0
+
+    def step(self, costs: np.ndarray) -> float:
+        lt = float(self.log_temperature)
+        T = math.log1p(math.exp(lt))  # softplus
+        x = (-costs.astype(np.float64)) / T
+        mx = x.max()
+        e = np.exp(x - mx)
+        se = e.sum()
+        lse = mx + math.log(se)
+        wc = float((e * costs).sum() / se)
+        dL_dT = self.epsilon + lse + wc / T
+        g = F32(dL_dT * (1.0 / (1.0 + math.exp(-lt))))
+        self.t += 1
+        self.m = F32(self.b1 * self.m + (1 - self.b1) * g)
+        self.v = F32(self.b2 * self.v + (1 - self.b2) * g * g)
+        bc1 = 1 - self.b1 ** self.t
+        bc2 = 1 - self.b2 ** self.t
+        denom = math.sqrt(float(self.v)) / math.sqrt(bc2) + self.eps
+        self.log_temperature = F32(lt - (self.lr / bc1) * float(self.m) / denom)
+        return float(np.exp(self.log_temperature))
+
+
+def savitzky_golay_coeffs(window_size: int, poly_order: int) -> np.ndarray:
+    """First row of pinv(vander(-h..h)) (src/pi_mpc/mppi.py:568-596)."""
+    if window_size % 2 == 0 or window_size <= poly_order:
+        raise ValueError("window_size must be odd and greater than poly_order.")
+    half = (window_size - 1) // 2
+    idx = np.arange(-half, half + 1, dtype=np.float64)
+    A = np.vander(idx, N=poly_order + 1, increasing=True)
+    return np.linalg.pinv(A)[0].astype(F32)
+
+
+def apply_savitzky_golay(y: np.ndarray, coeffs: np.ndarray) -> np.ndarray:
+    """Symmetric-flip padding + valid cross-correlation (src/pi_mpc/mppi.py:598-620)."""
+    pad = len(coeffs) // 2
+    yp = np.concatenate([y[:pad][::-1], y, y[-pad:][::-1]]).astype(F32)
+    n = len(y)
+    out = np.zeros(n, F32)
+    for j, cj in enumerate(coeffs):
+        out += yp[j:j + n] * cj
+    return out
+
+
+def sg_filter_sequence(history: np.ndarray, action_seq: np.ndarray, coeffs: np.ndarray) -> np.ndarray:
+    """Step 7 of forward() (src/pi_mpc/mppi.py:423-443): filter [history(T-1); a(T)], keep the last T."""
+    T = action_seq.shape[0]
+    prolonged = np.concatenate([history, action_seq], axis=0).astype(F32)
+    out = np.zeros_like(prolonged)
+    for i in range(prolonged.shape[1]):
+        out[:, i] = apply_savitzky_golay(prolonged[:, i], coeffs)
+    return out[-T:]

@@ -1,0 +1,433 @@
+"""pi_mpc.mppi.MPPI — host-side mirror of the reference solver (src/pi_mpc/mppi.py) whose
+forward() hot path runs as hand-written HIP on MI355X through the C ABI in include/mppi_hip.h.
+
+Same constructor, `forward(state, info={}) -> (action_seq[T,dc], state_seq[1,T+1,ds])`, `reset()`,
+`get_top_samples(k)`, `get_samples_from_posterior(...)` and error behaviour as the reference; the
+`dynamics` / `cost_func` callables are the plugin surface (pi_mpc/native.py explains how the shipped
+models are recognised without changing the call site).
+
+Device work per solve (native models): sample -> rollout+cost -> weights+reduce -> finalize, four
+kernel launches on torch's current stream with no host synchronisation when lambda is fixed and the
+Savitzky-Golay filter is off.  Auto-lambda (ESSPS/LBPS/MPO) and the SG filter stay on the host as in
+the reference.  There is NO CPU fallback: without the built extension or without a GPU the
+constructor raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, Dict, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from mppi_playground_amd import _capi
+from pi_mpc import _host
+from pi_mpc.native import resolve
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class MPPI(nn.Module):
+    """Model Predictive Path Integral control (Williams et al., T-RO 2017) — MI355X-native."""
+
+    def __init__(
+        self,
+        horizon: int,
+        num_samples: int,
+        dim_state: int,
+        dim_control: int,
+        dynamics: Callable[[torch.Tensor, torch.Tensor], torch.Tensor],
+        cost_func: Callable[[torch.Tensor, torch.Tensor, Dict], torch.Tensor],
+        u_min: torch.Tensor,
+        u_max: torch.Tensor,
+        sigmas: torch.Tensor,
+        lambda_: float | str,
+        lbps_delta: float = 0.01,
+        essps_target_ess: Optional[float] = None,
+        lambda_min: float = 0.01,
+        lambda_max: float = 10.0,
+        exploration: float = 0.0,
+        use_sg_filter: bool = False,
+        sg_window_size: int = 5,
+        sg_poly_order: int = 3,
+        device=torch.device("cuda"),
+        dtype=torch.float32,
+        seed: int = 42,
+        *,
+        noise_source: str = "philox",
+        shard_samples: bool = False,
+        process_group=None,
+    ) -> None:
+        """Arguments up to `seed` are the reference's (src/pi_mpc/mppi.py:24-47).
+
+        Extensions (keyword-only):
+            noise_source: "philox" (device Philox4x32-10 stream, default) or "torch_cpu" (draw with
+                torch's CPU generator exactly like the reference does on CPU — same seed, same
+                numbers — and upload; for parity runs).
+            shard_samples: treat `num_samples` as the GLOBAL sample count and let this rank own the
+                contiguous block rank*N/W .. (rank+1)*N/W of it (torch.distributed must be
+                initialised); one all_gather of 4+T*dc floats per solve combines the shards.
+        """
+        super().__init__()
+        assert u_min.shape == (dim_control,)
+        assert u_max.shape == (dim_control,)
+        assert sigmas.shape == (dim_control,)
+        if dtype != torch.float32:
+            raise ValueError("the HIP path computes in float32 (the reference default dtype)")
+        if not torch.cuda.is_available():
+            raise _capi.MppiError("no GPU visible: this MPPI runs its hot path on MI355X only "
+                                  "(no CPU fallback)")
+        _capi.load()  # fail loudly if the extension is missing
+        self._device = torch.device("cuda", torch.cuda.current_device())
+        self._dtype = dtype
+
+        self._horizon = horizon
+        self._num_samples = num_samples
+        self._dim_state = dim_state
+        self._dim_control = dim_control
+        self._dynamics = dynamics
+        self._cost_func = cost_func
+        self._u_min = u_min.clone().detach().to(self._device, self._dtype)
+        self._u_max = u_max.clone().detach().to(self._device, self._dtype)
+        self._sigmas = sigmas.clone().detach().to(self._device, self._dtype)
+        self._exploration = exploration
+        self._use_sg_filter = use_sg_filter
+        self._sg_window_size = sg_window_size
+        self._sg_poly_order = sg_poly_order
+        self._seed = int(seed)
+        if noise_source not in ("philox", "torch_cpu"):
+            raise ValueError("noise_source must be 'philox' or 'torch_cpu'")
+        self._noise_source = noise_source
+
+        # ---- sharding of num_samples
+        self._pg = process_group
+        self._world, self._rank = 1, 0
+        if shard_samples:
+            import torch.distributed as dist
+
+            if not dist.is_initialized():
+                raise RuntimeError("shard_samples=True needs torch.distributed to be initialised")
+            self._world = dist.get_world_size(process_group)
+            self._rank = dist.get_rank(process_group)
+            if num_samples % self._world != 0:
+                raise ValueError("num_samples must be divisible by the world size")
+        self._local_samples = num_samples // self._world
+        self._sample_offset = self._rank * self._local_samples
+
+        # ---- plugin recognition
+        dyn, cst = resolve(dynamics), resolve(cost_func)
+        if not (dyn and cst and dyn[0].model == cst[0].model and dyn[0].role == "dynamics"
+                and cst[0].role == "cost"):
+            raise NotImplementedError(
+                "dynamics/cost_func are not a recognised native model pair; the generic-callable path "
+                "(native sampling/softmax/reduction around user torch callables) is not available in "
+                "this build")
+        self._model = dyn[0].model
+        self._cost_tag, self._cost_owner = cst
+        self._dyn_tag, self._dyn_owner = dyn
+        ds, dc = _capi.MODEL_DIMS[self._model]
+        if (ds, dc) != (dim_state, dim_control):
+            raise AssertionError(f"model {self._model} has dim_state={ds}, dim_control={dc}")
+
+        # ---- auto lambda (src/pi_mpc/mppi.py:183-210)
+        self._lambda: float | str = lambda_
+        self._lbps_delta = lbps_delta
+        self._essps_target_ess = essps_target_ess if essps_target_ess is not None else num_samples / 10
+        self._lambda_min = lambda_min
+        self._lambda_max = lambda_max
+        if self._lambda == "MPO":
+            self._auto_lambda = "MPO"
+            self._lambda = 1.0
+            self._mpo = _host.MpoTemperature(1.0, 0.1, 0.2)
+        elif self._lambda == "LBPS":
+            self._auto_lambda = "LBPS"
+        elif self._lambda == "ESSPS":
+            self._auto_lambda = "ESSPS"
+        elif isinstance(self._lambda, float):
+            self._auto_lambda = None
+        else:
+            raise ValueError("lambda_ must be 'MPO', 'LBPS', 'ESSPS', or a float value.")
+
+        # ---- Savitzky-Golay (src/pi_mpc/mppi.py:160-165); raises ValueError like the reference
+        self._coeffs = _host.savitzky_golay_coeffs(sg_window_size, sg_poly_order)
+        self._actions_history_for_sg = np.zeros((horizon - 1, dim_control), np.float32)
+
+        # ---- device handle
+        cfg = _capi.MppiConfig()
+        cfg.model = _capi.MODEL_IDS[self._model]
+        cfg.horizon, cfg.dim_state, cfg.dim_control = horizon, dim_state, dim_control
+        cfg.num_samples = self._local_samples
+        cfg.sample_offset = self._sample_offset
+        cfg.inherit_count = int(num_samples * (1 - exploration))  # src/pi_mpc/mppi.py:266
+        for k in range(dim_control):
+            cfg.u_min[k] = float(u_min[k])
+            cfg.u_max[k] = float(u_max[k])
+            cfg.sigmas[k] = float(sigmas[k])
+        cfg.seed = self._seed
+        cfg.device = self._device.index
+        self._h = _capi.Handle(cfg)
+        self._uploaded = {}  # slot -> (id(cells), version)
+        self._params_set = None
+
+        # ---- RNG stream bookkeeping (src/pi_mpc/mppi.py:93,146-148; SURVEY B-Q1/Q2)
+        self._solve_idx = 0
+        self._cpu_gen = None
+        if noise_source == "torch_cpu":
+            self._cpu_gen = torch.Generator(device="cpu")
+            self._cpu_gen.manual_seed(self._seed)
+            self._draw_torch_cpu()  # the constructor consumes one [N,T,dc] draw
+        self._solve_idx = 1          # Philox: solve index 0 is the constructor's draw
+
+        # ---- outputs / lazily materialised attributes
+        T, dcn = horizon, dim_control
+        self._action_out = torch.zeros(T, dcn, device=self._device, dtype=dtype)
+        self._state_out = torch.zeros(1, T + 1, dim_state, device=self._device, dtype=dtype)
+        self._stats = torch.zeros(4, device=self._device, dtype=dtype)
+        self._summary = torch.zeros(_capi.SUMMARY_HEAD + T * dcn, device=self._device, dtype=dtype)
+        self._gathered = None
+        self._previous_action_seq = torch.zeros(T, dcn, device=self._device, dtype=dtype)
+        self._last_lambda = None
+        self._injected = None
+        self._mean_of_last_solve = self._previous_action_seq
+
+    # ------------------------------------------------------------------ helpers
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self._device).cuda_stream)
+
+    def _draw_torch_cpu(self) -> torch.Tensor:
+        """`MultivariateNormal(0, diag(sigma^2)).rsample([N])` on torch's CPU generator: bit-identical
+        to randn(N,T,dc) * sigma (SURVEY B-Q1).  Always draws the GLOBAL [N,T,dc] block so that every
+        shard sees the same stream."""
+        eps = torch.randn(self._num_samples, self._horizon, self._dim_control, generator=self._cpu_gen,
+                          dtype=torch.float32)
+        return eps * self._sigmas.cpu()
+
+    def _refresh_model_inputs(self):
+        prov = self._cost_tag.provider
+        if prov is None:
+            return
+        spec = prov(self._cost_owner)
+        params = spec.get("params")
+        if params is not None:
+            p = tuple(float(x) for x in params)
+            if p != self._params_set:
+                arr = (C.c_float * len(p))(*p)
+                self._h.call("mppi_set_model_params", arr, len(p))
+                self._params_set = p
+        for slot, grid in enumerate(spec.get("maps", ())):
+            key = (id(grid.cells), grid.version)
+            if self._uploaded.get(slot) != key:
+                cells = np.ascontiguousarray(grid.cells, dtype=np.uint8)
+                self._h.call("mppi_upload_map", slot, cells.ctypes.data_as(C.c_void_p), cells.shape[0],
+                             cells.shape[1], float(grid.cell_size), float(grid.origin[0]), float(grid.origin[1]))
+                self._uploaded[slot] = key
+        ref = spec.get("ref_path")
+        if ref is not None:
+            r = np.ascontiguousarray(ref, dtype=np.float32)
+            self._h.call("mppi_set_reference", r.ctypes.data_as(C.c_void_p), r.shape[0], self._stream())
+
+    def inject_noise(self, eps: torch.Tensor) -> None:
+        """Parity hook: use `eps` [N_local,T,dc] (already scaled by sigma) for the next solve instead of
+        drawing it."""
+        assert eps.shape == (self._local_samples, self._horizon, self._dim_control)
+        self._injected = eps.to(self._device, torch.float32).contiguous()
+
+    def set_warm_start(self, mean, sg_history=None) -> None:
+        """Overwrite `_previous_action_seq` (and optionally the SG history) — parity/test hook."""
+        m = torch.as_tensor(np.asarray(mean, np.float32)).to(self._device).contiguous()
+        assert m.shape == (self._horizon, self._dim_control)
+        self._previous_action_seq = m
+        self._h.call("mppi_set_mean", _ptr(m), 1, self._stream())
+        torch.cuda.current_stream(self._device).synchronize()
+        if sg_history is not None:
+            self._actions_history_for_sg = np.asarray(sg_history, np.float32).copy()
+
+    def stage_times_ms(self) -> Dict[str, float]:
+        """Mean device time per stage since the last call (needs set_option('timing', 1))."""
+        out = (C.c_float * 8)()
+        self._h.call("mppi_get_timing", out)
+        names = ("sample", "rollout_cost", "weights_reduce", "finalize")
+        return {n: float(out[i]) for i, n in enumerate(names)} | {"calls": float(out[4 + 1])}
+
+    def set_option(self, key: str, value: int) -> None:
+        self._h.call("mppi_set_option", key.encode(), int(value))
+
+    def reset(self):
+        """Reset the previous action sequence (src/pi_mpc/mppi.py:212-221)."""
+        self._previous_action_seq = torch.zeros(self._horizon, self._dim_control, device=self._device,
+                                                dtype=self._dtype)
+        self._h.call("mppi_set_mean", _ptr(self._previous_action_seq), 1, self._stream())
+        self._actions_history_for_sg = np.zeros((self._horizon - 1, self._dim_control), np.float32)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, state: torch.Tensor, info: Dict = {}) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Solve one MPPI step (src/pi_mpc/mppi.py:223-460)."""
+        assert state.shape == (self._dim_state,)
+        h, st = self._h, self._stream()
+        if torch.is_tensor(state) and state.is_cuda:
+            x0 = state.to(self._device, self._dtype).contiguous()
+            h.call("mppi_set_state", _ptr(x0), 1, st)
+        else:
+            x0h = np.ascontiguousarray(state.detach().cpu().numpy() if torch.is_tensor(state) else state,
+                                       dtype=np.float32)
+            h.call("mppi_set_state", x0h.ctypes.data_as(C.c_void_p), 0, st)
+            x0 = None
+        self._refresh_model_inputs()
+        self._mean_of_last_solve = self._previous_action_seq  # the mean this solve samples around
+
+        # Step 1: noise (src/pi_mpc/mppi.py:261-263)
+        if self._injected is not None:
+            h.call("mppi_inject_noise", _ptr(self._injected), st)
+            self._injected = None
+        elif self._noise_source == "torch_cpu":
+            eps = self._draw_torch_cpu()
+            lo = self._sample_offset
+            eps = eps[lo:lo + self._local_samples].to(self._device).contiguous()
+            h.call("mppi_inject_noise", _ptr(eps), st)
+        else:
+            h.call("mppi_sample", self._solve_idx, st)
+        self._solve_idx += 1
+
+        # Steps 1b-3: clamp, rollout, costs (src/pi_mpc/mppi.py:266-336)
+        h.call("mppi_rollout_cost", st)
+
+        # Step 4: temperature (host; src/pi_mpc/mppi.py:341-370)
+        costs_host = None
+        if self._auto_lambda is not None:
+            costs_host = self._gather_costs_host()
+            if self._auto_lambda == "LBPS":
+                self._lambda = _host.lbps_lambda(costs_host, self._lbps_delta, self._lambda_min, self._lambda_max)
+            elif self._auto_lambda == "ESSPS":
+                self._lambda = _host.essps_lambda(costs_host, self._essps_target_ess, self._lambda_min,
+                                                  self._lambda_max)
+        lam = float(self._lambda)
+        self._last_lambda = lam
+
+        # Steps 5-6: weights + weighted mean (src/pi_mpc/mppi.py:376-385)
+        sharded = self._world > 1
+        h.call("mppi_weights_reduce", lam, _ptr(self._summary) if sharded else None, st)
+        summaries, nsh = None, 1
+        if sharded:
+            import torch.distributed as dist
+
+            if self._gathered is None:
+                self._gathered = torch.empty(self._world, self._summary.numel(), device=self._device,
+                                             dtype=self._dtype)
+            dist.all_gather_into_tensor(self._gathered, self._summary, group=self._pg)
+            summaries, nsh = self._gathered, self._world
+
+        # Steps 6-8: normalise, warm start, batch-1 rollout (src/pi_mpc/mppi.py:381-385,448-452)
+        use_sg = self._use_sg_filter
+        h.call("mppi_finalize", _ptr(summaries), nsh, lam, 0 if use_sg else 1, _ptr(self._action_out),
+               None if use_sg else _ptr(self._state_out), _ptr(self._stats), st)
+
+        if self._auto_lambda == "MPO":  # after the weights, affects the next solve (mppi.py:387-398)
+            self._lambda = self._mpo.step(costs_host)
+
+        if use_sg:  # Step 7 on the host (src/pi_mpc/mppi.py:423-443)
+            a = self._action_out.cpu().numpy()
+            a = _host.sg_filter_sequence(self._actions_history_for_sg, a, self._coeffs)
+            self._action_out.copy_(torch.from_numpy(a))
+            h.call("mppi_set_mean", _ptr(self._action_out), 1, st)
+            h.call("mppi_rollout_actions", _ptr(self._action_out), 1, _ptr(self._state_out), st)
+            first = a[0]
+            self._actions_history_for_sg = np.concatenate([self._actions_history_for_sg[1:], first[None, :]])
+        optimal_action_seq = self._action_out.clone()
+        optimal_state_seq = self._state_out.clone()
+        self._previous_action_seq = optimal_action_seq
+        return optimal_action_seq, optimal_state_seq
+
+    def _gather_costs_host(self) -> np.ndarray:
+        """costs[N] on the host for the temperature search (all shards when sharded)."""
+        c = np.empty(self._local_samples, np.float32)
+        self._h.call("mppi_get_costs", c.ctypes.data_as(C.c_void_p), 0, self._stream())
+        if self._world > 1:
+            import torch.distributed as dist
+
+            t = torch.from_numpy(c).to(self._device)
+            out = torch.empty(self._num_samples, device=self._device, dtype=torch.float32)
+            dist.all_gather_into_tensor(out, t, group=self._pg)
+            c = out.cpu().numpy()
+        return c
+
+    # ------------------------------------------------------------------ lazily materialised state
+    @property
+    def _costs(self) -> torch.Tensor:
+        c = torch.empty(self._local_samples, device=self._device, dtype=self._dtype)
+        self._h.call("mppi_get_costs", _ptr(c), 1, self._stream())
+        return c
+
+    @property
+    def _weights(self) -> torch.Tensor:
+        """softmax(-costs/lambda) of the last solve (src/pi_mpc/mppi.py:376), this shard's slice."""
+        w = torch.empty(self._local_samples, device=self._device, dtype=self._dtype)
+        stats = self._stats.cpu().numpy()
+        self._h.call("mppi_weights", float(self._last_lambda), float(stats[0]), float(stats[1]), _ptr(w),
+                     self._stream())
+        return w
+
+    @property
+    def _action_noises(self) -> torch.Tensor:
+        e = torch.empty(self._local_samples, self._horizon, self._dim_control, device=self._device,
+                        dtype=self._dtype)
+        self._h.call("mppi_export_noise", _ptr(e), None, self._stream())
+        return e
+
+    def _perturbed_actions_for(self, mean: torch.Tensor) -> torch.Tensor:
+        """clamp(mean + eps) for the resident noise with an explicit mean (the mean of the LAST solve
+        has been overwritten by the warm start when store_mean was on)."""
+        u = torch.empty(self._local_samples, self._horizon, self._dim_control, device=self._device,
+                        dtype=self._dtype)
+        cur = torch.empty(self._horizon, self._dim_control, device=self._device, dtype=self._dtype)
+        st = self._stream()
+        self._h.call("mppi_get_mean", _ptr(cur), 1, st)
+        self._h.call("mppi_set_mean", _ptr(mean.contiguous()), 1, st)
+        self._h.call("mppi_export_noise", None, _ptr(u), st)
+        self._h.call("mppi_set_mean", _ptr(cur), 1, st)
+        return u
+
+    # ------------------------------------------------------------------ queries
+    def get_top_samples(self, num_samples: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Top-weighted trajectories of the last solve (src/pi_mpc/mppi.py:462-487).  The N state
+        trajectories are not kept in HBM; the k winners are re-rolled from the resident noise."""
+        assert num_samples <= self._num_samples
+        if self._world > 1:
+            raise NotImplementedError("get_top_samples on a sharded solver")
+        w = self._weights
+        top = torch.topk(w, num_samples)
+        idx = top.indices.to(torch.int64).contiguous()
+        out = torch.empty(num_samples, self._horizon + 1, self._dim_state, device=self._device, dtype=self._dtype)
+        st = self._stream()
+        # the rollouts must use the mean the solve sampled around, not the freshly stored warm start
+        cur = torch.empty(self._horizon, self._dim_control, device=self._device, dtype=self._dtype)
+        self._h.call("mppi_get_mean", _ptr(cur), 1, st)
+        self._h.call("mppi_set_mean", _ptr(self._mean_of_last_solve), 1, st)
+        self._h.call("mppi_rollout_samples", _ptr(idx), num_samples, _ptr(out), st)
+        self._h.call("mppi_set_mean", _ptr(cur), 1, st)
+        order = torch.argsort(top.values, descending=True)
+        return out[order], top.values[order]
+
+    def get_samples_from_posterior(self, optimal_solution: torch.Tensor, state: torch.Tensor,
+                                   num_samples: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        """N(optimal_solution, Sigma) samples and their rollouts (src/pi_mpc/mppi.py:489-506)."""
+        assert num_samples <= self._num_samples
+        g = torch.Generator(device="cpu")
+        g.manual_seed(self._seed + 7919 * self._solve_idx)
+        eps = torch.randn(num_samples, self._horizon, self._dim_control, generator=g) * self._sigmas.cpu()
+        samples = (optimal_solution.to(self._device) + eps.to(self._device)).contiguous()
+        st = self._stream()
+        x0 = torch.as_tensor(state, dtype=torch.float32).to(self._device).contiguous()
+        self._h.call("mppi_set_state", _ptr(x0), 1, st)
+        out = torch.empty(num_samples, self._horizon + 1, self._dim_state, device=self._device, dtype=self._dtype)
+        self._h.call("mppi_rollout_actions", _ptr(samples), num_samples, _ptr(out), st)
+        return samples, out
+
+    # ------------------------------------------------------------------ diagnostics
+    def last_stats(self) -> Dict[str, float]:
+        """{min cost, sum e, sum e^2, sum e*c, ess, lambda} of the last solve (synchronises)."""
+        s = self._stats.cpu().numpy().astype(np.float64)
+        return dict(cmin=s[0], sum_e=s[1], sum_e2=s[2], sum_ec=s[3], ess=s[1] * s[1] / s[2],
+                    lambda_=self._last_lambda)

@@ -150,6 +150,10 @@ class Problem:
         return out
 
 
+def num_threads() -> int:
+    return int(lib().oracle_num_threads())
+
+
 def softmax_weights(costs, lam):
     """mppi.py:376; returns (w[N] f32, stats dict)."""
     costs = _f32(costs)

@@ -1,0 +1,122 @@
+// Host build of the product's model functors (mppi_playground_amd/csrc/mppi_models.hpp) for
+// pre-GPU debugging of the model math, both FAST variants.  TEST-ONLY: the product never loads this
+// library; it exists so that tests can compare the device functors' arithmetic with the oracle on
+// a machine without a GPU.  The trajectory walk mirrors trajectory_cost() in mppi_kernels.hpp but
+// reads the reference layout eps[N][T][dc].
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../mppi_playground_amd/csrc/mppi_models.hpp"
+
+using namespace mppi;
+
+template <int MODEL, bool FAST>
+static float walk(const float* eps_row, const float* mean, const float* x0, int T, const float* umin,
+                  const float* umax, const ModelCtx& ctx, bool inherit, bool& bad, float* S_out) {
+    using M = Model<MODEL, FAST>;
+    constexpr int DS = M::DS, DC = M::DC;
+    float s[DS], pu[DC], pl[DC];
+    for (int j = 0; j < DS; ++j) s[j] = x0[j];
+    for (int k = 0; k < DC; ++k) pu[k] = pl[k] = 0.f;
+    float acc = 0.f;
+    for (int t = 0; t < T; ++t) {
+        float u[DC], sn[DS], ss[DS];
+        for (int k = 0; k < DC; ++k) {
+            const float m = inherit ? mean[t * DC + k] : 0.0f;
+            u[k] = clampf(m + eps_row[t * DC + k], umin[k], umax[k]);
+        }
+        if (t == 0) for (int k = 0; k < DC; ++k) pu[k] = u[k];
+        M::step(ctx, s, u, sn, ss, bad);
+        acc += M::cost(ctx, ss, u, pu, t, bad);
+        for (int k = 0; k < DC; ++k) { pl[k] = pu[k]; pu[k] = u[k]; }
+        for (int j = 0; j < DS; ++j) { if (S_out) S_out[t * DS + j] = ss[j]; s[j] = sn[j]; }
+    }
+    for (int j = 0; j < DS; ++j) if (S_out) S_out[T * DS + j] = s[j];
+    float zero[DC];
+    for (int k = 0; k < DC; ++k) zero[k] = 0.f;
+    return acc + M::cost(ctx, s, zero, pl, T - 1, bad);
+}
+
+template <int MODEL>
+static void run(int fast, int N, int T, int threshold, const float* x0, const float* mean, const float* eps,
+                const float* umin, const float* umax, const ModelCtx& ctx, float* costs, uint8_t* bad_out,
+                float* S_out) {
+    constexpr int DS = Model<MODEL, false>::DS, DC = Model<MODEL, false>::DC;
+    for (int i = 0; i < N; ++i) {
+        bool bad = false;
+        float* So = S_out ? S_out + (size_t)i * (T + 1) * DS : nullptr;
+        const float* row = eps + (size_t)i * T * DC;
+        float c = fast ? walk<MODEL, true>(row, mean, x0, T, umin, umax, ctx, i < threshold, bad, So)
+                       : walk<MODEL, false>(row, mean, x0, T, umin, umax, ctx, i < threshold, bad, So);
+        if (bad_out) bad_out[i] = bad ? 1 : 0;
+        if (fast && bad) { bool ig = false; c = walk<MODEL, false>(row, mean, x0, T, umin, umax, ctx, i < threshold, ig, So); }
+        costs[i] = c;
+    }
+}
+
+extern "C" {
+
+// maps: cells pointers + geometry as flat arrays; ref [rows][4]
+int emul_rollout_cost(int model, int fast, int N, int T, int threshold, const float* x0, const float* mean,
+                      const float* eps, const float* umin, const float* umax, const float* params, int nparams,
+                      const uint8_t* map0, const uint8_t* map1, const int* map_dims /*nx,ny*/,
+                      const float* map_geom /*cell,ox,oy*/, const float* ref, int ref_rows, float* costs,
+                      uint8_t* bad_out, float* S_out) {
+    ModelCtx ctx;
+    std::memset(&ctx, 0, sizeof(ctx));
+    for (int i = 0; i < nparams; ++i) ctx.P[i] = params[i];
+    std::vector<uint8_t> fused;
+    std::vector<float> ref8;
+    const uint8_t* mp[2] = {map0, map1};
+    for (int sidx = 0; sidx < 2; ++sidx) if (mp[sidx]) {
+        MapView& m = ctx.maps[sidx];
+        m.cells = mp[sidx]; m.nx = map_dims[0]; m.ny = map_dims[1];
+        m.cell = map_geom[0]; m.inv_cell = 1.0f / m.cell; m.ox = map_geom[1]; m.oy = map_geom[2];
+    }
+    if (map0 && map1) {
+        fused.resize((size_t)map_dims[0] * map_dims[1]);
+        for (size_t i = 0; i < fused.size(); ++i) fused[i] = map0[i] + map1[i];
+        ctx.fused = fused.data();
+    }
+    if (ref) {
+        ref8.resize((size_t)ref_rows * 8);
+        for (int i = 0; i < ref_rows; ++i) {
+            float* o = &ref8[(size_t)i * 8];
+            o[0] = ref[4 * i]; o[1] = ref[4 * i + 1]; o[2] = ref[4 * i + 2]; o[3] = ref[4 * i + 3];
+            o[4] = sinf(o[2]); o[5] = cosf(o[2]); o[6] = o[7] = 0.f;
+        }
+        ctx.ref = ref8.data(); ctx.ref_rows = ref_rows;
+    }
+    if (model == MPPI_MODEL_RACING) { ctx.tan_small = 1; ctx.inv_L = 1.0f / ctx.P[MPPI_RP_L]; }
+    switch (model) {
+    case MPPI_MODEL_PENDULUM: run<MPPI_MODEL_PENDULUM>(fast, N, T, threshold, x0, mean, eps, umin, umax, ctx, costs, bad_out, S_out); break;
+    case MPPI_MODEL_CARTPOLE: run<MPPI_MODEL_CARTPOLE>(fast, N, T, threshold, x0, mean, eps, umin, umax, ctx, costs, bad_out, S_out); break;
+    case MPPI_MODEL_MOUNTAINCAR: run<MPPI_MODEL_MOUNTAINCAR>(fast, N, T, threshold, x0, mean, eps, umin, umax, ctx, costs, bad_out, S_out); break;
+    case MPPI_MODEL_NAV2D: run<MPPI_MODEL_NAV2D>(fast, N, T, threshold, x0, mean, eps, umin, umax, ctx, costs, bad_out, S_out); break;
+    case MPPI_MODEL_RACING: run<MPPI_MODEL_RACING>(fast, N, T, threshold, x0, mean, eps, umin, umax, ctx, costs, bad_out, S_out); break;
+    default: return -1;
+    }
+    return 0;
+}
+
+// element-wise pins of the fast math against the library math
+void emul_sincos(const float* x, float* s, float* c, int n, int fast) {
+    for (int i = 0; i < n; ++i) { bool b = false; if (fast) sincos_f<true>(x[i], s[i], c[i], b); else sincos_f<false>(x[i], s[i], c[i], b); }
+}
+void emul_angle_normalize(const float* x, float* y, uint8_t* bad, int n, int mode /*0 lib,1 narrow,2 wide*/) {
+    for (int i = 0; i < n; ++i) {
+        bool b = false;
+        y[i] = mode == 0 ? angle_normalize<false>(x[i], b) : mode == 1 ? angle_normalize<true, false>(x[i], b) : angle_normalize<true, true>(x[i], b);
+        bad[i] = b;
+    }
+}
+void emul_tan(const float* x, float* y, int n, int fast) {
+    for (int i = 0; i < n; ++i) y[i] = fast ? tan_f<true>(x[i]) : tan_f<false>(x[i]);
+}
+void emul_div_cell(const float* x, float* y, int n, float cell, int fast) {
+    MapView m{}; m.cell = cell; m.inv_cell = 1.0f / cell;
+    for (int i = 0; i < n; ++i) y[i] = fast ? div_cell<true>(x[i], m) : div_cell<false>(x[i], m);
+}
+}

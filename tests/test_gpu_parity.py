@@ -1,0 +1,401 @@
+"""Parity of the HIP path (through the C ABI / pi_mpc.mppi.MPPI) against the oracle and the reference
+fixtures, on a real MI355X.  All tests here are marked `gpu`.
+
+Tolerances (fp32, north star: 1e-5 relative):
+  * costs: |gpu - oracle| <= 1e-5 * max|oracle| for every sample that is not within 1e-3 cell of a
+    map-rounding boundary (`margin`, computed by the oracle); at most a handful of boundary samples
+    may flip an occupancy cell under <=1.5-ulp sin/cos differences.
+  * action_seq / state_seq given the same costs: 1e-5 relative to max-abs.
+  * end-to-end against the reference fixtures: 1e-5, widened only by the conditioning of the softmax
+    (8 * eps32 * max|c| / lambda) when lambda is small against the cost scale.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import CASES, MODEL_CFG, load, oracle_problem, orc, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+EPS32 = float(np.finfo(np.float32).eps)
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need an MI355X; torch.cuda.is_available() is False")
+
+
+# ------------------------------------------------------------------------------ solver factory
+_envs = {}
+
+
+def make_solver(model, T, N, lambda_=1.0, **kw):
+    """Product MPPI with the shipped native plugins (no call-site changes vs the reference examples)."""
+    _need_gpu()
+    from pi_mpc.mppi import MPPI
+
+    cfg = MODEL_CFG[model]
+    common = dict(horizon=T, num_samples=N, u_min=torch.tensor(cfg["u_min"]), u_max=torch.tensor(cfg["u_max"]),
+                  sigmas=torch.tensor(cfg["sigmas"]), lambda_=lambda_, **kw)
+    ctrl = None
+    if model in ("pendulum", "cartpole", "mountaincar"):
+        from envs import classic_control as cc
+
+        dyn, cost = getattr(cc, f"{model}_dynamics"), getattr(cc, f"{model}_cost")
+        ds, dc = orc.MODEL_DIMS[orc.MODEL_IDS[model]]
+        solver = MPPI(dim_state=ds, dim_control=dc, dynamics=dyn, cost_func=cost, **common)
+    elif model == "nav2d":
+        from envs.navigation_2d import Navigation2DEnv
+
+        env = _envs.setdefault("nav2d", Navigation2DEnv())
+        solver = MPPI(dim_state=3, dim_control=2, dynamics=env.dynamics, cost_func=env.cost_function, **common)
+    else:
+        from envs.racing_controller import racing_controller
+        from envs.racing_env import RacingEnv
+
+        env = _envs.setdefault("racing", RacingEnv())
+        kw2 = {k: v for k, v in common.items() if k not in ("horizon", "num_samples", "u_min", "u_max", "sigmas",
+                                                             "lambda_")}
+        ctrl = racing_controller(env, horizon=T, num_samples=N, lambda_=lambda_, **kw2)
+        ctrl.set_cost_map(env._obstacle_map, env._lane_map)
+        solver = ctrl.solver
+    return solver, ctrl
+
+
+def used_lambda(g, cfg, k):
+    if cfg["lambda_"] == "MPO":
+        return 1.0 if k == 0 else float(g[f"lambda_{k - 1}"])
+    return float(g[f"lambda_{k}"])
+
+
+def check_costs(c_gpu, r, max_flips=None):
+    if max_flips is None:
+        max_flips = 3 + int(2e-4 * len(c_gpu))  # boundary samples only; see module docstring
+    scale = np.abs(r["costs"]).max()
+    diff = np.abs(c_gpu - r["costs"])
+    clear = r["margin"] > 1e-3
+    assert np.max(diff[clear]) <= TOL * scale, f"clear-sample cost error {np.max(diff[clear]) / scale:.2e}"
+    nflip = int((diff > TOL * scale).sum())
+    assert nflip <= max_flips, f"{nflip} samples differ beyond tolerance (all must be boundary samples)"
+    return nflip
+
+
+# ------------------------------------------------------------------------------ whole solve vs oracle / golden
+@pytest.mark.parametrize("math", [1, 0])
+@pytest.mark.parametrize("name", list(CASES))
+def test_forward_parity(name, math):
+    cfg, g = CASES[name], load(name)
+    model, T, N = cfg["model"], cfg["T"], cfg["N"]
+    kw = {k: cfg[k] for k in ("exploration", "use_sg_filter") if k in cfg}
+    solver, ctrl = make_solver(model, T, N, lambda_=cfg["lambda_"], **kw)
+    solver.set_option("math", math)
+    P = oracle_problem(model, N, T, cfg.get("exploration", 0.0))
+    from pi_mpc import _host
+
+    for k in range(int(g["K"])):
+        x0, mean, eps = g[f"x0_{k}"], g[f"mean_in_{k}"], g[f"eps_{k}"]
+        if ctrl is not None:
+            ctrl.set_reference(g[f"ref_path_{k}"])
+            P.set_ref_path(g[f"ref_path_{k}"])
+        solver.set_warm_start(mean, g[f"sg_hist_in_{k}"])
+        if cfg["lambda_"] == "MPO" and k > 0:
+            solver._lambda = float(g[f"lambda_{k - 1}"])
+        solver.inject_noise(torch.from_numpy(eps))
+        a, s = solver.forward(torch.from_numpy(x0))
+        assert a.shape == (T, P.dc) and s.shape == (1, T + 1, P.ds) and a.is_cuda
+        a, s = a.cpu().numpy(), s.cpu().numpy()
+        c_gpu = solver._costs.cpu().numpy()
+
+        # (1) costs against the oracle on identical inputs
+        r = P.rollout_cost(x0, mean, eps, want_margin=True)
+        nflip = check_costs(c_gpu, r)
+
+        # (2) temperature against the reference
+        lam = solver._last_lambda
+        lam_ref = used_lambda(g, cfg, k)
+        tol_lam = {"ESSPS": 1e-4, "LBPS": 2e-3, "MPO": 2e-4}.get(cfg["lambda_"], 0.0)
+        assert abs(lam - lam_ref) <= tol_lam * lam_ref + 1e-12
+
+        # (3) weights/reduction/finalize against the oracle fed with the GPU's own costs
+        w, st = orc.softmax_weights(c_gpu, lam)
+        a_or = P.weighted_actions(w, mean, eps)
+        if cfg.get("use_sg_filter"):
+            a_or = _host.sg_filter_sequence(g[f"sg_hist_in_{k}"], a_or, _host.savitzky_golay_coeffs(5, 3))
+        assert rel_err(a, a_or) < TOL
+        stats = solver.last_stats()
+        assert abs(stats["cmin"] - st["cmin"]) <= 1e-6 * abs(st["cmin"]) + 1e-12
+        assert abs(stats["ess"] - st["ess"]) <= 1e-4 * st["ess"]
+        assert rel_err(solver._weights.cpu().numpy(), w) < TOL
+        assert rel_err(s[0], P.rollout_single(x0, a)) < TOL
+
+        # (4) end to end against the reference fixture
+        cond = 8 * EPS32 * float(np.abs(c_gpu).max()) / lam
+        tol_e2e = max(TOL, cond) + (tol_lam * 10 if tol_lam else 0.0)
+        if nflip == 0:
+            assert rel_err(a, g[f"action_seq_{k}"]) < tol_e2e
+            assert rel_err(s, g[f"state_seq_{k}"]) < max(tol_e2e, TOL)
+
+
+def test_top_samples_match_reference():
+    name = "pendulum_T15_N256_fixed"
+    cfg, g = CASES[name], load(name)
+    solver, _ = make_solver("pendulum", 15, 256, lambda_=1.0)
+    solver.set_warm_start(g["mean_in_0"])
+    solver.inject_noise(torch.from_numpy(g["eps_0"]))
+    solver.forward(torch.from_numpy(g["x0_0"]))
+    ts, tw = solver.get_top_samples(8)
+    assert ts.shape == (8, 16, 2) and tw.shape == (8,)
+    assert rel_err(tw.cpu().numpy(), g["top8_weights_0"]) < TOL
+    assert rel_err(ts.cpu().numpy(), g["top8_states_0"]) < TOL
+    # mountaincar: the stored trajectories are the mutated views (SURVEY B-Q7)
+    g = load("mountaincar_T100_N256_fixed")
+    solver, _ = make_solver("mountaincar", 100, 256, lambda_=0.1)
+    solver.set_warm_start(g["mean_in_0"])
+    solver.inject_noise(torch.from_numpy(g["eps_0"]))
+    solver.forward(torch.from_numpy(g["x0_0"]))
+    ts, tw = solver.get_top_samples(8)
+    assert rel_err(ts.cpu().numpy(), g["top8_states_0"]) < TOL
+
+
+# ------------------------------------------------------------------------------ sampler / layouts
+def test_sampler_matches_philox_restatement():
+    solver, _ = make_solver("racing", 50, 1000, lambda_=1.0)
+    h, st = solver._h, solver._stream()
+    h.call("mppi_sample", 3, st)
+    eps = solver._action_noises.cpu().numpy()
+    ref = orc.philox_normal(42, 3, 0, 1000, 50, 2, [0.5, 0.1])
+    err = np.abs(eps - ref) / np.array([0.5, 0.1], np.float32)
+    print("sampler max abs err / sigma:", err.max())
+    assert err.max() < 1e-4  # hardware v_sin/v_cos/v_log vs libm
+    # dc = 1 model, odd row length (T*dc = 15 -> 4 groups, one padded)
+    solver, _ = make_solver("pendulum", 15, 200, lambda_=1.0)
+    solver._h.call("mppi_sample", 1, solver._stream())
+    eps = solver._action_noises.cpu().numpy()
+    assert np.abs(eps - orc.philox_normal(42, 1, 0, 200, 15, 1, [1.0])).max() < 1e-4
+
+
+def test_sampler_moments_full_size():
+    N, T = 1 << 20, 50
+    solver, _ = make_solver("racing", T, N, lambda_=1.0)
+    solver._h.call("mppi_sample", 1, solver._stream())
+    e = solver._action_noises
+    for k, sg in enumerate((0.5, 0.1)):
+        x = e[..., k].double()
+        assert abs(float(x.mean())) < 5 * sg / np.sqrt(N * T)
+        assert abs(float(x.std()) - sg) < 5e-4 * sg
+        assert abs(float((x ** 4).mean()) / sg ** 4 - 3.0) < 0.01  # kurtosis of a normal
+    # lag-1 correlation across time and across samples
+    x = e[..., 0].double()
+    assert abs(float((x[:, 1:] * x[:, :-1]).mean())) / 0.25 < 1e-3
+    assert abs(float((x[1:] * x[:-1]).mean())) / 0.25 < 1e-3
+    # a different solve index gives a different draw
+    solver._h.call("mppi_sample", 2, solver._stream())
+    assert float((solver._action_noises - e).abs().max()) > 0.1
+
+
+def test_inject_export_roundtrip_and_clamp():
+    rng = np.random.default_rng(5)
+    for model, T, N in (("racing", 50, 1000), ("pendulum", 15, 130), ("mountaincar", 100, 65), ("cartpole", 64, 64)):
+        solver, _ = make_solver(model, T, N, lambda_=1.0, exploration=0.25)
+        dc = solver._dim_control
+        eps = rng.standard_normal((N, T, dc)).astype(np.float32)
+        mean = rng.standard_normal((T, dc)).astype(np.float32) * 0.3
+        solver.set_warm_start(mean)
+        solver._h.call("mppi_inject_noise", C.c_void_p(torch.from_numpy(eps).cuda().data_ptr()), solver._stream())
+        torch.cuda.synchronize()
+        assert np.array_equal(solver._action_noises.cpu().numpy(), eps)
+        u = solver._perturbed_actions_for(torch.from_numpy(mean).cuda()).cpu().numpy()
+        thr = int(N * 0.75)
+        cfg = MODEL_CFG[model]
+        ref = eps.copy()
+        ref[:thr] = mean + eps[:thr]
+        ref = np.minimum(np.maximum(ref, np.array(cfg["u_min"], np.float32)), np.array(cfg["u_max"], np.float32))
+        assert np.array_equal(u, ref)
+
+
+def _summary(solver, lam):
+    out = torch.zeros(4 + solver._horizon * solver._dim_control, device="cuda")
+    solver._h.call("mppi_weights_reduce", float(lam), C.c_void_p(out.data_ptr()), solver._stream())
+    return out
+
+
+def test_shard_invariance_and_combine():
+    """Two half shards (sample_offset) reproduce the unsharded noise bit for bit and, combined by
+    mppi_finalize(num_shards=2), the unsharded action."""
+    from mppi_playground_amd import _capi
+
+    N, T = 4096, 50
+    full, ctrl = make_solver("racing", T, N, lambda_=5000.0)  # large lambda: many samples carry weight
+    x0 = _envs["racing"]._robot_state.clone()
+    ref, _ = ctrl.calc_ref_trajectory(x0, _envs["racing"].racing_center_path, 0, T, DL=0.1, lookahead_distance=3,
+                                      reference_path_interval=0.85)
+    ctrl.set_reference(ref)
+    a_full, s_full = full.forward(x0)
+    eps_full = full._action_noises.cpu().numpy()
+    stats_full = full.last_stats()
+
+    halves, sums = [], []
+    for r in range(2):
+        sol, c2 = make_solver("racing", T, N // 2, lambda_=5000.0)
+        # re-create the handle as shard r of a global N
+        cfg = _capi.MppiConfig()
+        cfg.model, cfg.horizon, cfg.dim_state, cfg.dim_control = 4, T, 4, 2
+        cfg.num_samples, cfg.sample_offset, cfg.inherit_count = N // 2, r * (N // 2), N
+        for k in range(2):
+            cfg.u_min[k], cfg.u_max[k], cfg.sigmas[k] = (MODEL_CFG["racing"][q][k] for q in ("u_min", "u_max", "sigmas"))
+        cfg.seed, cfg.device = 42, 0
+        sol._h.close()
+        sol._h = _capi.Handle(cfg)
+        sol._uploaded, sol._params_set = {}, None
+        c2.set_reference(ref)
+        sol._h.call("mppi_set_state", C.c_void_p(x0.data_ptr()), 1, sol._stream())
+        sol._refresh_model_inputs()
+        sol._h.call("mppi_sample", 1, sol._stream())
+        sol._h.call("mppi_rollout_cost", sol._stream())
+        sums.append(_summary(sol, 5000.0))
+        halves.append(sol)
+        assert np.array_equal(sol._action_noises.cpu().numpy(), eps_full[r * (N // 2):(r + 1) * (N // 2)])
+    both = torch.stack(sums).contiguous()
+    a = torch.zeros(T, 2, device="cuda")
+    s = torch.zeros(1, T + 1, 4, device="cuda")
+    stats = torch.zeros(4, device="cuda")
+    halves[0]._h.call("mppi_finalize", C.c_void_p(both.data_ptr()), 2, 5000.0, 0, C.c_void_p(a.data_ptr()),
+                      C.c_void_p(s.data_ptr()), C.c_void_p(stats.data_ptr()), halves[0]._stream())
+    assert rel_err(a.cpu().numpy(), a_full.cpu().numpy()) < 2e-6
+    assert rel_err(s.cpu().numpy(), s_full.cpu().numpy()) < 2e-6
+    st = stats.cpu().numpy()
+    assert abs(st[0] - stats_full["cmin"]) == 0.0
+    assert abs(st[1] - stats_full["sum_e"]) <= 1e-5 * stats_full["sum_e"]
+
+
+# ------------------------------------------------------------------------------ full size (BASELINE configs)
+def test_racing_full_size_against_oracle():
+    """C3: racing N = 1,048,576, T = 50, lambda = 1.  The oracle (8 threads) takes a few seconds."""
+    N, T = 1 << 20, 50
+    solver, ctrl = make_solver("racing", T, N, lambda_=1.0)
+    env = _envs["racing"]
+    x0 = env._robot_state.clone()
+    ref, _ = ctrl.calc_ref_trajectory(x0, env.racing_center_path, 0, T, DL=0.1, lookahead_distance=3,
+                                      reference_path_interval=0.85)
+    ctrl.set_reference(ref)
+    a1, s1 = solver.forward(x0)
+    c_gpu = solver._costs.cpu().numpy()
+    eps = solver._action_noises.cpu().numpy()
+    stats = solver.last_stats()
+    P = oracle_problem("racing", N, T, ref_path=ref.numpy())
+    mean = np.zeros((T, 2), np.float32)
+    r = P.rollout_cost(x0.cpu().numpy(), mean, eps, want_margin=True)
+    nflip = check_costs(c_gpu, r)
+    print("full-size racing: boundary flips", nflip, "of", N)
+    w, st = orc.softmax_weights(c_gpu, 1.0)
+    assert rel_err(a1.cpu().numpy(), P.weighted_actions(w, mean, eps)) < TOL
+    assert abs(stats["ess"] - st["ess"]) <= 1e-4 * st["ess"]
+    assert rel_err(s1.cpu().numpy()[0], P.rollout_single(x0.cpu().numpy(), a1.cpu().numpy())) < TOL
+    # size-independent properties: weights sum to one, bounds respected, determinism
+    assert abs(float(solver._weights.double().sum()) - 1.0) < 1e-5
+    lo, hi = np.array(MODEL_CFG["racing"]["u_min"]), np.array(MODEL_CFG["racing"]["u_max"])
+    assert np.all(a1.cpu().numpy() >= lo - 1e-6) and np.all(a1.cpu().numpy() <= hi + 1e-6)
+    solver2, ctrl2 = make_solver("racing", T, N, lambda_=1.0)
+    ctrl2.set_reference(ref)
+    a2, s2 = solver2.forward(x0)
+    assert torch.equal(a1, a2) and torch.equal(s1, s2)  # same seed, same solve index -> bit-identical
+    # second solve warm-starts from the first (no time shift, mppi.py:452)
+    a3, _ = solver.forward(x0)
+    assert torch.isfinite(a3).all()
+    mean_now = torch.empty(T, 2, device="cuda")
+    solver._h.call("mppi_get_mean", C.c_void_p(mean_now.data_ptr()), 1, solver._stream())
+    assert torch.equal(mean_now, a3)
+
+
+def test_uniform_costs_give_sample_mean_full_size():
+    """Linearity check of the weighted reduction at C5 size: equal costs -> plain mean of U."""
+    N, T = 262144, 64
+    solver, _ = make_solver("cartpole", T, N, lambda_=1.0)
+    h, st = solver._h, solver._stream()
+    h.call("mppi_sample", 1, st)
+    c = torch.full((N,), 3.25, device="cuda")
+    h.call("mppi_set_costs", C.c_void_p(c.data_ptr()), 1, st)
+    h.call("mppi_weights_reduce", 1.0, None, st)
+    a = torch.zeros(T, 1, device="cuda")
+    stats = torch.zeros(4, device="cuda")
+    h.call("mppi_finalize", None, 1, 1.0, 0, C.c_void_p(a.data_ptr()), None, C.c_void_p(stats.data_ptr()), st)
+    u = solver._perturbed_actions_for(torch.zeros(T, 1, device="cuda"))
+    assert rel_err(a.cpu().numpy(), u.double().mean(dim=0).cpu().numpy()) < 1e-5
+    s = stats.cpu().numpy()
+    assert s[0] == 3.25 and abs(s[1] - N) < 1e-3 * N and abs(s[1] * s[1] / s[2] - N) < 1e-3 * N  # ESS = N
+
+
+@pytest.mark.parametrize("model,T,N,lam", [("nav2d", 50, 65536, "ESSPS"), ("cartpole", 64, 262144, "ESSPS")])
+def test_baseline_configs_against_oracle(model, T, N, lam):
+    """C2 / C5 at full size: costs and action against the oracle on the device-drawn noise."""
+    kw = dict(use_sg_filter=True) if model == "cartpole" else {}
+    solver, _ = make_solver(model, T, N, lambda_=lam, **kw)
+    x0 = {"nav2d": np.array([-9.0, -9.0, np.pi / 4], np.float32),
+          "cartpole": np.array([0.01, 0.0, 0.02, 0.0], np.float32)}[model]
+    a, s = solver.forward(torch.from_numpy(x0))
+    c_gpu = solver._costs.cpu().numpy()
+    eps = solver._action_noises.cpu().numpy()
+    P = oracle_problem(model, N, T)
+    mean = np.zeros((T, P.dc), np.float32)
+    r = P.rollout_cost(x0, mean, eps, want_margin=True)
+    check_costs(c_gpu, r)
+    lam_used = solver._last_lambda
+    from pi_mpc import _host
+
+    assert abs(_host.compute_ess(_host.softmax_weights(c_gpu, lam_used)) - N / 10) < 1e-3 * N / 10
+    w, _ = orc.softmax_weights(c_gpu, lam_used)
+    a_or = P.weighted_actions(w, mean, eps)
+    if kw:
+        a_or = _host.sg_filter_sequence(np.zeros((T - 1, P.dc), np.float32), a_or, _host.savitzky_golay_coeffs(5, 3))
+    assert rel_err(a.cpu().numpy(), a_or) < TOL
+    assert rel_err(s.cpu().numpy()[0], P.rollout_single(x0, a.cpu().numpy())) < TOL
+
+
+# ------------------------------------------------------------------------------ API / error behaviour
+def test_error_behaviour_matches_reference():
+    _need_gpu()
+    from envs import classic_control as cc
+    from pi_mpc.mppi import MPPI
+
+    base = dict(horizon=15, num_samples=100, dim_state=2, dim_control=1, dynamics=cc.pendulum_dynamics,
+                cost_func=cc.pendulum_cost, u_min=torch.tensor([-2.0]), u_max=torch.tensor([2.0]),
+                sigmas=torch.tensor([1.0]))
+    with pytest.raises(ValueError):
+        MPPI(lambda_=1, **base)  # int is not accepted (mppi.py:205-210)
+    with pytest.raises(ValueError):
+        MPPI(lambda_="nope", **base)
+    with pytest.raises(ValueError):
+        MPPI(lambda_=1.0, sg_window_size=4, **base)
+    with pytest.raises(AssertionError):
+        MPPI(lambda_=1.0, **{**base, "u_min": torch.tensor([-2.0, 0.0])})
+    s = MPPI(lambda_=1.0, **base)
+    with pytest.raises(AssertionError):
+        s.forward(torch.zeros(3))
+    a, st = s(np.array([np.pi, 0.0]))  # nn.Module.__call__, float64 ndarray state (example/pendulum.py:73-77)
+    assert a.shape == (15, 1) and st.shape == (1, 16, 2)
+    s.reset()
+    assert float(s._previous_action_seq.abs().max()) == 0.0
+
+
+def test_racing_controller_closed_loop_smoke():
+    """The reference's control loop (example/racing.py:221-266) minus rendering, default sizes."""
+    _need_gpu()
+    from envs.racing_controller import racing_controller
+    from envs.racing_env import RacingEnv
+
+    env = RacingEnv()
+    ctrl = racing_controller(env)
+    with pytest.raises(ValueError):
+        ctrl.update(env.reset(), env.racing_center_path)  # maps not set (example/racing.py:83-90)
+    ctrl.set_cost_map(env._obstacle_map, env._lane_map)
+    state = env.reset()
+    for _ in range(20):
+        action_seq, state_seq = ctrl.update(state, env.racing_center_path)
+        state, done = env.step(action_seq[0, :])
+        coll = env.collision_check(state=state_seq)
+        top, tw = ctrl.get_top_samples(num_samples=300)
+        assert top.shape == (300, 26, 4) and coll.shape[-1] == 26
+    assert float(state[3]) > 0.5  # the car accelerates along the track

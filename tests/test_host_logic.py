@@ -1,0 +1,154 @@
+"""Host-side logic that needs no GPU: temperature tuning + SG filter against the reference fixtures,
+the env set-up code against the reference's maps, reference-window selection, the C-ABI symbol table,
+and the loud failure without a device."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import CASES, ROOT, load, nav2d_env_fixture, oracle_problem, racing_env_fixture, rel_err
+from pi_mpc import _host
+
+
+@pytest.mark.parametrize("name", ["pendulum_T50_N1000_essps", "nav2d_T50_N512_essps", "cartpole_T64_N1024_essps_sg"])
+def test_essps_lambda(name):
+    g, cfg = load(name), CASES[name]
+    for k in range(3):
+        lam = _host.essps_lambda(g[f"costs_{k}"], cfg["N"] / 10, 0.01, 10.0)
+        assert abs(lam - float(g[f"lambda_{k}"])) <= 1e-5 * float(g[f"lambda_{k}"])
+
+
+def test_lbps_lambda():
+    # the bounded scalar minimiser stops at xatol=1e-5 on a flat, fp32-noisy objective
+    g = load("pendulum_T15_N256_lbps")
+    for k in range(3):
+        lam = _host.lbps_lambda(g[f"costs_{k}"], 0.01, 0.01, 10.0)
+        assert abs(lam - float(g[f"lambda_{k}"])) <= 1e-3 * float(g[f"lambda_{k}"])
+
+
+def test_mpo_temperature():
+    # the reference's fp32 autograd gradient cancels ~600 against ~600 (|g| ~ 1): 2e-4 is its noise
+    g = load("pendulum_T15_N256_mpo")
+    m = _host.MpoTemperature()
+    for k in range(3):
+        lam = m.step(g[f"costs_{k}"])
+        assert abs(lam - float(g[f"lambda_{k}"])) <= 2e-4 * float(g[f"lambda_{k}"])
+
+
+def test_savitzky_golay():
+    co = _host.savitzky_golay_coeffs(5, 3)
+    assert np.allclose(co * 35, [-3, 12, 17, 12, -3], atol=1e-5)
+    with pytest.raises(ValueError):
+        _host.savitzky_golay_coeffs(4, 3)
+    with pytest.raises(ValueError):
+        _host.savitzky_golay_coeffs(3, 3)
+    g = load("cartpole_T64_N1024_essps_sg")
+    P = oracle_problem("cartpole", 1024, 64)
+    for k in range(3):
+        a = P.weighted_actions(g[f"weights_{k}"], g[f"mean_in_{k}"], g[f"eps_{k}"])
+        f = _host.sg_filter_sequence(g[f"sg_hist_in_{k}"], a, co)
+        assert rel_err(f, g[f"action_seq_{k}"]) < 1e-5
+        if k + 1 < 3:  # history shift-in of the applied first action (mppi.py:455-458)
+            hist = np.concatenate([g[f"sg_hist_in_{k}"][1:], f[:1]])
+            assert rel_err(hist, g[f"sg_hist_in_{k + 1}"]) < 1e-5 or np.abs(hist).max() < 1e-6
+
+
+@pytest.fixture(scope="module")
+def racing_env():
+    from envs.racing_env import RacingEnv
+
+    return RacingEnv(device="cpu")
+
+
+def test_racing_env_matches_reference_maps(racing_env):
+    e = racing_env_fixture()
+    assert np.array_equal(racing_env._obstacle_map.grid_spec().cells, e["obst"])
+    assert np.array_equal(racing_env._lane_map.grid_spec().cells, e["lane"])
+    assert np.array_equal(racing_env.racing_center_path.numpy(), e["center_path"])
+    assert np.array_equal(racing_env._robot_state.numpy(), e["start_state"])
+    assert racing_env._obstacle_map.x_lim == [-40.0, 40.0]
+    c = np.array([[c[0][0], c[0][1], c[1]] for c in racing_env._obstacle_map.circle_obs_list])
+    assert np.array_equal(c, e["circles"])
+
+
+def test_nav2d_env_matches_reference_map():
+    from envs.navigation_2d import Navigation2DEnv
+
+    env, n = Navigation2DEnv(device="cpu"), nav2d_env_fixture()
+    assert np.array_equal(env._obstacle_map.grid_spec().cells, n["map"])
+    assert np.array_equal(env._robot_state.numpy(), n["start_state"])
+    assert np.array_equal(env._goal_pos.numpy(), n["goal"])
+
+
+def test_calc_ref_trajectory(racing_env):
+    from envs.racing_controller import racing_controller
+
+    ctrl = racing_controller.__new__(racing_controller)
+    ctrl.env = racing_env
+    for name in ("racing_T50_N512_fixed", "racing_T25_N256_fixed"):
+        g, T = load(name), CASES[name]["T"]
+        for k in range(3):
+            ref, ind = ctrl.calc_ref_trajectory(torch.tensor(g[f"x0_{k}"]), racing_env.racing_center_path,
+                                                int(g[f"cind_in_{k}"]), T, DL=0.1, lookahead_distance=3,
+                                                reference_path_interval=0.85)
+            assert np.array_equal(ref.numpy(), g[f"ref_path_{k}"]) and ind == int(g[f"cind_out_{k}"])
+    # past the end of the course the whole target-velocity column drops to zero
+    n = len(racing_env.racing_center_path)
+    ref, _ = ctrl.calc_ref_trajectory(racing_env.racing_center_path[n - 5, :3].clone().repeat(2)[:4],
+                                      racing_env.racing_center_path, n - 5, 10, DL=0.1, lookahead_distance=3,
+                                      reference_path_interval=0.85)
+    assert float(ref[:, 3].abs().max()) == 0.0
+
+
+def test_torch_plugins_match_oracle_states(racing_env):
+    """The torch callables of the shipped plugins (used by env.step and any torch caller) follow the
+    same math as the oracle."""
+    from envs import classic_control as cc
+
+    rng = np.random.default_rng(3)
+    for model, dyn in (("pendulum", cc.pendulum_dynamics), ("cartpole", cc.cartpole_dynamics)):
+        P = oracle_problem(model, 1, 1)
+        s = rng.standard_normal(P.ds).astype(np.float32) * 0.1
+        u = rng.standard_normal((1, 1)).astype(np.float32)
+        ours = dyn(torch.tensor(s[None]), torch.tensor(u)).numpy()[0]
+        assert rel_err(ours, P.rollout_single(s, u)[1]) < 1e-6
+    s = np.array([-15.7, -23.9, 2.1, 3.0], np.float32)
+    u = np.array([[1.0, 0.1]], np.float32)
+    P = oracle_problem("racing", 1, 1)
+    ours = racing_env.dynamics(torch.tensor(s[None]), torch.tensor(u)).numpy()[0]
+    assert rel_err(ours, P.rollout_single(s, u)[1]) < 1e-6
+
+
+def test_capi_exports_every_declared_symbol():
+    """The built library loads without a GPU and exports exactly what include/mppi_hip.h declares."""
+    from mppi_playground_amd import _build, _capi
+
+    _build.build()
+    hdr = open(os.path.join(ROOT, "include", "mppi_hip.h")).read()
+    declared = set(re.findall(r"\b(mppi_[a-z_]+)\s*\(", hdr))
+    assert declared == set(_capi.SYMBOLS)
+    lib = ctypes.CDLL(_capi.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert b"gfx950" in _capi.load().mppi_version()
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_fails_loudly_without_gpu():
+    from envs.classic_control import pendulum_cost, pendulum_dynamics
+    from mppi_playground_amd import _capi
+    from pi_mpc.mppi import MPPI
+
+    with pytest.raises(_capi.MppiError):
+        MPPI(15, 100, 2, 1, pendulum_dynamics, pendulum_cost, torch.tensor([-2.0]), torch.tensor([2.0]),
+             torch.tensor([1.0]), 1.0)
+
+
+def test_constructor_errors_match_reference():
+    from mppi_playground_amd import _capi
+
+    if not torch.cuda.is_available():
+        pytest.skip("constructor needs a GPU beyond the shape asserts")

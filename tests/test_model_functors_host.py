@@ -1,0 +1,102 @@
+"""Pre-GPU check of the product's model functors: mppi_models.hpp compiled for the host
+(tests/host_emul, test-only) against the oracle on the golden inputs, for both math variants, plus
+pins of the fast math paths against the library math."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import emul
+from helpers import CASES, MODEL_CFG, load, nav2d_env_fixture, oracle_problem, orc, racing_env_fixture, rel_err
+
+F32 = np.float32
+
+
+def _model_inputs(model):
+    if model == "racing":
+        e = racing_env_fixture()
+        return orc.racing_params(), [e["obst"], e["lane"]], (e["cell"], e["origin"][0], e["origin"][1])
+    if model == "nav2d":
+        e = nav2d_env_fixture()
+        return orc.nav2d_params(), [e["map"]], (e["cell"], e["origin"][0], e["origin"][1])
+    return (), (), None
+
+
+@pytest.mark.parametrize("fast", [0, 1])
+@pytest.mark.parametrize("name", list(CASES))
+def test_functors_vs_oracle(name, fast):
+    cfg, g = CASES[name], load(name)
+    m, N, T = cfg["model"], cfg["N"], cfg["T"]
+    mid = orc.MODEL_IDS[m]
+    ds, _ = orc.MODEL_DIMS[mid]
+    P = oracle_problem(m, N, T, cfg.get("exploration", 0.0))
+    params, maps, geom = _model_inputs(m)
+    mc = MODEL_CFG[m]
+    for k in range(int(g["K"])):
+        ref = g[f"ref_path_{k}"] if m == "racing" else None
+        if ref is not None:
+            P.set_ref_path(ref)
+        r = P.rollout_cost(g[f"x0_{k}"], g[f"mean_in_{k}"], g[f"eps_{k}"], want_S=True, want_margin=True)
+        c, bad, S = emul.rollout_cost(mid, fast, g[f"x0_{k}"], g[f"mean_in_{k}"], g[f"eps_{k}"], mc["u_min"],
+                                      mc["u_max"], int(N * (1 - cfg.get("exploration", 0.0))), params, maps, geom,
+                                      ref, want_S=True, ds=ds)
+        assert bad.sum() == 0  # the fast paths stay in range on the shipped models
+        clear = r["margin"] > 1e-3  # samples that are not within 1e-3 cell of a rounding boundary
+        scale = np.abs(r["costs"]).max()
+        assert np.max(np.abs(c - r["costs"])[clear]) <= 1e-5 * scale
+        assert (np.abs(c - r["costs"]) > 1e-5 * scale).sum() <= 2  # flips, if any, only at boundaries
+        if not fast:
+            assert np.array_equal(S, r["S"])  # library math: same operations as the oracle
+        else:
+            assert rel_err(S, r["S"]) < 1e-5
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _ulp(a, ref):
+    u = np.spacing(np.abs(ref.astype(F32))).astype(np.float64)
+    return np.max(np.abs(a.astype(np.float64) - ref) / u)
+
+
+def test_fast_sincos_tan_accuracy():
+    L = emul.lib()
+    x = np.linspace(-np.pi, np.pi, 2000001).astype(F32)
+    s, c = np.empty_like(x), np.empty_like(x)
+    L.emul_sincos(_p(x), _p(s), _p(c), x.size, 1)
+    assert _ulp(s, np.sin(x.astype(np.float64))) < 1.6 and _ulp(c, np.cos(x.astype(np.float64))) < 1.6
+    x = np.linspace(-200, 200, 2000001).astype(F32)
+    s, c = np.empty_like(x), np.empty_like(x)
+    L.emul_sincos(_p(x), _p(s), _p(c), x.size, 1)
+    assert _ulp(s, np.sin(x.astype(np.float64))) < 2.5 and _ulp(c, np.cos(x.astype(np.float64))) < 2.5
+    x = np.linspace(-0.25, 0.25, 1000001).astype(F32)
+    y = np.empty_like(x)
+    L.emul_tan(_p(x), _p(y), x.size, 1)
+    assert _ulp(y, np.tan(x.astype(np.float64))) < 1.0
+
+
+@pytest.mark.parametrize("mode,width", [(1, 12.0), (2, 9.0e4)])
+def test_fast_angle_normalize_is_bit_identical(mode, width):
+    L = emul.lib()
+    rng = np.random.default_rng(0)
+    x = np.concatenate([(rng.random(1000000) * 2 - 1) * width,
+                        np.pi * np.arange(-6, 7)]).astype(F32)
+    x = np.concatenate([x, np.nextafter(x, F32(np.inf)), np.nextafter(x, F32(-np.inf))])
+    y0, y1, b0, b1 = np.empty_like(x), np.empty_like(x), np.empty(x.size, np.uint8), np.empty(x.size, np.uint8)
+    L.emul_angle_normalize(_p(x), _p(y0), _p(b0), x.size, 0)
+    L.emul_angle_normalize(_p(x), _p(y1), _p(b1), x.size, mode)
+    ok = b1 == 0
+    assert ok.mean() > 0.85
+    assert np.array_equal(y0[ok].view(np.uint32), y1[ok].view(np.uint32))
+
+
+@pytest.mark.parametrize("cell", [0.1, 0.05, 0.01, 0.3, 0.25])
+def test_markstein_division_is_correctly_rounded(cell):
+    L = emul.lib()
+    rng = np.random.default_rng(1)
+    x = np.concatenate([((rng.random(4000000) * 2 - 1) * 45), np.arange(-400, 401) * cell + cell / 2]).astype(F32)
+    y0, y1 = np.empty_like(x), np.empty_like(x)
+    L.emul_div_cell(_p(x), _p(y0), x.size, cell, 0)
+    L.emul_div_cell(_p(x), _p(y1), x.size, cell, 1)
+    assert np.array_equal(y0, y1)

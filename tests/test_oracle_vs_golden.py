@@ -1,0 +1,94 @@
+"""The CPU oracle (oracle/mppi_oracle.c) against the fixtures captured from the real reference
+(tests/golden/make_golden.py).  Tolerance: 1e-5 relative to the max-abs of each tensor (SURVEY
+Appendix D); observed ~2e-7."""
+import numpy as np
+import pytest
+
+from helpers import CASES, load, oracle_problem, orc, racing_env_fixture, nav2d_env_fixture, rel_err
+
+TOL = 1e-5
+
+
+def used_lambda(g, cfg, k):
+    """lambda the reference used for the weights of solve k (MPO updates it AFTER the weights)."""
+    if cfg["lambda_"] == "MPO":
+        return 1.0 if k == 0 else float(g[f"lambda_{k - 1}"])
+    return float(g[f"lambda_{k}"])
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_rollout_costs_states(name):
+    cfg, g = CASES[name], load(name)
+    P = oracle_problem(cfg["model"], cfg["N"], cfg["T"], cfg.get("exploration", 0.0))
+    for k in range(int(g["K"])):
+        if cfg["model"] == "racing":
+            P.set_ref_path(g[f"ref_path_{k}"])
+        keep = f"S_{k}" in g.files
+        r = P.rollout_cost(g[f"x0_{k}"], g[f"mean_in_{k}"], g[f"eps_{k}"], want_U=keep, want_S=keep,
+                           want_stage=keep)
+        assert rel_err(r["costs"], g[f"costs_{k}"]) < TOL
+        if keep:
+            assert np.array_equal(r["U"], g[f"U_{k}"])  # clamp(mean + eps) is exact
+            assert rel_err(r["S"], g[f"S_{k}"]) < TOL
+            assert rel_err(r["stage"], g[f"stage_costs_{k}"]) < TOL
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_weights_action_state_seq(name):
+    cfg, g = CASES[name], load(name)
+    P = oracle_problem(cfg["model"], cfg["N"], cfg["T"], cfg.get("exploration", 0.0))
+    for k in range(int(g["K"])):
+        lam = used_lambda(g, cfg, k)
+        w, st = orc.softmax_weights(g[f"costs_{k}"], lam)
+        assert rel_err(w, g[f"weights_{k}"]) < TOL
+        a = P.weighted_actions(g[f"weights_{k}"], g[f"mean_in_{k}"], g[f"eps_{k}"])
+        if not cfg.get("use_sg_filter"):
+            assert rel_err(a, g[f"action_seq_{k}"]) < TOL
+        s = P.rollout_single(g[f"x0_{k}"], g[f"action_seq_{k}"])
+        assert rel_err(s, g[f"state_seq_{k}"][0]) < TOL
+
+
+def test_top_samples_are_reference_rows():
+    # get_top_samples returns rows of _state_seq_batch sorted by weight (mppi.py:462-487)
+    g = load("pendulum_T15_N256_fixed")
+    order = np.argsort(-g["weights_0"], kind="stable")[:8]
+    assert np.allclose(g["top8_weights_0"], g["weights_0"][order])
+    assert np.allclose(g["top8_states_0"], g["S_0"][order])
+
+
+def test_angle_normalize_and_occupancy_pins():
+    pins = load("model_pins")
+    assert np.array_equal(orc.angle_normalize(pins["an_in"]), pins["an_out"])
+    e, n = racing_env_fixture(), nav2d_env_fixture()
+    assert np.array_equal(orc.occ(e["obst"], e["cell"], e["origin"], pins["occ_pts"]), pins["occ_obst"].ravel())
+    assert np.array_equal(orc.occ(e["lane"], e["cell"], e["origin"], pins["occ_pts"]), pins["occ_lane"].ravel())
+    assert np.array_equal(orc.occ(n["map"], n["cell"], n["origin"], pins["occ_nav_pts"]), pins["occ_nav"].ravel())
+
+
+@pytest.mark.parametrize("seed", [0, 42])
+@pytest.mark.parametrize("n", [1000, 15000])
+def test_torch_cpu_normal_stream(seed, n):
+    """mt19937 + Box-Muller restatement of torch's CPU normal_() (SURVEY B-Q1): two consecutive draws."""
+    g = load("torch_cpu_randn")
+    s = orc.TorchCpuStream(seed)
+    a, b = s.randn(n), s.randn(n)
+    assert np.max(np.abs(a - g[f"randn_seed{seed}_n{n}_a"])) < 2e-6
+    assert np.max(np.abs(b - g[f"randn_seed{seed}_n{n}_b"])) < 2e-6
+
+
+def test_ctor_draw_is_part_of_the_stream():
+    """The constructor consumes one [N,T,dc] draw before the first solve (mppi.py:146-148)."""
+    g = load("pendulum_T15_N256_fixed")
+    s = orc.TorchCpuStream(42)
+    n = 256 * 15
+    assert np.max(np.abs(s.randn(n).reshape(256, 15, 1) - g["ctor_eps"])) < 2e-6
+    assert np.max(np.abs(s.randn(n).reshape(256, 15, 1) - g["eps_0"])) < 2e-6
+
+
+def test_philox_restatement_statistics():
+    eps = orc.philox_normal(42, 1, 0, 4096, 50, 2, [0.5, 0.1])
+    assert abs(eps[..., 0].std() - 0.5) < 0.01 and abs(eps[..., 1].std() - 0.1) < 0.002
+    assert abs(eps.mean()) < 0.005
+    # counter-based: a shard starting at 1000 reproduces rows 1000.. of the full draw
+    part = orc.philox_normal(42, 1, 1000, 64, 50, 2, [0.5, 0.1])
+    assert np.array_equal(part, eps[1000:1064])
