@@ -24,6 +24,7 @@ import torch.nn as nn
 from mppi_playground_amd import _capi
 from pi_mpc import _host
 from pi_mpc.native import resolve
+from pi_mpc.sharding import all_gather_summaries, shard_range
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -112,10 +113,7 @@ class MPPI(nn.Module):
                 raise RuntimeError("shard_samples=True needs torch.distributed to be initialised")
             self._world = dist.get_world_size(process_group)
             self._rank = dist.get_rank(process_group)
-            if num_samples % self._world != 0:
-                raise ValueError("num_samples must be divisible by the world size")
-        self._local_samples = num_samples // self._world
-        self._sample_offset = self._rank * self._local_samples
+        self._sample_offset, self._local_samples = shard_range(num_samples, self._world, self._rank)
 
         # ---- plugin recognition
         dyn, cst = resolve(dynamics), resolve(cost_func)
@@ -310,14 +308,8 @@ class MPPI(nn.Module):
         sharded = self._world > 1
         h.call("mppi_weights_reduce", lam, _ptr(self._summary) if sharded else None, st)
         summaries, nsh = None, 1
-        if sharded:
-            import torch.distributed as dist
-
-            if self._gathered is None:
-                self._gathered = torch.empty(self._world, self._summary.numel(), device=self._device,
-                                             dtype=self._dtype)
-            dist.all_gather_into_tensor(self._gathered, self._summary, group=self._pg)
-            summaries, nsh = self._gathered, self._world
+        if sharded:  # the only exchange of the solve: 4+T*dc floats per rank over RCCL/xGMI
+            summaries, nsh = all_gather_summaries(self._summary, self._pg), self._world
 
         # Steps 6-8: normalise, warm start, batch-1 rollout (src/pi_mpc/mppi.py:381-385,448-452)
         use_sg = self._use_sg_filter

@@ -1,0 +1,77 @@
+"""The N>1 path on CPU: two gloo ranks each own half of num_samples, build their shard summary (from
+oracle costs), exchange it with the product's one all_gather, and combine — the result must equal the
+unsharded oracle solve.  (The device kernels' side of the same contract is covered by
+tests/test_gpu_parity.py::test_shard_invariance_and_combine.)"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from helpers import CASES, load, oracle_problem, orc, rel_err
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, name, q):
+    import mppi_playground_amd  # noqa: F401
+    from pi_mpc.sharding import all_gather_summaries, combine_summaries, local_summary, shard_range
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cfg, g = CASES[name], load(name)
+        N, T = cfg["N"], cfg["T"]
+        lam = float(g["lambda_0"])
+        off, n = shard_range(N, world, rank)
+        # every rank evaluates only its block of the global sample range (threshold is global)
+        P = oracle_problem(cfg["model"], N, T, cfg.get("exploration", 0.0))
+        if cfg["model"] == "racing":
+            P.set_ref_path(g["ref_path_0"])
+        full = P.rollout_cost(g["x0_0"], g["mean_in_0"], g["eps_0"], want_U=True)
+        c, U = full["costs"][off:off + n], full["U"][off:off + n]
+        summ = torch.from_numpy(local_summary(c, U, lam))
+        gathered = all_gather_summaries(summ)
+        assert gathered.shape == (world, 4 + T * P.dc)
+        a, stats = combine_summaries(gathered.numpy(), lam)
+        if rank == 0:
+            w, st = orc.softmax_weights(full["costs"], lam)
+            a_ref = P.weighted_actions(w, g["mean_in_0"], g["eps_0"])
+            q.put((rel_err(a.reshape(T, -1), a_ref), abs(stats["cmin"] - st["cmin"]),
+                   abs(stats["sum_e"] - st["sum_e"]) / st["sum_e"], rel_err(a.reshape(T, -1), g["action_seq_0"])))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["nav2d_T30_N256_fixed_explore", "racing_T50_N512_fixed", "pendulum_T15_N256_fixed"])
+def test_two_rank_shard_combine(name):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    err_a, err_cmin, err_se, err_gold = q.get(timeout=10)
+    assert err_a < 2e-6 and err_cmin == 0.0 and err_se < 1e-6
+    assert err_gold < 5e-5  # against the reference fixture (softmax conditioning at lambda=1)
+
+
+def test_shard_range():
+    from pi_mpc.sharding import shard_range
+
+    assert shard_range(8388608, 8, 3) == (3 * 1048576, 1048576)
+    with pytest.raises(ValueError):
+        shard_range(10, 4, 0)
