@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--samples", type=int, default=1 << 20, help="samples per GPU")
     ap.add_argument("--horizon", type=int, default=50)
     ap.add_argument("--math", type=int, default=1, help="1 = fast-path math (default), 0 = library math")
+    ap.add_argument("--noise-regen", type=int, default=1,
+                    help="1 = regenerate the Philox noise in registers (default), 0 = materialise the noise tiles")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -66,6 +68,7 @@ def main():
     ctrl.set_cost_map(env._obstacle_map, env._lane_map)
     solver = ctrl.solver
     solver.set_option("math", args.math)
+    solver.set_option("noise_regen", args.noise_regen)
     state = env.reset()
     ref, _ = ctrl.calc_ref_trajectory(state, env.racing_center_path, 0, T, DL=0.1, lookahead_distance=3,
                                       reference_path_interval=0.85)
@@ -116,7 +119,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "racing kinematic-bicycle MPPI solve (BASELINE configs[2]/[3])",
                        "num_samples_per_gpu": N_local, "num_samples_total": N_total, "horizon": T,
-                       "lambda": 1.0, "noise": "device philox4x32-10", "math": "fast" if args.math else "library",
+                       "lambda": 1.0, "noise": "device philox4x32-10 (" + ("regenerated in registers" if args.noise_regen else "materialised tiles") + ")", "math": "fast" if args.math else "library",
                        "sharding": f"num_samples x{world}" if world > 1 else "none"},
             "solves_per_sec": solves_per_s,
             "roofline": {"bound": "hbm", "kernel": "rollout_cost_kernel<racing>", "achieved": achieved,

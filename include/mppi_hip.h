@@ -110,12 +110,19 @@ int mppi_set_reference(mppi_handle_t h, const float* ref_host, int rows, void* s
 /* `_previous_action_seq` (mppi.py:157,255,452).  on_device != 0: pointer is a device pointer. */
 int mppi_set_mean(mppi_handle_t h, const float* mean, int on_device, void* stream);
 int mppi_get_mean(mppi_handle_t h, float* mean_out, int on_device, void* stream);
-/* forward(state) argument (mppi.py:247-253), dim_state floats. */
+/* forward(state) argument (mppi.py:247-253), dim_state floats (copied). */
 int mppi_set_state(mppi_handle_t h, const float* x0, int on_device, void* stream);
+/* Zero-copy variant: the kernels read the state from the caller's device buffer, which must stay
+ * valid and unmodified until the work enqueued up to the next mppi_set_state/mppi_bind_state ran. */
+int mppi_bind_state(mppi_handle_t h, const float* x0_dev);
 
 /* Step 1 — `_noise_distribution.rsample` (mppi.py:261-263): eps ~ N(0, diag(sigma^2)) from the
  * device Philox4x32-10 stream, counter = (global sample index, float4 group, solve_idx): results
- * do not depend on how num_samples is sharded. */
+ * do not depend on how num_samples is sharded.  With option "noise_regen" = 1 (default) this only
+ * fixes the identity of the solve's noise: the rollout and reduction kernels regenerate it in
+ * registers and it is written to HBM only when an entry point needs the tiles
+ * (mppi_export_noise, mppi_rollout_samples); with "noise_regen" = 0 the tiles are written here and
+ * read back by both consumers (same values bit for bit). */
 int mppi_sample(mppi_handle_t h, uint32_t solve_idx, void* stream);
 /* Parity mode: load externally drawn noise eps[N][T][dc] (reference layout, device pointer)
  * into the tiled buffer (replaces mppi_sample for that solve). */
@@ -157,7 +164,8 @@ int mppi_rollout_actions(mppi_handle_t h, const float* actions_dev, int k, float
 int mppi_rollout_samples(mppi_handle_t h, const int64_t* idx_dev, int k, float* states_out_dev, void* stream);
 
 /* Tuning knobs (not in the reference): "math" 0 = library sin/cos/tan/fmod/div, 1 = range-checked
- * fast paths (default); "reduce_blocks" grid of the weighted reduction. */
+ * fast paths (default); "noise_regen" (see mppi_sample); "reduce_blocks" grid of the weighted
+ * reduction; "timing" (see mppi_get_timing). */
 int mppi_set_option(mppi_handle_t h, const char* key, int64_t value);
 /* Device time per stage from HIP event pairs recorded on the caller's stream around every stage call
  * since the last drain (no host synchronisation while recording): out[0..3] = mean ms of

@@ -19,7 +19,7 @@ SUMMARY_HEAD = 4
 SYMBOLS = [
     "mppi_version", "mppi_device_count", "mppi_last_error", "mppi_create", "mppi_destroy",
     "mppi_set_model_params", "mppi_upload_map", "mppi_set_reference", "mppi_set_mean", "mppi_get_mean",
-    "mppi_set_state", "mppi_sample", "mppi_inject_noise", "mppi_export_noise", "mppi_rollout_cost",
+    "mppi_set_state", "mppi_bind_state", "mppi_sample", "mppi_inject_noise", "mppi_export_noise", "mppi_rollout_cost",
     "mppi_get_costs", "mppi_set_costs", "mppi_weights_reduce", "mppi_finalize", "mppi_weights",
     "mppi_rollout_actions", "mppi_rollout_samples", "mppi_set_option", "mppi_get_timing",
 ]
@@ -63,6 +63,7 @@ def load():
     lib.mppi_set_mean.argtypes = [vp, vp, i32, vp]
     lib.mppi_get_mean.argtypes = [vp, vp, i32, vp]
     lib.mppi_set_state.argtypes = [vp, vp, i32, vp]
+    lib.mppi_bind_state.argtypes = [vp, vp]
     lib.mppi_sample.argtypes = [vp, u32, vp]
     lib.mppi_inject_noise.argtypes = [vp, vp, vp]
     lib.mppi_export_noise.argtypes = [vp, vp, vp, vp]

@@ -22,8 +22,21 @@ struct MppiSolver {
     // device buffers
     float4* noise = nullptr;
     float* costs = nullptr;
-    unsigned* min_key = nullptr;
-    float* x0 = nullptr;
+    unsigned* min_key = nullptr;   // two slots, toggled per rollout (no memset between solves)
+    int min_slot = 0;
+    float* x0 = nullptr;           // owned copy of the state ...
+    const float* x0_cur = nullptr; // ... or a borrowed device pointer (mppi_bind_state)
+    // pinned staging ring for small host -> device uploads without a stream synchronisation
+    static constexpr int RING = 8;
+    float* stage[RING] = {};
+    hipEvent_t stage_ev[RING] = {};
+    size_t stage_floats = 0;
+    int stage_next = 0;
+    // noise identity of the current solve and whether the tiles hold it
+    GenCtx gen{};
+    int noise_regen = 1;           // 1: Philox noise is regenerated in the kernels, never stored
+    bool tiles_valid = false;      // the noise tiles hold the current solve's noise
+    bool injected = false;         // ... because it was injected (cannot be regenerated)
     float* mean = nullptr;
     float* ref = nullptr;
     int ref_cap = 0;
@@ -191,9 +204,13 @@ int mppi_create(const MppiConfig* cfg, mppi_handle_t* out) {
     HIP_TRY(h, hipMalloc(&h->noise, noise_bytes));
     HIP_TRY(h, hipMemset(h->noise, 0, noise_bytes));
     HIP_TRY(h, hipMalloc(&h->costs, sizeof(float) * (size_t)d.N));
-    HIP_TRY(h, hipMalloc(&h->min_key, sizeof(unsigned)));
+    HIP_TRY(h, hipMalloc(&h->min_key, 2 * sizeof(unsigned)));
+    HIP_TRY(h, hipMemset(h->min_key, 0xFF, 2 * sizeof(unsigned)));
     HIP_TRY(h, hipMalloc(&h->x0, sizeof(float) * MPPI_MAX_DIM_STATE));
     HIP_TRY(h, hipMemset(h->x0, 0, sizeof(float) * MPPI_MAX_DIM_STATE));
+    h->x0_cur = h->x0;
+    h->gen = GenCtx{(uint32_t)cfg->seed, (uint32_t)(cfg->seed >> 32), 0u};
+    d.dc = md.dc;
     HIP_TRY(h, hipMalloc(&h->mean, sizeof(float) * (size_t)d.row));
     HIP_TRY(h, hipMemset(h->mean, 0, sizeof(float) * (size_t)d.row));  // mppi.py:157
     const int max_blocks = 2048;
@@ -211,6 +228,10 @@ int mppi_destroy(mppi_handle_t h) {
     (void)hipFree(h->mean); (void)hipFree(h->ref); (void)hipFree(h->partials); (void)hipFree(h->heads);
     (void)hipFree(h->summary); (void)hipFree(h->map_cells[0]); (void)hipFree(h->map_cells[1]);
     (void)hipFree(h->map_fused);
+    for (int i = 0; i < MppiSolver::RING; ++i) {
+        if (h->stage[i]) (void)hipHostFree(h->stage[i]);
+        if (h->stage_ev[i]) (void)hipEventDestroy(h->stage_ev[i]);
+    }
     for (auto& pool : h->ev_pool) for (auto& e : pool) if (e) (void)hipEventDestroy(e);
     delete h;
     return MPPI_OK;
@@ -251,34 +272,65 @@ int mppi_upload_map(mppi_handle_t h, int slot, const uint8_t* cells, int nx, int
     return MPPI_OK;
 }
 
+// Pinned staging slot of at least `floats` floats; waits (rarely) for the slot's previous upload.
+static int stage_slot(mppi_handle_t h, size_t floats, float** out, hipEvent_t* ev) {
+    if (floats > h->stage_floats) {
+        for (int i = 0; i < MppiSolver::RING; ++i) {
+            if (h->stage_ev[i]) HIP_TRY(h, hipEventSynchronize(h->stage_ev[i]));
+            if (h->stage[i]) { (void)hipHostFree(h->stage[i]); h->stage[i] = nullptr; }
+            HIP_TRY(h, hipHostMalloc((void**)&h->stage[i], sizeof(float) * floats, hipHostMallocDefault));
+            if (!h->stage_ev[i]) HIP_TRY(h, hipEventCreateWithFlags(&h->stage_ev[i], hipEventDisableTiming));
+        }
+        h->stage_floats = floats;
+    }
+    const int i = h->stage_next;
+    h->stage_next = (i + 1) % MppiSolver::RING;
+    HIP_TRY(h, hipEventSynchronize(h->stage_ev[i]));  // no-op unless 8 uploads are still in flight
+    *out = h->stage[i];
+    *ev = h->stage_ev[i];
+    return MPPI_OK;
+}
+
+// host -> device upload of a few floats through the pinned ring: asynchronous, no host wait
+static int upload_small(mppi_handle_t h, float* dst_dev, const float* src_host, size_t floats, hipStream_t s) {
+    float* st = nullptr; hipEvent_t ev = nullptr;
+    if (int rc = stage_slot(h, std::max<size_t>(floats, 64), &st, &ev)) return rc;
+    std::memcpy(st, src_host, sizeof(float) * floats);
+    HIP_TRY(h, hipMemcpyAsync(dst_dev, st, sizeof(float) * floats, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipEventRecord(ev, s));
+    return MPPI_OK;
+}
+
 int mppi_set_reference(mppi_handle_t h, const float* ref, int rows, void* stream) {
     if (!h || !ref || rows < 1) return fail(h, MPPI_E_INVALID, "bad reference");
     hipStream_t s = (hipStream_t)stream;
     if (rows > h->ref_cap) {
-        if (h->ref) (void)hipFree(h->ref);
+        if (h->ref) { HIP_TRY(h, hipDeviceSynchronize()); (void)hipFree(h->ref); }
         h->ref = nullptr;
         HIP_TRY(h, hipMalloc(&h->ref, sizeof(float) * 8 * (size_t)rows));
         h->ref_cap = rows;
     }
-    std::vector<float> buf((size_t)rows * 8);
+    float* st = nullptr; hipEvent_t ev = nullptr;
+    if (int rc = stage_slot(h, (size_t)rows * 8, &st, &ev)) return rc;
     for (int i = 0; i < rows; ++i) {
-        float* o = &buf[(size_t)i * 8];
+        float* o = st + (size_t)i * 8;
         o[0] = ref[4 * i]; o[1] = ref[4 * i + 1]; o[2] = ref[4 * i + 2]; o[3] = ref[4 * i + 3];
         o[4] = sinf(o[2]); o[5] = cosf(o[2]);  // torch.sin/cos of the fp32 scalar, racing.py:127-139
         o[6] = o[7] = 0.0f;
     }
-    HIP_TRY(h, hipMemcpyAsync(h->ref, buf.data(), sizeof(float) * buf.size(), hipMemcpyHostToDevice, s));
-    HIP_TRY(h, hipStreamSynchronize(s));  // buf is a stack-lifetime staging buffer
+    HIP_TRY(h, hipMemcpyAsync(h->ref, st, sizeof(float) * 8 * (size_t)rows, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipEventRecord(ev, s));
     h->ctx.ref = h->ref;
     h->ctx.ref_rows = rows;
     return MPPI_OK;
 }
 
+// device <-> device / device -> host copies of small vectors
 static int copy_small(mppi_handle_t h, void* dst, const void* src, size_t bytes, bool dst_dev, bool src_dev, hipStream_t s) {
-    const hipMemcpyKind kind = dst_dev ? (src_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice)
-                                       : (src_dev ? hipMemcpyDeviceToHost : hipMemcpyHostToHost);
+    if (dst_dev && !src_dev) return upload_small(h, (float*)dst, (const float*)src, bytes / sizeof(float), s);
+    const hipMemcpyKind kind = dst_dev ? hipMemcpyDeviceToDevice : (src_dev ? hipMemcpyDeviceToHost : hipMemcpyHostToHost);
     HIP_TRY(h, hipMemcpyAsync(dst, src, bytes, kind, s));
-    if (!dst_dev || !src_dev) HIP_TRY(h, hipStreamSynchronize(s));
+    if (!dst_dev) HIP_TRY(h, hipStreamSynchronize(s));
     return MPPI_OK;
 }
 
@@ -292,18 +344,38 @@ int mppi_get_mean(mppi_handle_t h, float* out, int on_device, void* stream) {
 }
 int mppi_set_state(mppi_handle_t h, const float* x0, int on_device, void* stream) {
     if (!h || !x0) return fail(h, MPPI_E_INVALID, "null");
+    h->x0_cur = h->x0;
     return copy_small(h, h->x0, x0, sizeof(float) * (size_t)h->ds, true, on_device != 0, (hipStream_t)stream);
+}
+int mppi_bind_state(mppi_handle_t h, const float* x0_dev) {
+    if (!h || !x0_dev) return fail(h, MPPI_E_INVALID, "null");
+    h->x0_cur = x0_dev;
+    return MPPI_OK;
+}
+
+static int materialize_tiles(mppi_handle_t h, hipStream_t s) {
+    const unsigned grid = (unsigned)((h->d.tiles + 3) / 4);
+    hipLaunchKernelGGL(sample_kernel, dim3(grid), dim3(BLOCK), 0, s, h->noise, h->d, h->gen);
+    HIP_TRY(h, hipGetLastError());
+    h->tiles_valid = true;
+    return MPPI_OK;
 }
 
 int mppi_sample(mppi_handle_t h, uint32_t solve_idx, void* stream) {
     if (!h) return MPPI_E_INVALID;
     hipStream_t s = (hipStream_t)stream;
+    h->gen.solve_idx = solve_idx;
+    h->injected = false;
+    h->tiles_valid = false;
+    if (h->noise_regen) return MPPI_OK;  // consumers regenerate eps(seed, solve, i, t, k) in registers
     StageTimer tm(h, 0, s);
-    const unsigned grid = (unsigned)((h->d.tiles + 3) / 4);
-    hipLaunchKernelGGL(sample_kernel, dim3(grid), dim3(BLOCK), 0, s, h->noise, h->d, (uint32_t)h->cfg.seed,
-                       (uint32_t)(h->cfg.seed >> 32), solve_idx);
-    HIP_TRY(h, hipGetLastError());
-    return MPPI_OK;
+    return materialize_tiles(h, s);
+}
+
+// the tiles must hold the current noise for the layout/gather entry points
+static int need_tiles(mppi_handle_t h, hipStream_t s) {
+    if (h->tiles_valid) return MPPI_OK;
+    return materialize_tiles(h, s);
 }
 
 int mppi_inject_noise(mppi_handle_t h, const float* eps_dev, void* stream) {
@@ -312,12 +384,15 @@ int mppi_inject_noise(mppi_handle_t h, const float* eps_dev, void* stream) {
     const dim3 grid((unsigned)h->d.tiles, (unsigned)((h->d.row + CONV_COLS - 1) / CONV_COLS));
     hipLaunchKernelGGL(inject_kernel, grid, dim3(BLOCK), 0, s, eps_dev, h->noise, h->d);
     HIP_TRY(h, hipGetLastError());
+    h->injected = true;
+    h->tiles_valid = true;
     return MPPI_OK;
 }
 
 int mppi_export_noise(mppi_handle_t h, float* eps_out, float* act_out, void* stream) {
     if (!h) return MPPI_E_INVALID;
     hipStream_t s = (hipStream_t)stream;
+    if (int rc = need_tiles(h, s)) return rc;
     const dim3 grid((unsigned)h->d.tiles, (unsigned)((h->d.row + CONV_COLS - 1) / CONV_COLS));
     hipLaunchKernelGGL(export_kernel, grid, dim3(BLOCK), 0, s, h->noise, h->mean, eps_out, act_out, h->d);
     HIP_TRY(h, hipGetLastError());
@@ -329,11 +404,21 @@ int mppi_rollout_cost(mppi_handle_t h, void* stream) {
     if (int rc = check_ready(h)) return rc;
     hipStream_t s = (hipStream_t)stream;
     StageTimer tm(h, 1, s);
-    HIP_TRY(h, hipMemsetAsync(h->min_key, 0xFF, sizeof(unsigned), s));
+    const bool gen = h->noise_regen && !h->injected;
+    if (!gen && !h->tiles_valid) return fail(h, MPPI_E_STATE, "no noise: call mppi_sample or mppi_inject_noise first");
+    h->min_slot ^= 1;
+    unsigned* mk = h->min_key + h->min_slot;
+    unsigned* mk_next = h->min_key + (h->min_slot ^ 1);
     const unsigned grid = (unsigned)((h->d.tiles + 3) / 4);
 #define CALL_ROLLOUT(MODEL, FASTV)                                                                    \
-    hipLaunchKernelGGL((rollout_cost_kernel<MODEL, FASTV>), dim3(grid), dim3(BLOCK), 0, s, h->noise, h->mean, \
-                       h->x0, h->costs, h->min_key, h->d, h->ctx)
+    do {                                                                                              \
+        if (gen)                                                                                      \
+            hipLaunchKernelGGL((rollout_cost_kernel<MODEL, FASTV, true>), dim3(grid), dim3(BLOCK), 0, s, h->noise, \
+                               h->mean, h->x0_cur, h->costs, mk, mk_next, h->d, h->gen, h->ctx);     \
+        else                                                                                          \
+            hipLaunchKernelGGL((rollout_cost_kernel<MODEL, FASTV, false>), dim3(grid), dim3(BLOCK), 0, s, h->noise, \
+                               h->mean, h->x0_cur, h->costs, mk, mk_next, h->d, h->gen, h->ctx);     \
+    } while (0)
     MPPI_DISPATCH(h, CALL_ROLLOUT);
 #undef CALL_ROLLOUT
     HIP_TRY(h, hipGetLastError());
@@ -357,9 +442,9 @@ int mppi_set_costs(mppi_handle_t h, const float* src, int on_device, void* strea
     if (!h || !src) return fail(h, MPPI_E_INVALID, "null");
     hipStream_t s = (hipStream_t)stream;
     if (int rc = copy_small(h, h->costs, src, sizeof(float) * (size_t)h->d.N, true, on_device != 0, s)) return rc;
-    HIP_TRY(h, hipMemsetAsync(h->min_key, 0xFF, sizeof(unsigned), s));
+    HIP_TRY(h, hipMemsetAsync(h->min_key + h->min_slot, 0xFF, sizeof(unsigned), s));
     const unsigned grid = (unsigned)std::min<int64_t>((h->d.N + BLOCK - 1) / BLOCK, 1024);
-    hipLaunchKernelGGL(min_cost_kernel, dim3(grid), dim3(BLOCK), 0, s, h->costs, h->d.N, h->min_key);
+    hipLaunchKernelGGL(min_cost_kernel, dim3(grid), dim3(BLOCK), 0, s, h->costs, h->d.N, h->min_key + h->min_slot);
     HIP_TRY(h, hipGetLastError());
     return MPPI_OK;
 }
@@ -371,14 +456,18 @@ int mppi_weights_reduce(mppi_handle_t h, float lambda, float* summary_out_dev, v
     int64_t blocks = std::min<int64_t>(h->reduce_blocks, (h->d.tiles + 3) / 4);
     blocks = std::max<int64_t>(1, std::min<int64_t>(blocks, 2048));
     const dim3 grid((unsigned)blocks, (unsigned)h->nchunks);
-    if (h->CH == 8)
-        hipLaunchKernelGGL((weights_reduce_kernel<8>), grid, dim3(BLOCK), 0, s, h->noise, h->mean, h->costs,
-                           h->min_key, h->partials, h->heads, h->d, lambda);
-    else
-        hipLaunchKernelGGL((weights_reduce_kernel<32>), grid, dim3(BLOCK), 0, s, h->noise, h->mean, h->costs,
-                           h->min_key, h->partials, h->heads, h->d, lambda);
+    const bool gen = h->noise_regen && !h->injected;
+    if (!gen && !h->tiles_valid) return fail(h, MPPI_E_STATE, "no noise: call mppi_sample or mppi_inject_noise first");
+    const unsigned* mk = h->min_key + h->min_slot;
+#define CALL_REDUCE(CHV, GENV)                                                                        \
+    hipLaunchKernelGGL((weights_reduce_kernel<CHV, GENV>), grid, dim3(BLOCK), 0, s, h->noise, h->mean, h->costs, mk, \
+                       h->partials, h->heads, h->d, h->gen, lambda)
+    if (h->CH == 8) { if (gen) CALL_REDUCE(8, true); else CALL_REDUCE(8, false); }
+    else { if (gen) CALL_REDUCE(32, true); else CALL_REDUCE(32, false); }
+#undef CALL_REDUCE
     HIP_TRY(h, hipGetLastError());
-    hipLaunchKernelGGL(summarize_kernel, dim3(1), dim3(BLOCK), 0, s, h->partials, h->heads, h->min_key, (int)blocks,
+    const unsigned sgrid = (unsigned)((h->colsp + SUM_COLS - 1) / SUM_COLS + 1);
+    hipLaunchKernelGGL(summarize_kernel, dim3(sgrid), dim3(BLOCK), 0, s, h->partials, h->heads, mk, (int)blocks,
                        h->colsp, h->d.row, h->summary);
     HIP_TRY(h, hipGetLastError());
     if (summary_out_dev)
@@ -398,7 +487,7 @@ int mppi_finalize(mppi_handle_t h, const float* summaries_dev, int num_shards, f
     const size_t shmem = sizeof(float) * (size_t)h->d.row;
 #define CALL_FINALIZE(MODEL, FASTV)                                                                   \
     hipLaunchKernelGGL((finalize_kernel<MODEL, FASTV>), dim3(1), dim3(BLOCK), shmem, s, sums, num_shards, lambda, \
-                       h->d.row, h->d.T, h->x0, store_mean ? h->mean : (float*)nullptr, action_out, state_out, \
+                       h->d.row, h->d.T, h->x0_cur, store_mean ? h->mean : (float*)nullptr, action_out, state_out, \
                        stats_out, h->ctx)
     MPPI_DISPATCH(h, CALL_FINALIZE);
 #undef CALL_FINALIZE
@@ -422,7 +511,7 @@ int mppi_rollout_actions(mppi_handle_t h, const float* actions_dev, int k, float
     const unsigned grid = (unsigned)((k + WAVE - 1) / WAVE);
 #define CALL_RA(MODEL, FASTV)                                                                         \
     hipLaunchKernelGGL((rollout_actions_kernel<MODEL, FASTV>), dim3(grid), dim3(WAVE), 0, s, actions_dev, k, h->d.T, \
-                       h->x0, states_out, h->ctx)
+                       h->x0_cur, states_out, h->ctx)
     MPPI_DISPATCH(h, CALL_RA);
 #undef CALL_RA
     HIP_TRY(h, hipGetLastError());
@@ -433,10 +522,11 @@ int mppi_rollout_samples(mppi_handle_t h, const int64_t* idx_dev, int k, float* 
     if (!h || !idx_dev || !states_out || k < 1) return fail(h, MPPI_E_INVALID, "bad rollout_samples arguments");
     if (int rc = check_ready(h)) return rc;
     hipStream_t s = (hipStream_t)stream;
+    if (int rc = need_tiles(h, s)) return rc;
     const unsigned grid = (unsigned)((k + WAVE - 1) / WAVE);
 #define CALL_RS(MODEL, FASTV)                                                                         \
     hipLaunchKernelGGL((rollout_samples_kernel<MODEL, FASTV>), dim3(grid), dim3(WAVE), 0, s, h->noise, h->mean, \
-                       idx_dev, k, h->x0, states_out, h->d, h->ctx)
+                       idx_dev, k, h->x0_cur, states_out, h->d, h->ctx)
     MPPI_DISPATCH(h, CALL_RS);
 #undef CALL_RS
     HIP_TRY(h, hipGetLastError());
@@ -449,6 +539,7 @@ int mppi_set_option(mppi_handle_t h, const char* key, int64_t value) {
     if (k == "math") { h->math_fast = value ? 1 : 0; return MPPI_OK; }
     if (k == "reduce_blocks") { h->reduce_blocks = (int)std::max<int64_t>(1, std::min<int64_t>(value, 2048)); return MPPI_OK; }
     if (k == "timing") { h->timing = value ? 1 : 0; return MPPI_OK; }
+    if (k == "noise_regen") { h->noise_regen = value ? 1 : 0; h->tiles_valid = h->tiles_valid && h->injected; return MPPI_OK; }
     return fail(h, MPPI_E_INVALID, "unknown option " + k);
 }
 

@@ -22,8 +22,13 @@ struct Dims {
     int64_t tiles;          // ceil(N/64)
     int64_t sample_offset;  // global index of local sample 0
     int64_t inherit_count;  // global threshold of mppi.py:266
-    int32_t T, R, row;      // horizon, float4 groups per trajectory, row = T*dc
+    int32_t T, R, row, dc;  // horizon, float4 groups per trajectory, row = T*dc, dim_control
     float u_min[MPPI_MAX_DIM_CONTROL], u_max[MPPI_MAX_DIM_CONTROL], sigma[MPPI_MAX_DIM_CONTROL];
+};
+
+// Identity of the noise of one solve: eps[i][t][k] is a pure function of (seed, solve, global i, t, k).
+struct GenCtx {
+    uint32_t seed_lo, seed_hi, solve_idx;
 };
 
 __device__ __forceinline__ unsigned float_to_key(float f) {  // order-preserving map for atomicMin
@@ -46,29 +51,40 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Step 1: eps ~ N(0, diag(sigma^2)) written as lane-major tiles.  HBM-write bound:
-// 16 B per lane per Philox call, one 1 KiB store per wave instruction.
-__global__ __launch_bounds__(BLOCK) void sample_kernel(float4* __restrict__ noise, Dims d, uint32_t seed_lo,
-                                                       uint32_t seed_hi, uint32_t solve_idx) {
+// Step 1: eps ~ N(0, diag(sigma^2)).  gen_noise4() is THE definition of the device noise: float4
+// group r of global sample gi.  It is used by sample_kernel (materialise the lane-major tiles) and,
+// in "regen" mode, directly by the rollout and reduction kernels, which then never touch HBM for
+// the noise (Philox + Box-Muller is ~25 VALU per normal, cheaper than a 16 B/lane HBM round trip).
+__device__ __forceinline__ float4 gen_noise4(uint64_t gi, int r, const GenCtx& g, const Dims& d) {
+    const u32x4 x = philox4x32_10((uint32_t)gi, (uint32_t)(gi >> 32), (uint32_t)r, g.solve_idx, g.seed_lo, g.seed_hi);
+    float z[4];
+    box_muller(x.x, x.y, z[0], z[1]);
+    box_muller(x.z, x.w, z[2], z[3]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int f = 4 * r + j;
+        const float sg = (d.dc == 1) ? d.sigma[0] : d.sigma[f & 1];  // dc in {1, 2}
+        z[j] = (f < d.row) ? z[j] * sg : 0.0f;
+    }
+    return make_float4(z[0], z[1], z[2], z[3]);
+}
+
+// HBM-write bound: 16 B per lane per Philox call, one 1 KiB store per wave instruction.
+__global__ __launch_bounds__(BLOCK) void sample_kernel(float4* __restrict__ noise, Dims d, GenCtx g) {
     const int lane = threadIdx.x & 63;
     const int64_t tile = (int64_t)blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6);
     if (tile >= d.tiles) return;
     const uint64_t gi = (uint64_t)(d.sample_offset + tile * 64 + lane);
     float4* out = noise + tile * d.R * 64 + lane;
-    const int dc = d.row / d.T;
-    for (int r = 0; r < d.R; ++r) {
-        const u32x4 x = philox4x32_10((uint32_t)gi, (uint32_t)(gi >> 32), (uint32_t)r, solve_idx, seed_lo, seed_hi);
-        float z[4];
-        box_muller(x.x, x.y, z[0], z[1]);
-        box_muller(x.z, x.w, z[2], z[3]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int f = 4 * r + j;
-            const float sg = (dc == 1) ? d.sigma[0] : d.sigma[f & 1];  // dc in {1, 2}
-            z[j] = (f < d.row) ? z[j] * sg : 0.0f;
-        }
-        out[(int64_t)r * 64] = make_float4(z[0], z[1], z[2], z[3]);
-    }
+    for (int r = 0; r < d.R; ++r) out[(int64_t)r * 64] = gen_noise4(gi, r, g, d);
+}
+
+// One float4 group of a lane's noise row: from the tiles (GEN=false) or regenerated (GEN=true).
+template <bool GEN>
+__device__ __forceinline__ float4 noise_group(const float4* __restrict__ np, int r, uint64_t gi, const GenCtx& g,
+                                              const Dims& d) {
+    if (GEN) return gen_noise4(gi, r, g, d);
+    return np[(int64_t)r * 64];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -77,10 +93,10 @@ __global__ __launch_bounds__(BLOCK) void sample_kernel(float4* __restrict__ nois
 //
 // trajectory_cost(): one lane walks one trajectory.  `np` points at the lane's first float4 of the
 // tile; consecutive groups are 64 float4 apart.
-template <int MODEL, bool FAST>
-__device__ __forceinline__ float trajectory_cost(const float4* __restrict__ np, const float* __restrict__ mean,
-                                                 const float* __restrict__ x0, const Dims& d, const ModelCtx& ctx,
-                                                 bool inherit, bool& bad) {
+template <int MODEL, bool FAST, bool GEN>
+__device__ __forceinline__ float trajectory_cost(const float4* __restrict__ np, uint64_t gi, const GenCtx& gen,
+                                                 const float* __restrict__ mean, const float* __restrict__ x0,
+                                                 const Dims& d, const ModelCtx& ctx, bool inherit, bool& bad) {
     using M = Model<MODEL, FAST>;
     constexpr int DS = M::DS, DC = M::DC, SPG = 4 / DC;
     float s[DS], pu[DC], pl[DC];
@@ -90,9 +106,9 @@ __device__ __forceinline__ float trajectory_cost(const float4* __restrict__ np, 
     for (int k = 0; k < DC; ++k) pu[k] = pl[k] = 0.0f;
     float acc = 0.0f;
     int t = 0;
-    float4 e = np[0];
+    float4 e = noise_group<GEN>(np, 0, gi, gen, d);
     for (int r = 0; r < d.R; ++r) {
-        const float4 en = (r + 1 < d.R) ? np[(int64_t)(r + 1) * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 en = (r + 1 < d.R) ? noise_group<GEN>(np, r + 1, gi, gen, d) : make_float4(0.f, 0.f, 0.f, 0.f);
         const float ev[4] = {e.x, e.y, e.z, e.w};
 #pragma unroll
         for (int g = 0; g < SPG; ++g) {
@@ -129,26 +145,32 @@ __device__ __forceinline__ float trajectory_cost(const float4* __restrict__ np, 
     return acc + term;
 }
 
-template <int MODEL, bool FAST>
+template <int MODEL, bool FAST, bool GEN>
 __global__ __launch_bounds__(BLOCK) void rollout_cost_kernel(const float4* __restrict__ noise,
                                                              const float* __restrict__ mean,
                                                              const float* __restrict__ x0,
                                                              float* __restrict__ costs,
-                                                             unsigned* __restrict__ min_key, Dims d, ModelCtx ctx) {
+                                                             unsigned* __restrict__ min_key,
+                                                             unsigned* __restrict__ next_min_key, Dims d, GenCtx gen,
+                                                             ModelCtx ctx) {
     __shared__ float s_min[BLOCK / WAVE];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int64_t tile = (int64_t)blockIdx.x * (BLOCK / WAVE) + wid;
+    // the minimum key is double-buffered: this launch accumulates into `min_key` (reset by the
+    // previous launch) and resets the other slot for the next one -> no memset between solves
+    if (blockIdx.x == 0 && threadIdx.x == 0) *next_min_key = 0xFFFFFFFFu;
     float total = INFINITY;
     if (tile < d.tiles) {
         const int64_t i = tile * 64 + lane;
+        const uint64_t gi = (uint64_t)(d.sample_offset + i);
         const bool inherit = (d.sample_offset + i) < d.inherit_count;
         const float4* np = noise + tile * d.R * 64 + lane;
         bool bad = false;
-        total = trajectory_cost<MODEL, FAST>(np, mean, x0, d, ctx, inherit, bad);
+        total = trajectory_cost<MODEL, FAST, GEN>(np, gi, gen, mean, x0, d, ctx, inherit, bad);
         if (FAST) {
             if (bad) {  // a fast path left its validity range: redo this lane with the library math
                 bool ignore = false;
-                total = trajectory_cost<MODEL, false>(np, mean, x0, d, ctx, inherit, ignore);
+                total = trajectory_cost<MODEL, false, GEN>(np, gi, gen, mean, x0, d, ctx, inherit, ignore);
             }
         }
         if (i < d.N) costs[i] = total;
@@ -168,53 +190,35 @@ __global__ __launch_bounds__(BLOCK) void rollout_cost_kernel(const float4* __res
 // ------------------------------------------------------------------------------------------
 // Steps 5-6: e_i = exp((-c_i)/lambda - max_j(-c_j)/lambda) and A = sum_i e_i * clamp(mean + eps_i)
 // (mppi.py:376-384, un-normalised).  Each lane accumulates its own trajectories over the tiles its
-// wave owns in NACC registers, then a butterfly reduce-scatter combines the 64 lanes with
-// NACC-1 (+ log) shuffles instead of 6*NACC.  Tiles whose 64 weights are all exactly zero are
-// skipped without touching their noise (exact: they contribute 0).
-template <int NACC>
-__device__ __forceinline__ void wave_reduce_scatter(float (&a)[NACC], int lane) {
-    int cur = NACC;
-#pragma unroll
-    for (int mask = 32; mask >= 1; mask >>= 1) {
-        if (cur > 1) {
-            const int half = cur >> 1;
-            const bool hi = (lane & mask) != 0;
-#pragma unroll
-            for (int j = 0; j < half; ++j) {
-                const float send = hi ? a[j] : a[j + half];
-                const float keep = hi ? a[j + half] : a[j];
-                a[j] = keep + __shfl_xor(send, mask);
-            }
-            cur = half;
-        } else {
-            a[0] += __shfl_xor(a[0], mask);
-        }
-    }
-}
-
+// wave owns in NACC registers; the 64 lanes are then combined through a padded LDS tile, 32
+// accumulators at a time (compact code: a fully unrolled register butterfly is ~40 KB of
+// straight-line instructions executed once per wave and ran instruction-fetch bound).  Tiles whose
+// 64 weights are all exactly zero are skipped without touching their noise (exact: they add 0).
 // partials layout: [gridDim.x][colsp] with colsp = gridDim.y * CH * 4; heads: [gridDim.x][4]
-template <int CH>  // float4 groups per column chunk (8 or 32)
+template <int CH, bool GEN>  // float4 groups per column chunk (8 or 32)
 __global__ __launch_bounds__(BLOCK) void weights_reduce_kernel(const float4* __restrict__ noise,
                                                                const float* __restrict__ mean,
                                                                const float* __restrict__ costs,
                                                                const unsigned* __restrict__ min_key,
                                                                float* __restrict__ partials,
-                                                               float* __restrict__ heads, Dims d, float lambda) {
+                                                               float* __restrict__ heads, Dims d, GenCtx gen,
+                                                               float lambda) {
     constexpr int NACC = CH * 4;
-    __shared__ float s_cols[BLOCK / WAVE][NACC];
-    __shared__ float s_head[BLOCK / WAVE][4];
+    constexpr int NW = BLOCK / WAVE;
+    __shared__ float s_red[NW][32][WAVE + 1];
+    __shared__ float s_cols[NW][NACC];
+    __shared__ float s_head[NW][4];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int r0 = blockIdx.y * CH;  // first float4 group of this column chunk
     const int nr = min(CH, d.R - r0);
-    const int dc = d.row / d.T;
     const float cmin = key_to_float(*min_key);
     const float xmax = (-cmin) / lambda;
     float acc[NACC];
 #pragma unroll
     for (int j = 0; j < NACC; ++j) acc[j] = 0.0f;
     float se = 0.0f, se2 = 0.0f, sec = 0.0f;
-    const int64_t wave_id = (int64_t)blockIdx.x * (BLOCK / WAVE) + wid;
-    const int64_t nwaves = (int64_t)gridDim.x * (BLOCK / WAVE);
+    const int64_t wave_id = (int64_t)blockIdx.x * NW + wid;
+    const int64_t nwaves = (int64_t)gridDim.x * NW;
     for (int64_t tile = wave_id; tile < d.tiles; tile += nwaves) {
         const int64_t i = tile * 64 + lane;
         float e = 0.0f, c = 0.0f;
@@ -226,19 +230,21 @@ __global__ __launch_bounds__(BLOCK) void weights_reduce_kernel(const float4* __r
         se += e;
         se2 = fmaf(e, e, se2);
         sec = fmaf(e, c, sec);
+        const uint64_t gi = (uint64_t)(d.sample_offset + i);
         const bool inherit = (d.sample_offset + i) < d.inherit_count;
-        const float4* np = noise + (tile * d.R + r0) * 64 + lane;
+        const float4* np = noise + (tile * d.R) * 64 + lane;
 #pragma unroll
         for (int r = 0; r < CH; ++r) {
             if (r < nr) {
-                const float4 n4 = np[(int64_t)r * 64];
+                const float4 n4 = noise_group<GEN>(np, r0 + r, gi, gen, d);
                 const float nv[4] = {n4.x, n4.y, n4.z, n4.w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int f = 4 * (r0 + r) + j;
                     if (f < d.row) {
-                        const int k = (dc == 1) ? 0 : (f & 1);
-                        const float m = inherit ? mean[f] : 0.0f;
+                        const int k = (d.dc == 1) ? 0 : (f & 1);
+                        const float mv = mean[f];
+                        const float m = inherit ? mv : 0.0f;
                         const float u = clampf(m + nv[j], d.u_min[k], d.u_max[k]);
                         acc[4 * r + j] = fmaf(e, u, acc[4 * r + j]);
                     }
@@ -246,61 +252,82 @@ __global__ __launch_bounds__(BLOCK) void weights_reduce_kernel(const float4* __r
             }
         }
     }
-    wave_reduce_scatter<NACC>(acc, lane);
+    // cross-lane reduction, 32 accumulators per pass: every lane stores its 32 values as a column of
+    // s_red[wid][j][lane]; lane l then sums row j = l & 31 over lanes [32*(l>>5), +32) (row stride 65
+    // floats: conflict-free), and the two halves are added with one shuffle.
+#pragma unroll
+    for (int p = 0; p < NACC / 32; ++p) {
+#pragma unroll
+        for (int j = 0; j < 32; ++j) s_red[wid][j][lane] = acc[p * 32 + j];
+        __builtin_amdgcn_wave_barrier();
+        const float* rowp = &s_red[wid][lane & 31][(lane >> 5) * 32];
+        float v = 0.0f;
+        for (int k = 0; k < 32; ++k) v += rowp[k];
+        v += __shfl_xor(v, 32);
+        if (lane < 32) s_cols[wid][p * 32 + lane] = v;
+        __builtin_amdgcn_wave_barrier();
+    }
     se = wave_sum(se);
     se2 = wave_sum(se2);
     sec = wave_sum(sec);
-    // after the butterfly lane l holds columns [l*NACC/64, (l+1)*NACC/64) when NACC >= 64, and
-    // column l >> (6 - log2 NACC) (replicated) when NACC < 64
-    if (NACC >= 64) {
-        constexpr int PER = NACC / 64 > 0 ? NACC / 64 : 1;
-#pragma unroll
-        for (int j = 0; j < PER; ++j) s_cols[wid][lane * PER + j] = acc[j];
-    } else {
-        constexpr int REP = 64 / (NACC < 64 ? NACC : 64);
-        if ((lane % REP) == 0) s_cols[wid][lane / REP] = acc[0];
-    }
     if (lane == 0) { s_head[wid][0] = se; s_head[wid][1] = se2; s_head[wid][2] = sec; s_head[wid][3] = 0.f; }
     __syncthreads();
     const int colsp = gridDim.y * NACC;
     for (int cidx = threadIdx.x; cidx < NACC; cidx += BLOCK) {
         float v = 0.0f;
 #pragma unroll
-        for (int w = 0; w < BLOCK / WAVE; ++w) v += s_cols[w][cidx];
+        for (int w = 0; w < NW; ++w) v += s_cols[w][cidx];
         partials[(int64_t)blockIdx.x * colsp + blockIdx.y * NACC + cidx] = v;
     }
     if (blockIdx.y == 0 && threadIdx.x < 4) {
         float v = 0.0f;
 #pragma unroll
-        for (int w = 0; w < BLOCK / WAVE; ++w) v += s_head[w][threadIdx.x];
+        for (int w = 0; w < NW; ++w) v += s_head[w][threadIdx.x];
         heads[(int64_t)blockIdx.x * 4 + threadIdx.x] = v;
     }
 }
 
 // Sum the per-block partials into one shard summary {min c, sum e, sum e^2, sum e*c, A[row]}.
+// One block per 16 columns: thread (c = tid & 15, g = tid >> 4) sums rows g, g+16, ... of column
+// 16*blockIdx.x + c (64 B coalesced row segments), then the 16 row groups combine through LDS.  The
+// last block also folds the three scalar heads.  Deterministic (fixed order).
+constexpr int SUM_COLS = 16;
 __global__ __launch_bounds__(BLOCK) void summarize_kernel(const float* __restrict__ partials,
                                                           const float* __restrict__ heads,
                                                           const unsigned* __restrict__ min_key, int nblocks,
                                                           int colsp, int row, float* __restrict__ summary) {
-    for (int cidx = threadIdx.x; cidx < row + 3; cidx += BLOCK) {
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        if (cidx < row) {
-            int b = 0;
-            for (; b + 4 <= nblocks; b += 4) {
-                a0 += partials[(int64_t)(b + 0) * colsp + cidx];
-                a1 += partials[(int64_t)(b + 1) * colsp + cidx];
-                a2 += partials[(int64_t)(b + 2) * colsp + cidx];
-                a3 += partials[(int64_t)(b + 3) * colsp + cidx];
+    __shared__ float s_part[BLOCK / SUM_COLS][SUM_COLS + 1];
+    const int c = threadIdx.x & (SUM_COLS - 1), g = threadIdx.x / SUM_COLS;
+    constexpr int NG = BLOCK / SUM_COLS;
+    const bool head_block = blockIdx.x == gridDim.x - 1;
+    float a0 = 0.f, a1 = 0.f;
+    if (!head_block) {
+        const int col = blockIdx.x * SUM_COLS + c;
+        if (col < colsp) {
+            int b = g;
+            for (; b + NG < nblocks; b += 2 * NG) {
+                a0 += partials[(int64_t)b * colsp + col];
+                a1 += partials[(int64_t)(b + NG) * colsp + col];
             }
-            for (; b < nblocks; ++b) a0 += partials[(int64_t)b * colsp + cidx];
-            summary[MPPI_SUMMARY_HEAD + cidx] = (a0 + a1) + (a2 + a3);
+            if (b < nblocks) a0 += partials[(int64_t)b * colsp + col];
+        }
+    } else if (c < 3) {
+        for (int b = g; b < nblocks; b += NG) a0 += heads[(int64_t)b * 4 + c];
+    }
+    s_part[g][c] = a0 + a1;
+    __syncthreads();
+    if (threadIdx.x < SUM_COLS) {
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < NG; ++q) v += s_part[q][threadIdx.x];
+        if (!head_block) {
+            const int col = blockIdx.x * SUM_COLS + threadIdx.x;
+            if (col < row) summary[MPPI_SUMMARY_HEAD + col] = v;
         } else {
-            const int h = cidx - row;  // 0..2 -> sum e, sum e^2, sum e*c
-            for (int b = 0; b < nblocks; ++b) a0 += heads[(int64_t)b * 4 + h];
-            summary[1 + h] = a0;
+            if (threadIdx.x < 3) summary[1 + threadIdx.x] = v;
+            if (threadIdx.x == 3) summary[0] = key_to_float(*min_key);
         }
     }
-    if (threadIdx.x == 0) summary[0] = key_to_float(*min_key);
 }
 
 // One trajectory rolled out from explicit actions (reference layout row) or from noise, writing the
@@ -468,7 +495,7 @@ __global__ __launch_bounds__(BLOCK) void export_kernel(const float4* __restrict_
     const int c0 = blockIdx.y * CONV_COLS;
     const int nc = min(CONV_COLS, d.row - c0);
     const int ngroups = (nc + 3) / 4;
-    const int dc = d.row / d.T;
+    const int dc = d.dc;
     for (int idx = threadIdx.x; idx < 64 * ngroups; idx += BLOCK) {
         const int g = idx / 64, l = idx % 64;
         const float4 v = noise[(tile * d.R + (c0 / 4) + g) * 64 + l];

@@ -168,6 +168,8 @@ class MPPI(nn.Module):
         cfg.device = self._device.index
         self._h = _capi.Handle(cfg)
         self._uploaded = {}  # slot -> (id(cells), version)
+        self._ref_uploaded = None
+        self._x0_keep = None
         self._params_set = None
 
         # ---- RNG stream bookkeeping (src/pi_mpc/mppi.py:93,146-148; SURVEY B-Q1/Q2)
@@ -223,9 +225,10 @@ class MPPI(nn.Module):
                              cells.shape[1], float(grid.cell_size), float(grid.origin[0]), float(grid.origin[1]))
                 self._uploaded[slot] = key
         ref = spec.get("ref_path")
-        if ref is not None:
+        if ref is not None and ref is not self._ref_uploaded:  # re-upload only a NEW reference window
             r = np.ascontiguousarray(ref, dtype=np.float32)
             self._h.call("mppi_set_reference", r.ctypes.data_as(C.c_void_p), r.shape[0], self._stream())
+            self._ref_uploaded = ref
 
     def inject_noise(self, eps: torch.Tensor) -> None:
         """Parity hook: use `eps` [N_local,T,dc] (already scaled by sigma) for the next solve instead of
@@ -248,7 +251,8 @@ class MPPI(nn.Module):
         out = (C.c_float * 8)()
         self._h.call("mppi_get_timing", out)
         names = ("sample", "rollout_cost", "weights_reduce", "finalize")
-        return {n: float(out[i]) for i, n in enumerate(names)} | {"calls": float(out[4 + 1])}
+        # a stage that launched nothing (e.g. `sample` when the noise is regenerated in registers) is 0
+        return {n: max(float(out[i]), 0.0) for i, n in enumerate(names)} | {"calls": float(out[4 + 1])}
 
     def set_option(self, key: str, value: int) -> None:
         self._h.call("mppi_set_option", key.encode(), int(value))
@@ -266,13 +270,13 @@ class MPPI(nn.Module):
         assert state.shape == (self._dim_state,)
         h, st = self._h, self._stream()
         if torch.is_tensor(state) and state.is_cuda:
-            x0 = state.to(self._device, self._dtype).contiguous()
-            h.call("mppi_set_state", _ptr(x0), 1, st)
+            # zero-copy: the kernels read the caller's tensor (kept alive until the next solve)
+            self._x0_keep = state.detach().to(self._device, self._dtype).contiguous()
+            h.call("mppi_bind_state", _ptr(self._x0_keep))
         else:
             x0h = np.ascontiguousarray(state.detach().cpu().numpy() if torch.is_tensor(state) else state,
                                        dtype=np.float32)
             h.call("mppi_set_state", x0h.ctypes.data_as(C.c_void_p), 0, st)
-            x0 = None
         self._refresh_model_inputs()
         self._mean_of_last_solve = self._previous_action_seq  # the mean this solve samples around
 
@@ -313,6 +317,9 @@ class MPPI(nn.Module):
 
         # Steps 6-8: normalise, warm start, batch-1 rollout (src/pi_mpc/mppi.py:381-385,448-452)
         use_sg = self._use_sg_filter
+        # fresh output tensors every solve (the kernel writes straight into what is returned)
+        self._action_out = torch.empty(self._horizon, self._dim_control, device=self._device, dtype=self._dtype)
+        self._state_out = torch.empty(1, self._horizon + 1, self._dim_state, device=self._device, dtype=self._dtype)
         h.call("mppi_finalize", _ptr(summaries), nsh, lam, 0 if use_sg else 1, _ptr(self._action_out),
                None if use_sg else _ptr(self._state_out), _ptr(self._stats), st)
 
@@ -327,10 +334,8 @@ class MPPI(nn.Module):
             h.call("mppi_rollout_actions", _ptr(self._action_out), 1, _ptr(self._state_out), st)
             first = a[0]
             self._actions_history_for_sg = np.concatenate([self._actions_history_for_sg[1:], first[None, :]])
-        optimal_action_seq = self._action_out.clone()
-        optimal_state_seq = self._state_out.clone()
-        self._previous_action_seq = optimal_action_seq
-        return optimal_action_seq, optimal_state_seq
+        self._previous_action_seq = self._action_out
+        return self._action_out, self._state_out
 
     def _gather_costs_host(self) -> np.ndarray:
         """costs[N] on the host for the temperature search (all shards when sharded)."""

@@ -196,6 +196,30 @@ def test_sampler_moments_full_size():
     assert float((solver._action_noises - e).abs().max()) > 0.1
 
 
+@pytest.mark.parametrize("model,T,N", [("racing", 50, 5000), ("nav2d", 30, 1000), ("pendulum", 15, 777),
+                                       ("cartpole", 64, 640), ("mountaincar", 100, 320)])
+def test_regenerated_noise_equals_materialised_tiles(model, T, N):
+    """`noise_regen` = 1 (Philox regenerated in the rollout / reduction registers) and = 0 (tiles written
+    by sample_kernel and read back) are the same computation: costs and action must be bit-identical."""
+    outs = []
+    for regen in (1, 0):
+        solver, ctrl = make_solver(model, T, N, lambda_=50.0 if model in ("racing", "nav2d") else 1.0)
+        solver.set_option("noise_regen", regen)
+        if ctrl is not None:
+            env = _envs["racing"]
+            ref, _ = ctrl.calc_ref_trajectory(env._robot_state, env.racing_center_path, 0, T, DL=0.1,
+                                              lookahead_distance=3, reference_path_interval=0.85)
+            ctrl.set_reference(ref)
+        x0 = {"racing": None, "nav2d": [-9.0, -9.0, 0.785], "pendulum": [3.0, 0.1], "cartpole": [0.01, 0, 0.02, 0],
+              "mountaincar": [-0.5, 0.0]}[model]
+        x0 = _envs["racing"]._robot_state.clone() if x0 is None else torch.tensor(x0, dtype=torch.float32)
+        a1, s1 = solver.forward(x0)
+        a2, s2 = solver.forward(x0)  # second solve: warm start + next solve index
+        outs.append((solver._costs.cpu(), a1.cpu(), s1.cpu(), a2.cpu(), s2.cpu(), solver._action_noises.cpu()))
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
+
+
 def test_inject_export_roundtrip_and_clamp():
     rng = np.random.default_rng(5)
     for model, T, N in (("racing", 50, 1000), ("pendulum", 15, 130), ("mountaincar", 100, 65), ("cartpole", 64, 64)):
