@@ -412,12 +412,13 @@ int mppi_rollout_cost(mppi_handle_t h, void* stream) {
     const unsigned grid = (unsigned)((h->d.tiles + 3) / 4);
 #define CALL_ROLLOUT(MODEL, FASTV)                                                                    \
     do {                                                                                              \
+        const size_t shmem = sizeof(float) * ((size_t)4 * h->d.R + (size_t)h->d.T * Model<MODEL, FASTV>::KROW); \
         if (gen)                                                                                      \
-            hipLaunchKernelGGL((rollout_cost_kernel<MODEL, FASTV, true>), dim3(grid), dim3(BLOCK), 0, s, h->noise, \
-                               h->mean, h->x0_cur, h->costs, mk, mk_next, h->d, h->gen, h->ctx);     \
+            hipLaunchKernelGGL((rollout_cost_kernel<MODEL, FASTV, true>), dim3(grid), dim3(BLOCK), shmem, s, \
+                               h->noise, h->mean, h->x0_cur, h->costs, mk, mk_next, h->d, h->gen, h->ctx); \
         else                                                                                          \
-            hipLaunchKernelGGL((rollout_cost_kernel<MODEL, FASTV, false>), dim3(grid), dim3(BLOCK), 0, s, h->noise, \
-                               h->mean, h->x0_cur, h->costs, mk, mk_next, h->d, h->gen, h->ctx);     \
+            hipLaunchKernelGGL((rollout_cost_kernel<MODEL, FASTV, false>), dim3(grid), dim3(BLOCK), shmem, s, \
+                               h->noise, h->mean, h->x0_cur, h->costs, mk, mk_next, h->d, h->gen, h->ctx); \
     } while (0)
     MPPI_DISPATCH(h, CALL_ROLLOUT);
 #undef CALL_ROLLOUT

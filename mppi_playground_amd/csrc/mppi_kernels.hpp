@@ -93,11 +93,17 @@ __device__ __forceinline__ float4 noise_group(const float4* __restrict__ np, int
 //
 // trajectory_cost(): one lane walks one trajectory.  `np` points at the lane's first float4 of the
 // tile; consecutive groups are 64 float4 apart.
+// `mean4` (R float4 groups, same grouping as the noise row) and `ktab` (KROW floats per step) are the
+// block's LDS copies of the wave-uniform per-step inputs: LDS returns in order, so the compiler can
+// keep the fetch of the next group / next row in flight (lgkmcnt(N)) while the current step computes,
+// which scalar (SMEM) loads — out of order, lgkmcnt(0) only — do not allow.
 template <int MODEL, bool FAST, bool GEN>
 __device__ __forceinline__ float trajectory_cost(const float4* __restrict__ np, uint64_t gi, const GenCtx& gen,
-                                                 const float* __restrict__ mean, const float* __restrict__ x0,
-                                                 const Dims& d, const ModelCtx& ctx, bool inherit, bool& bad) {
+                                                 const float4* mean4, const float* ktab,
+                                                 const float* __restrict__ x0, const Dims& d, const ModelCtx& ctx,
+                                                 bool inherit, bool& bad) {
     using M = Model<MODEL, FAST>;
+    using K = typename M::K;
     constexpr int DS = M::DS, DC = M::DC, SPG = 4 / DC;
     float s[DS], pu[DC], pl[DC];
 #pragma unroll
@@ -106,18 +112,24 @@ __device__ __forceinline__ float trajectory_cost(const float4* __restrict__ np, 
     for (int k = 0; k < DC; ++k) pu[k] = pl[k] = 0.0f;
     float acc = 0.0f;
     int t = 0;
+    K knext = M::load_k(ktab, 0);
     float4 e = noise_group<GEN>(np, 0, gi, gen, d);
+    float4 m4 = mean4[0];
     for (int r = 0; r < d.R; ++r) {
+        const int rn = min(r + 1, d.R - 1);
         const float4 en = (r + 1 < d.R) ? noise_group<GEN>(np, r + 1, gi, gen, d) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 m4n = mean4[rn];
         const float ev[4] = {e.x, e.y, e.z, e.w};
+        const float mv[4] = {m4.x, m4.y, m4.z, m4.w};
 #pragma unroll
         for (int g = 0; g < SPG; ++g) {
             if (t < d.T) {
+                const K kcur = knext;
+                knext = M::load_k(ktab, min(t + 1, d.T - 1));
                 float u[DC];
 #pragma unroll
                 for (int k = 0; k < DC; ++k) {
-                    const float mv = mean[t * DC + k];  // uniform (scalar) load, unconditional
-                    const float m = inherit ? mv : 0.0f;
+                    const float m = inherit ? mv[g * DC + k] : 0.0f;
                     u[k] = clampf(m + ev[g * DC + k], d.u_min[k], d.u_max[k]);
                 }
                 if (t == 0) {
@@ -126,7 +138,7 @@ __device__ __forceinline__ float trajectory_cost(const float4* __restrict__ np, 
                 }
                 float sn[DS], ss[DS];
                 M::step(ctx, s, u, sn, ss, bad);
-                acc += M::cost(ctx, ss, u, pu, t, bad);
+                acc += M::cost(ctx, kcur, ss, u, pu, bad);
 #pragma unroll
                 for (int k = 0; k < DC; ++k) { pl[k] = pu[k]; pu[k] = u[k]; }
 #pragma unroll
@@ -135,13 +147,14 @@ __device__ __forceinline__ float trajectory_cost(const float4* __restrict__ np, 
             }
         }
         e = en;
+        m4 = m4n;
     }
     // terminal cost: zero action, stale prev_action U[:, max(T-2,0)] and stale t = T-1
-    // (mppi.py:318-328)
+    // (mppi.py:318-328); knext already holds the constants of row T-1
     float zero[DC];
 #pragma unroll
     for (int k = 0; k < DC; ++k) zero[k] = 0.0f;
-    const float term = M::cost(ctx, s, zero, pl, d.T - 1, bad);
+    const float term = M::cost(ctx, knext, s, zero, pl, bad);
     return acc + term;
 }
 
@@ -153,7 +166,14 @@ __global__ __launch_bounds__(BLOCK) void rollout_cost_kernel(const float4* __res
                                                              unsigned* __restrict__ min_key,
                                                              unsigned* __restrict__ next_min_key, Dims d, GenCtx gen,
                                                              ModelCtx ctx) {
+    using M = Model<MODEL, FAST>;
     __shared__ float s_min[BLOCK / WAVE];
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];  // [4*R] mean groups, then [T*KROW] step rows
+    float4* s_mean4 = reinterpret_cast<float4*>(s_dyn);
+    float* s_ktab = s_dyn + 4 * d.R;
+    for (int f = threadIdx.x; f < 4 * d.R; f += BLOCK) s_dyn[f] = f < d.row ? mean[f] : 0.0f;
+    for (int f = threadIdx.x; f < d.T * M::KROW; f += BLOCK) s_ktab[f] = ctx.ref[f];
+    __syncthreads();
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int64_t tile = (int64_t)blockIdx.x * (BLOCK / WAVE) + wid;
     // the minimum key is double-buffered: this launch accumulates into `min_key` (reset by the
@@ -166,11 +186,11 @@ __global__ __launch_bounds__(BLOCK) void rollout_cost_kernel(const float4* __res
         const bool inherit = (d.sample_offset + i) < d.inherit_count;
         const float4* np = noise + tile * d.R * 64 + lane;
         bool bad = false;
-        total = trajectory_cost<MODEL, FAST, GEN>(np, gi, gen, mean, x0, d, ctx, inherit, bad);
+        total = trajectory_cost<MODEL, FAST, GEN>(np, gi, gen, s_mean4, s_ktab, x0, d, ctx, inherit, bad);
         if (FAST) {
             if (bad) {  // a fast path left its validity range: redo this lane with the library math
                 bool ignore = false;
-                total = trajectory_cost<MODEL, false, GEN>(np, gi, gen, mean, x0, d, ctx, inherit, ignore);
+                total = trajectory_cost<MODEL, false, GEN>(np, gi, gen, s_mean4, s_ktab, x0, d, ctx, inherit, ignore);
             }
         }
         if (i < d.N) costs[i] = total;

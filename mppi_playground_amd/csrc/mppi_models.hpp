@@ -167,12 +167,20 @@ MPPI_HD float occ_lookup(const MapView& m, const uint8_t* cells, float px, float
 // ---------------------------------------------------------------------------------- models
 // step(ctx, s, u, sn, ss, bad): sn = dynamics(s, u); ss = what the reference leaves in S[:, t]
 // after the call (== s except for mountaincar, whose dynamics mutates its input views).
-// cost(ctx, s, u, pu, t, bad): cost_func(state, action, info{prev_action, t}).
+// load_k(tab, t): the wave-uniform per-step constants of cost_func's info["t"] (racing: the
+//   reference row, KROW floats per step); the rollout kernel copies the table into LDS once per
+//   block and fetches row t+1 while step t computes.
+// cost(ctx, k, s, u, pu, bad): cost_func(state, action, info{prev_action, t}).
 template <int MODEL, bool FAST>
 struct Model;
 
+struct NoStepConst {};
+
 template <bool FAST>
-struct Model<MPPI_MODEL_PENDULUM, FAST> {  // example/pendulum.py:17-47
+struct Model<MPPI_MODEL_PENDULUM, FAST> {
+    using K = NoStepConst;
+    static constexpr int KROW = 0;
+    static MPPI_HD K load_k(const float*, int) { return K{}; }  // example/pendulum.py:17-47
     static constexpr int DS = 2, DC = 1;
     static MPPI_HD void step(const ModelCtx&, const float* s, const float* u, float* sn, float* ss, bool& bad) {
         const float th = s[0], thdot = s[1];
@@ -185,14 +193,17 @@ struct Model<MPPI_MODEL_PENDULUM, FAST> {  // example/pendulum.py:17-47
         ss[0] = s[0]; ss[1] = s[1];
         sn[0] = newth; sn[1] = newthdot;
     }
-    static MPPI_HD float cost(const ModelCtx&, const float* s, const float*, const float*, int, bool& bad) {
+    static MPPI_HD float cost(const ModelCtx&, const K&, const float* s, const float*, const float*, bool& bad) {
         const float a = angle_normalize<FAST, true>(s[0], bad);  // theta is never wrapped by the dynamics
         return a * a + 0.1f * (s[1] * s[1]);
     }
 };
 
 template <bool FAST>
-struct Model<MPPI_MODEL_CARTPOLE, FAST> {  // example/cartpole.py:17-81
+struct Model<MPPI_MODEL_CARTPOLE, FAST> {
+    using K = NoStepConst;
+    static constexpr int KROW = 0;
+    static MPPI_HD K load_k(const float*, int) { return K{}; }  // example/cartpole.py:17-81
     static constexpr int DS = 4, DC = 1;
     static MPPI_HD void step(const ModelCtx&, const float* s, const float* u, float* sn, float* ss, bool& bad) {
         const float x = s[0], x_dt = s[1], theta = s[2], theta_dt = s[3];
@@ -214,14 +225,17 @@ struct Model<MPPI_MODEL_CARTPOLE, FAST> {  // example/cartpole.py:17-81
         ss[0] = s[0]; ss[1] = s[1]; ss[2] = s[2]; ss[3] = s[3];
         sn[0] = newx; sn[1] = newx_dt; sn[2] = newtheta; sn[3] = newtheta_dt;
     }
-    static MPPI_HD float cost(const ModelCtx&, const float* s, const float*, const float*, int, bool& bad) {
+    static MPPI_HD float cost(const ModelCtx&, const K&, const float* s, const float*, const float*, bool& bad) {
         const float a = angle_normalize<FAST>(s[2], bad);
         return a * a + 0.1f * (s[3] * s[3]) + 0.1f * (s[0] * s[0]);
     }
 };
 
 template <bool FAST>
-struct Model<MPPI_MODEL_MOUNTAINCAR, FAST> {  // example/mountaincar.py:17-55
+struct Model<MPPI_MODEL_MOUNTAINCAR, FAST> {
+    using K = NoStepConst;
+    static constexpr int KROW = 0;
+    static MPPI_HD K load_k(const float*, int) { return K{}; }  // example/mountaincar.py:17-55
     static constexpr int DS = 2, DC = 1;
     static MPPI_HD void step(const ModelCtx&, const float* s, const float* u, float* sn, float* ss, bool& bad) {
         const float position = s[0], velocity = s[1];
@@ -235,14 +249,17 @@ struct Model<MPPI_MODEL_MOUNTAINCAR, FAST> {  // example/mountaincar.py:17-55
         ss[0] = p1; ss[1] = v1;  // `velocity +=` / `position +=` act on views of S[:, t]
         sn[0] = p2; sn[1] = v2;
     }
-    static MPPI_HD float cost(const ModelCtx&, const float* s, const float*, const float*, int, bool&) {
+    static MPPI_HD float cost(const ModelCtx&, const K&, const float* s, const float*, const float*, bool&) {
         const float d = 0.45f - s[0];
         return d * d;
     }
 };
 
 template <bool FAST>
-struct Model<MPPI_MODEL_NAV2D, FAST> {  // src/envs/navigation_2d.py:218-279
+struct Model<MPPI_MODEL_NAV2D, FAST> {
+    using K = NoStepConst;
+    static constexpr int KROW = 0;
+    static MPPI_HD K load_k(const float*, int) { return K{}; }  // src/envs/navigation_2d.py:218-279
     static constexpr int DS = 3, DC = 2;
     static MPPI_HD void step(const ModelCtx& c, const float* s, const float* u, float* sn, float* ss, bool& bad) {
         const float* P = c.P;
@@ -260,7 +277,7 @@ struct Model<MPPI_MODEL_NAV2D, FAST> {  // src/envs/navigation_2d.py:218-279
         sn[1] = clampf(new_y, P[MPPI_NP_YLO], P[MPPI_NP_YHI]);
         sn[2] = new_theta;
     }
-    static MPPI_HD float cost(const ModelCtx& c, const float* s, const float*, const float*, int, bool&) {
+    static MPPI_HD float cost(const ModelCtx& c, const K&, const float* s, const float*, const float*, bool&) {
         const float* P = c.P;
         const float dx = s[0] - P[MPPI_NP_GX], dy = s[1] - P[MPPI_NP_GY];
         const float goal_cost = sqrtf(dx * dx + dy * dy);
@@ -272,6 +289,12 @@ struct Model<MPPI_MODEL_NAV2D, FAST> {  // src/envs/navigation_2d.py:218-279
 template <bool FAST>
 struct Model<MPPI_MODEL_RACING, FAST> {  // src/envs/racing_env.py:327-372, example/racing.py:110-159
     static constexpr int DS = 4, DC = 2;
+    struct K { float xr, yr, vr, sinp, cosp; };  // reference_path[t] with sin/cos of its yaw
+    static constexpr int KROW = 8;                // floats per row of the step-constant table
+    static MPPI_HD K load_k(const float* tab, int t) {  // tab = ctx.ref or its LDS copy
+        const float* r = tab + 8 * t;
+        return K{r[0], r[1], r[3], r[4], r[5]};
+    }
     static MPPI_HD void step(const ModelCtx& c, const float* s, const float* u, float* sn, float* ss, bool& bad) {
         const float* P = c.P;
         const float x = s[0], y = s[1], v = s[3];
@@ -300,15 +323,14 @@ struct Model<MPPI_MODEL_RACING, FAST> {  // src/envs/racing_env.py:327-372, exam
         sn[2] = new_theta;
         sn[3] = clampf(new_v, -P[MPPI_RP_VMAX], P[MPPI_RP_VMAX]);
     }
-    static MPPI_HD float cost(const ModelCtx& c, const float* s, const float* u, const float* pu, int t, bool&) {
+    static MPPI_HD float cost(const ModelCtx& c, const K& k, const float* s, const float* u, const float* pu, bool&) {
         const float* P = c.P;
-        const float* r = c.ref + 8 * t;
-        const float sinp = r[4], cosp = r[5];
-        const float ex = s[0] - r[0], ey = s[1] - r[1];
+        const float sinp = k.sinp, cosp = k.cosp;
+        const float ex = s[0] - k.xr, ey = s[1] - k.yr;
         const float ec = sinp * ex - cosp * ey;
         const float el = -cosp * ex - sinp * ey;
         const float path_cost = P[MPPI_RP_QC] * (ec * ec) + P[MPPI_RP_QL] * (el * el);
-        const float dv = s[3] - r[3];
+        const float dv = s[3] - k.vr;
         const float velocity_cost = P[MPPI_RP_QV] * (dv * dv);
         float occ;
         if (FAST) {  // host-checked precondition: both maps share geometry and are fused (0..2)

@@ -17,10 +17,11 @@ from pi_mpc.native import native_model
 
 def _nav_inputs(env: "Navigation2DEnv") -> dict:
     m = env._obstacle_map
-    params = [float(env.u_min[0]), float(env.u_max[0]), float(env.u_min[1]), float(env.u_max[1]), env.delta_t,
-              m.x_lim[0], m.x_lim[1], m.y_lim[0], m.y_lim[1], float(env._goal_pos[0]), float(env._goal_pos[1]),
-              env.obstacle_weight]
-    return {"params": params, "maps": [m.grid_spec()], "ref_path": None}
+    if env._params is None:  # read the device tensors back once, not per solve
+        env._params = [float(env.u_min[0]), float(env.u_max[0]), float(env.u_min[1]), float(env.u_max[1]),
+                       env.delta_t, m.x_lim[0], m.x_lim[1], m.y_lim[0], m.y_lim[1], float(env._goal_pos[0]),
+                       float(env._goal_pos[1]), env.obstacle_weight]
+    return {"params": env._params, "maps": [m.grid_spec()], "ref_path": None}
 
 
 class Navigation2DEnv:
@@ -41,6 +42,7 @@ class Navigation2DEnv:
         self._x_lim = torch.tensor(self._obstacle_map.x_lim, device=self._device, dtype=dtype)
         self._y_lim = torch.tensor(self._obstacle_map.y_lim, device=self._device, dtype=dtype)
         self._robot_state = torch.zeros(3, device=self._device, dtype=dtype)
+        self._params = None
         self.reset()
 
     def reset(self) -> torch.Tensor:

@@ -52,6 +52,7 @@ class RacingEnv:
         self._start_pos = self.racing_center_path[0, :2].clone()
         self._goal_pos = self.racing_center_path[-1, :2].clone()
         self._robot_state = torch.zeros(4, device=self._device, dtype=dtype)
+        self._dyn_params = None
         self.reset()
 
     def reset(self) -> torch.Tensor:
@@ -68,11 +69,14 @@ class RacingEnv:
         return self._robot_state, reached
 
     def model_params(self, weights) -> list:
-        """MPPI_RP_* vector: dynamics constants here + the controller's six cost weights."""
-        m = self._obstacle_map
-        return [float(self.u_min[0]), float(self.u_max[0]), float(self.u_min[1]), float(self.u_max[1]),
-                float(self.L), float(self.V_MAX), self.delta_t, m.x_lim[0], m.x_lim[1], m.y_lim[0], m.y_lim[1],
-                *[float(w) for w in weights]]
+        """MPPI_RP_* vector: dynamics constants here + the controller's six cost weights.  The env
+        constants are read back from the device tensors once (no per-solve synchronisation)."""
+        if self._dyn_params is None:
+            m = self._obstacle_map
+            self._dyn_params = [float(self.u_min[0]), float(self.u_max[0]), float(self.u_min[1]),
+                                float(self.u_max[1]), float(self.L), float(self.V_MAX), self.delta_t,
+                                m.x_lim[0], m.x_lim[1], m.y_lim[0], m.y_lim[1]]
+        return [*self._dyn_params, *[float(w) for w in weights]]
 
     @native_model("racing", "dynamics", _racing_dyn_inputs)
     def dynamics(self, state: torch.Tensor, action: torch.Tensor, delta_t: float = 0.1) -> torch.Tensor:

@@ -212,7 +212,7 @@ class MPPI(nn.Module):
         spec = prov(self._cost_owner)
         params = spec.get("params")
         if params is not None:
-            p = tuple(float(x) for x in params)
+            p = tuple(params)
             if p != self._params_set:
                 arr = (C.c_float * len(p))(*p)
                 self._h.call("mppi_set_model_params", arr, len(p))

@@ -29,14 +29,14 @@ static float walk(const float* eps_row, const float* mean, const float* x0, int 
         }
         if (t == 0) for (int k = 0; k < DC; ++k) pu[k] = u[k];
         M::step(ctx, s, u, sn, ss, bad);
-        acc += M::cost(ctx, ss, u, pu, t, bad);
+        acc += M::cost(ctx, M::load_k(ctx.ref, t), ss, u, pu, bad);
         for (int k = 0; k < DC; ++k) { pl[k] = pu[k]; pu[k] = u[k]; }
         for (int j = 0; j < DS; ++j) { if (S_out) S_out[t * DS + j] = ss[j]; s[j] = sn[j]; }
     }
     for (int j = 0; j < DS; ++j) if (S_out) S_out[T * DS + j] = s[j];
     float zero[DC];
     for (int k = 0; k < DC; ++k) zero[k] = 0.f;
-    return acc + M::cost(ctx, s, zero, pl, T - 1, bad);
+    return acc + M::cost(ctx, M::load_k(ctx.ref, T - 1), s, zero, pl, bad);
 }
 
 template <int MODEL>
