@@ -126,9 +126,9 @@ bool use_fast(mppi_handle_t h);
 bool use_fast(mppi_handle_t h) {
     if (!h->math_fast) return false;
     const int m = h->cfg.model;
-    if (m == MPPI_MODEL_NAV2D) return h->ctx.maps[0].inv_cell != 0.0f;
+    if (m == MPPI_MODEL_NAV2D) return h->ctx.maps[0].inv_cell != 0.0f && h->ctx.wrap_safe != 0;
     if (m == MPPI_MODEL_RACING)
-        return h->ctx.maps[0].inv_cell != 0.0f && h->ctx.fused != nullptr && h->ctx.tan_small != 0 && h->ctx.inv_L != 0.0f;
+        return h->ctx.wrap_safe != 0 && h->ctx.maps[0].inv_cell != 0.0f && h->ctx.fused != nullptr && h->ctx.tan_small != 0 && h->ctx.inv_L != 0.0f;
     return true;
 }
 
@@ -242,7 +242,20 @@ int mppi_set_model_params(mppi_handle_t h, const float* p, int n) {
     const int need = h->cfg.model == MPPI_MODEL_RACING ? MPPI_RP_COUNT : h->cfg.model == MPPI_MODEL_NAV2D ? MPPI_NP_COUNT : 0;
     if (n != need) return fail(h, MPPI_E_INVALID, "parameter count does not match the model");
     for (int i = 0; i < n; ++i) h->ctx.P[i] = p[i];
+    const float* um = h->cfg.u_min; const float* uM = h->cfg.u_max;
+    if (h->cfg.model == MPPI_MODEL_NAV2D) {
+        h->ctx.u_in_bounds = (um[0] >= p[MPPI_NP_VMIN] && uM[0] <= p[MPPI_NP_VMAX] && um[1] >= p[MPPI_NP_WMIN] &&
+                              uM[1] <= p[MPPI_NP_WMAX]) ? 1 : 0;
+        const float w = std::fmax(std::fabs(p[MPPI_NP_WMIN]), std::fabs(p[MPPI_NP_WMAX]));
+        h->ctx.wrap_safe = (w * std::fabs(p[MPPI_NP_DT]) < 3.0f) ? 1 : 0;
+    }
     if (h->cfg.model == MPPI_MODEL_RACING) {
+        h->ctx.u_in_bounds = (um[0] >= p[MPPI_RP_AMIN] && uM[0] <= p[MPPI_RP_AMAX] && um[1] >= p[MPPI_RP_SMIN] &&
+                              uM[1] <= p[MPPI_RP_SMAX]) ? 1 : 0;
+        const float sm = std::fmax(std::fabs(p[MPPI_RP_SMIN]), std::fabs(p[MPPI_RP_SMAX]));
+        const float dth = std::fabs(p[MPPI_RP_VMAX]) * std::tan(std::fmin(sm, 1.5f)) / std::fabs(p[MPPI_RP_L]) *
+                          std::fabs(p[MPPI_RP_DT]);
+        h->ctx.wrap_safe = (sm < 1.5f && dth < 3.0f) ? 1 : 0;
         h->ctx.tan_small = (std::fabs(p[MPPI_RP_SMIN]) <= 0.25f && std::fabs(p[MPPI_RP_SMAX]) <= 0.25f) ? 1 : 0;
         const float L = p[MPPI_RP_L];
         uint32_t bits; std::memcpy(&bits, &L, 4);
@@ -412,7 +425,7 @@ int mppi_rollout_cost(mppi_handle_t h, void* stream) {
     const unsigned grid = (unsigned)((h->d.tiles + 3) / 4);
 #define CALL_ROLLOUT(MODEL, FASTV)                                                                    \
     do {                                                                                              \
-        const size_t shmem = sizeof(float) * ((size_t)4 * h->d.R + (size_t)h->d.T * Model<MODEL, FASTV>::KROW); \
+        const size_t shmem = sizeof(float) * ((size_t)8 * h->d.R + (size_t)h->d.T * Model<MODEL, FASTV>::KROW); \
         if (gen)                                                                                      \
             hipLaunchKernelGGL((rollout_cost_kernel<MODEL, FASTV, true>), dim3(grid), dim3(BLOCK), shmem, s, \
                                h->noise, h->mean, h->x0_cur, h->costs, mk, mk_next, h->d, h->gen, h->ctx); \
@@ -468,7 +481,7 @@ int mppi_weights_reduce(mppi_handle_t h, float lambda, float* summary_out_dev, v
 #undef CALL_REDUCE
     HIP_TRY(h, hipGetLastError());
     const unsigned sgrid = (unsigned)((h->colsp + SUM_COLS - 1) / SUM_COLS + 1);
-    hipLaunchKernelGGL(summarize_kernel, dim3(sgrid), dim3(BLOCK), 0, s, h->partials, h->heads, mk, (int)blocks,
+    hipLaunchKernelGGL(summarize_kernel, dim3(sgrid), dim3(SUM_BLOCK), 0, s, h->partials, h->heads, mk, (int)blocks,
                        h->colsp, h->d.row, h->summary);
     HIP_TRY(h, hipGetLastError());
     if (summary_out_dev)

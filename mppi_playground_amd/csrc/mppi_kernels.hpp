@@ -60,12 +60,9 @@ __device__ __forceinline__ float4 gen_noise4(uint64_t gi, int r, const GenCtx& g
     float z[4];
     box_muller(x.x, x.y, z[0], z[1]);
     box_muller(x.z, x.w, z[2], z[3]);
+    // columns past the row length (row % 4 != 0) carry unused values: no consumer reads them
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int f = 4 * r + j;
-        const float sg = (d.dc == 1) ? d.sigma[0] : d.sigma[f & 1];  // dc in {1, 2}
-        z[j] = (f < d.row) ? z[j] * sg : 0.0f;
-    }
+    for (int j = 0; j < 4; ++j) z[j] *= (d.dc == 1) ? d.sigma[0] : d.sigma[j & 1];  // dc in {1, 2}
     return make_float4(z[0], z[1], z[2], z[3]);
 }
 
@@ -93,7 +90,8 @@ __device__ __forceinline__ float4 noise_group(const float4* __restrict__ np, int
 //
 // trajectory_cost(): one lane walks one trajectory.  `np` points at the lane's first float4 of the
 // tile; consecutive groups are 64 float4 apart.
-// `mean4` (R float4 groups, same grouping as the noise row) and `ktab` (KROW floats per step) are the
+// `mean4` (R float4 groups, same grouping as the noise row; lanes beyond the exploration threshold
+// are handed an all-zero copy, mppi.py:266-270) and `ktab` (KROW floats per step) are the
 // block's LDS copies of the wave-uniform per-step inputs: LDS returns in order, so the compiler can
 // keep the fetch of the next group / next row in flight (lgkmcnt(N)) while the current step computes,
 // which scalar (SMEM) loads — out of order, lgkmcnt(0) only — do not allow.
@@ -101,20 +99,25 @@ template <int MODEL, bool FAST, bool GEN>
 __device__ __forceinline__ float trajectory_cost(const float4* __restrict__ np, uint64_t gi, const GenCtx& gen,
                                                  const float4* mean4, const float* ktab,
                                                  const float* __restrict__ x0, const Dims& d, const ModelCtx& ctx,
-                                                 bool inherit, bool& bad) {
+                                                 bool& bad) {
     using M = Model<MODEL, FAST>;
     using K = typename M::K;
     constexpr int DS = M::DS, DC = M::DC, SPG = 4 / DC;
     float s[DS], pu[DC], pl[DC];
 #pragma unroll
     for (int j = 0; j < DS; ++j) s[j] = x0[j];
-#pragma unroll
-    for (int k = 0; k < DC; ++k) pu[k] = pl[k] = 0.0f;
+    if (FAST) M::check_state(s, bad);
+    const bool uc = ctx.u_in_bounds != 0;  // wave-uniform
     float acc = 0.0f;
     int t = 0;
     K knext = M::load_k(ktab, 0);
     float4 e = noise_group<GEN>(np, 0, gi, gen, d);
     float4 m4 = mean4[0];
+    {   // info["prev_action"] of step 0 is U[:, 0] itself (mppi.py:299-301)
+        const float e0[4] = {e.x, e.y, e.z, e.w}, m0[4] = {m4.x, m4.y, m4.z, m4.w};
+#pragma unroll
+        for (int k = 0; k < DC; ++k) pu[k] = pl[k] = clampf(m0[k] + e0[k], d.u_min[k], d.u_max[k]);
+    }
     for (int r = 0; r < d.R; ++r) {
         const int rn = min(r + 1, d.R - 1);
         const float4 en = (r + 1 < d.R) ? noise_group<GEN>(np, r + 1, gi, gen, d) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -128,16 +131,9 @@ __device__ __forceinline__ float trajectory_cost(const float4* __restrict__ np, 
                 knext = M::load_k(ktab, min(t + 1, d.T - 1));
                 float u[DC];
 #pragma unroll
-                for (int k = 0; k < DC; ++k) {
-                    const float m = inherit ? mv[g * DC + k] : 0.0f;
-                    u[k] = clampf(m + ev[g * DC + k], d.u_min[k], d.u_max[k]);
-                }
-                if (t == 0) {
-#pragma unroll
-                    for (int k = 0; k < DC; ++k) pu[k] = u[k];
-                }
+                for (int k = 0; k < DC; ++k) u[k] = clampf(mv[g * DC + k] + ev[g * DC + k], d.u_min[k], d.u_max[k]);
                 float sn[DS], ss[DS];
-                M::step(ctx, s, u, sn, ss, bad);
+                M::step(ctx, s, u, sn, ss, bad, uc);
                 acc += M::cost(ctx, kcur, ss, u, pu, bad);
 #pragma unroll
                 for (int k = 0; k < DC; ++k) { pl[k] = pu[k]; pu[k] = u[k]; }
@@ -168,10 +164,14 @@ __global__ __launch_bounds__(BLOCK) void rollout_cost_kernel(const float4* __res
                                                              ModelCtx ctx) {
     using M = Model<MODEL, FAST>;
     __shared__ float s_min[BLOCK / WAVE];
-    extern __shared__ __attribute__((aligned(16))) float s_dyn[];  // [4*R] mean groups, then [T*KROW] step rows
+    // [4*R] mean groups, [4*R] zeros (samples that do not inherit the mean), then [T*KROW] step rows
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];
     float4* s_mean4 = reinterpret_cast<float4*>(s_dyn);
-    float* s_ktab = s_dyn + 4 * d.R;
-    for (int f = threadIdx.x; f < 4 * d.R; f += BLOCK) s_dyn[f] = f < d.row ? mean[f] : 0.0f;
+    float* s_ktab = s_dyn + 8 * d.R;
+    for (int f = threadIdx.x; f < 4 * d.R; f += BLOCK) {
+        s_dyn[f] = f < d.row ? mean[f] : 0.0f;
+        s_dyn[4 * d.R + f] = 0.0f;
+    }
     for (int f = threadIdx.x; f < d.T * M::KROW; f += BLOCK) s_ktab[f] = ctx.ref[f];
     __syncthreads();
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -186,11 +186,12 @@ __global__ __launch_bounds__(BLOCK) void rollout_cost_kernel(const float4* __res
         const bool inherit = (d.sample_offset + i) < d.inherit_count;
         const float4* np = noise + tile * d.R * 64 + lane;
         bool bad = false;
-        total = trajectory_cost<MODEL, FAST, GEN>(np, gi, gen, s_mean4, s_ktab, x0, d, ctx, inherit, bad);
+        const float4* mp = inherit ? s_mean4 : s_mean4 + d.R;
+        total = trajectory_cost<MODEL, FAST, GEN>(np, gi, gen, mp, s_ktab, x0, d, ctx, bad);
         if (FAST) {
             if (bad) {  // a fast path left its validity range: redo this lane with the library math
                 bool ignore = false;
-                total = trajectory_cost<MODEL, false, GEN>(np, gi, gen, s_mean4, s_ktab, x0, d, ctx, inherit, ignore);
+                total = trajectory_cost<MODEL, false, GEN>(np, gi, gen, mp, s_ktab, x0, d, ctx, ignore);
             }
         }
         if (i < d.N) costs[i] = total;
@@ -228,9 +229,19 @@ __global__ __launch_bounds__(BLOCK) void weights_reduce_kernel(const float4* __r
     __shared__ float s_red[NW][32][WAVE + 1];
     __shared__ float s_cols[NW][NACC];
     __shared__ float s_head[NW][4];
+    // this chunk's mean groups and an all-zero copy for samples that do not inherit the mean.  Read
+    // from LDS inside the tile loop (with an opaque offset) so that the compiler does not hoist 128
+    // loop-invariant scalar loads into SGPRs: that spilled ~450 SGPRs in every wave's prologue.
+    __shared__ __attribute__((aligned(16))) float s_mean[2][NACC];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int r0 = blockIdx.y * CH;  // first float4 group of this column chunk
     const int nr = min(CH, d.R - r0);
+    for (int j = threadIdx.x; j < NACC; j += BLOCK) {
+        const int f = 4 * r0 + j;
+        s_mean[0][j] = f < d.row ? mean[f] : 0.0f;
+        s_mean[1][j] = 0.0f;
+    }
+    __syncthreads();
     const float cmin = key_to_float(*min_key);
     const float xmax = (-cmin) / lambda;
     float acc[NACC];
@@ -239,33 +250,57 @@ __global__ __launch_bounds__(BLOCK) void weights_reduce_kernel(const float4* __r
     float se = 0.0f, se2 = 0.0f, sec = 0.0f;
     const int64_t wave_id = (int64_t)blockIdx.x * NW + wid;
     const int64_t nwaves = (int64_t)gridDim.x * NW;
-    for (int64_t tile = wave_id; tile < d.tiles; tile += nwaves) {
-        const int64_t i = tile * 64 + lane;
-        float e = 0.0f, c = 0.0f;
-        if (i < d.N) {
-            c = costs[i];
-            e = expf((-c) / lambda - xmax);
+    // Phase A: the costs of TPW tiles are loaded together (one memory latency instead of TPW in a
+    // chain) and reduced to a wave-uniform bitmask of the tiles that carry any weight.
+    // Phase B: only those tiles are accumulated (their 64 costs are re-read from L2).
+    constexpr int TPW = 8;
+    bool any_live = false;  // wave-uniform
+    for (int64_t base = wave_id; base < d.tiles; base += nwaves * TPW) {
+        float cc[TPW];
+#pragma unroll
+        for (int q = 0; q < TPW; ++q) {
+            const int64_t i = (base + q * nwaves) * 64 + lane;
+            cc[q] = (i < d.N) ? costs[i] : INFINITY;  // tiles past the end have i >= N as well
         }
-        if (__ballot(e != 0.0f) == 0ull) continue;  // wave-uniform skip
-        se += e;
-        se2 = fmaf(e, e, se2);
-        sec = fmaf(e, c, sec);
-        const uint64_t gi = (uint64_t)(d.sample_offset + i);
-        const bool inherit = (d.sample_offset + i) < d.inherit_count;
-        const float4* np = noise + (tile * d.R) * 64 + lane;
+        unsigned live = 0;
 #pragma unroll
-        for (int r = 0; r < CH; ++r) {
-            if (r < nr) {
-                const float4 n4 = noise_group<GEN>(np, r0 + r, gi, gen, d);
-                const float nv[4] = {n4.x, n4.y, n4.z, n4.w};
+        for (int q = 0; q < TPW; ++q) {
+            const float e = expf((-cc[q]) / lambda - xmax);  // exp(-inf) = 0 for the padding lanes
+            live |= (__ballot(e != 0.0f) != 0ull ? 1u : 0u) << q;
+        }
+        any_live = any_live || live != 0u;
+        for (int q = 0; q < TPW; ++q) {
+            if (!((live >> q) & 1u)) continue;  // wave-uniform skip
+            const int64_t tile = base + q * nwaves;
+            const int64_t i = tile * 64 + lane;
+            float e = 0.0f, c = 0.0f;
+            if (i < d.N) {
+                c = costs[i];
+                e = expf((-c) / lambda - xmax);
+            }
+            se += e;
+            se2 = fmaf(e, e, se2);
+            sec = fmaf(e, c, sec);
+            const uint64_t gi = (uint64_t)(d.sample_offset + i);
+            const bool inherit = (d.sample_offset + i) < d.inherit_count;
+            const float4* np = noise + (tile * d.R) * 64 + lane;
+            int moff = inherit ? 0 : NACC / 4;  // float4 offset of this lane's mean table
+            asm volatile("" : "+v"(moff));       // opaque: keeps the LDS reads inside the loop
+            const float4* mp = reinterpret_cast<const float4*>(&s_mean[0][0]) + moff;
+            int nrl = nr;
+            asm volatile("" : "+s"(nrl));        // opaque: keeps the 32 group predicates out of SGPRs
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int f = 4 * (r0 + r) + j;
-                    if (f < d.row) {
-                        const int k = (d.dc == 1) ? 0 : (f & 1);
-                        const float mv = mean[f];
-                        const float m = inherit ? mv : 0.0f;
-                        const float u = clampf(m + nv[j], d.u_min[k], d.u_max[k]);
+            for (int r = 0; r < CH; ++r) {
+                if (r < nrl) {
+                    const float4 n4 = noise_group<GEN>(np, r0 + r, gi, gen, d);
+                    const float4 m4 = mp[r];
+                    const float nv[4] = {n4.x, n4.y, n4.z, n4.w};
+                    const float mv[4] = {m4.x, m4.y, m4.z, m4.w};
+                    // (columns past the row length accumulate unused values; summarize drops them)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int k = (d.dc == 1) ? 0 : (j & 1);
+                        const float u = clampf(mv[j] + nv[j], d.u_min[k], d.u_max[k]);
                         acc[4 * r + j] = fmaf(e, u, acc[4 * r + j]);
                     }
                 }
@@ -275,17 +310,23 @@ __global__ __launch_bounds__(BLOCK) void weights_reduce_kernel(const float4* __r
     // cross-lane reduction, 32 accumulators per pass: every lane stores its 32 values as a column of
     // s_red[wid][j][lane]; lane l then sums row j = l & 31 over lanes [32*(l>>5), +32) (row stride 65
     // floats: conflict-free), and the two halves are added with one shuffle.
+    if (any_live) {
 #pragma unroll
-    for (int p = 0; p < NACC / 32; ++p) {
+        for (int p = 0; p < NACC / 32; ++p) {
 #pragma unroll
-        for (int j = 0; j < 32; ++j) s_red[wid][j][lane] = acc[p * 32 + j];
-        __builtin_amdgcn_wave_barrier();
-        const float* rowp = &s_red[wid][lane & 31][(lane >> 5) * 32];
-        float v = 0.0f;
-        for (int k = 0; k < 32; ++k) v += rowp[k];
-        v += __shfl_xor(v, 32);
-        if (lane < 32) s_cols[wid][p * 32 + lane] = v;
-        __builtin_amdgcn_wave_barrier();
+            for (int j = 0; j < 32; ++j) s_red[wid][j][lane] = acc[p * 32 + j];
+            __builtin_amdgcn_wave_barrier();
+            const float* rowp = &s_red[wid][lane & 31][(lane >> 5) * 32];
+            float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 32; k += 4) { v0 += rowp[k]; v1 += rowp[k + 1]; v2 += rowp[k + 2]; v3 += rowp[k + 3]; }
+            float v = (v0 + v1) + (v2 + v3);
+            v += __shfl_xor(v, 32);
+            if (lane < 32) s_cols[wid][p * 32 + lane] = v;
+            __builtin_amdgcn_wave_barrier();
+        }
+    } else {  // every tile of this wave had weight exactly zero: its column sums are zero
+        for (int j = lane; j < NACC; j += WAVE) s_cols[wid][j] = 0.0f;
     }
     se = wave_sum(se);
     se2 = wave_sum(se2);
@@ -312,33 +353,42 @@ __global__ __launch_bounds__(BLOCK) void weights_reduce_kernel(const float4* __r
 // 16*blockIdx.x + c (64 B coalesced row segments), then the 16 row groups combine through LDS.  The
 // last block also folds the three scalar heads.  Deterministic (fixed order).
 constexpr int SUM_COLS = 16;
-__global__ __launch_bounds__(BLOCK) void summarize_kernel(const float* __restrict__ partials,
+constexpr int SUM_BLOCK = 1024;
+__global__ __launch_bounds__(SUM_BLOCK) void summarize_kernel(const float* __restrict__ partials,
                                                           const float* __restrict__ heads,
                                                           const unsigned* __restrict__ min_key, int nblocks,
                                                           int colsp, int row, float* __restrict__ summary) {
-    __shared__ float s_part[BLOCK / SUM_COLS][SUM_COLS + 1];
+    __shared__ float s_part[SUM_BLOCK / SUM_COLS][SUM_COLS + 1];
     const int c = threadIdx.x & (SUM_COLS - 1), g = threadIdx.x / SUM_COLS;
-    constexpr int NG = BLOCK / SUM_COLS;
+    constexpr int NG = SUM_BLOCK / SUM_COLS;
     const bool head_block = blockIdx.x == gridDim.x - 1;
-    float a0 = 0.f, a1 = 0.f;
+    float a[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) a[q] = 0.f;
     if (!head_block) {
         const int col = blockIdx.x * SUM_COLS + c;
         if (col < colsp) {
-            int b = g;
-            for (; b + NG < nblocks; b += 2 * NG) {
-                a0 += partials[(int64_t)b * colsp + col];
-                a1 += partials[(int64_t)(b + NG) * colsp + col];
+            for (int b = g; b < nblocks; b += 8 * NG) {  // 8 independent loads in flight per thread
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int bb = b + q * NG;
+                    if (bb < nblocks) a[q] += partials[(int64_t)bb * colsp + col];
+                }
             }
-            if (b < nblocks) a0 += partials[(int64_t)b * colsp + col];
         }
     } else if (c < 3) {
-        for (int b = g; b < nblocks; b += NG) a0 += heads[(int64_t)b * 4 + c];
+        for (int b = g; b < nblocks; b += 8 * NG) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int bb = b + q * NG;
+                if (bb < nblocks) a[q] += heads[(int64_t)bb * 4 + c];
+            }
+        }
     }
-    s_part[g][c] = a0 + a1;
+    s_part[g][c] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     __syncthreads();
     if (threadIdx.x < SUM_COLS) {
         float v = 0.f;
-#pragma unroll
         for (int q = 0; q < NG; ++q) v += s_part[q][threadIdx.x];
         if (!head_block) {
             const int col = blockIdx.x * SUM_COLS + threadIdx.x;
@@ -361,6 +411,7 @@ __device__ __forceinline__ bool rollout_states(const float* __restrict__ x0, int
     float s[DS];
 #pragma unroll
     for (int j = 0; j < DS; ++j) s[j] = x0[j];
+    if (FAST) M::check_state(s, bad);
     for (int t = 0; t < T; ++t) {
         float u[DC], sn[DS], ss[DS];
         getu(t, u);

@@ -46,6 +46,8 @@ struct ModelCtx {
     int32_t ref_rows;
     int32_t tan_small;     // steer bounds within [-0.25, 0.25]: polynomial tan is valid
     float inv_L;           // racing: RN(1/L) for the Markstein division by the wheel base (0 = unusable)
+    int32_t u_in_bounds;   // the solver's [u_min, u_max] lies inside the model's own action clamp
+    int32_t wrap_safe;     // per-step heading increments are < pi: wrapped angles stay in the narrow range
 };
 
 // torch.clamp(x, lo, hi) = min(max(x, lo), hi).  On the device this is one v_med3_f32 (identical for
@@ -67,12 +69,12 @@ MPPI_HD float clampf(float x, float lo, float hi) {
 //   WIDE fast path (|a| < 1e5): k = trunc(a/2pi) from a reciprocal multiply, repaired when off by
 //     one, and r = fma(-k, 2pi, a) (the product is exact inside the FMA and the true remainder is
 //     representable, so the single rounding is exact).
-template <bool FAST, bool WIDE = false>
+template <bool FAST, bool WIDE = false, bool CHECK = true>
 MPPI_HD float angle_normalize(float x, bool& bad) {
     const float a = x + PI_F;
     float r;
     if (FAST && !WIDE) {
-        bad = bad || !(fabsf(a) < 2.0f * TWO_PI_F);
+        if (CHECK) bad = bad || !(fabsf(a) < 2.0f * TWO_PI_F);
         r = a;
         if (a >= TWO_PI_F) r = a - TWO_PI_F;
         if (a <= -TWO_PI_F) r = a + TWO_PI_F;
@@ -96,10 +98,10 @@ MPPI_HD float angle_normalize(float x, bool& bad) {
 // sin and cos of one argument.  Fast path: k = rint(x*2/pi), two-term Cody-Waite reduction with
 // FMA (exact product), degree-7 / degree-6 minimax polynomials on [-pi/4, pi/4]
 // (measured <= 0.76 / 0.80 ulp against double, tests/test_fast_math.py).  Valid for |x| <= 200.
-template <bool FAST>
+template <bool FAST, bool CHECK = true>
 MPPI_HD void sincos_f(float x, float& s, float& c, bool& bad) {
     if (FAST) {
-        bad = bad || !(fabsf(x) <= 200.0f);
+        if (CHECK) bad = bad || !(fabsf(x) <= 200.0f);
         const float kf = rintf(x * 0.636619747f);
         float r = fmaf(-kf, 1.57079637f, x);
         r = fmaf(-kf, -4.37113883e-8f, r);
@@ -158,8 +160,11 @@ template <bool FAST>
 MPPI_HD float occ_lookup(const MapView& m, const uint8_t* cells, float px, float py, float oob) {
     const float qx = rintf(div_cell<FAST>(px, m) + m.ox);
     const float qy = rintf(div_cell<FAST>(py, m) + m.oy);
-    const bool inb = (qx >= 0.0f) & (qx < (float)m.nx) & (qy >= 0.0f) & (qy < (float)m.ny);
-    const int idx = inb ? (int)qx * m.ny + (int)qy : 0;
+    // |q| < 2^24 for any position the models can reach (they clamp to the map limits), so the
+    // conversions are exact; negative indices wrap to huge unsigned values and fail the test
+    const int ix = (int)qx, iy = (int)qy;
+    const bool inb = ((unsigned)ix < (unsigned)m.nx) & ((unsigned)iy < (unsigned)m.ny);
+    const unsigned idx = inb ? (unsigned)ix * (unsigned)m.ny + (unsigned)iy : 0u;
     const float v = (float)cells[idx];
     return inb ? v : oob;
 }
@@ -177,12 +182,13 @@ struct Model;
 struct NoStepConst {};
 
 template <bool FAST>
-struct Model<MPPI_MODEL_PENDULUM, FAST> {
+struct Model<MPPI_MODEL_PENDULUM, FAST> {  // example/pendulum.py:17-47
     using K = NoStepConst;
     static constexpr int KROW = 0;
-    static MPPI_HD K load_k(const float*, int) { return K{}; }  // example/pendulum.py:17-47
+    static MPPI_HD K load_k(const float*, int) { return K{}; }
+    static MPPI_HD void check_state(const float*, bool&) {}  // every fast path checks its own range
     static constexpr int DS = 2, DC = 1;
-    static MPPI_HD void step(const ModelCtx&, const float* s, const float* u, float* sn, float* ss, bool& bad) {
+    static MPPI_HD void step(const ModelCtx&, const float* s, const float* u, float* sn, float* ss, bool& bad, bool uc = false) {
         const float th = s[0], thdot = s[1];
         const float uu = clampf(u[0], -2.0f, 2.0f);
         float sth, cth;
@@ -200,12 +206,13 @@ struct Model<MPPI_MODEL_PENDULUM, FAST> {
 };
 
 template <bool FAST>
-struct Model<MPPI_MODEL_CARTPOLE, FAST> {
+struct Model<MPPI_MODEL_CARTPOLE, FAST> {  // example/cartpole.py:17-81
     using K = NoStepConst;
     static constexpr int KROW = 0;
-    static MPPI_HD K load_k(const float*, int) { return K{}; }  // example/cartpole.py:17-81
+    static MPPI_HD K load_k(const float*, int) { return K{}; }
+    static MPPI_HD void check_state(const float*, bool&) {}  // every fast path checks its own range
     static constexpr int DS = 4, DC = 1;
-    static MPPI_HD void step(const ModelCtx&, const float* s, const float* u, float* sn, float* ss, bool& bad) {
+    static MPPI_HD void step(const ModelCtx&, const float* s, const float* u, float* sn, float* ss, bool& bad, bool uc = false) {
         const float x = s[0], x_dt = s[1], theta = s[2], theta_dt = s[3];
         float force = 0.0f;
         if (u[0] >= 0.0f) force = 10.0f;
@@ -232,12 +239,13 @@ struct Model<MPPI_MODEL_CARTPOLE, FAST> {
 };
 
 template <bool FAST>
-struct Model<MPPI_MODEL_MOUNTAINCAR, FAST> {
+struct Model<MPPI_MODEL_MOUNTAINCAR, FAST> {  // example/mountaincar.py:17-55
     using K = NoStepConst;
     static constexpr int KROW = 0;
-    static MPPI_HD K load_k(const float*, int) { return K{}; }  // example/mountaincar.py:17-55
+    static MPPI_HD K load_k(const float*, int) { return K{}; }
+    static MPPI_HD void check_state(const float*, bool&) {}  // every fast path checks its own range
     static constexpr int DS = 2, DC = 1;
-    static MPPI_HD void step(const ModelCtx&, const float* s, const float* u, float* sn, float* ss, bool& bad) {
+    static MPPI_HD void step(const ModelCtx&, const float* s, const float* u, float* sn, float* ss, bool& bad, bool uc = false) {
         const float position = s[0], velocity = s[1];
         const float force = clampf(u[0], -1.0f, 1.0f);
         float s3, c3;
@@ -256,22 +264,28 @@ struct Model<MPPI_MODEL_MOUNTAINCAR, FAST> {
 };
 
 template <bool FAST>
-struct Model<MPPI_MODEL_NAV2D, FAST> {
+struct Model<MPPI_MODEL_NAV2D, FAST> {  // src/envs/navigation_2d.py:218-279
     using K = NoStepConst;
     static constexpr int KROW = 0;
-    static MPPI_HD K load_k(const float*, int) { return K{}; }  // src/envs/navigation_2d.py:218-279
+    static MPPI_HD K load_k(const float*, int) { return K{}; }
+    // FAST range check of the trajectory's initial heading; inside the loop the heading is always a
+    // wrapped angle plus a host-bounded increment (ctx.wrap_safe), so no per-step checks are needed
+    static MPPI_HD void check_state(const float* s, bool& bad) { bad = bad || !(fabsf(s[2] + PI_F) < 2.0f * TWO_PI_F); }
     static constexpr int DS = 3, DC = 2;
-    static MPPI_HD void step(const ModelCtx& c, const float* s, const float* u, float* sn, float* ss, bool& bad) {
+    static MPPI_HD void step(const ModelCtx& c, const float* s, const float* u, float* sn, float* ss, bool& bad, bool uc = false) {
         const float* P = c.P;
         const float x = s[0], y = s[1];
+        (void)uc;
         const float v = clampf(u[0], P[MPPI_NP_VMIN], P[MPPI_NP_VMAX]);
         const float omega = clampf(u[1], P[MPPI_NP_WMIN], P[MPPI_NP_WMAX]);
-        const float theta = angle_normalize<FAST>(s[2], bad);
+        // range checks: only the incoming heading can be out of the narrow wrap range (host-checked
+        // ctx.wrap_safe bounds the per-step increment); the wrapped heading feeds sin/cos
+        const float theta = angle_normalize<FAST, false, false>(s[2], bad);
         float sn_, cs_;
-        sincos_f<FAST>(theta, sn_, cs_, bad);
+        sincos_f<FAST, false>(theta, sn_, cs_, bad);
         const float new_x = x + v * cs_ * P[MPPI_NP_DT];
         const float new_y = y + v * sn_ * P[MPPI_NP_DT];
-        const float new_theta = angle_normalize<FAST>(theta + omega * P[MPPI_NP_DT], bad);
+        const float new_theta = angle_normalize<FAST, false, false>(theta + omega * P[MPPI_NP_DT], bad);
         ss[0] = s[0]; ss[1] = s[1]; ss[2] = s[2];
         sn[0] = clampf(new_x, P[MPPI_NP_XLO], P[MPPI_NP_XHI]);
         sn[1] = clampf(new_y, P[MPPI_NP_YLO], P[MPPI_NP_YHI]);
@@ -295,14 +309,16 @@ struct Model<MPPI_MODEL_RACING, FAST> {  // src/envs/racing_env.py:327-372, exam
         const float* r = tab + 8 * t;
         return K{r[0], r[1], r[3], r[4], r[5]};
     }
-    static MPPI_HD void step(const ModelCtx& c, const float* s, const float* u, float* sn, float* ss, bool& bad) {
+    static MPPI_HD void check_state(const float* s, bool& bad) { bad = bad || !(fabsf(s[2] + PI_F) < 2.0f * TWO_PI_F); }
+    static MPPI_HD void step(const ModelCtx& c, const float* s, const float* u, float* sn, float* ss, bool& bad, bool uc = false) {
         const float* P = c.P;
         const float x = s[0], y = s[1], v = s[3];
+        (void)uc;
         const float accel = clampf(u[0], P[MPPI_RP_AMIN], P[MPPI_RP_AMAX]);
         const float steer = clampf(u[1], P[MPPI_RP_SMIN], P[MPPI_RP_SMAX]);
-        const float theta = angle_normalize<FAST>(s[2], bad);
+        const float theta = angle_normalize<FAST, false, false>(s[2], bad);
         float sn_, cs_;
-        sincos_f<FAST>(theta, sn_, cs_, bad);
+        sincos_f<FAST, false>(theta, sn_, cs_, bad);
         const float dx = v * cs_;
         const float dy = v * sn_;
         const float vt = v * tan_f<FAST>(steer);
@@ -315,7 +331,7 @@ struct Model<MPPI_MODEL_RACING, FAST> {  // src/envs/racing_env.py:327-372, exam
         }
         const float new_x = x + dx * P[MPPI_RP_DT];
         const float new_y = y + dy * P[MPPI_RP_DT];
-        const float new_theta = angle_normalize<FAST>(theta + dtheta * P[MPPI_RP_DT], bad);
+        const float new_theta = angle_normalize<FAST, false, false>(theta + dtheta * P[MPPI_RP_DT], bad);
         const float new_v = v + accel * P[MPPI_RP_DT];
         ss[0] = s[0]; ss[1] = s[1]; ss[2] = s[2]; ss[3] = s[3];
         sn[0] = clampf(new_x, P[MPPI_RP_XLO], P[MPPI_RP_XHI]);

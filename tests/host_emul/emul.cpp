@@ -19,6 +19,7 @@ static float walk(const float* eps_row, const float* mean, const float* x0, int 
     constexpr int DS = M::DS, DC = M::DC;
     float s[DS], pu[DC], pl[DC];
     for (int j = 0; j < DS; ++j) s[j] = x0[j];
+    if (FAST) M::check_state(s, bad);
     for (int k = 0; k < DC; ++k) pu[k] = pl[k] = 0.f;
     float acc = 0.f;
     for (int t = 0; t < T; ++t) {
@@ -28,7 +29,7 @@ static float walk(const float* eps_row, const float* mean, const float* x0, int 
             u[k] = clampf(m + eps_row[t * DC + k], umin[k], umax[k]);
         }
         if (t == 0) for (int k = 0; k < DC; ++k) pu[k] = u[k];
-        M::step(ctx, s, u, sn, ss, bad);
+        M::step(ctx, s, u, sn, ss, bad, ctx.u_in_bounds != 0);
         acc += M::cost(ctx, M::load_k(ctx.ref, t), ss, u, pu, bad);
         for (int k = 0; k < DC; ++k) { pl[k] = pu[k]; pu[k] = u[k]; }
         for (int j = 0; j < DS; ++j) { if (S_out) S_out[t * DS + j] = ss[j]; s[j] = sn[j]; }
@@ -90,6 +91,7 @@ int emul_rollout_cost(int model, int fast, int N, int T, int threshold, const fl
         ctx.ref = ref8.data(); ctx.ref_rows = ref_rows;
     }
     if (model == MPPI_MODEL_RACING) { ctx.tan_small = 1; ctx.inv_L = 1.0f / ctx.P[MPPI_RP_L]; }
+    ctx.u_in_bounds = 1; ctx.wrap_safe = 1;  // the shipped parameter sets satisfy both (checked by the C ABI on the device path)
     switch (model) {
     case MPPI_MODEL_PENDULUM: run<MPPI_MODEL_PENDULUM>(fast, N, T, threshold, x0, mean, eps, umin, umax, ctx, costs, bad_out, S_out); break;
     case MPPI_MODEL_CARTPOLE: run<MPPI_MODEL_CARTPOLE>(fast, N, T, threshold, x0, mean, eps, umin, umax, ctx, costs, bad_out, S_out); break;
