@@ -44,8 +44,14 @@ enum {
     MPPI_E_NODEVICE = -4   /* no gfx950 device visible                 */
 };
 
-/* Native model plugins = the five shipped dynamics/cost pairs. */
+/* Native model plugins = the five shipped dynamics/cost pairs.
+ * MPPI_MODEL_GENERIC: the callables are opaque to the library (any torch dynamics/cost): the host
+ * evaluates them on the exported actions and hands the costs back with mppi_set_costs; sampling,
+ * softmax, the weighted reduction and the warm start still run here.  mppi_rollout_cost, the
+ * state output of mppi_finalize and the mppi_rollout_* entry points are unavailable
+ * (MPPI_E_INVALID). */
 enum {
+    MPPI_MODEL_GENERIC = -1,
     MPPI_MODEL_PENDULUM = 0,    /* example/pendulum.py:17-47                                  */
     MPPI_MODEL_CARTPOLE = 1,    /* example/cartpole.py:17-81                                  */
     MPPI_MODEL_MOUNTAINCAR = 2, /* example/mountaincar.py:17-55                               */
@@ -63,15 +69,15 @@ enum { MPPI_NP_VMIN = 0, MPPI_NP_VMAX, MPPI_NP_WMIN, MPPI_NP_WMAX, MPPI_NP_DT, M
 
 #define MPPI_MAX_PARAMS 32
 #define MPPI_MAX_DIM_STATE 4
-#define MPPI_MAX_DIM_CONTROL 2
+#define MPPI_MAX_DIM_CONTROL 4
 #define MPPI_SUMMARY_HEAD 4 /* {min cost, sum e, sum e^2, sum e*c} */
 
 /* Constructor arguments that reach the device path (MPPI.__init__, mppi.py:24-47,109-121). */
 typedef struct MppiConfig {
     int32_t model;          /* MPPI_MODEL_*                                                     */
     int32_t horizon;        /* T                                                                */
-    int32_t dim_state;      /* must match the model                                             */
-    int32_t dim_control;    /* must match the model                                             */
+    int32_t dim_state;      /* must match the model (any value >= 1 for MPPI_MODEL_GENERIC)     */
+    int32_t dim_control;    /* must match the model (1, 2 or 4 for GENERIC; pad 3 to 4)         */
     int64_t num_samples;    /* N held by THIS handle (= the local shard when sharded)           */
     int64_t sample_offset;  /* global index of local sample 0 (0 when not sharded)              */
     int64_t inherit_count;  /* global threshold int(N_global*(1-exploration)), mppi.py:266      */

@@ -11,6 +11,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmppi_hip.so")
 
+MODEL_GENERIC = -1
+MAX_DIM_CONTROL = 4
 MODEL_IDS = {"pendulum": 0, "cartpole": 1, "mountaincar": 2, "nav2d": 3, "racing": 4}
 MODEL_DIMS = {"pendulum": (2, 1), "cartpole": (4, 1), "mountaincar": (2, 1), "nav2d": (3, 2), "racing": (4, 2)}
 SUMMARY_HEAD = 4
@@ -29,7 +31,7 @@ class MppiConfig(C.Structure):
     _fields_ = [
         ("model", C.c_int32), ("horizon", C.c_int32), ("dim_state", C.c_int32), ("dim_control", C.c_int32),
         ("num_samples", C.c_int64), ("sample_offset", C.c_int64), ("inherit_count", C.c_int64),
-        ("u_min", C.c_float * 2), ("u_max", C.c_float * 2), ("sigmas", C.c_float * 2),
+        ("u_min", C.c_float * 4), ("u_max", C.c_float * 4), ("sigmas", C.c_float * 4),
         ("seed", C.c_uint64), ("device", C.c_int32), ("reserved", C.c_int32),
     ]
 

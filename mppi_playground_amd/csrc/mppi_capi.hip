@@ -114,6 +114,7 @@ bool use_fast(mppi_handle_t h);
     do {                                                                                              \
         const bool fast_ = use_fast(h);                                                               \
         switch ((h)->cfg.model) {                                                                     \
+        case MPPI_MODEL_GENERIC: /* only reached by mppi_finalize without a state output */          \
         case MPPI_MODEL_PENDULUM: if (fast_) { CALL(MPPI_MODEL_PENDULUM, true); } else { CALL(MPPI_MODEL_PENDULUM, false); } break; \
         case MPPI_MODEL_CARTPOLE: if (fast_) { CALL(MPPI_MODEL_CARTPOLE, true); } else { CALL(MPPI_MODEL_CARTPOLE, false); } break; \
         case MPPI_MODEL_MOUNTAINCAR: if (fast_) { CALL(MPPI_MODEL_MOUNTAINCAR, true); } else { CALL(MPPI_MODEL_MOUNTAINCAR, false); } break; \
@@ -134,6 +135,8 @@ bool use_fast(mppi_handle_t h) {
 
 int check_ready(mppi_handle_t h) {
     const int m = h->cfg.model;
+    if (m == MPPI_MODEL_GENERIC)
+        return fail(h, MPPI_E_INVALID, "generic model: dynamics/cost are host callables, this entry point is unavailable");
     if ((m == MPPI_MODEL_NAV2D || m == MPPI_MODEL_RACING) && !h->map_cells[0])
         return fail(h, MPPI_E_STATE, "obstacle map (slot 0) not uploaded");
     if (m == MPPI_MODEL_RACING && !h->map_cells[1]) return fail(h, MPPI_E_STATE, "lane map (slot 1) not uploaded");
@@ -176,8 +179,15 @@ int mppi_create(const MppiConfig* cfg, mppi_handle_t* out) {
     if (!cfg || !out) return MPPI_E_INVALID;
     *out = nullptr;
     ModelDims md{};
-    if (!model_dims(cfg->model, md)) return MPPI_E_INVALID;
-    if (cfg->dim_state != md.ds || cfg->dim_control != md.dc) return MPPI_E_INVALID;
+    if (cfg->model == MPPI_MODEL_GENERIC) {
+        // the lane-major rows need 4 % dim_control == 0 (callers pad 3 controls to 4 with sigma = 0)
+        if (cfg->dim_state < 1 || (cfg->dim_control != 1 && cfg->dim_control != 2 && cfg->dim_control != 4))
+            return MPPI_E_INVALID;
+        md = {cfg->dim_state, cfg->dim_control};
+    } else {
+        if (!model_dims(cfg->model, md)) return MPPI_E_INVALID;
+        if (cfg->dim_state != md.ds || cfg->dim_control != md.dc) return MPPI_E_INVALID;
+    }
     if (cfg->horizon < 1 || cfg->num_samples < 1) return MPPI_E_INVALID;
     if (mppi_device_count() <= 0) return MPPI_E_NODEVICE;
     MppiSolver* h = new (std::nothrow) MppiSolver();
@@ -206,8 +216,9 @@ int mppi_create(const MppiConfig* cfg, mppi_handle_t* out) {
     HIP_TRY(h, hipMalloc(&h->costs, sizeof(float) * (size_t)d.N));
     HIP_TRY(h, hipMalloc(&h->min_key, 2 * sizeof(unsigned)));
     HIP_TRY(h, hipMemset(h->min_key, 0xFF, 2 * sizeof(unsigned)));
-    HIP_TRY(h, hipMalloc(&h->x0, sizeof(float) * MPPI_MAX_DIM_STATE));
-    HIP_TRY(h, hipMemset(h->x0, 0, sizeof(float) * MPPI_MAX_DIM_STATE));
+    const size_t x0_floats = (size_t)std::max(md.ds, MPPI_MAX_DIM_STATE);
+    HIP_TRY(h, hipMalloc(&h->x0, sizeof(float) * x0_floats));
+    HIP_TRY(h, hipMemset(h->x0, 0, sizeof(float) * x0_floats));
     h->x0_cur = h->x0;
     h->gen = GenCtx{(uint32_t)cfg->seed, (uint32_t)(cfg->seed >> 32), 0u};
     d.dc = md.dc;
@@ -493,7 +504,9 @@ int mppi_weights_reduce(mppi_handle_t h, float lambda, float* summary_out_dev, v
 int mppi_finalize(mppi_handle_t h, const float* summaries_dev, int num_shards, float lambda, int store_mean,
                   float* action_out, float* state_out, float* stats_out, void* stream) {
     if (!h || !(lambda > 0.0f) || num_shards < 1) return fail(h, MPPI_E_INVALID, "bad finalize arguments");
-    if (int rc = check_ready(h)) return rc;
+    const bool generic = h->cfg.model == MPPI_MODEL_GENERIC;
+    if (generic && state_out) return fail(h, MPPI_E_INVALID, "generic model: roll the action out with the host dynamics");
+    if (!generic) { if (int rc = check_ready(h)) return rc; }
     hipStream_t s = (hipStream_t)stream;
     StageTimer tm(h, 3, s);
     const float* sums = summaries_dev ? summaries_dev : h->summary;

@@ -31,6 +31,12 @@ struct GenCtx {
     uint32_t seed_lo, seed_hi, solve_idx;
 };
 
+// control dimension of column j of a float4 group (flat horizon index 4r + j): dc is 1, 2 or 4, so it
+// does not depend on r (a row-dependent index would make the per-column bounds 4*CH distinct
+// loop-invariant scalars, which the compiler hoists and spills).  dim_control = 3 is padded to 4 by
+// the caller.
+__device__ __forceinline__ int ctrl_index(int j, int dc) { return j & (dc - 1); }
+
 __device__ __forceinline__ unsigned float_to_key(float f) {  // order-preserving map for atomicMin
     const unsigned b = __float_as_uint(f);
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
@@ -62,7 +68,7 @@ __device__ __forceinline__ float4 gen_noise4(uint64_t gi, int r, const GenCtx& g
     box_muller(x.z, x.w, z[2], z[3]);
     // columns past the row length (row % 4 != 0) carry unused values: no consumer reads them
 #pragma unroll
-    for (int j = 0; j < 4; ++j) z[j] *= (d.dc == 1) ? d.sigma[0] : d.sigma[j & 1];  // dc in {1, 2}
+    for (int j = 0; j < 4; ++j) z[j] *= d.sigma[ctrl_index(j, d.dc)];
     return make_float4(z[0], z[1], z[2], z[3]);
 }
 
@@ -299,7 +305,7 @@ __global__ __launch_bounds__(BLOCK) void weights_reduce_kernel(const float4* __r
                     // (columns past the row length accumulate unused values; summarize drops them)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const int k = (d.dc == 1) ? 0 : (j & 1);
+                        const int k = ctrl_index(j, d.dc);
                         const float u = clampf(mv[j] + nv[j], d.u_min[k], d.u_max[k]);
                         acc[4 * r + j] = fmaf(e, u, acc[4 * r + j]);
                     }
@@ -582,7 +588,7 @@ __global__ __launch_bounds__(BLOCK) void export_kernel(const float4* __restrict_
             if (eps_out) eps_out[i * d.row + f] = e;
             if (act_out) {
                 const bool inherit = (d.sample_offset + i) < d.inherit_count;
-                const int k = (dc == 1) ? 0 : (f & 1);
+                const int k = f % dc;
                 const float m = inherit ? mean[f] : 0.0f;
                 act_out[i * d.row + f] = clampf(m + e, d.u_min[k], d.u_max[k]);
             }

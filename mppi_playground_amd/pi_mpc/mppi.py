@@ -117,18 +117,24 @@ class MPPI(nn.Module):
 
         # ---- plugin recognition
         dyn, cst = resolve(dynamics), resolve(cost_func)
-        if not (dyn and cst and dyn[0].model == cst[0].model and dyn[0].role == "dynamics"
+        if (dyn and cst and dyn[0].model == cst[0].model and dyn[0].role == "dynamics"
                 and cst[0].role == "cost"):
-            raise NotImplementedError(
-                "dynamics/cost_func are not a recognised native model pair; the generic-callable path "
-                "(native sampling/softmax/reduction around user torch callables) is not available in "
-                "this build")
-        self._model = dyn[0].model
-        self._cost_tag, self._cost_owner = cst
-        self._dyn_tag, self._dyn_owner = dyn
-        ds, dc = _capi.MODEL_DIMS[self._model]
-        if (ds, dc) != (dim_state, dim_control):
-            raise AssertionError(f"model {self._model} has dim_state={ds}, dim_control={dc}")
+            self._model = dyn[0].model  # fused on the device
+            self._cost_tag, self._cost_owner = cst
+            self._dyn_tag, self._dyn_owner = dyn
+            ds, dc = _capi.MODEL_DIMS[self._model]
+            if (ds, dc) != (dim_state, dim_control):
+                raise AssertionError(f"model {self._model} has dim_state={ds}, dim_control={dc}")
+        else:
+            # opaque callables (any torch dynamics / cost, e.g. the reference examples' TorchScript
+            # closures): sampling, softmax, reduction and warm start run in the library, the two
+            # T-step loops run the user's callables on GPU tensors exactly like the reference
+            self._model = None
+            self._cost_tag = self._cost_owner = self._dyn_tag = self._dyn_owner = None
+            if dim_control not in (1, 2, 4):
+                # the lane-major noise rows hold whole float4 groups per step (every shipped example has
+                # 1 or 2 controls)
+                raise NotImplementedError("the HIP path supports dim_control in {1, 2, 4}")
 
         # ---- auto lambda (src/pi_mpc/mppi.py:183-210)
         self._lambda: float | str = lambda_
@@ -155,7 +161,7 @@ class MPPI(nn.Module):
 
         # ---- device handle
         cfg = _capi.MppiConfig()
-        cfg.model = _capi.MODEL_IDS[self._model]
+        cfg.model = _capi.MODEL_IDS[self._model] if self._model is not None else _capi.MODEL_GENERIC
         cfg.horizon, cfg.dim_state, cfg.dim_control = horizon, dim_state, dim_control
         cfg.num_samples = self._local_samples
         cfg.sample_offset = self._sample_offset
@@ -192,6 +198,8 @@ class MPPI(nn.Module):
         self._last_lambda = None
         self._injected = None
         self._mean_of_last_solve = self._previous_action_seq
+        self._state_seq_batch_buf = None
+        self._x0_tensor = None
 
     # ------------------------------------------------------------------ helpers
     def _stream(self):
@@ -206,7 +214,7 @@ class MPPI(nn.Module):
         return eps * self._sigmas.cpu()
 
     def _refresh_model_inputs(self):
-        prov = self._cost_tag.provider
+        prov = self._cost_tag.provider if self._cost_tag is not None else None
         if prov is None:
             return
         spec = prov(self._cost_owner)
@@ -294,7 +302,10 @@ class MPPI(nn.Module):
         self._solve_idx += 1
 
         # Steps 1b-3: clamp, rollout, costs (src/pi_mpc/mppi.py:266-336)
-        h.call("mppi_rollout_cost", st)
+        if self._model is not None:
+            h.call("mppi_rollout_cost", st)
+        else:
+            self._generic_rollout_costs(state, info)
 
         # Step 4: temperature (host; src/pi_mpc/mppi.py:341-370)
         costs_host = None
@@ -320,8 +331,9 @@ class MPPI(nn.Module):
         # fresh output tensors every solve (the kernel writes straight into what is returned)
         self._action_out = torch.empty(self._horizon, self._dim_control, device=self._device, dtype=self._dtype)
         self._state_out = torch.empty(1, self._horizon + 1, self._dim_state, device=self._device, dtype=self._dtype)
+        native = self._model is not None
         h.call("mppi_finalize", _ptr(summaries), nsh, lam, 0 if use_sg else 1, _ptr(self._action_out),
-               None if use_sg else _ptr(self._state_out), _ptr(self._stats), st)
+               _ptr(self._state_out) if (native and not use_sg) else None, _ptr(self._stats), st)
 
         if self._auto_lambda == "MPO":  # after the weights, affects the next solve (mppi.py:387-398)
             self._lambda = self._mpo.step(costs_host)
@@ -331,11 +343,60 @@ class MPPI(nn.Module):
             a = _host.sg_filter_sequence(self._actions_history_for_sg, a, self._coeffs)
             self._action_out.copy_(torch.from_numpy(a))
             h.call("mppi_set_mean", _ptr(self._action_out), 1, st)
-            h.call("mppi_rollout_actions", _ptr(self._action_out), 1, _ptr(self._state_out), st)
+            if native:
+                h.call("mppi_rollout_actions", _ptr(self._action_out), 1, _ptr(self._state_out), st)
             first = a[0]
             self._actions_history_for_sg = np.concatenate([self._actions_history_for_sg[1:], first[None, :]])
+        if not native:  # Step 8 with the user's dynamics (src/pi_mpc/mppi.py:448-449,508-524)
+            self._state_out = self._states_prediction(self._x0_tensor, self._action_out.repeat(1, 1, 1))
         self._previous_action_seq = self._action_out
         return self._action_out, self._state_out
+
+    # ------------------------------------------------------------------ generic (opaque callables) path
+    def _generic_rollout_costs(self, state, info: Dict) -> None:
+        """Steps 2-3 of forward() with the user's torch callables on GPU tensors, same call sequence and
+        `info` protocol as the reference (src/pi_mpc/mppi.py:280-336); the summed costs go back to the
+        library with mppi_set_costs."""
+        N, T = self._local_samples, self._horizon
+        x0 = torch.as_tensor(np.asarray(state) if not torch.is_tensor(state) else state)
+        x0 = x0.to(self._device, self._dtype)
+        self._x0_tensor = x0
+        # clamp(mean + eps) in the reference layout [N,T,dc]; the handle's warm start still holds the
+        # mean of this solve (it is replaced by mppi_finalize)
+        U = torch.empty(N, T, self._dim_control, device=self._device, dtype=self._dtype)
+        self._h.call("mppi_export_noise", None, _ptr(U), self._stream())
+        self._perturbed_action_seqs = U
+        S = self._state_seq_batch_buf
+        if S is None or S.shape[0] != N:
+            S = self._state_seq_batch_buf = torch.zeros(N, T + 1, self._dim_state, device=self._device,
+                                                        dtype=self._dtype)
+        S[:, 0, :] = x0.repeat(N, 1)
+        for t in range(T):
+            S[:, t + 1, :] = self._dynamics(S[:, t, :], U[:, t, :])
+        costs = torch.zeros(N, T, device=self._device, dtype=self._dtype)
+        initial_state = S[:, 0, :]
+        for t in range(T):
+            p = t - 1 if t > 0 else 0
+            info["prev_state"] = S[:, p, :]
+            info["prev_action"] = U[:, p, :]
+            info["initial_state"] = initial_state
+            info["t"] = t
+            costs[:, t] = self._cost_func(S[:, t, :], U[:, t, :], info)
+        info["prev_state"] = S[:, -2, :]
+        zero_action = torch.zeros(N, self._dim_control, device=self._device, dtype=self._dtype)
+        terminal = self._cost_func(S[:, -1, :], zero_action, info)
+        total = (torch.sum(costs, dim=1) + terminal).contiguous()
+        self._h.call("mppi_set_costs", _ptr(total), 1, self._stream())
+        self._generic_costs_keep = total
+
+    def _states_prediction(self, state: torch.Tensor, action_seqs: torch.Tensor) -> torch.Tensor:
+        """src/pi_mpc/mppi.py:508-524 with the user's dynamics."""
+        out = torch.zeros(action_seqs.shape[0], self._horizon + 1, self._dim_state, device=self._device,
+                          dtype=self._dtype)
+        out[:, 0, :] = state
+        for t in range(self._horizon):
+            out[:, t + 1, :] = self._dynamics(out[:, t, :], action_seqs[:, t, :])
+        return out
 
     def _gather_costs_host(self) -> np.ndarray:
         """costs[N] on the host for the temperature search (all shards when sharded)."""
@@ -395,6 +456,9 @@ class MPPI(nn.Module):
             raise NotImplementedError("get_top_samples on a sharded solver")
         w = self._weights
         top = torch.topk(w, num_samples)
+        if self._model is None:  # the generic path keeps _state_seq_batch like the reference
+            order = torch.argsort(top.values, descending=True)
+            return self._state_seq_batch_buf[top.indices][order], top.values[order]
         idx = top.indices.to(torch.int64).contiguous()
         out = torch.empty(num_samples, self._horizon + 1, self._dim_state, device=self._device, dtype=self._dtype)
         st = self._stream()
@@ -415,6 +479,9 @@ class MPPI(nn.Module):
         g.manual_seed(self._seed + 7919 * self._solve_idx)
         eps = torch.randn(num_samples, self._horizon, self._dim_control, generator=g) * self._sigmas.cpu()
         samples = (optimal_solution.to(self._device) + eps.to(self._device)).contiguous()
+        if self._model is None:
+            x0g = torch.as_tensor(state, dtype=torch.float32).to(self._device)
+            return samples, self._states_prediction(x0g, samples)
         st = self._stream()
         x0 = torch.as_tensor(state, dtype=torch.float32).to(self._device).contiguous()
         self._h.call("mppi_set_state", _ptr(x0), 1, st)

@@ -378,6 +378,95 @@ def test_baseline_configs_against_oracle(model, T, N, lam):
     assert rel_err(s.cpu().numpy()[0], P.rollout_single(x0, a.cpu().numpy())) < TOL
 
 
+# ------------------------------------------------------------------------------ generic (opaque callables) path
+def _untagged(fn):
+    """A plain closure around a plugin: what the reference examples pass (no native tag)."""
+    return lambda *a: fn(*a)
+
+
+@pytest.mark.parametrize("name", ["pendulum_T15_N256_fixed", "mountaincar_T100_N256_fixed", "cartpole_T10_N100_fixed",
+                                  "pendulum_T15_N200_explore"])
+def test_generic_callable_path_matches_reference(name):
+    """Opaque torch callables (the reference's plugin surface as-is): library sampling/softmax/
+    reduction around the user's T-step loops.  Must agree with the reference fixture and with the
+    fused native kernels (mountaincar: including the in-place mutation quirk)."""
+    _need_gpu()
+    from envs import classic_control as cc
+    from pi_mpc.mppi import MPPI
+
+    cfg, g = CASES[name], load(name)
+    model, T, N = cfg["model"], cfg["T"], cfg["N"]
+    mc = MODEL_CFG[model]
+    ds, dc = orc.MODEL_DIMS[orc.MODEL_IDS[model]]
+    kw = {k: cfg[k] for k in ("exploration",) if k in cfg}
+    gen = MPPI(horizon=T, num_samples=N, dim_state=ds, dim_control=dc,
+               dynamics=_untagged(getattr(cc, f"{model}_dynamics")), cost_func=_untagged(getattr(cc, f"{model}_cost")),
+               u_min=torch.tensor(mc["u_min"]), u_max=torch.tensor(mc["u_max"]), sigmas=torch.tensor(mc["sigmas"]),
+               lambda_=cfg["lambda_"], **kw)
+    assert gen._model is None
+    nat, _ = make_solver(model, T, N, lambda_=cfg["lambda_"], **kw)
+    for k in range(int(g["K"])):
+        outs = []
+        for sol in (gen, nat):
+            sol.set_warm_start(g[f"mean_in_{k}"])
+            sol.inject_noise(torch.from_numpy(g[f"eps_{k}"]))
+            a, s = sol.forward(torch.from_numpy(g[f"x0_{k}"]))
+            outs.append((a.cpu().numpy(), s.cpu().numpy(), sol._costs.cpu().numpy()))
+        (ag, sg, cg), (an, sn, cn) = outs
+        assert rel_err(cg, g[f"costs_{k}"]) < TOL and rel_err(cg, cn) < TOL
+        cond = 8 * EPS32 * float(np.abs(cg).max()) / float(cfg["lambda_"])
+        assert rel_err(ag, g[f"action_seq_{k}"]) < max(TOL, cond) and rel_err(ag, an) < max(TOL, cond)
+        assert rel_err(sg, g[f"state_seq_{k}"]) < max(TOL, cond) and rel_err(sg, sn) < max(TOL, cond)
+        if f"S_{k}" in g.files:
+            assert rel_err(gen._state_seq_batch_buf.cpu().numpy(), g[f"S_{k}"]) < TOL
+            assert np.array_equal(gen._perturbed_action_seqs.cpu().numpy(), g[f"U_{k}"])
+    ts, tw = gen.get_top_samples(8)
+    assert ts.shape == (8, T + 1, ds)
+
+
+def test_generic_path_four_controls():
+    """dim_control = 4, dim_state = 5 on a toy linear model, checked against plain torch on the exported
+    noise (exercises the control-index/sigma/bounds mapping beyond the shipped 1- and 2-control models)."""
+    _need_gpu()
+    from pi_mpc.mppi import MPPI
+
+    T, N, ds, dc = 11, 500, 5, 4
+    B = torch.arange(ds * dc, dtype=torch.float32).reshape(ds, dc).cuda() / 10.0
+
+    def dyn(s, u):
+        return s + 0.1 * (u @ B.T)
+
+    def cost(s, u, info):
+        return (s ** 2).sum(dim=1) + 0.01 * (u ** 2).sum(dim=1)
+
+    sig = torch.tensor([0.5, 1.0, 0.2, 0.7])
+    sol = MPPI(horizon=T, num_samples=N, dim_state=ds, dim_control=dc, dynamics=dyn, cost_func=cost,
+               u_min=torch.tensor([-1.0, -2.0, -0.3, -1.5]), u_max=torch.tensor([1.0, 2.0, 0.3, 0.5]), sigmas=sig,
+               lambda_=0.7)
+    with pytest.raises(NotImplementedError):
+        MPPI(horizon=T, num_samples=N, dim_state=ds, dim_control=3, dynamics=dyn, cost_func=cost,
+             u_min=torch.zeros(3), u_max=torch.ones(3), sigmas=torch.ones(3), lambda_=0.7)
+    x0 = torch.ones(ds)
+    a, s = sol.forward(x0)
+    eps = sol._action_noises
+    assert abs(float(eps[..., 1].std()) - 1.0) < 0.05 and abs(float(eps[..., 2].std()) - 0.2) < 0.01
+    ref = orc.philox_normal(42, 1, 0, N, T, dc, sig.numpy())
+    assert np.abs(eps.cpu().numpy() - ref).max() < 1e-4
+    U = torch.clamp(eps, sol._u_min, sol._u_max)
+    S = torch.zeros(N, T + 1, ds, device="cuda")
+    S[:, 0] = x0.cuda()
+    c = torch.zeros(N, device="cuda")
+    for t in range(T):
+        S[:, t + 1] = dyn(S[:, t], U[:, t])
+        c += cost(S[:, t], U[:, t], None)
+    c += cost(S[:, T], torch.zeros(N, dc, device="cuda"), None)
+    w = torch.softmax(-c.double() / 0.7, dim=0)
+    a_ref = (w.view(N, 1, 1) * U.double()).sum(0)
+    assert rel_err(a.cpu().numpy(), a_ref.cpu().numpy()) < 1e-5
+    a2, _ = sol.forward(x0)  # warm start carried
+    assert torch.isfinite(a2).all()
+
+
 # ------------------------------------------------------------------------------ API / error behaviour
 def test_error_behaviour_matches_reference():
     _need_gpu()
