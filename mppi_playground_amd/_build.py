@@ -10,7 +10,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libmppi_hip.so")
 SOURCES = ["mppi_capi.hip"]
 DEPS = ["mppi_capi.hip", "mppi_kernels.hpp", "mppi_models.hpp", "philox.hpp", os.path.join("..", "..", "include", "mppi_hip.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-slp-vectorize",
          "-fhip-fp32-correctly-rounded-divide-sqrt"]
 
 

@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmppi_hip.so")
+# MPPI_HIP_LIB selects an alternative build of the same library (compiler-flag experiments)
+LIB_PATH = os.environ.get("MPPI_HIP_LIB") or os.path.join(_HERE, "csrc", "libmppi_hip.so")
 
 MODEL_GENERIC = -1
 MAX_DIM_CONTROL = 4

@@ -160,8 +160,11 @@ __device__ __forceinline__ float trajectory_cost(const float4* __restrict__ np, 
     return acc + term;
 }
 
+#ifndef MPPI_ROLLOUT_ATTR
+#define MPPI_ROLLOUT_ATTR  // e.g. __attribute__((amdgpu_waves_per_eu(8))) for occupancy experiments
+#endif
 template <int MODEL, bool FAST, bool GEN>
-__global__ __launch_bounds__(BLOCK) void rollout_cost_kernel(const float4* __restrict__ noise,
+__global__ __launch_bounds__(BLOCK) MPPI_ROLLOUT_ATTR void rollout_cost_kernel(const float4* __restrict__ noise,
                                                              const float* __restrict__ mean,
                                                              const float* __restrict__ x0,
                                                              float* __restrict__ costs,
