@@ -127,9 +127,9 @@ bool use_fast(mppi_handle_t h);
 bool use_fast(mppi_handle_t h) {
     if (!h->math_fast) return false;
     const int m = h->cfg.model;
-    if (m == MPPI_MODEL_NAV2D) return h->ctx.maps[0].inv_cell != 0.0f && h->ctx.wrap_safe != 0;
+    if (m == MPPI_MODEL_NAV2D) return h->ctx.maps[0].inv_cell != 0.0f && h->ctx.wrap_safe != 0 && h->ctx.u_in_bounds != 0;
     if (m == MPPI_MODEL_RACING)
-        return h->ctx.wrap_safe != 0 && h->ctx.maps[0].inv_cell != 0.0f && h->ctx.fused != nullptr && h->ctx.tan_small != 0 && h->ctx.inv_L != 0.0f;
+        return h->ctx.wrap_safe != 0 && h->ctx.u_in_bounds != 0 && h->ctx.maps[0].inv_cell != 0.0f && h->ctx.fused != nullptr && h->ctx.tan_small != 0 && h->ctx.inv_L != 0.0f;
     return true;
 }
 
@@ -436,12 +436,13 @@ int mppi_rollout_cost(mppi_handle_t h, void* stream) {
     const unsigned grid = (unsigned)((h->d.tiles + 3) / 4);
 #define CALL_ROLLOUT(MODEL, FASTV)                                                                    \
     do {                                                                                              \
-        const size_t shmem = sizeof(float) * ((size_t)8 * h->d.R + (size_t)h->d.T * Model<MODEL, FASTV>::KROW); \
+        const size_t shmem = sizeof(float) * ((size_t)8 * h->d.R + (size_t)h->d.T * ModelT<MODEL, FASTV>::KROW); \
+        constexpr bool UCV = FASTV;  /* the FAST kernels exist in the u_in_bounds form only (see use_fast) */ \
         if (gen)                                                                                      \
-            hipLaunchKernelGGL((rollout_cost_kernel<MODEL, FASTV, true>), dim3(grid), dim3(BLOCK), shmem, s, \
+            hipLaunchKernelGGL((rollout_cost_kernel<MODEL, FASTV, true, UCV>), dim3(grid), dim3(BLOCK), shmem, s, \
                                h->noise, h->mean, h->x0_cur, h->costs, mk, mk_next, h->d, h->gen, h->ctx); \
         else                                                                                          \
-            hipLaunchKernelGGL((rollout_cost_kernel<MODEL, FASTV, false>), dim3(grid), dim3(BLOCK), shmem, s, \
+            hipLaunchKernelGGL((rollout_cost_kernel<MODEL, FASTV, false, UCV>), dim3(grid), dim3(BLOCK), shmem, s, \
                                h->noise, h->mean, h->x0_cur, h->costs, mk, mk_next, h->d, h->gen, h->ctx); \
     } while (0)
     MPPI_DISPATCH(h, CALL_ROLLOUT);

@@ -101,55 +101,72 @@ __device__ __forceinline__ float4 noise_group(const float4* __restrict__ np, int
 // block's LDS copies of the wave-uniform per-step inputs: LDS returns in order, so the compiler can
 // keep the fetch of the next group / next row in flight (lgkmcnt(N)) while the current step computes,
 // which scalar (SMEM) loads — out of order, lgkmcnt(0) only — do not allow.
-template <int MODEL, bool FAST, bool GEN>
+// UC: the solver's clamp range lies inside the model's own action clamp (compile-time so that the
+// second clamp disappears).
+template <int MODEL, bool FAST, bool GEN, bool UC>
 __device__ __forceinline__ float trajectory_cost(const float4* __restrict__ np, uint64_t gi, const GenCtx& gen,
                                                  const float4* mean4, const float* ktab,
                                                  const float* __restrict__ x0, const Dims& d, const ModelCtx& ctx,
                                                  bool& bad) {
-    using M = Model<MODEL, FAST>;
+    using M = ModelT<MODEL, FAST>;
     using K = typename M::K;
     constexpr int DS = M::DS, DC = M::DC, SPG = 4 / DC;
     float s[DS], pu[DC], pl[DC];
 #pragma unroll
     for (int j = 0; j < DS; ++j) s[j] = x0[j];
     if (FAST) M::check_state(s, bad);
-    const bool uc = ctx.u_in_bounds != 0;  // wave-uniform
+    // clamp bounds live in VGPRs: v_med3_f32 takes one SGPR operand only, and the compiler would
+    // otherwise re-materialise the second bound with a v_mov in every step
+    float lo[DC], hi[DC];
+#pragma unroll
+    for (int k = 0; k < DC; ++k) {
+        lo[k] = d.u_min[k]; hi[k] = d.u_max[k];
+        asm volatile("" : "+v"(hi[k]));
+    }
     float acc = 0.0f;
-    int t = 0;
     K knext = M::load_k(ktab, 0);
     float4 e = noise_group<GEN>(np, 0, gi, gen, d);
     float4 m4 = mean4[0];
     {   // info["prev_action"] of step 0 is U[:, 0] itself (mppi.py:299-301)
         const float e0[4] = {e.x, e.y, e.z, e.w}, m0[4] = {m4.x, m4.y, m4.z, m4.w};
 #pragma unroll
-        for (int k = 0; k < DC; ++k) pu[k] = pl[k] = clampf(m0[k] + e0[k], d.u_min[k], d.u_max[k]);
+        for (int k = 0; k < DC; ++k) pu[k] = pl[k] = clampf(m0[k] + e0[k], lo[k], hi[k]);
     }
-    for (int r = 0; r < d.R; ++r) {
+    int t = 0;
+    auto one_step = [&](const float* ev, const float* mv) {
+        const K kcur = knext;
+        knext = M::load_k(ktab, min(t + 1, d.T - 1));
+        float u[DC];
+#pragma unroll
+        for (int k = 0; k < DC; ++k) u[k] = clampf(mv[k] + ev[k], lo[k], hi[k]);
+        float sn[DS], ss[DS];
+        M::step(ctx, s, u, sn, ss, bad, UC);
+        acc += M::cost(ctx, kcur, ss, u, pu, bad);
+#pragma unroll
+        for (int k = 0; k < DC; ++k) { pl[k] = pu[k]; pu[k] = u[k]; }
+#pragma unroll
+        for (int j = 0; j < DS; ++j) s[j] = sn[j];
+        ++t;
+    };
+    // groups that lie completely inside the horizon: SPG steps each, no per-step bound checks
+    const int full = d.T / SPG;
+    for (int r = 0; r < full; ++r) {
         const int rn = min(r + 1, d.R - 1);
-        const float4 en = (r + 1 < d.R) ? noise_group<GEN>(np, r + 1, gi, gen, d) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 en = noise_group<GEN>(np, rn, gi, gen, d);
         const float4 m4n = mean4[rn];
         const float ev[4] = {e.x, e.y, e.z, e.w};
         const float mv[4] = {m4.x, m4.y, m4.z, m4.w};
 #pragma unroll
-        for (int g = 0; g < SPG; ++g) {
-            if (t < d.T) {
-                const K kcur = knext;
-                knext = M::load_k(ktab, min(t + 1, d.T - 1));
-                float u[DC];
-#pragma unroll
-                for (int k = 0; k < DC; ++k) u[k] = clampf(mv[g * DC + k] + ev[g * DC + k], d.u_min[k], d.u_max[k]);
-                float sn[DS], ss[DS];
-                M::step(ctx, s, u, sn, ss, bad, uc);
-                acc += M::cost(ctx, kcur, ss, u, pu, bad);
-#pragma unroll
-                for (int k = 0; k < DC; ++k) { pl[k] = pu[k]; pu[k] = u[k]; }
-#pragma unroll
-                for (int j = 0; j < DS; ++j) s[j] = sn[j];
-                ++t;
-            }
-        }
+        for (int g = 0; g < SPG; ++g) one_step(ev + g * DC, mv + g * DC);
         e = en;
         m4 = m4n;
+    }
+    if (t < d.T) {  // ragged last group (T*dc not a multiple of 4)
+        const float ev[4] = {e.x, e.y, e.z, e.w};
+        const float mv[4] = {m4.x, m4.y, m4.z, m4.w};
+#pragma unroll
+        for (int g = 0; g < SPG; ++g)
+            if (t < d.T) one_step(ev + g * DC, mv + g * DC);
     }
     // terminal cost: zero action, stale prev_action U[:, max(T-2,0)] and stale t = T-1
     // (mppi.py:318-328); knext already holds the constants of row T-1
@@ -163,7 +180,7 @@ __device__ __forceinline__ float trajectory_cost(const float4* __restrict__ np, 
 #ifndef MPPI_ROLLOUT_ATTR
 #define MPPI_ROLLOUT_ATTR  // e.g. __attribute__((amdgpu_waves_per_eu(8))) for occupancy experiments
 #endif
-template <int MODEL, bool FAST, bool GEN>
+template <int MODEL, bool FAST, bool GEN, bool UC>
 __global__ __launch_bounds__(BLOCK) MPPI_ROLLOUT_ATTR void rollout_cost_kernel(const float4* __restrict__ noise,
                                                              const float* __restrict__ mean,
                                                              const float* __restrict__ x0,
@@ -171,7 +188,7 @@ __global__ __launch_bounds__(BLOCK) MPPI_ROLLOUT_ATTR void rollout_cost_kernel(c
                                                              unsigned* __restrict__ min_key,
                                                              unsigned* __restrict__ next_min_key, Dims d, GenCtx gen,
                                                              ModelCtx ctx) {
-    using M = Model<MODEL, FAST>;
+    using M = ModelT<MODEL, FAST>;
     __shared__ float s_min[BLOCK / WAVE];
     // [4*R] mean groups, [4*R] zeros (samples that do not inherit the mean), then [T*KROW] step rows
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];
@@ -196,11 +213,11 @@ __global__ __launch_bounds__(BLOCK) MPPI_ROLLOUT_ATTR void rollout_cost_kernel(c
         const float4* np = noise + tile * d.R * 64 + lane;
         bool bad = false;
         const float4* mp = inherit ? s_mean4 : s_mean4 + d.R;
-        total = trajectory_cost<MODEL, FAST, GEN>(np, gi, gen, mp, s_ktab, x0, d, ctx, bad);
+        total = trajectory_cost<MODEL, FAST, GEN, UC>(np, gi, gen, mp, s_ktab, x0, d, ctx, bad);
         if (FAST) {
             if (bad) {  // a fast path left its validity range: redo this lane with the library math
                 bool ignore = false;
-                total = trajectory_cost<MODEL, false, GEN>(np, gi, gen, mp, s_ktab, x0, d, ctx, ignore);
+                total = trajectory_cost<MODEL, false, GEN, false>(np, gi, gen, mp, s_ktab, x0, d, ctx, ignore);
             }
         }
         if (i < d.N) costs[i] = total;
@@ -414,7 +431,7 @@ __global__ __launch_bounds__(SUM_BLOCK) void summarize_kernel(const float* __res
 template <int MODEL, bool FAST, class GETU>
 __device__ __forceinline__ bool rollout_states(const float* __restrict__ x0, int T, const ModelCtx& ctx,
                                                float* __restrict__ out, GETU getu) {
-    using M = Model<MODEL, FAST>;
+    using M = ModelT<MODEL, FAST>;
     constexpr int DS = M::DS, DC = M::DC;
     bool bad = false;
     float s[DS];
@@ -450,7 +467,7 @@ __global__ __launch_bounds__(BLOCK) void finalize_kernel(const float* __restrict
                                                          float* __restrict__ action_out,
                                                          float* __restrict__ state_out, float* __restrict__ stats_out,
                                                          ModelCtx ctx) {
-    constexpr int DC = Model<MODEL, FAST>::DC;
+    constexpr int DC = ModelT<MODEL, FAST>::DC;
     extern __shared__ __attribute__((aligned(16))) float s_act[];  // [row]
     const int stride = MPPI_SUMMARY_HEAD + row;
     float xmax = -INFINITY, cmin = INFINITY;
@@ -503,7 +520,7 @@ template <int MODEL, bool FAST>
 __global__ __launch_bounds__(WAVE) void rollout_actions_kernel(const float* __restrict__ actions, int k, int T,
                                                                const float* __restrict__ x0,
                                                                float* __restrict__ states, ModelCtx ctx) {
-    constexpr int DS = Model<MODEL, FAST>::DS, DC = Model<MODEL, FAST>::DC;
+    constexpr int DS = ModelT<MODEL, FAST>::DS, DC = ModelT<MODEL, FAST>::DC;
     const int q = blockIdx.x * WAVE + threadIdx.x;
     if (q >= k) return;
     const float* a = actions + (int64_t)q * T * DC;
@@ -521,7 +538,7 @@ __global__ __launch_bounds__(WAVE) void rollout_samples_kernel(const float4* __r
                                                                const int64_t* __restrict__ idx, int k,
                                                                const float* __restrict__ x0,
                                                                float* __restrict__ states, Dims d, ModelCtx ctx) {
-    constexpr int DS = Model<MODEL, FAST>::DS, DC = Model<MODEL, FAST>::DC;
+    constexpr int DS = ModelT<MODEL, FAST>::DS, DC = ModelT<MODEL, FAST>::DC;
     const int q = blockIdx.x * WAVE + threadIdx.x;
     if (q >= k) return;
     const int64_t i = idx[q];

@@ -15,7 +15,7 @@ using namespace mppi;
 template <int MODEL, bool FAST>
 static float walk(const float* eps_row, const float* mean, const float* x0, int T, const float* umin,
                   const float* umax, const ModelCtx& ctx, bool inherit, bool& bad, float* S_out) {
-    using M = Model<MODEL, FAST>;
+    using M = ModelT<MODEL, FAST>;
     constexpr int DS = M::DS, DC = M::DC;
     float s[DS], pu[DC], pl[DC];
     for (int j = 0; j < DS; ++j) s[j] = x0[j];
@@ -44,7 +44,7 @@ template <int MODEL>
 static void run(int fast, int N, int T, int threshold, const float* x0, const float* mean, const float* eps,
                 const float* umin, const float* umax, const ModelCtx& ctx, float* costs, uint8_t* bad_out,
                 float* S_out) {
-    constexpr int DS = Model<MODEL, false>::DS, DC = Model<MODEL, false>::DC;
+    constexpr int DS = ModelT<MODEL, false>::DS, DC = ModelT<MODEL, false>::DC;
     for (int i = 0; i < N; ++i) {
         bool bad = false;
         float* So = S_out ? S_out + (size_t)i * (T + 1) * DS : nullptr;
@@ -104,8 +104,17 @@ int emul_rollout_cost(int model, int fast, int N, int T, int threshold, const fl
 }
 
 // element-wise pins of the fast math against the library math
+using namespace mppi::strict;  // element-wise pins: same functions in both contraction variants
 void emul_sincos(const float* x, float* s, float* c, int n, int fast) {
     for (int i = 0; i < n; ++i) { bool b = false; if (fast) sincos_f<true>(x[i], s[i], c[i], b); else sincos_f<false>(x[i], s[i], c[i], b); }
+}
+// in-loop wraps of the kinematic models against the library wrap: mode 0 rewrap_f, 1 wrap_inc_f
+void emul_loop_wraps(const float* x, float* fast_out, float* lib_out, int n, int mode) {
+    for (int i = 0; i < n; ++i) {
+        bool b = false;
+        fast_out[i] = mode == 0 ? rewrap_f(x[i]) : wrap_inc_f(x[i]);
+        lib_out[i] = angle_normalize<false>(x[i], b);
+    }
 }
 void emul_angle_normalize(const float* x, float* y, uint8_t* bad, int n, int mode /*0 lib,1 narrow,2 wide*/) {
     for (int i = 0; i < n; ++i) {

@@ -91,6 +91,28 @@ def test_fast_angle_normalize_is_bit_identical(mode, width):
     assert np.array_equal(y0[ok].view(np.uint32), y1[ok].view(np.uint32))
 
 
+def test_in_loop_wraps_are_bit_identical():
+    """rewrap_f on wrapped angles and wrap_inc_f on wrapped angle + bounded increment reproduce the
+    library angle_normalize bit for bit (the ranges the FAST kinematic models guarantee)."""
+    L = emul.lib()
+    rng = np.random.default_rng(2)
+    pi32 = F32(3.14159274)
+    th = (rng.random(2000000) * 2 - 1).astype(np.float64) * np.pi
+    th = np.concatenate([th, [-np.pi, 0.0, -0.0, np.pi * 0.5, -np.pi * 0.5]]).astype(F32)
+    th = th[(th >= -pi32) & (th < pi32)]
+    # wrapped angles: outputs of the library wrap itself
+    lib0 = np.empty_like(th); tmp = np.empty_like(th)
+    L.emul_loop_wraps(_p(th), _p(tmp), _p(lib0), th.size, 0)
+    wrapped = lib0.copy()
+    f, l = np.empty_like(wrapped), np.empty_like(wrapped)
+    L.emul_loop_wraps(_p(wrapped), _p(f), _p(l), wrapped.size, 0)
+    assert np.array_equal(f.view(np.uint32), l.view(np.uint32))
+    inc = ((rng.random(wrapped.size) * 2 - 1) * 3.0).astype(F32)
+    x = (wrapped + inc).astype(F32)
+    L.emul_loop_wraps(_p(x), _p(f), _p(l), x.size, 1)
+    assert np.array_equal(f.view(np.uint32), l.view(np.uint32))
+
+
 @pytest.mark.parametrize("cell", [0.1, 0.05, 0.01, 0.3, 0.25])
 def test_markstein_division_is_correctly_rounded(cell):
     L = emul.lib()
