@@ -159,6 +159,13 @@ int mppi_weights_reduce(mppi_handle_t h, float lambda, float* summary_out_dev, v
 int mppi_finalize(mppi_handle_t h, const float* summaries_dev, int num_shards, float lambda, int store_mean,
                   float* action_out_dev, float* state_seq_out_dev, float* stats_out_dev, void* stream);
 
+/* Device half of the automatic temperature searches (`_compute_ess`, `_lbps_objective`,
+ * `_essps_objective`, the MPO dual; mppi.py:341-370,387-398,526-566): softmax statistics of this
+ * shard's costs for one lambda, out5_host = {min c, max c, sum e, sum e^2, sum e*c} with
+ * e_i = exp((-c_i)/lambda - (-min c)/lambda).  ESS = (sum e)^2 / sum e^2, E_w[c] = sum e*c / sum e,
+ * logsumexp(-c/lambda) = -min c/lambda + log(sum e).  The root-finders stay on the host.  Synchronises. */
+int mppi_softmax_stats(mppi_handle_t h, float lambda, double* out5_host, void* stream);
+
 /* `_weights` (mppi.py:376) for this shard given the GLOBAL {min c, sum e}: w_out_dev[N]. */
 int mppi_weights(mppi_handle_t h, float lambda, float cmin_global, float sum_e_global, float* w_out_dev,
                  void* stream);

@@ -43,6 +43,8 @@ struct MppiSolver {
     float* partials = nullptr;
     float* heads = nullptr;
     float* summary = nullptr;
+    float* stats_part = nullptr;     // [STATS_BLOCKS][4]
+    double* stats_host = nullptr;    // mapped pinned [5]
     uint8_t* map_cells[2] = {nullptr, nullptr};
     uint8_t* map_fused = nullptr;
     std::vector<uint8_t> map_host[2];
@@ -228,6 +230,8 @@ int mppi_create(const MppiConfig* cfg, mppi_handle_t* out) {
     HIP_TRY(h, hipMalloc(&h->partials, sizeof(float) * (size_t)max_blocks * h->colsp));
     HIP_TRY(h, hipMalloc(&h->heads, sizeof(float) * (size_t)max_blocks * 4));
     HIP_TRY(h, hipMalloc(&h->summary, sizeof(float) * (size_t)(MPPI_SUMMARY_HEAD + d.row)));
+    HIP_TRY(h, hipMalloc(&h->stats_part, sizeof(float) * 4 * STATS_BLOCKS));
+    HIP_TRY(h, hipHostMalloc((void**)&h->stats_host, sizeof(double) * 8, hipHostMallocMapped));
     std::memset(&h->ctx, 0, sizeof(h->ctx));
     HIP_TRY(h, hipDeviceSynchronize());
     return MPPI_OK;
@@ -238,7 +242,8 @@ int mppi_destroy(mppi_handle_t h) {
     (void)hipFree(h->noise); (void)hipFree(h->costs); (void)hipFree(h->min_key); (void)hipFree(h->x0);
     (void)hipFree(h->mean); (void)hipFree(h->ref); (void)hipFree(h->partials); (void)hipFree(h->heads);
     (void)hipFree(h->summary); (void)hipFree(h->map_cells[0]); (void)hipFree(h->map_cells[1]);
-    (void)hipFree(h->map_fused);
+    (void)hipFree(h->map_fused); (void)hipFree(h->stats_part);
+    if (h->stats_host) (void)hipHostFree(h->stats_host);
     for (int i = 0; i < MppiSolver::RING; ++i) {
         if (h->stage[i]) (void)hipHostFree(h->stage[i]);
         if (h->stage_ev[i]) (void)hipEventDestroy(h->stage_ev[i]);
@@ -520,6 +525,22 @@ int mppi_finalize(mppi_handle_t h, const float* summaries_dev, int num_shards, f
     MPPI_DISPATCH(h, CALL_FINALIZE);
 #undef CALL_FINALIZE
     HIP_TRY(h, hipGetLastError());
+    return MPPI_OK;
+}
+
+int mppi_softmax_stats(mppi_handle_t h, float lambda, double* out5_host, void* stream) {
+    if (!h || !out5_host || !(lambda > 0.0f)) return fail(h, MPPI_E_INVALID, "bad softmax_stats arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned* mk = h->min_key + h->min_slot;
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(STATS_BLOCKS, (h->d.N + BLOCK - 1) / BLOCK));
+    hipLaunchKernelGGL(stats_partial_kernel, dim3(blocks), dim3(BLOCK), 0, s, h->costs, h->d.N, mk, lambda, h->stats_part);
+    HIP_TRY(h, hipGetLastError());
+    double* dev_out = nullptr;
+    HIP_TRY(h, hipHostGetDevicePointer((void**)&dev_out, h->stats_host, 0));
+    hipLaunchKernelGGL(stats_combine_kernel, dim3(1), dim3(WAVE), 0, s, h->stats_part, blocks, mk, dev_out);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipStreamSynchronize(s));
+    for (int i = 0; i < 5; ++i) out5_host[i] = h->stats_host[i];
     return MPPI_OK;
 }
 

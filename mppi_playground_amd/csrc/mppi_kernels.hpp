@@ -508,6 +508,59 @@ __global__ __launch_bounds__(BLOCK) void finalize_kernel(const float* __restrict
     }
 }
 
+// Softmax statistics of the cost vector for one temperature — the device half of the auto-lambda
+// searches (ESSPS / LBPS / MPO, mppi.py:341-370,387-398,526-566): the root-finders stay on the host
+// and ask for {sum e, sum e^2, sum e*c, max c} with e_i = exp((-c_i)/lambda - (-cmin)/lambda), instead
+// of pulling costs[N] over PCIe and running ~10-40 softmaxes on the CPU.  Two tiny launches
+// (per-block partials, then a fixed-order combine written to mapped host memory): deterministic.
+constexpr int STATS_BLOCKS = 256;
+__global__ __launch_bounds__(BLOCK) void stats_partial_kernel(const float* __restrict__ costs, int64_t N,
+                                                             const unsigned* __restrict__ min_key, float lambda,
+                                                             float* __restrict__ part /*[STATS_BLOCKS][4]*/) {
+    __shared__ float s_p[BLOCK / WAVE][4];
+    const float cmin = key_to_float(*min_key);
+    const float xmax = (-cmin) / lambda;
+    float se = 0.f, se2 = 0.f, sec = 0.f, cmax = -INFINITY;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < N; i += (int64_t)gridDim.x * BLOCK) {
+        const float c = costs[i];
+        const float e = expf((-c) / lambda - xmax);
+        se += e;
+        se2 = fmaf(e, e, se2);
+        sec = fmaf(e, c, sec);
+        cmax = fmaxf(cmax, c);
+    }
+    se = wave_sum(se); se2 = wave_sum(se2); sec = wave_sum(sec);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) cmax = fmaxf(cmax, __shfl_xor(cmax, m));
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) { s_p[wid][0] = se; s_p[wid][1] = se2; s_p[wid][2] = sec; s_p[wid][3] = cmax; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        float v = s_p[0][threadIdx.x];
+#pragma unroll
+        for (int w = 1; w < BLOCK / WAVE; ++w) v = threadIdx.x == 3 ? fmaxf(v, s_p[w][3]) : v + s_p[w][threadIdx.x];
+        part[blockIdx.x * 4 + threadIdx.x] = v;
+    }
+}
+__global__ __launch_bounds__(WAVE) void stats_combine_kernel(const float* __restrict__ part, int nblocks,
+                                                            const unsigned* __restrict__ min_key,
+                                                            double* __restrict__ out /*[5] mapped host*/) {
+    double se = 0.0, se2 = 0.0, sec = 0.0;
+    float cmax = -INFINITY;
+    for (int b = threadIdx.x; b < nblocks; b += WAVE) {
+        se += part[b * 4]; se2 += part[b * 4 + 1]; sec += part[b * 4 + 2];
+        cmax = fmaxf(cmax, part[b * 4 + 3]);
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        se += __shfl_xor(se, m); se2 += __shfl_xor(se2, m); sec += __shfl_xor(sec, m);
+        cmax = fmaxf(cmax, __shfl_xor(cmax, m));
+    }
+    if (threadIdx.x == 0) {
+        out[0] = (double)key_to_float(*min_key); out[1] = (double)cmax; out[2] = se; out[3] = se2; out[4] = sec;
+    }
+}
+
 // `_weights` (mppi.py:376) given the global min cost and sum e.
 __global__ __launch_bounds__(BLOCK) void weights_kernel(const float* __restrict__ costs, int64_t N, float lambda,
                                                         float cmin, float sum_e, float* __restrict__ w) {

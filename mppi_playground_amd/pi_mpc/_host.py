@@ -52,6 +52,35 @@ def lbps_lambda(costs: np.ndarray, delta: float, lam_min: float, lam_max: float)
     return float(res.x)
 
 
+# ---- the same searches driven by device-side softmax statistics ---------------------------------------
+# `stats(lam)` returns {cmin, cmax, se, se2, sec} with e_i = exp((-c_i)/lam - (-cmin)/lam) summed over all
+# samples (mppi_softmax_stats, combined across shards): the O(N) work stays on the GPU, the scalar
+# root-finding stays here.
+def ess_from_stats(st) -> float:
+    return st["se"] * st["se"] / st["se2"]
+
+
+def essps_lambda_stats(stats, target_ess: float, lam_min: float, lam_max: float) -> float:
+    """src/pi_mpc/mppi.py:351-370 with ESS(lambda) evaluated on the device."""
+    if target_ess <= ess_from_stats(stats(lam_min)):
+        return lam_min
+    if target_ess >= ess_from_stats(stats(lam_max)):
+        return lam_max
+    return brentq(lambda lam: ess_from_stats(stats(lam)) - target_ess, lam_min, lam_max)
+
+
+def lbps_lambda_stats(stats, delta: float, lam_min: float, lam_max: float) -> float:
+    """src/pi_mpc/mppi.py:341-349,534-557 with the softmax sums evaluated on the device."""
+
+    def objective(lam):
+        st = stats(lam)
+        expected_return = -st["sec"] / st["se"]
+        penalty = (st["cmax"] - st["cmin"]) * math.sqrt((1 - delta) / delta) / math.sqrt(ess_from_stats(st))
+        return -(expected_return - penalty)
+
+    return float(minimize_scalar(objective, bounds=(lam_min, lam_max), method="bounded").x)
+
+
 class MpoTemperature:
     """MPO E-step dual on the temperature (src/pi_mpc/mppi.py:191-200,387-398): one Adam(lr=0.2) step
     per solve on loss = softplus(logT) * (eps + logsumexp(-c / softplus(logT))), then
@@ -67,15 +96,26 @@ class MpoTemperature:
         self.v = F32(0.0)
         self.t = 0
 
+    def temperature(self) -> float:
+        """softplus(logT): the temperature inside the dual (not the lambda used for the weights)."""
+        return math.log1p(math.exp(float(self.log_temperature)))
+
     def step(self, costs: np.ndarray) -> float:
-        lt = float(self.log_temperature)
-        T = math.log1p(math.exp(lt))  # softplus
+        T = self.temperature()
         x = (-costs.astype(np.float64)) / T
         mx = x.max()
         e = np.exp(x - mx)
         se = e.sum()
-        lse = mx + math.log(se)
-        wc = float((e * costs).sum() / se)
+        return self.step_from_sums(mx + math.log(se), float((e * costs).sum() / se))
+
+    def step_from_stats(self, st) -> float:
+        """`st` = softmax statistics at lambda = self.temperature()."""
+        T = self.temperature()
+        return self.step_from_sums(-st["cmin"] / T + math.log(st["se"]), st["sec"] / st["se"])
+
+    def step_from_sums(self, lse: float, wc: float) -> float:
+        lt = float(self.log_temperature)
+        T = self.temperature()
         dL_dT = self.epsilon + lse + wc / T
         g = F32(dL_dT * (1.0 / (1.0 + math.exp(-lt))))
         self.t += 1

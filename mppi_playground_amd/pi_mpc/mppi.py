@@ -61,6 +61,7 @@ class MPPI(nn.Module):
         noise_source: str = "philox",
         shard_samples: bool = False,
         process_group=None,
+        auto_lambda_stats: str = "device",
     ) -> None:
         """Arguments up to `seed` are the reference's (src/pi_mpc/mppi.py:24-47).
 
@@ -68,6 +69,9 @@ class MPPI(nn.Module):
             noise_source: "philox" (device Philox4x32-10 stream, default) or "torch_cpu" (draw with
                 torch's CPU generator exactly like the reference does on CPU — same seed, same
                 numbers — and upload; for parity runs).
+            auto_lambda_stats: "device" (default) evaluates the softmax sums of the ESSPS/LBPS/MPO searches
+                on the GPU (mppi_softmax_stats; the root-finders stay on the host), "host" copies
+                costs[N] to the CPU and evaluates them in numpy like the reference does.
             shard_samples: treat `num_samples` as the GLOBAL sample count and let this rank own the
                 contiguous block rank*N/W .. (rank+1)*N/W of it (torch.distributed must be
                 initialised); one all_gather of 4+T*dc floats per solve combines the shards.
@@ -99,6 +103,9 @@ class MPPI(nn.Module):
         self._sg_window_size = sg_window_size
         self._sg_poly_order = sg_poly_order
         self._seed = int(seed)
+        if auto_lambda_stats not in ("device", "host"):
+            raise ValueError("auto_lambda_stats must be 'device' or 'host'")
+        self._auto_lambda_stats = auto_lambda_stats
         if noise_source not in ("philox", "torch_cpu"):
             raise ValueError("noise_source must be 'philox' or 'torch_cpu'")
         self._noise_source = noise_source
@@ -309,13 +316,18 @@ class MPPI(nn.Module):
 
         # Step 4: temperature (host; src/pi_mpc/mppi.py:341-370)
         costs_host = None
-        if self._auto_lambda is not None:
+        on_dev = self._auto_lambda_stats == "device"
+        if self._auto_lambda is not None and not on_dev:
             costs_host = self._gather_costs_host()
-            if self._auto_lambda == "LBPS":
-                self._lambda = _host.lbps_lambda(costs_host, self._lbps_delta, self._lambda_min, self._lambda_max)
-            elif self._auto_lambda == "ESSPS":
-                self._lambda = _host.essps_lambda(costs_host, self._essps_target_ess, self._lambda_min,
-                                                  self._lambda_max)
+        if self._auto_lambda == "LBPS":
+            self._lambda = (_host.lbps_lambda_stats(self._softmax_stats, self._lbps_delta, self._lambda_min,
+                                                    self._lambda_max) if on_dev else
+                            _host.lbps_lambda(costs_host, self._lbps_delta, self._lambda_min, self._lambda_max))
+        elif self._auto_lambda == "ESSPS":
+            self._lambda = (_host.essps_lambda_stats(self._softmax_stats, self._essps_target_ess, self._lambda_min,
+                                                     self._lambda_max) if on_dev else
+                            _host.essps_lambda(costs_host, self._essps_target_ess, self._lambda_min,
+                                               self._lambda_max))
         lam = float(self._lambda)
         self._last_lambda = lam
 
@@ -336,7 +348,8 @@ class MPPI(nn.Module):
                _ptr(self._state_out) if (native and not use_sg) else None, _ptr(self._stats), st)
 
         if self._auto_lambda == "MPO":  # after the weights, affects the next solve (mppi.py:387-398)
-            self._lambda = self._mpo.step(costs_host)
+            self._lambda = (self._mpo.step_from_stats(self._softmax_stats(self._mpo.temperature())) if on_dev
+                            else self._mpo.step(costs_host))
 
         if use_sg:  # Step 7 on the host (src/pi_mpc/mppi.py:423-443)
             a = self._action_out.cpu().numpy()
@@ -397,6 +410,26 @@ class MPPI(nn.Module):
         for t in range(self._horizon):
             out[:, t + 1, :] = self._dynamics(out[:, t, :], action_seqs[:, t, :])
         return out
+
+    def _softmax_stats(self, lam: float) -> Dict[str, float]:
+        """{cmin, cmax, se, se2, sec} of softmax(-costs/lam) over ALL samples, reduced on the device
+        (one 40-byte read-back per probe; one all_gather of 5 doubles per probe when sharded)."""
+        out = (C.c_double * 5)()
+        self._h.call("mppi_softmax_stats", float(lam), out, self._stream())
+        cmin, cmax, se, se2, sec = (float(v) for v in out)
+        if self._world > 1:
+            import torch.distributed as dist
+
+            mine = torch.tensor([cmin, cmax, se, se2, sec], dtype=torch.float64, device=self._device)
+            allv = torch.empty(self._world * 5, dtype=torch.float64, device=self._device)
+            dist.all_gather_into_tensor(allv, mine, group=self._pg)
+            a = allv.view(self._world, 5).cpu().numpy()
+            lam32 = np.float32(lam)
+            x = ((-a[:, 0].astype(np.float32)) / lam32).astype(np.float64)
+            f = np.exp(x - x.max())
+            cmin, cmax = float(a[:, 0].min()), float(a[:, 1].max())
+            se, se2, sec = float((f * a[:, 2]).sum()), float((f * f * a[:, 3]).sum()), float((f * a[:, 4]).sum())
+        return dict(cmin=cmin, cmax=cmax, se=se, se2=se2, sec=sec)
 
     def _gather_costs_host(self) -> np.ndarray:
         """costs[N] on the host for the temperature search (all shards when sharded)."""

@@ -378,6 +378,30 @@ def test_baseline_configs_against_oracle(model, T, N, lam):
     assert rel_err(s.cpu().numpy()[0], P.rollout_single(x0, a.cpu().numpy())) < TOL
 
 
+@pytest.mark.parametrize("lam_mode", ["ESSPS", "LBPS", "MPO"])
+def test_device_softmax_stats_drive_the_same_temperature(lam_mode):
+    """auto_lambda_stats='device' (sums on the GPU) and 'host' (costs copied to numpy) find the same lambda
+    and the same action; the raw statistics match a float64 numpy evaluation."""
+    N, T = 65536, 50
+    outs = []
+    for mode in ("device", "host"):
+        solver, _ = make_solver("nav2d", T, N, lambda_=lam_mode, auto_lambda_stats=mode)
+        x0 = torch.tensor([-9.0, -9.0, 0.785])
+        a, s = solver.forward(x0)
+        a2, _ = solver.forward(x0)
+        outs.append((solver._last_lambda, a.cpu().numpy(), a2.cpu().numpy(), solver))
+    tol = {"ESSPS": 1e-4, "LBPS": 5e-3, "MPO": 1e-3}[lam_mode]
+    assert abs(outs[0][0] - outs[1][0]) <= tol * outs[1][0]
+    assert rel_err(outs[0][1], outs[1][1]) < 20 * tol
+    solver = outs[0][3]
+    c = solver._costs.cpu().numpy().astype(np.float64)
+    st = solver._softmax_stats(3.0)
+    e = np.exp(-(c - c.min()) / 3.0)
+    assert st["cmin"] == c.min() and st["cmax"] == c.max()
+    assert abs(st["se"] - e.sum()) <= 1e-5 * e.sum() and abs(st["se2"] - (e * e).sum()) <= 1e-5 * (e * e).sum()
+    assert abs(st["sec"] - (e * c).sum()) <= 1e-5 * (e * c).sum()
+
+
 # ------------------------------------------------------------------------------ generic (opaque callables) path
 def _untagged(fn):
     """A plain closure around a plugin: what the reference examples pass (no native tag)."""

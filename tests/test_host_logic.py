@@ -38,6 +38,34 @@ def test_mpo_temperature():
         assert abs(lam - float(g[f"lambda_{k}"])) <= 2e-4 * float(g[f"lambda_{k}"])
 
 
+def _np_stats(costs):
+    """numpy stand-in of mppi_softmax_stats (float64 sums)."""
+    def stats(lam):
+        x = (-costs.astype(np.float32)) / np.float32(lam)
+        e = np.exp((x - x.max()).astype(np.float32)).astype(np.float64)
+        return dict(cmin=float(costs.min()), cmax=float(costs.max()), se=e.sum(), se2=(e * e).sum(),
+                    sec=(e * costs).sum())
+    return stats
+
+
+def test_stats_driven_searches_match_reference():
+    """The device-statistics form of the three temperature searches gives the reference's lambdas."""
+    for name in ("pendulum_T50_N1000_essps", "nav2d_T50_N512_essps", "cartpole_T64_N1024_essps_sg"):
+        g, cfg = load(name), CASES[name]
+        for k in range(3):
+            lam = _host.essps_lambda_stats(_np_stats(g[f"costs_{k}"]), cfg["N"] / 10, 0.01, 10.0)
+            assert abs(lam - float(g[f"lambda_{k}"])) <= 1e-5 * float(g[f"lambda_{k}"])
+    g = load("pendulum_T15_N256_lbps")
+    for k in range(3):
+        lam = _host.lbps_lambda_stats(_np_stats(g[f"costs_{k}"]), 0.01, 0.01, 10.0)
+        assert abs(lam - float(g[f"lambda_{k}"])) <= 1e-3 * float(g[f"lambda_{k}"])
+    g = load("pendulum_T15_N256_mpo")
+    m = _host.MpoTemperature()
+    for k in range(3):
+        lam = m.step_from_stats(_np_stats(g[f"costs_{k}"])(m.temperature()))
+        assert abs(lam - float(g[f"lambda_{k}"])) <= 2e-4 * float(g[f"lambda_{k}"])
+
+
 def test_savitzky_golay():
     co = _host.savitzky_golay_coeffs(5, 3)
     assert np.allclose(co * 35, [-3, 12, 17, 12, -3], atol=1e-5)
