@@ -112,6 +112,21 @@ def main():
         t_roll = stages["rollout_cost"] * 1e-3
         achieved = b_alg_rollout / t_roll / 1e9
         dev_solve_ms = sum(stages[k] for k in ("sample", "rollout_cost", "weights_reduce", "finalize"))
+        # PMC-derived constants of the dominant kernel for THIS configuration (profiles/pmc_constants.json)
+        traffic, valu = None, None
+        try:
+            if (N_local, T, args.math) == (1 << 20, 50, 1):
+                pc = json.load(open(os.path.join(ROOT, "profiles", "pmc_constants.json")))
+                k = pc["rollout_regen" if args.noise_regen else "rollout_tiles"]
+                traffic = int((2 * k["fetch_kb"] + k["write_kb"]) * 1024)
+                peak = 1024 * 2.4e9 / 2  # wave64 VALU instructions/s: 1024 SIMD32s, 2 cycles each, 2.4 GHz
+                valu = {"kernel": "rollout_cost_kernel<racing>", "valu_insts_per_launch": k["valu_insts"],
+                        "achieved_Ginst_per_s": k["valu_insts"] / t_roll / 1e9, "peak_Ginst_per_s": peak / 1e9,
+                        "frac": k["valu_insts"] / t_roll / peak,
+                        "note": "wave64 VALU instructions (SQ_INSTS_VALU, rocprofv3) / live kernel time; the kernel "
+                                "is VALU-issue bound (2.97 cycles/instruction/SIMD measured), not HBM bound"}
+        except Exception:
+            pass
         out = {
             "metric": "sample_steps_per_sec", "value": value, "unit": "sample-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -124,13 +139,15 @@ def main():
             "solves_per_sec": solves_per_s,
             "roofline": {"bound": "hbm", "kernel": "rollout_cost_kernel<racing>", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "algorithmic_bytes_per_launch": b_alg_rollout,
+                         "traffic": traffic, "algorithmic_bytes_per_launch": b_alg_rollout,
                          "kernel_ms": stages["rollout_cost"]},
             "solve_roofline": {"algorithmic_bytes_per_solve": b_alg_solve, "device_ms_per_solve": dev_solve_ms,
                                "achieved_GBps": b_alg_solve / (dev_solve_ms * 1e-3) / 1e9,
                                "frac_of_8TBps": b_alg_solve / (dev_solve_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "stages_ms": {k: stages[k] for k in ("sample", "rollout_cost", "weights_reduce", "finalize")},
         }
+        if valu is not None:
+            out["valu_roofline"] = valu
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(np, T, ref.numpy(), x0.cpu().numpy())
         print(json.dumps(out), flush=True)
