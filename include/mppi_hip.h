@@ -165,6 +165,10 @@ int mppi_finalize(mppi_handle_t h, const float* summaries_dev, int num_shards, f
  * e_i = exp((-c_i)/lambda - (-min c)/lambda).  ESS = (sum e)^2 / sum e^2, E_w[c] = sum e*c / sum e,
  * logsumexp(-c/lambda) = -min c/lambda + log(sum e).  The root-finders stay on the host.  Synchronises. */
 int mppi_softmax_stats(mppi_handle_t h, float lambda, double* out5_host, void* stream);
+/* The same for `count` (1..32) temperatures in ONE pass over the costs: out_host[count][3] =
+ * {sum e, sum e^2, sum e*c} per lambda (each relative to this shard's min c).  Lets the ESSPS
+ * bracketing search probe a whole grid of lambdas per round trip.  Synchronises. */
+int mppi_softmax_stats_multi(mppi_handle_t h, const float* lambdas_host, int count, double* out_host, void* stream);
 
 /* `_weights` (mppi.py:376) for this shard given the GLOBAL {min c, sum e}: w_out_dev[N]. */
 int mppi_weights(mppi_handle_t h, float lambda, float cmin_global, float sum_e_global, float* w_out_dev,

@@ -23,7 +23,7 @@ SYMBOLS = [
     "mppi_version", "mppi_device_count", "mppi_last_error", "mppi_create", "mppi_destroy",
     "mppi_set_model_params", "mppi_upload_map", "mppi_set_reference", "mppi_set_mean", "mppi_get_mean",
     "mppi_set_state", "mppi_bind_state", "mppi_sample", "mppi_inject_noise", "mppi_export_noise", "mppi_rollout_cost",
-    "mppi_get_costs", "mppi_set_costs", "mppi_weights_reduce", "mppi_finalize", "mppi_softmax_stats", "mppi_weights",
+    "mppi_get_costs", "mppi_set_costs", "mppi_weights_reduce", "mppi_finalize", "mppi_softmax_stats", "mppi_softmax_stats_multi", "mppi_weights",
     "mppi_rollout_actions", "mppi_rollout_samples", "mppi_set_option", "mppi_get_timing",
 ]
 
@@ -76,6 +76,7 @@ def load():
     lib.mppi_weights_reduce.argtypes = [vp, f32, vp, vp]
     lib.mppi_finalize.argtypes = [vp, vp, i32, f32, i32, vp, vp, vp, vp]
     lib.mppi_softmax_stats.argtypes = [vp, f32, vp, vp]
+    lib.mppi_softmax_stats_multi.argtypes = [vp, vp, i32, vp, vp]
     lib.mppi_weights.argtypes = [vp, f32, f32, f32, vp, vp]
     lib.mppi_rollout_actions.argtypes = [vp, vp, i32, vp, vp]
     lib.mppi_rollout_samples.argtypes = [vp, vp, i32, vp, vp]

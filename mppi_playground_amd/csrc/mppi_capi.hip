@@ -43,8 +43,8 @@ struct MppiSolver {
     float* partials = nullptr;
     float* heads = nullptr;
     float* summary = nullptr;
-    float* stats_part = nullptr;     // [STATS_BLOCKS][4]
-    double* stats_host = nullptr;    // mapped pinned [5]
+    float* stats_part = nullptr;     // [STATS_BLOCKS][max(4, STATS_L*3)]
+    double* stats_host = nullptr;    // mapped pinned [8 + STATS_L*3]
     uint8_t* map_cells[2] = {nullptr, nullptr};
     uint8_t* map_fused = nullptr;
     std::vector<uint8_t> map_host[2];
@@ -230,8 +230,8 @@ int mppi_create(const MppiConfig* cfg, mppi_handle_t* out) {
     HIP_TRY(h, hipMalloc(&h->partials, sizeof(float) * (size_t)max_blocks * h->colsp));
     HIP_TRY(h, hipMalloc(&h->heads, sizeof(float) * (size_t)max_blocks * 4));
     HIP_TRY(h, hipMalloc(&h->summary, sizeof(float) * (size_t)(MPPI_SUMMARY_HEAD + d.row)));
-    HIP_TRY(h, hipMalloc(&h->stats_part, sizeof(float) * 4 * STATS_BLOCKS));
-    HIP_TRY(h, hipHostMalloc((void**)&h->stats_host, sizeof(double) * 8, hipHostMallocMapped));
+    HIP_TRY(h, hipMalloc(&h->stats_part, sizeof(float) * STATS_L * 3 * STATS_BLOCKS));
+    HIP_TRY(h, hipHostMalloc((void**)&h->stats_host, sizeof(double) * (8 + STATS_L * 3), hipHostMallocMapped));
     std::memset(&h->ctx, 0, sizeof(h->ctx));
     HIP_TRY(h, hipDeviceSynchronize());
     return MPPI_OK;
@@ -541,6 +541,29 @@ int mppi_softmax_stats(mppi_handle_t h, float lambda, double* out5_host, void* s
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipStreamSynchronize(s));
     for (int i = 0; i < 5; ++i) out5_host[i] = h->stats_host[i];
+    return MPPI_OK;
+}
+
+int mppi_softmax_stats_multi(mppi_handle_t h, const float* lambdas_host, int count, double* out_host, void* stream) {
+    if (!h || !lambdas_host || !out_host || count < 1 || count > STATS_L)
+        return fail(h, MPPI_E_INVALID, "bad softmax_stats_multi arguments (1..32 lambdas)");
+    LambdaGrid g{};
+    g.count = count;
+    for (int l = 0; l < STATS_L; ++l) {
+        g.lam[l] = l < count ? lambdas_host[l] : 1.0f;
+        if (!(g.lam[l] > 0.0f)) return fail(h, MPPI_E_INVALID, "lambda must be > 0");
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned* mk = h->min_key + h->min_slot;
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(STATS_BLOCKS, (h->d.N + BLOCK - 1) / BLOCK));
+    hipLaunchKernelGGL(stats_multi_partial_kernel, dim3(blocks), dim3(BLOCK), 0, s, h->costs, h->d.N, mk, g, h->stats_part);
+    HIP_TRY(h, hipGetLastError());
+    double* dev_out = nullptr;
+    HIP_TRY(h, hipHostGetDevicePointer((void**)&dev_out, h->stats_host, 0));
+    hipLaunchKernelGGL(stats_multi_combine_kernel, dim3(1), dim3(STATS_COMB_THREADS), 0, s, h->stats_part, blocks, dev_out + 8);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipStreamSynchronize(s));
+    for (int j = 0; j < count * 3; ++j) out_host[j] = h->stats_host[8 + j];
     return MPPI_OK;
 }
 

@@ -561,6 +561,72 @@ __global__ __launch_bounds__(WAVE) void stats_combine_kernel(const float* __rest
     }
 }
 
+// The same statistics for up to STATS_L temperatures in one pass over the costs (a grid of lambdas
+// for the bracketing search of ESSPS): part [blocks][STATS_L][3] = {sum e, sum e^2, sum e*c}.
+constexpr int STATS_L = 32;
+struct LambdaGrid {
+    float lam[STATS_L];
+    int32_t count;
+};
+__global__ __launch_bounds__(BLOCK) void stats_multi_partial_kernel(const float* __restrict__ costs, int64_t N,
+                                                                   const unsigned* __restrict__ min_key,
+                                                                   LambdaGrid g, float* __restrict__ part) {
+    __shared__ float s_p[BLOCK / WAVE][STATS_L][3];
+    const float cmin = key_to_float(*min_key);
+    float se[STATS_L], se2[STATS_L], sec[STATS_L];
+#pragma unroll
+    for (int l = 0; l < STATS_L; ++l) se[l] = se2[l] = sec[l] = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < N; i += (int64_t)gridDim.x * BLOCK) {
+        const float c = costs[i];
+#pragma unroll
+        for (int l = 0; l < STATS_L; ++l) {
+            if (l < g.count) {
+                const float e = expf((-c) / g.lam[l] - (-cmin) / g.lam[l]);
+                se[l] += e;
+                se2[l] = fmaf(e, e, se2[l]);
+                sec[l] = fmaf(e, c, sec[l]);
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int l = 0; l < STATS_L; ++l) {
+        const float a = wave_sum(se[l]), b = wave_sum(se2[l]), c3 = wave_sum(sec[l]);
+        if (lane == 0) { s_p[wid][l][0] = a; s_p[wid][l][1] = b; s_p[wid][l][2] = c3; }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < STATS_L * 3; j += BLOCK) {
+        float v = 0.0f;
+#pragma unroll
+        for (int w = 0; w < BLOCK / WAVE; ++w) v += (&s_p[w][0][0])[j];
+        part[(int64_t)blockIdx.x * STATS_L * 3 + j] = v;
+    }
+}
+constexpr int STATS_COMB_THREADS = 960;  // 96 columns x 10 row groups
+__global__ __launch_bounds__(1024) void stats_multi_combine_kernel(const float* __restrict__ part, int nblocks,
+                                                                   double* __restrict__ out /*[STATS_L][3] mapped*/) {
+    constexpr int COLS = STATS_L * 3, GROUPS = STATS_COMB_THREADS / COLS;
+    __shared__ double s_acc[GROUPS][COLS];
+    const int j = threadIdx.x % COLS, g = threadIdx.x / COLS;
+    if (g < GROUPS) {
+        double v0 = 0.0, v1 = 0.0;
+        int b = g;
+        for (; b + GROUPS < nblocks; b += 2 * GROUPS) {  // two independent loads in flight
+            v0 += part[(int64_t)b * COLS + j];
+            v1 += part[(int64_t)(b + GROUPS) * COLS + j];
+        }
+        if (b < nblocks) v0 += part[(int64_t)b * COLS + j];
+        s_acc[g][j] = v0 + v1;
+    }
+    __syncthreads();
+    if (threadIdx.x < COLS) {
+        double v = 0.0;
+#pragma unroll
+        for (int q = 0; q < GROUPS; ++q) v += s_acc[q][threadIdx.x];
+        out[threadIdx.x] = v;
+    }
+}
+
 // `_weights` (mppi.py:376) given the global min cost and sum e.
 __global__ __launch_bounds__(BLOCK) void weights_kernel(const float* __restrict__ costs, int64_t N, float lambda,
                                                         float cmin, float sum_e, float* __restrict__ w) {

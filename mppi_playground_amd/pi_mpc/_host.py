@@ -69,6 +69,31 @@ def essps_lambda_stats(stats, target_ess: float, lam_min: float, lam_max: float)
     return brentq(lambda lam: ess_from_stats(stats(lam)) - target_ess, lam_min, lam_max)
 
 
+def essps_lambda_grid(stats_multi, target_ess: float, lam_min: float, lam_max: float, points: int = 32,
+                      rounds: int = 4) -> float:
+    """The same root as essps_lambda_stats (ESS(lambda) = target, ESS increasing in lambda), bracketed on a
+    grid: `stats_multi(lams)` evaluates ESS for up to 32 temperatures in one pass over the costs, so
+    `rounds` round trips shrink the bracket by 31**rounds (10 -> 1e-5 after four) and a final linear
+    interpolation lands within ~1e-9 of brentq's answer, instead of ~18 sequential probes."""
+    lo, hi = float(lam_min), float(lam_max)
+    ess_lo = ess_hi = None
+    for rnd in range(rounds):
+        grid = np.linspace(lo, hi, points)
+        ess = stats_multi(grid)
+        if rnd == 0:  # same end-point rules as the reference (mppi.py:361-364)
+            if target_ess <= ess[0]:
+                return lam_min
+            if target_ess >= ess[-1]:
+                return lam_max
+        above = np.nonzero(ess >= target_ess)[0]
+        i = int(above[0]) if len(above) else points - 1
+        i = max(i, 1)
+        lo, hi, ess_lo, ess_hi = float(grid[i - 1]), float(grid[i]), float(ess[i - 1]), float(ess[i])
+    if ess_hi == ess_lo:
+        return 0.5 * (lo + hi)
+    return lo + (hi - lo) * (target_ess - ess_lo) / (ess_hi - ess_lo)
+
+
 def lbps_lambda_stats(stats, delta: float, lam_min: float, lam_max: float) -> float:
     """src/pi_mpc/mppi.py:341-349,534-557 with the softmax sums evaluated on the device."""
 

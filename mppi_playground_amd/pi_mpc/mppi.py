@@ -62,6 +62,7 @@ class MPPI(nn.Module):
         shard_samples: bool = False,
         process_group=None,
         auto_lambda_stats: str = "device",
+        essps_search: str = "grid",
     ) -> None:
         """Arguments up to `seed` are the reference's (src/pi_mpc/mppi.py:24-47).
 
@@ -72,6 +73,9 @@ class MPPI(nn.Module):
             auto_lambda_stats: "device" (default) evaluates the softmax sums of the ESSPS/LBPS/MPO searches
                 on the GPU (mppi_softmax_stats; the root-finders stay on the host), "host" copies
                 costs[N] to the CPU and evaluates them in numpy like the reference does.
+            essps_search: with device statistics, "grid" (default) brackets the ESSPS root with 32 lambdas
+                per pass over the costs (4 round trips), "brentq" probes one lambda at a time like the
+                reference's scipy call; both return the same root (to ~1e-9).
             shard_samples: treat `num_samples` as the GLOBAL sample count and let this rank own the
                 contiguous block rank*N/W .. (rank+1)*N/W of it (torch.distributed must be
                 initialised); one all_gather of 4+T*dc floats per solve combines the shards.
@@ -106,6 +110,9 @@ class MPPI(nn.Module):
         if auto_lambda_stats not in ("device", "host"):
             raise ValueError("auto_lambda_stats must be 'device' or 'host'")
         self._auto_lambda_stats = auto_lambda_stats
+        if essps_search not in ("grid", "brentq"):
+            raise ValueError("essps_search must be 'grid' or 'brentq'")
+        self._essps_search = essps_search
         if noise_source not in ("philox", "torch_cpu"):
             raise ValueError("noise_source must be 'philox' or 'torch_cpu'")
         self._noise_source = noise_source
@@ -324,8 +331,10 @@ class MPPI(nn.Module):
                                                     self._lambda_max) if on_dev else
                             _host.lbps_lambda(costs_host, self._lbps_delta, self._lambda_min, self._lambda_max))
         elif self._auto_lambda == "ESSPS":
-            self._lambda = (_host.essps_lambda_stats(self._softmax_stats, self._essps_target_ess, self._lambda_min,
-                                                     self._lambda_max) if on_dev else
+            self._lambda = ((_host.essps_lambda_grid(self._ess_grid, self._essps_target_ess, self._lambda_min,
+                                                     self._lambda_max) if self._essps_search == "grid" else
+                             _host.essps_lambda_stats(self._softmax_stats, self._essps_target_ess, self._lambda_min,
+                                                      self._lambda_max)) if on_dev else
                             _host.essps_lambda(costs_host, self._essps_target_ess, self._lambda_min,
                                                self._lambda_max))
         lam = float(self._lambda)
@@ -430,6 +439,34 @@ class MPPI(nn.Module):
             cmin, cmax = float(a[:, 0].min()), float(a[:, 1].max())
             se, se2, sec = float((f * a[:, 2]).sum()), float((f * f * a[:, 3]).sum()), float((f * a[:, 4]).sum())
         return dict(cmin=cmin, cmax=cmax, se=se, se2=se2, sec=sec)
+
+    def _ess_grid(self, lams) -> np.ndarray:
+        """ESS(lambda) for up to 32 lambdas from ONE pass over the costs on the device
+        (mppi_softmax_stats_multi; shards combined with one all_gather per call)."""
+        lams = np.ascontiguousarray(lams, dtype=np.float32)
+        L = len(lams)
+        out = np.zeros((L, 3), np.float64)
+        self._h.call("mppi_softmax_stats_multi", lams.ctypes.data_as(C.c_void_p), L, out.ctypes.data_as(C.c_void_p),
+                     self._stream())
+        se, se2 = out[:, 0], out[:, 1]
+        if self._world > 1:
+            import torch.distributed as dist
+
+            cmin = self.last_local_cmin()
+            mine = torch.from_numpy(np.concatenate([[cmin], out.ravel()])).to(self._device)
+            allv = torch.empty(self._world * mine.numel(), dtype=torch.float64, device=self._device)
+            dist.all_gather_into_tensor(allv, mine, group=self._pg)
+            a = allv.view(self._world, -1).cpu().numpy()
+            cm, st = a[:, 0], a[:, 1:].reshape(self._world, L, 3)
+            x = (-cm.astype(np.float32))[:, None] / lams[None, :]          # [W, L] fp32 like the kernel
+            f = np.exp(x.astype(np.float64) - x.max(axis=0, keepdims=True))
+            se, se2 = (f * st[:, :, 0]).sum(0), (f * f * st[:, :, 1]).sum(0)
+        return se * se / se2
+
+    def last_local_cmin(self) -> float:
+        out = (C.c_double * 5)()
+        self._h.call("mppi_softmax_stats", 1.0, out, self._stream())
+        return float(out[0])
 
     def _gather_costs_host(self) -> np.ndarray:
         """costs[N] on the host for the temperature search (all shards when sharded)."""

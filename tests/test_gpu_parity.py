@@ -486,6 +486,14 @@ def test_device_softmax_stats_drive_the_same_temperature(lam_mode):
         outs.append((solver._last_lambda, a.cpu().numpy(), a2.cpu().numpy(), solver))
     tol = {"ESSPS": 1e-4, "LBPS": 5e-3, "MPO": 1e-3}[lam_mode]
     assert abs(outs[0][0] - outs[1][0]) <= tol * outs[1][0]
+    if lam_mode == "ESSPS":  # grid bracketing (default) and one-lambda-at-a-time brentq find the same root
+        sb, _ = make_solver("nav2d", T, N, lambda_="ESSPS", essps_search="brentq")
+        sb.forward(torch.tensor([-9.0, -9.0, 0.785]))
+        sg, _ = make_solver("nav2d", T, N, lambda_="ESSPS", essps_search="grid")
+        sg.forward(torch.tensor([-9.0, -9.0, 0.785]))
+        assert abs(sb._last_lambda - sg._last_lambda) <= 1e-6 * sb._last_lambda
+        ess = sg._ess_grid([sg._last_lambda])[0]
+        assert abs(ess - N / 10) <= 1e-4 * N / 10
     assert rel_err(outs[0][1], outs[1][1]) < 20 * tol
     solver = outs[0][3]
     c = solver._costs.cpu().numpy().astype(np.float64)

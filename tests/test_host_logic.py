@@ -55,6 +55,9 @@ def test_stats_driven_searches_match_reference():
         for k in range(3):
             lam = _host.essps_lambda_stats(_np_stats(g[f"costs_{k}"]), cfg["N"] / 10, 0.01, 10.0)
             assert abs(lam - float(g[f"lambda_{k}"])) <= 1e-5 * float(g[f"lambda_{k}"])
+            multi = lambda lams, c=g[f"costs_{k}"]: np.array([_host.ess_from_stats(_np_stats(c)(l)) for l in lams])  # noqa: E731
+            lam_g = _host.essps_lambda_grid(multi, cfg["N"] / 10, 0.01, 10.0)
+            assert abs(lam_g - float(g[f"lambda_{k}"])) <= 1e-5 * float(g[f"lambda_{k}"])
     g = load("pendulum_T15_N256_lbps")
     for k in range(3):
         lam = _host.lbps_lambda_stats(_np_stats(g[f"costs_{k}"]), 0.01, 0.01, 10.0)
