@@ -40,6 +40,8 @@ def main():
     ap.add_argument("--noise-regen", type=int, default=1,
                     help="1 = regenerate the Philox noise in registers (default), 0 = materialise the noise tiles")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--timing", type=int, default=2, help="HIP-event instrumentation inside the timed region: "
+                    "1 = every stage, 2 = dominant kernel only, 0 = none (stage times from a second pass)")
     args = ap.parse_args()
 
     import numpy as np
@@ -83,7 +85,7 @@ def main():
     for _ in range(args.warmup):
         solver.forward(x0)
     sync()
-    solver.set_option("timing", 1)
+    solver.set_option("timing", args.timing)
     solver.stage_times_ms()  # drain
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -91,6 +93,15 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     stages = solver.stage_times_ms()
+    if args.timing != 1:  # complete the per-stage picture with a separate instrumented pass
+        solver.set_option("timing", 1)
+        for _ in range(min(args.steps, 50)):
+            solver.forward(x0)
+        torch.cuda.synchronize()
+        extra = solver.stage_times_ms()
+        if args.timing == 2:
+            extra["rollout_cost"] = stages["rollout_cost"]
+        stages = extra
     solver.set_option("timing", 0)
     if world > 1:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)

@@ -99,7 +99,7 @@ struct StageTimer {
         return pool[h->ev_used[stage]++];
     }
     StageTimer(mppi_handle_t h_, int stage_, hipStream_t s_) : h(h_), stage(stage_), s(s_) {
-        if (!h->timing) return;
+        if (!h->timing || (h->timing == 2 && stage != 1)) return;  // timing = 2: rollout_cost stage only
         hipEvent_t start = next(h, stage);
         stop = start ? next(h, stage) : nullptr;
         if (start && stop) (void)hipEventRecord(start, s);
@@ -610,7 +610,7 @@ int mppi_set_option(mppi_handle_t h, const char* key, int64_t value) {
     const std::string k(key);
     if (k == "math") { h->math_fast = value ? 1 : 0; return MPPI_OK; }
     if (k == "reduce_blocks") { h->reduce_blocks = (int)std::max<int64_t>(1, std::min<int64_t>(value, 2048)); return MPPI_OK; }
-    if (k == "timing") { h->timing = value ? 1 : 0; return MPPI_OK; }
+    if (k == "timing") { h->timing = (int)value; return MPPI_OK; }
     if (k == "noise_regen") { h->noise_regen = value ? 1 : 0; h->tiles_valid = h->tiles_valid && h->injected; return MPPI_OK; }
     return fail(h, MPPI_E_INVALID, "unknown option " + k);
 }

@@ -196,6 +196,43 @@ def test_top_samples_match_reference():
     assert rel_err(ts.cpu().numpy(), g["top8_states_0"]) < TOL
 
 
+@pytest.mark.parametrize("model,T,N,expl", [("pendulum", 1, 5, 0.0), ("pendulum", 2, 64, 0.5), ("pendulum", 7, 65, 1.0),
+                                            ("racing", 1, 3, 0.0), ("racing", 3, 130, 0.3), ("nav2d", 2, 1, 0.0),
+                                            ("cartpole", 5, 63, 0.0), ("mountaincar", 9, 200, 0.9)])
+def test_edge_sizes_against_oracle(model, T, N, expl):
+    """Ragged shapes: horizons shorter than one float4 group, sample counts that are not a multiple of 64
+    (or smaller than a wave), exploration splits that fall inside a tile, all against the oracle."""
+    solver, ctrl = make_solver(model, T, N, lambda_=2.5, exploration=expl)
+    x0 = {"pendulum": [3.0, 0.1], "cartpole": [0.01, 0.0, 0.02, 0.0], "mountaincar": [-0.5, 0.0],
+          "nav2d": [-9.0, -9.0, 0.785], "racing": None}[model]
+    P = oracle_problem(model, N, T, expl)
+    if ctrl is not None:
+        env = _envs["racing"]
+        x0 = env._robot_state.cpu().numpy()
+        ref, _ = ctrl.calc_ref_trajectory(env._robot_state, env.racing_center_path, 0, T, DL=0.1,
+                                          lookahead_distance=3, reference_path_interval=0.85)
+        ctrl.set_reference(ref)
+        P.set_ref_path(ref.numpy())
+    x0 = np.asarray(x0, np.float32)
+    mean = (np.random.default_rng(T * 131 + N).standard_normal((T, P.dc)) * 0.2).astype(np.float32)
+    for k in range(2):
+        solver.set_warm_start(mean)
+        a, s = solver.forward(torch.from_numpy(x0))
+        eps = solver._action_noises.cpu().numpy()
+        c = solver._costs.cpu().numpy()
+        assert eps.shape == (N, T, P.dc) and c.shape == (N,)
+        r = P.rollout_cost(x0, mean, eps, want_margin=True, want_U=True)
+        check_costs(c, r)
+        w, st = orc.softmax_weights(c, 2.5)
+        assert rel_err(a.cpu().numpy(), P.weighted_actions(w, mean, eps)) < TOL
+        assert rel_err(s.cpu().numpy()[0], P.rollout_single(x0, a.cpu().numpy())) < TOL
+        assert np.array_equal(solver._perturbed_actions_for(torch.from_numpy(mean).cuda()).cpu().numpy(), r["U"])
+        k8 = min(8, N)
+        ts, tw = solver.get_top_samples(k8)
+        assert ts.shape == (k8, T + 1, P.ds) and rel_err(tw.cpu().numpy(), np.sort(w)[::-1][:k8]) < TOL
+        mean = a.cpu().numpy()
+
+
 # ------------------------------------------------------------------------------ sampler / layouts
 def test_sampler_matches_philox_restatement():
     solver, _ = make_solver("racing", 50, 1000, lambda_=1.0)
