@@ -39,6 +39,8 @@ def main():
     ap.add_argument("--math", type=int, default=1, help="1 = fast-path math (default), 0 = library math")
     ap.add_argument("--noise-regen", type=int, default=1,
                     help="1 = regenerate the Philox noise in registers (default), 0 = materialise the noise tiles")
+    ap.add_argument("--mapping", type=int, default=0, help="0 = lane per trajectory (default), 1 = the literal "
+                    "wavefront-per-trajectory rollout (comparison only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--timing", type=int, default=2, help="HIP-event instrumentation inside the timed region: "
                     "1 = every stage, 2 = dominant kernel only, 0 = none (stage times from a second pass)")
@@ -71,6 +73,7 @@ def main():
     solver = ctrl.solver
     solver.set_option("math", args.math)
     solver.set_option("noise_regen", args.noise_regen)
+    solver.set_option("mapping", args.mapping)
     state = env.reset()
     ref, _ = ctrl.calc_ref_trajectory(state, env.racing_center_path, 0, T, DL=0.1, lookahead_distance=3,
                                       reference_path_interval=0.85)
@@ -146,6 +149,7 @@ def main():
             "config": {"workload": "racing kinematic-bicycle MPPI solve (BASELINE configs[2]/[3])",
                        "num_samples_per_gpu": N_local, "num_samples_total": N_total, "horizon": T,
                        "lambda": 1.0, "noise": "device philox4x32-10 (" + ("regenerated in registers" if args.noise_regen else "materialised tiles") + ")", "math": "fast" if args.math else "library",
+                       "mapping": "lane-per-trajectory" if not args.mapping else "wavefront-per-trajectory",
                        "sharding": f"num_samples x{world}" if world > 1 else "none"},
             "solves_per_sec": solves_per_s,
             "roofline": {"bound": "hbm", "kernel": "rollout_cost_kernel<racing>", "achieved": achieved,

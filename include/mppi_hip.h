@@ -181,7 +181,8 @@ int mppi_rollout_actions(mppi_handle_t h, const float* actions_dev, int k, float
 int mppi_rollout_samples(mppi_handle_t h, const int64_t* idx_dev, int k, float* states_out_dev, void* stream);
 
 /* Tuning knobs (not in the reference): "math" 0 = library sin/cos/tan/fmod/div, 1 = range-checked
- * fast paths (default); "noise_regen" (see mppi_sample); "reduce_blocks" grid of the weighted
+ * fast paths (default); "noise_regen" (see mppi_sample); "mapping" 0 = lane per trajectory (default), 1 =
+ * the north star's literal wavefront-per-trajectory rollout (comparison only, ~20x slower); "reduce_blocks" grid of the weighted
  * reduction; "timing" (see mppi_get_timing). */
 int mppi_set_option(mppi_handle_t h, const char* key, int64_t value);
 /* Device time per stage from HIP event pairs recorded on the caller's stream around every stage call

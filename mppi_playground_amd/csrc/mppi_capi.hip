@@ -34,6 +34,8 @@ struct MppiSolver {
     int stage_next = 0;
     // noise identity of the current solve and whether the tiles hold it
     GenCtx gen{};
+    int mapping = 0;               // 0: lane per trajectory (default); 1: wavefront per trajectory (comparison)
+    float* noise_std = nullptr;    // [N][T][dc] copy of the noise for the wavefront-per-trajectory variant
     int noise_regen = 1;           // 1: Philox noise is regenerated in the kernels, never stored
     bool tiles_valid = false;      // the noise tiles hold the current solve's noise
     bool injected = false;         // ... because it was injected (cannot be regenerated)
@@ -242,7 +244,7 @@ int mppi_destroy(mppi_handle_t h) {
     (void)hipFree(h->noise); (void)hipFree(h->costs); (void)hipFree(h->min_key); (void)hipFree(h->x0);
     (void)hipFree(h->mean); (void)hipFree(h->ref); (void)hipFree(h->partials); (void)hipFree(h->heads);
     (void)hipFree(h->summary); (void)hipFree(h->map_cells[0]); (void)hipFree(h->map_cells[1]);
-    (void)hipFree(h->map_fused); (void)hipFree(h->stats_part);
+    (void)hipFree(h->map_fused); (void)hipFree(h->stats_part); (void)hipFree(h->noise_std);
     if (h->stats_host) (void)hipHostFree(h->stats_host);
     for (int i = 0; i < MppiSolver::RING; ++i) {
         if (h->stage[i]) (void)hipHostFree(h->stage[i]);
@@ -432,6 +434,28 @@ int mppi_rollout_cost(mppi_handle_t h, void* stream) {
     if (!h) return MPPI_E_INVALID;
     if (int rc = check_ready(h)) return rc;
     hipStream_t s = (hipStream_t)stream;
+    if (h->mapping == 1) {  // comparison variant: one wavefront per trajectory, reference-layout noise
+        if (!h->noise_std) HIP_TRY(h, hipMalloc(&h->noise_std, sizeof(float) * (size_t)h->d.N * h->d.row));
+        if (int rc = need_tiles(h, s)) return rc;
+        const dim3 cgrid((unsigned)h->d.tiles, (unsigned)((h->d.row + CONV_COLS - 1) / CONV_COLS));
+        hipLaunchKernelGGL(export_kernel, cgrid, dim3(BLOCK), 0, s, h->noise, h->mean, h->noise_std, (float*)nullptr, h->d);
+        HIP_TRY(h, hipGetLastError());
+        StageTimer tmw(h, 1, s);
+        h->min_slot ^= 1;
+        unsigned* mkw = h->min_key + h->min_slot;
+        unsigned* mkw_next = h->min_key + (h->min_slot ^ 1);
+        const unsigned wgrid = (unsigned)std::min<int64_t>((h->d.N + 3) / 4, 256 * 8 * 4);
+#define CALL_WAVE(MODEL, FASTV)                                                                       \
+        do {                                                                                          \
+            const size_t shw = sizeof(float) * 4 * ((size_t)4 * h->d.R + (size_t)(h->d.T + 1) * ModelT<MODEL, FASTV>::DS); \
+            hipLaunchKernelGGL((rollout_cost_wave_kernel<MODEL, FASTV>), dim3(wgrid), dim3(BLOCK), shw, s, h->noise_std, \
+                               h->mean, h->x0_cur, h->costs, mkw, mkw_next, h->d, h->ctx);           \
+        } while (0)
+        MPPI_DISPATCH(h, CALL_WAVE);
+#undef CALL_WAVE
+        HIP_TRY(h, hipGetLastError());
+        return MPPI_OK;
+    }
     StageTimer tm(h, 1, s);
     const bool gen = h->noise_regen && !h->injected;
     if (!gen && !h->tiles_valid) return fail(h, MPPI_E_STATE, "no noise: call mppi_sample or mppi_inject_noise first");
@@ -611,6 +635,7 @@ int mppi_set_option(mppi_handle_t h, const char* key, int64_t value) {
     if (k == "math") { h->math_fast = value ? 1 : 0; return MPPI_OK; }
     if (k == "reduce_blocks") { h->reduce_blocks = (int)std::max<int64_t>(1, std::min<int64_t>(value, 2048)); return MPPI_OK; }
     if (k == "timing") { h->timing = (int)value; return MPPI_OK; }
+    if (k == "mapping") { h->mapping = value ? 1 : 0; return MPPI_OK; }
     if (k == "noise_regen") { h->noise_regen = value ? 1 : 0; h->tiles_valid = h->tiles_valid && h->injected; return MPPI_OK; }
     return fail(h, MPPI_E_INVALID, "unknown option " + k);
 }

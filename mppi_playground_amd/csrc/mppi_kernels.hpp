@@ -235,6 +235,79 @@ __global__ __launch_bounds__(BLOCK) MPPI_ROLLOUT_ATTR void rollout_cost_kernel(c
 }
 
 // ------------------------------------------------------------------------------------------
+// The north star's literal mapping, kept for comparison (mppi_set_option("mapping", 1)): ONE WAVEFRONT
+// PER TRAJECTORY.  The wave loads the trajectory's [T*dc] noise row from the reference layout
+// [N][T][dc] with coalesced float4 loads and stages U = clamp(mean + eps) in LDS; lane 0 walks the
+// serial recurrence S[t+1] = f(S[t], U[t]) writing the states to LDS (63 lanes idle: the recurrence
+// cannot be spread over lanes); then lane t evaluates the stage cost of step t (lane T the terminal
+// cost) and a wavefront shuffle reduction sums them.  Same model functors, same results up to the
+// summation order of the T+1 stage costs.  Measured 20x slower than the lane-per-trajectory mapping
+//  because the recurrence runs on 1/64 of the machine.
+template <int MODEL, bool FAST>
+__global__ __launch_bounds__(BLOCK) void rollout_cost_wave_kernel(const float* __restrict__ eps_std,
+                                                                  const float* __restrict__ mean,
+                                                                  const float* __restrict__ x0,
+                                                                  float* __restrict__ costs,
+                                                                  unsigned* __restrict__ min_key,
+                                                                  unsigned* __restrict__ next_min_key, Dims d,
+                                                                  ModelCtx ctx) {
+    using M = ModelT<MODEL, FAST>;
+    using K = typename M::K;
+    constexpr int DS = M::DS, DC = M::DC, NW = BLOCK / WAVE;
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];  // per wave: U[row4] then S[(T+1)*DS]
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int row4 = 4 * d.R;
+    float* sU = s_dyn + (size_t)wid * (row4 + (d.T + 1) * DS);
+    float* sS = sU + row4;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *next_min_key = 0xFFFFFFFFu;
+    float wmin = INFINITY;
+    const int64_t nwaves = (int64_t)gridDim.x * NW;
+    for (int64_t i = (int64_t)blockIdx.x * NW + wid; i < d.N; i += nwaves) {
+        const bool inherit = (d.sample_offset + i) < d.inherit_count;  // wave-uniform
+        const float* erow = eps_std + i * d.row;
+        for (int f = lane; f < d.row; f += WAVE) {  // coalesced row load, clamp, stage in LDS
+            const float m = inherit ? mean[f] : 0.0f;
+            sU[f] = clampf(m + erow[f], d.u_min[f % DC], d.u_max[f % DC]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        bool bad = false;
+        if (lane == 0) {  // the serial recurrence: one lane
+            float s[DS];
+#pragma unroll
+            for (int j = 0; j < DS; ++j) s[j] = x0[j];
+            if (FAST) M::check_state(s, bad);
+            for (int t = 0; t < d.T; ++t) {
+                float u[DC], sn[DS], ss[DS];
+#pragma unroll
+                for (int k = 0; k < DC; ++k) u[k] = sU[t * DC + k];
+                M::step(ctx, s, u, sn, ss, bad, false);
+#pragma unroll
+                for (int j = 0; j < DS; ++j) { sS[t * DS + j] = ss[j]; s[j] = sn[j]; }
+            }
+#pragma unroll
+            for (int j = 0; j < DS; ++j) sS[d.T * DS + j] = s[j];
+        }
+        __builtin_amdgcn_wave_barrier();
+        float part = 0.0f;
+        for (int t = lane; t <= d.T; t += WAVE) {  // time-parallel stage costs
+            float st[DS], u[DC], pu[DC];
+#pragma unroll
+            for (int j = 0; j < DS; ++j) st[j] = sS[t * DS + j];
+            const bool term = t == d.T;
+            const int tp = term ? max(d.T - 2, 0) : max(t - 1, 0);
+#pragma unroll
+            for (int k = 0; k < DC; ++k) { u[k] = term ? 0.0f : sU[t * DC + k]; pu[k] = sU[tp * DC + k]; }
+            const K kk = M::load_k(ctx.ref, term ? d.T - 1 : t);
+            part += M::cost(ctx, kk, st, u, pu, bad);
+        }
+        const float total = wave_sum(part);
+        if (lane == 0) { costs[i] = total; wmin = fminf(wmin, total); }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0 && wmin < INFINITY) atomicMin(min_key, float_to_key(wmin));
+}
+
+// ------------------------------------------------------------------------------------------
 // Steps 5-6: e_i = exp((-c_i)/lambda - max_j(-c_j)/lambda) and A = sum_i e_i * clamp(mean + eps_i)
 // (mppi.py:376-384, un-normalised).  Each lane accumulates its own trajectories over the tiles its
 // wave owns in NACC registers; the 64 lanes are then combined through a padded LDS tile, 32

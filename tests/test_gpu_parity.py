@@ -293,6 +293,34 @@ def test_regenerated_noise_equals_materialised_tiles(model, T, N):
         assert torch.equal(x, y)
 
 
+@pytest.mark.parametrize("model,T,N", [("racing", 50, 3000), ("pendulum", 15, 500), ("mountaincar", 100, 300),
+                                       ("nav2d", 30, 777), ("cartpole", 64, 256)])
+def test_wavefront_per_trajectory_variant_agrees(model, T, N):
+    """The north star's literal mapping (one wavefront per trajectory, serial recurrence on lane 0,
+    time-parallel costs, shuffle reduction) computes the same costs as the lane-per-trajectory kernel up
+    to the summation order of the stage costs."""
+    solver, ctrl = make_solver(model, T, N, lambda_=3.0, exploration=0.1)
+    if ctrl is not None:
+        env = _envs["racing"]
+        ref, _ = ctrl.calc_ref_trajectory(env._robot_state, env.racing_center_path, 0, T, DL=0.1,
+                                          lookahead_distance=3, reference_path_interval=0.85)
+        ctrl.set_reference(ref)
+        x0 = env._robot_state.clone()
+    else:
+        x0 = torch.tensor({"pendulum": [3.0, 0.1], "mountaincar": [-0.5, 0.0], "nav2d": [-9.0, -9.0, 0.785],
+                           "cartpole": [0.01, 0.0, 0.02, 0.0]}[model])
+    mean = (np.random.default_rng(N).standard_normal((T, solver._dim_control)) * 0.2).astype(np.float32)
+    res = []
+    for mapping in (0, 1):
+        solver.set_option("mapping", mapping)
+        solver.set_warm_start(mean)
+        solver._solve_idx = 5
+        a, s = solver.forward(x0)
+        res.append((solver._costs.cpu().numpy(), a.cpu().numpy()))
+    assert rel_err(res[1][0], res[0][0]) < 2e-6
+    assert rel_err(res[1][1], res[0][1]) < 1e-4
+
+
 def test_inject_export_roundtrip_and_clamp():
     rng = np.random.default_rng(5)
     for model, T, N in (("racing", 50, 1000), ("pendulum", 15, 130), ("mountaincar", 100, 65), ("cartpole", 64, 64)):
