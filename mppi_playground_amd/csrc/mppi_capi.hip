@@ -576,6 +576,7 @@ int mppi_softmax_stats_multi(mppi_handle_t h, const float* lambdas_host, int cou
     for (int l = 0; l < STATS_L; ++l) {
         g.lam[l] = l < count ? lambdas_host[l] : 1.0f;
         if (!(g.lam[l] > 0.0f)) return fail(h, MPPI_E_INVALID, "lambda must be > 0");
+        g.inv_lam[l] = 1.0f / g.lam[l];
     }
     hipStream_t s = (hipStream_t)stream;
     const unsigned* mk = h->min_key + h->min_slot;

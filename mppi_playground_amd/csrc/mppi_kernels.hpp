@@ -639,6 +639,7 @@ __global__ __launch_bounds__(WAVE) void stats_combine_kernel(const float* __rest
 constexpr int STATS_L = 32;
 struct LambdaGrid {
     float lam[STATS_L];
+    float inv_lam[STATS_L];
     int32_t count;
 };
 __global__ __launch_bounds__(BLOCK) void stats_multi_partial_kernel(const float* __restrict__ costs, int64_t N,
@@ -651,10 +652,13 @@ __global__ __launch_bounds__(BLOCK) void stats_multi_partial_kernel(const float*
     for (int l = 0; l < STATS_L; ++l) se[l] = se2[l] = sec[l] = 0.0f;
     for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < N; i += (int64_t)gridDim.x * BLOCK) {
         const float c = costs[i];
+        const float dc0 = cmin - c;  // <= 0, exact for costs within a factor 2 of the minimum
 #pragma unroll
         for (int l = 0; l < STATS_L; ++l) {
             if (l < g.count) {
-                const float e = expf((-c) / g.lam[l] - (-cmin) / g.lam[l]);
+                // exp(-(c - cmin)/lambda) with the reciprocal of lambda: this kernel only brackets the
+                // temperature (the weights themselves use the reference's (-c)/lambda - max form)
+                const float e = expf(dc0 * g.inv_lam[l]);
                 se[l] += e;
                 se2[l] = fmaf(e, e, se2[l]);
                 sec[l] = fmaf(e, c, sec[l]);
