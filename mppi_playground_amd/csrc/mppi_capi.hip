@@ -34,6 +34,7 @@ struct MppiSolver {
     int stage_next = 0;
     // noise identity of the current solve and whether the tiles hold it
     GenCtx gen{};
+    int last_reduce_blocks = 0;    // grid of the last weights_reduce (finalize folds its partials)
     int mapping = 0;               // 0: lane per trajectory (default); 1: wavefront per trajectory (comparison)
     float* noise_std = nullptr;    // [N][T][dc] copy of the noise for the wavefront-per-trajectory variant
     int noise_regen = 1;           // 1: Philox noise is regenerated in the kernels, never stored
@@ -508,8 +509,11 @@ int mppi_weights_reduce(mppi_handle_t h, float lambda, float* summary_out_dev, v
     if (!h || !(lambda > 0.0f)) return fail(h, MPPI_E_INVALID, "lambda must be > 0");
     hipStream_t s = (hipStream_t)stream;
     StageTimer tm(h, 2, s);
+    // one wave per tile up to reduce_blocks blocks (dense weights need the parallelism; with sparse
+    // weights most waves only run the phase-A check)
     int64_t blocks = std::min<int64_t>(h->reduce_blocks, (h->d.tiles + 3) / 4);
     blocks = std::max<int64_t>(1, std::min<int64_t>(blocks, 2048));
+    h->last_reduce_blocks = (int)blocks;
     const dim3 grid((unsigned)blocks, (unsigned)h->nchunks);
     const bool gen = h->noise_regen && !h->injected;
     if (!gen && !h->tiles_valid) return fail(h, MPPI_E_STATE, "no noise: call mppi_sample or mppi_inject_noise first");
@@ -521,13 +525,14 @@ int mppi_weights_reduce(mppi_handle_t h, float lambda, float* summary_out_dev, v
     else { if (gen) CALL_REDUCE(32, true); else CALL_REDUCE(32, false); }
 #undef CALL_REDUCE
     HIP_TRY(h, hipGetLastError());
-    const unsigned sgrid = (unsigned)((h->colsp + SUM_COLS - 1) / SUM_COLS + 1);
-    hipLaunchKernelGGL(summarize_kernel, dim3(sgrid), dim3(SUM_BLOCK), 0, s, h->partials, h->heads, mk, (int)blocks,
-                       h->colsp, h->d.row, h->summary);
-    HIP_TRY(h, hipGetLastError());
-    if (summary_out_dev)
+    if (summary_out_dev) {  // sharded use: the summary is needed before the collective
+        const unsigned sgrid = (unsigned)((h->colsp + SUM_COLS - 1) / SUM_COLS + 1);
+        hipLaunchKernelGGL(summarize_kernel, dim3(sgrid), dim3(SUM_BLOCK), 0, s, h->partials, h->heads, mk, (int)blocks,
+                           h->colsp, h->d.row, h->summary);
+        HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipMemcpyAsync(summary_out_dev, h->summary, sizeof(float) * (size_t)(MPPI_SUMMARY_HEAD + h->d.row),
                                   hipMemcpyDeviceToDevice, s));
+    }
     return MPPI_OK;
 }
 
@@ -539,13 +544,34 @@ int mppi_finalize(mppi_handle_t h, const float* summaries_dev, int num_shards, f
     if (!generic) { if (int rc = check_ready(h)) return rc; }
     hipStream_t s = (hipStream_t)stream;
     StageTimer tm(h, 3, s);
-    const float* sums = summaries_dev ? summaries_dev : h->summary;
-    if (!summaries_dev) num_shards = 1;
-    const size_t shmem = sizeof(float) * (size_t)h->d.row;
+    bool own = summaries_dev == nullptr;
+    if (own && h->last_reduce_blocks < 1) return fail(h, MPPI_E_STATE, "mppi_finalize before mppi_weights_reduce");
+    if (own) num_shards = 1;
+    const size_t shmem = sizeof(float) * ((size_t)2 * h->d.row + MPPI_SUMMARY_HEAD);
+    const unsigned* mk = h->min_key + h->min_slot;
+    if (own && h->last_reduce_blocks > 128) {
+        // many partial rows (large N): fold them with the multi-block summarize kernel (4.4 us at 512 rows;
+        // the single finalize block would need ~11 us), then finalize from the summary
+        const unsigned sgrid = (unsigned)((h->colsp + SUM_COLS - 1) / SUM_COLS + 1);
+        hipLaunchKernelGGL(summarize_kernel, dim3(sgrid), dim3(SUM_BLOCK), 0, s, h->partials, h->heads, mk,
+                           h->last_reduce_blocks, h->colsp, h->d.row, h->summary);
+        HIP_TRY(h, hipGetLastError());
+        summaries_dev = h->summary;
+        own = false;
+    }
 #define CALL_FINALIZE(MODEL, FASTV)                                                                   \
-    hipLaunchKernelGGL((finalize_kernel<MODEL, FASTV>), dim3(1), dim3(BLOCK), shmem, s, sums, num_shards, lambda, \
-                       h->d.row, h->d.T, h->x0_cur, store_mean ? h->mean : (float*)nullptr, action_out, state_out, \
-                       stats_out, h->ctx)
+    do {                                                                                              \
+        if (own)                                                                                      \
+            hipLaunchKernelGGL((finalize_kernel<MODEL, FASTV, true>), dim3(1), dim3(FIN_BLOCK), shmem, s,        \
+                               (const float*)nullptr, 1, h->partials, h->heads, mk, h->last_reduce_blocks, h->colsp, \
+                               h->summary, lambda, h->d.row, h->d.T, h->x0_cur, store_mean ? h->mean : (float*)nullptr, \
+                               action_out, state_out, stats_out, h->ctx);                             \
+        else                                                                                          \
+            hipLaunchKernelGGL((finalize_kernel<MODEL, FASTV, false>), dim3(1), dim3(FIN_BLOCK), shmem, s,       \
+                               summaries_dev, num_shards, (const float*)nullptr, (const float*)nullptr, mk, 0, 0, \
+                               (float*)nullptr, lambda, h->d.row, h->d.T, h->x0_cur,                  \
+                               store_mean ? h->mean : (float*)nullptr, action_out, state_out, stats_out, h->ctx); \
+    } while (0)
     MPPI_DISPATCH(h, CALL_FINALIZE);
 #undef CALL_FINALIZE
     HIP_TRY(h, hipGetLastError());

@@ -533,16 +533,68 @@ __device__ __forceinline__ void rollout_states_checked(const float* __restrict__
 
 // Combine shard summaries, normalise, store the warm start, roll the result out with batch 1
 // (mppi.py:381-385,448-452,508-524).
-template <int MODEL, bool FAST>
-__global__ __launch_bounds__(BLOCK) void finalize_kernel(const float* __restrict__ summaries, int num_shards,
-                                                         float lambda, int row, int T,
-                                                         const float* __restrict__ x0, float* __restrict__ mean_store,
-                                                         float* __restrict__ action_out,
-                                                         float* __restrict__ state_out, float* __restrict__ stats_out,
-                                                         ModelCtx ctx) {
+// OWN = true (single shard, few partial rows): the kernel first folds this handle's per-block
+// partials into the shard summary itself (FIN_BLOCK threads = 128 columns x 8 row groups, fixed order)
+// — no separate summarize launch; the summary is also written to `summary_out` for later readers.
+// OWN = false: `summaries` holds `num_shards` summary vectors (the all_gathered shards, or this
+// handle's own summary produced by summarize_kernel when there are many partial rows).
+constexpr int FIN_BLOCK = 1024;
+template <int MODEL, bool FAST, bool OWN>
+__global__ __launch_bounds__(FIN_BLOCK) void finalize_kernel(const float* __restrict__ summaries, int num_shards,
+                                                             const float* __restrict__ partials,
+                                                             const float* __restrict__ heads,
+                                                             const unsigned* __restrict__ min_key, int nblocks,
+                                                             int colsp, float* __restrict__ summary_out, float lambda,
+                                                             int row, int T, const float* __restrict__ x0,
+                                                             float* __restrict__ mean_store,
+                                                             float* __restrict__ action_out,
+                                                             float* __restrict__ state_out,
+                                                             float* __restrict__ stats_out, ModelCtx ctx) {
     constexpr int DC = ModelT<MODEL, FAST>::DC;
-    extern __shared__ __attribute__((aligned(16))) float s_act[];  // [row]
+    extern __shared__ __attribute__((aligned(16))) float s_fin[];  // [row] action, then [4 + row] own summary
+    float* s_act = s_fin;
+    float* s_sum = s_fin + row;
+    __shared__ float s_part[FIN_BLOCK / 128][128 + 1];
     const int stride = MPPI_SUMMARY_HEAD + row;
+    if (OWN) {
+        constexpr int NG = FIN_BLOCK / 128;
+        const int c = threadIdx.x & 127, g = threadIdx.x >> 7;
+        for (int c0 = 0; c0 < row + 3; c0 += 128) {  // column chunks; the last 3 "columns" are the heads
+            const int col = c0 + c;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            if (col < row + 3) {
+                const bool is_head = col >= row;
+                const float* base = is_head ? heads + (col - row) : partials + col;
+                const int64_t ld = is_head ? 4 : colsp;
+                int bidx = g;
+                for (; bidx + 3 * NG < nblocks; bidx += 4 * NG) {
+                    a0 += base[(int64_t)bidx * ld];
+                    a1 += base[(int64_t)(bidx + NG) * ld];
+                    a2 += base[(int64_t)(bidx + 2 * NG) * ld];
+                    a3 += base[(int64_t)(bidx + 3 * NG) * ld];
+                }
+                for (; bidx < nblocks; bidx += NG) a0 += base[(int64_t)bidx * ld];
+            }
+            s_part[g][c] = (a0 + a1) + (a2 + a3);
+            __syncthreads();
+            if (threadIdx.x < 128 && col < row + 3) {
+                float v = 0.f;
+#pragma unroll
+                for (int q = 0; q < NG; ++q) v += s_part[q][threadIdx.x];
+                const int dst = col < row ? MPPI_SUMMARY_HEAD + col : 1 + (col - row);
+                s_sum[dst] = v;
+                if (summary_out) summary_out[dst] = v;
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            s_sum[0] = key_to_float(*min_key);
+            if (summary_out) summary_out[0] = s_sum[0];
+        }
+        __syncthreads();
+        summaries = s_sum;  // (generic address space: LDS)
+        num_shards = 1;
+    }
     float xmax = -INFINITY, cmin = INFINITY;
     for (int g = 0; g < num_shards; ++g) {
         const float m = summaries[(int64_t)g * stride];
@@ -557,7 +609,7 @@ __global__ __launch_bounds__(BLOCK) void finalize_kernel(const float* __restrict
         se2 = fmaf(f * f, sm[2], se2);
         sec = fmaf(f, sm[3], sec);
     }
-    for (int cidx = threadIdx.x; cidx < row; cidx += BLOCK) {
+    for (int cidx = threadIdx.x; cidx < row; cidx += FIN_BLOCK) {
         float a = 0.f;
         for (int g = 0; g < num_shards; ++g) {
             const float* sm = summaries + (int64_t)g * stride;
