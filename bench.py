@@ -137,6 +137,7 @@ def main():
                 valu = {"kernel": "rollout_cost_kernel<racing>", "valu_insts_per_launch": k["valu_insts"],
                         "achieved_Ginst_per_s": k["valu_insts"] / t_roll / 1e9, "peak_Ginst_per_s": peak / 1e9,
                         "frac": k["valu_insts"] / t_roll / peak,
+                        "measured_peak_Ginst_per_s": pc.get("valu_issue_ubench", {}).get("mul_add_Ginst_per_s"),
                         "note": "wave64 VALU instructions (SQ_INSTS_VALU, rocprofv3) / live kernel time; the kernel "
                                 "is VALU-issue bound (2.97 cycles/instruction/SIMD measured), not HBM bound"}
         except Exception:
