@@ -44,7 +44,8 @@ enum {
     MPPI_E_NODEVICE = -4   /* no gfx950 device visible                 */
 };
 
-/* Native model plugins = the five shipped dynamics/cost pairs.
+/* Native model plugins = the five shipped dynamics/cost pairs and the two
+ * remaining example models.
  * MPPI_MODEL_GENERIC: the callables are opaque to the library (any torch dynamics/cost): the host
  * evaluates them on the exported actions and hands the costs back with mppi_set_costs; sampling,
  * softmax, the weighted reduction and the warm start still run here.  mppi_rollout_cost, the
@@ -56,7 +57,9 @@ enum {
     MPPI_MODEL_CARTPOLE = 1,    /* example/cartpole.py:17-81                                  */
     MPPI_MODEL_MOUNTAINCAR = 2, /* example/mountaincar.py:17-55                               */
     MPPI_MODEL_NAV2D = 3,       /* src/envs/navigation_2d.py:218-279                          */
-    MPPI_MODEL_RACING = 4       /* src/envs/racing_env.py:327-372 + example/racing.py:110-159 */
+    MPPI_MODEL_RACING = 4,      /* src/envs/racing_env.py:327-372 + example/racing.py:110-159 */
+    MPPI_MODEL_MJCARTPOLE = 5,  /* example/mujoco_cartpole.py:20-81 (continuous force, masspole = 1) */
+    MPPI_MODEL_GOALZONE = 6     /* src/envs/goal_in_danger_zone.py:113-156 (7-state unicycle + circle) */
 };
 
 /* Racing parameter vector (mppi_set_model_params), racing_env.py:37-42,341-370, racing.py:41-46 */
@@ -67,8 +70,12 @@ enum { MPPI_RP_AMIN = 0, MPPI_RP_AMAX, MPPI_RP_SMIN, MPPI_RP_SMAX, MPPI_RP_L, MP
 enum { MPPI_NP_VMIN = 0, MPPI_NP_VMAX, MPPI_NP_WMIN, MPPI_NP_WMAX, MPPI_NP_DT, MPPI_NP_XLO, MPPI_NP_XHI,
        MPPI_NP_YLO, MPPI_NP_YHI, MPPI_NP_GX, MPPI_NP_GY, MPPI_NP_QO, MPPI_NP_COUNT };
 
+/* Goal-in-danger-zone parameter vector, goal_in_danger_zone.py:78-87,113-156 */
+enum { MPPI_GP_VMIN = 0, MPPI_GP_VMAX, MPPI_GP_WMIN, MPPI_GP_WMAX, MPPI_GP_DT, MPPI_GP_GX, MPPI_GP_GY, MPPI_GP_CX,
+       MPPI_GP_CY, MPPI_GP_RADIUS, MPPI_GP_PENALTY, MPPI_GP_COUNT };
+
 #define MPPI_MAX_PARAMS 32
-#define MPPI_MAX_DIM_STATE 4
+#define MPPI_MAX_DIM_STATE 8
 #define MPPI_MAX_DIM_CONTROL 4
 #define MPPI_SUMMARY_HEAD 4 /* {min cost, sum e, sum e^2, sum e*c} */
 

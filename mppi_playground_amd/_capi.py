@@ -14,8 +14,9 @@ LIB_PATH = os.environ.get("MPPI_HIP_LIB") or os.path.join(_HERE, "csrc", "libmpp
 
 MODEL_GENERIC = -1
 MAX_DIM_CONTROL = 4
-MODEL_IDS = {"pendulum": 0, "cartpole": 1, "mountaincar": 2, "nav2d": 3, "racing": 4}
-MODEL_DIMS = {"pendulum": (2, 1), "cartpole": (4, 1), "mountaincar": (2, 1), "nav2d": (3, 2), "racing": (4, 2)}
+MODEL_IDS = {"pendulum": 0, "cartpole": 1, "mountaincar": 2, "nav2d": 3, "racing": 4, "mjcartpole": 5, "goalzone": 6}
+MODEL_DIMS = {"pendulum": (2, 1), "cartpole": (4, 1), "mountaincar": (2, 1), "nav2d": (3, 2), "racing": (4, 2),
+              "mjcartpole": (4, 1), "goalzone": (7, 2)}
 SUMMARY_HEAD = 4
 
 # every symbol include/mppi_hip.h declares

@@ -83,6 +83,8 @@ bool model_dims(int model, ModelDims& md) {
     case MPPI_MODEL_MOUNTAINCAR: md = {2, 1}; return true;
     case MPPI_MODEL_NAV2D: md = {3, 2}; return true;
     case MPPI_MODEL_RACING: md = {4, 2}; return true;
+    case MPPI_MODEL_MJCARTPOLE: md = {4, 1}; return true;
+    case MPPI_MODEL_GOALZONE: md = {7, 2}; return true;
     }
     return false;
 }
@@ -125,6 +127,8 @@ bool use_fast(mppi_handle_t h);
         case MPPI_MODEL_MOUNTAINCAR: if (fast_) { CALL(MPPI_MODEL_MOUNTAINCAR, true); } else { CALL(MPPI_MODEL_MOUNTAINCAR, false); } break; \
         case MPPI_MODEL_NAV2D: if (fast_) { CALL(MPPI_MODEL_NAV2D, true); } else { CALL(MPPI_MODEL_NAV2D, false); } break; \
         case MPPI_MODEL_RACING: if (fast_) { CALL(MPPI_MODEL_RACING, true); } else { CALL(MPPI_MODEL_RACING, false); } break; \
+        case MPPI_MODEL_MJCARTPOLE: if (fast_) { CALL(MPPI_MODEL_MJCARTPOLE, true); } else { CALL(MPPI_MODEL_MJCARTPOLE, false); } break; \
+        case MPPI_MODEL_GOALZONE: if (fast_) { CALL(MPPI_MODEL_GOALZONE, true); } else { CALL(MPPI_MODEL_GOALZONE, false); } break; \
         }                                                                                             \
     } while (0)
 
@@ -133,6 +137,7 @@ bool use_fast(mppi_handle_t h) {
     if (!h->math_fast) return false;
     const int m = h->cfg.model;
     if (m == MPPI_MODEL_NAV2D) return h->ctx.maps[0].inv_cell != 0.0f && h->ctx.wrap_safe != 0 && h->ctx.u_in_bounds != 0;
+    if (m == MPPI_MODEL_GOALZONE) return h->ctx.wrap_safe != 0 && h->ctx.u_in_bounds != 0;
     if (m == MPPI_MODEL_RACING)
         return h->ctx.wrap_safe != 0 && h->ctx.u_in_bounds != 0 && h->ctx.maps[0].inv_cell != 0.0f && h->ctx.fused != nullptr && h->ctx.tan_small != 0 && h->ctx.inv_L != 0.0f;
     return true;
@@ -258,10 +263,17 @@ int mppi_destroy(mppi_handle_t h) {
 
 int mppi_set_model_params(mppi_handle_t h, const float* p, int n) {
     if (!h || n < 0 || n > MPPI_MAX_PARAMS || (n > 0 && !p)) return fail(h, MPPI_E_INVALID, "bad params");
-    const int need = h->cfg.model == MPPI_MODEL_RACING ? MPPI_RP_COUNT : h->cfg.model == MPPI_MODEL_NAV2D ? MPPI_NP_COUNT : 0;
+    const int need = h->cfg.model == MPPI_MODEL_RACING ? MPPI_RP_COUNT : h->cfg.model == MPPI_MODEL_NAV2D ? MPPI_NP_COUNT
+                     : h->cfg.model == MPPI_MODEL_GOALZONE ? MPPI_GP_COUNT : 0;
     if (n != need) return fail(h, MPPI_E_INVALID, "parameter count does not match the model");
     for (int i = 0; i < n; ++i) h->ctx.P[i] = p[i];
     const float* um = h->cfg.u_min; const float* uM = h->cfg.u_max;
+    if (h->cfg.model == MPPI_MODEL_GOALZONE) {
+        h->ctx.u_in_bounds = (um[0] >= p[MPPI_GP_VMIN] && uM[0] <= p[MPPI_GP_VMAX] && um[1] >= p[MPPI_GP_WMIN] &&
+                              uM[1] <= p[MPPI_GP_WMAX]) ? 1 : 0;
+        const float w = std::fmax(std::fabs(p[MPPI_GP_WMIN]), std::fabs(p[MPPI_GP_WMAX]));
+        h->ctx.wrap_safe = (w * std::fabs(p[MPPI_GP_DT]) < 3.0f) ? 1 : 0;
+    }
     if (h->cfg.model == MPPI_MODEL_NAV2D) {
         h->ctx.u_in_bounds = (um[0] >= p[MPPI_NP_VMIN] && uM[0] <= p[MPPI_NP_VMAX] && um[1] >= p[MPPI_NP_WMIN] &&
                               uM[1] <= p[MPPI_NP_WMAX]) ? 1 : 0;

@@ -70,3 +70,26 @@ def mountaincar_dynamics(state: torch.Tensor, action: torch.Tensor) -> torch.Ten
 @native_model("mountaincar", "cost")
 def mountaincar_cost(state: torch.Tensor, action: torch.Tensor, info) -> torch.Tensor:
     return (0.45 - state[:, 0]) ** 2
+
+
+# ------------------------------------------------------------------ MuJoCo-style cart-pole (InvertedPendulum-v4)
+@native_model("mjcartpole", "dynamics")
+def mjcartpole_dynamics(state: torch.Tensor, action: torch.Tensor) -> torch.Tensor:
+    """Continuous force, pole mass 1 (the reference's example/mujoco_cartpole.py:20-68)."""
+    x, x_dt, theta, theta_dt = state[:, 0:1], state[:, 1:2], state[:, 2:3], state[:, 3:4]
+    force = action[:, 0:1]
+    gravity, masscart, masspole, length, tau = 9.8, 1.0, 1.0, 0.5, 0.02
+    total_mass, polemass_length = masspole + masscart, masspole * length
+    cos, sin = torch.cos(theta), torch.sin(theta)
+    temp = (force + polemass_length * theta_dt ** 2 * sin) / total_mass
+    thetaacc = (gravity * sin - cos * temp) / (length * (4.0 / 3.0 - masspole * cos ** 2 / total_mass))
+    xacc = temp - polemass_length * thetaacc * cos / total_mass
+    newx = torch.clamp(x + tau * x_dt, -1.0, 1.0)
+    lim = 12 * 2 * torch.pi / 360
+    newtheta = torch.clamp(theta + tau * theta_dt, -lim, lim)
+    return torch.cat((newx, x_dt + tau * xacc, newtheta, theta_dt + tau * thetaacc), dim=1)
+
+
+@native_model("mjcartpole", "cost")
+def mjcartpole_cost(state: torch.Tensor, action: torch.Tensor, info) -> torch.Tensor:
+    return angle_normalize(state[:, 2]) ** 2 + 0.1 * state[:, 3] ** 2 + 0.1 * state[:, 0] ** 2

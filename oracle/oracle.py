@@ -14,10 +14,11 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
 
-PENDULUM, CARTPOLE, MOUNTAINCAR, NAV2D, RACING = range(5)
+PENDULUM, CARTPOLE, MOUNTAINCAR, NAV2D, RACING, MJCARTPOLE, GOALZONE = range(7)
 MODEL_IDS = {"pendulum": PENDULUM, "cartpole": CARTPOLE, "mountaincar": MOUNTAINCAR,
-             "nav2d": NAV2D, "racing": RACING}
-MODEL_DIMS = {PENDULUM: (2, 1), CARTPOLE: (4, 1), MOUNTAINCAR: (2, 1), NAV2D: (3, 2), RACING: (4, 2)}
+             "nav2d": NAV2D, "racing": RACING, "mjcartpole": MJCARTPOLE, "goalzone": GOALZONE}
+MODEL_DIMS = {PENDULUM: (2, 1), CARTPOLE: (4, 1), MOUNTAINCAR: (2, 1), NAV2D: (3, 2), RACING: (4, 2),
+              MJCARTPOLE: (4, 1), GOALZONE: (7, 2)}
 
 
 class OracleMap(C.Structure):
@@ -80,6 +81,11 @@ def nav2d_params(u_min=(0.0, -1.0), u_max=(2.0, 1.0), dt=0.1, x_lim=(-10.0, 10.0
                  y_lim=(-10.0, 10.0), goal=(9.0, 9.0), Qo=10000.0):
     return [u_min[0], u_max[0], u_min[1], u_max[1], dt, x_lim[0], x_lim[1], y_lim[0], y_lim[1],
             goal[0], goal[1], Qo]
+
+
+def goalzone_params(goal, center=(0.0, 0.0), radius=10.0, u_min=(-1.0, -1.0), u_max=(1.0, 1.0), dt=0.1,
+                    penalty=1000.0):
+    return [u_min[0], u_max[0], u_min[1], u_max[1], dt, goal[0], goal[1], center[0], center[1], radius, penalty]
 
 
 class Problem:

@@ -41,6 +41,11 @@ def _import_reference():
         sys.modules.setdefault(n, types.ModuleType(n))
     sys.modules["moviepy.video.io.ImageSequenceClip"].ImageSequenceClip = object
     sys.modules["fire"].Fire = lambda f: None
+    gym = sys.modules["gymnasium"]  # GoalInDangerZoneEnv subclasses gym.Env and builds spaces.Box in __init__
+    gym.Env = object
+    gym.spaces = types.ModuleType("gymnasium.spaces")
+    gym.spaces.Box = lambda *a, **k: None
+    sys.modules["gymnasium.spaces"] = gym.spaces
     import matplotlib
 
     matplotlib.use("Agg")
@@ -192,6 +197,37 @@ def main():
     run_case("mountaincar_T100_N256_fixed",
              classic("mountaincar", "dynamics", "cost_func", horizon=100, num_samples=256,
                      lambda_=0.1, **mc), [-0.5, 0.0], 3, pred_next, keep_S=True)
+
+    # MuJoCo-style cart-pole (example/mujoco_cartpole.py:20-79): continuous force, masspole = 1
+    run_case("mjcartpole_T50_N256_fixed",
+             classic("mujoco_cartpole", "dynamics", "cost_func", horizon=50, num_samples=256,
+                     lambda_=1.0, **cart), [0.01, 0.0, 0.05, 0.0], 3, pred_next, keep_S=True)
+
+    # ------------------------------------------------------------ goal in danger zone
+    from envs.goal_in_danger_zone import GoalInDangerZoneEnv
+
+    np.random.seed(42)
+    gz = GoalInDangerZoneEnv(render_mode="rgb_array", seed=42)
+    gz._set_goal(gz._danger_zone)
+    gz._set_initial_state(gz._danger_zone)
+    gz_x0 = np.concatenate([gz._pos, [gz._angle], gz._goal - gz._pos,
+                            np.array(gz._danger_zone.center) - gz._pos]).astype(np.float32)
+    gz_extra = {"goal": np.asarray(gz._goal, np.float64), "center": np.asarray(gz._danger_zone.center, np.float64),
+                "radius": np.float64(gz._danger_zone.radius), "x0": gz_x0}
+    np.savez_compressed(os.path.join(OUT, "goalzone_env.npz"), **gz_extra)
+
+    def goalzone(**kw):
+        def make():
+            rec = Recorder(gz.parallel_cost)
+            solver = MPPI(dim_state=7, dim_control=2, dynamics=gz.parallel_step, cost_func=rec,
+                          u_min=torch.tensor([-1.0, -1.0]), u_max=torch.tensor([1.0, 1.0]),
+                          sigmas=torch.tensor([0.5, 0.5]), device=cpu, **kw)
+            return solver, rec, {}
+
+        return make
+
+    run_case("goalzone_T30_N256_fixed", goalzone(horizon=30, num_samples=256, lambda_=1.0), gz_x0, 3, pred_next,
+             keep_S=True)
 
     # ------------------------------------------------------------ navigation 2d
     from envs.navigation_2d import Navigation2DEnv

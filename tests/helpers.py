@@ -27,6 +27,8 @@ CASES = {
     "nav2d_T30_N256_fixed_explore": dict(model="nav2d", T=30, N=256, lambda_=1.0, exploration=0.25),
     "racing_T50_N512_fixed": dict(model="racing", T=50, N=512, lambda_=1.0),
     "racing_T25_N256_fixed": dict(model="racing", T=25, N=256, lambda_=1.0),
+    "mjcartpole_T50_N256_fixed": dict(model="mjcartpole", T=50, N=256, lambda_=1.0),
+    "goalzone_T30_N256_fixed": dict(model="goalzone", T=30, N=256, lambda_=1.0),
 }
 
 MODEL_CFG = {
@@ -35,6 +37,8 @@ MODEL_CFG = {
     "mountaincar": dict(u_min=[-1.0], u_max=[1.0], sigmas=[1.0]),
     "nav2d": dict(u_min=[0.0, -1.0], u_max=[2.0, 1.0], sigmas=[0.5, 0.5]),
     "racing": dict(u_min=[-2.0, -0.25], u_max=[2.0, 0.25], sigmas=[0.5, 0.1]),
+    "mjcartpole": dict(u_min=[-3.0], u_max=[3.0], sigmas=[1.0]),
+    "goalzone": dict(u_min=[-1.0, -1.0], u_max=[1.0, 1.0], sigmas=[0.5, 0.5]),
 }
 
 
@@ -73,6 +77,13 @@ def nav2d_env_fixture():
     return _env_cache["nav2d"]
 
 
+def goalzone_env_fixture():
+    if "goalzone" not in _env_cache:
+        e = load("goalzone_env")
+        _env_cache["goalzone"] = dict(goal=e["goal"], center=e["center"], radius=float(e["radius"]), x0=e["x0"])
+    return _env_cache["goalzone"]
+
+
 def oracle_problem(model, N, T, exploration=0.0, ref_path=None):
     cfg = MODEL_CFG[model]
     params, maps = (), ()
@@ -84,6 +95,9 @@ def oracle_problem(model, N, T, exploration=0.0, ref_path=None):
         e = nav2d_env_fixture()
         params = orc.nav2d_params()
         maps = [(e["map"], e["cell"], e["origin"])]
+    elif model == "goalzone":
+        e = goalzone_env_fixture()
+        params = orc.goalzone_params(np.float32(e["goal"]), np.float32(e["center"]), e["radius"])
     return orc.Problem(model, N, T, cfg["u_min"], cfg["u_max"], exploration=exploration, params=params,
                        maps=maps, ref_path=ref_path)
 

@@ -98,6 +98,8 @@ int emul_rollout_cost(int model, int fast, int N, int T, int threshold, const fl
     case MPPI_MODEL_MOUNTAINCAR: run<MPPI_MODEL_MOUNTAINCAR>(fast, N, T, threshold, x0, mean, eps, umin, umax, ctx, costs, bad_out, S_out); break;
     case MPPI_MODEL_NAV2D: run<MPPI_MODEL_NAV2D>(fast, N, T, threshold, x0, mean, eps, umin, umax, ctx, costs, bad_out, S_out); break;
     case MPPI_MODEL_RACING: run<MPPI_MODEL_RACING>(fast, N, T, threshold, x0, mean, eps, umin, umax, ctx, costs, bad_out, S_out); break;
+    case MPPI_MODEL_MJCARTPOLE: run<MPPI_MODEL_MJCARTPOLE>(fast, N, T, threshold, x0, mean, eps, umin, umax, ctx, costs, bad_out, S_out); break;
+    case MPPI_MODEL_GOALZONE: run<MPPI_MODEL_GOALZONE>(fast, N, T, threshold, x0, mean, eps, umin, umax, ctx, costs, bad_out, S_out); break;
     default: return -1;
     }
     return 0;

@@ -41,7 +41,15 @@ def make_solver(model, T, N, lambda_=1.0, **kw):
     common = dict(horizon=T, num_samples=N, u_min=torch.tensor(cfg["u_min"]), u_max=torch.tensor(cfg["u_max"]),
                   sigmas=torch.tensor(cfg["sigmas"]), lambda_=lambda_, **kw)
     ctrl = None
-    if model in ("pendulum", "cartpole", "mountaincar"):
+    if model == "goalzone":
+        from envs.goal_in_danger_zone import GoalInDangerZoneEnv
+        from helpers import goalzone_env_fixture
+
+        env = GoalInDangerZoneEnv()
+        env._goal = goalzone_env_fixture()["goal"]
+        solver = MPPI(dim_state=7, dim_control=2, dynamics=env.parallel_step, cost_func=env.parallel_cost, **common)
+        return solver, None
+    if model in ("pendulum", "cartpole", "mountaincar", "mjcartpole"):
         from envs import classic_control as cc
 
         dyn, cost = getattr(cc, f"{model}_dynamics"), getattr(cc, f"{model}_cost")
@@ -141,7 +149,8 @@ def test_forward_parity(name, math):
 
 @pytest.mark.parametrize("name", ["pendulum_T15_N256_fixed", "pendulum_T15_N200_explore", "cartpole_T10_N100_fixed",
                                   "mountaincar_T100_N256_fixed", "nav2d_T30_N256_fixed_explore", "racing_T25_N256_fixed",
-                                  "pendulum_T50_N1000_essps", "cartpole_T64_N1024_essps_sg"])
+                                  "pendulum_T50_N1000_essps", "cartpole_T64_N1024_essps_sg", "mjcartpole_T50_N256_fixed",
+                                  "goalzone_T30_N256_fixed"])
 def test_identical_seed_closed_loop_matches_reference(name):
     """`noise_source="torch_cpu"`, seed 42: the solver draws the reference's own CPU noise stream (the
     constructor consumes one draw, mppi.py:146-148) — nothing is injected.  Three closed-loop solves must

@@ -19,6 +19,11 @@ def _model_inputs(model):
     if model == "nav2d":
         e = nav2d_env_fixture()
         return orc.nav2d_params(), [e["map"]], (e["cell"], e["origin"][0], e["origin"][1])
+    if model == "goalzone":
+        from helpers import goalzone_env_fixture
+
+        e = goalzone_env_fixture()
+        return orc.goalzone_params(np.float32(e["goal"]), np.float32(e["center"]), e["radius"]), (), None
     return (), (), None
 
 
