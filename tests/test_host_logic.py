@@ -198,10 +198,3 @@ def test_fails_loudly_without_gpu():
     with pytest.raises(_capi.MppiError):
         MPPI(15, 100, 2, 1, pendulum_dynamics, pendulum_cost, torch.tensor([-2.0]), torch.tensor([2.0]),
              torch.tensor([1.0]), 1.0)
-
-
-def test_constructor_errors_match_reference():
-    from mppi_playground_amd import _capi
-
-    if not torch.cuda.is_available():
-        pytest.skip("constructor needs a GPU beyond the shape asserts")
