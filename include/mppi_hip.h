@@ -116,6 +116,26 @@ int mppi_set_model_params(mppi_handle_t h, const float* params_host, int n);
  * slot 0 = obstacle map (nav2d, racing), slot 1 = lane map (racing).  Synchronises. */
 int mppi_upload_map(mppi_handle_t h, int slot, const uint8_t* cells_host, int nx, int ny, float cell_size,
                     float origin_x, float origin_y);
+/* Map construction on the device, bit-exact with the reference's host loops.  Both build slot `slot` in place
+ * (same geometry arguments as mppi_upload_map), run on `stream` and return after the grid is complete; the caller
+ * orders them against solves in flight on OTHER streams.
+ *
+ * ObstacleMap.add_circle_obstacle / add_rectangle_obstacle (obstacle_map_2d.py:103-158) for a whole obstacle list:
+ *   circles [n_circles][3] = (ci, cj, r): centre cell np.round(center/cell + origin) and radius ceil(radius/cell)
+ *                            in cells; every disc cell i^2+j^2 <= r^2 is written at clip(ci+i), clip(cj+j) (:118-123);
+ *   rects   [n_rects][4]   = (x0, x1, y0, y1): the clipped half-open slice map[x0:x1, y0:y1] = 1 (:146-158).
+ * The float -> cell conversions stay with the caller (per obstacle, float64 numpy semantics). */
+int mppi_build_obstacle_map(mppi_handle_t h, int slot, int nx, int ny, float cell_size, float origin_x, float origin_y,
+                            const int32_t* circles_host, int n_circles, const int32_t* rects_host, int n_rects,
+                            void* stream);
+/* LaneMap.populate_map (lane_map_2d.py:68-88): seeds [n_seeds][2] = in-bounds centre-line cells (:71-77); a cell is
+ * drivable (0) iff its Euclidean distance transform value is <= (lane_width/2)/cell (:80-82), evaluated as the
+ * integer test  min_seeds(dx^2+dy^2) <= max_d2  with max_d2 = the largest integer whose float64 sqrt is <= that
+ * bound (computed by the caller). */
+int mppi_build_lane_map(mppi_handle_t h, int slot, int nx, int ny, float cell_size, float origin_x, float origin_y,
+                        const int32_t* seeds_host, int n_seeds, int64_t max_d2, void* stream);
+/* Read a slot's grid back (cells_host may be NULL to query nx, ny only).  Synchronises the device. */
+int mppi_download_map(mppi_handle_t h, int slot, uint8_t* cells_host, int* nx, int* ny);
 /* racing_controller.reference_path = calc_ref_trajectory(...) (example/racing.py:73-81):
  * ref [rows][4] = (x, y, yaw, v_target), rows >= T (the cost reads rows 0..T-1). */
 int mppi_set_reference(mppi_handle_t h, const float* ref_host, int rows, void* stream);

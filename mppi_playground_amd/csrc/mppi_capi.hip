@@ -50,7 +50,7 @@ struct MppiSolver {
     double* stats_host = nullptr;    // mapped pinned [8 + STATS_L*3]
     uint8_t* map_cells[2] = {nullptr, nullptr};
     uint8_t* map_fused = nullptr;
-    std::vector<uint8_t> map_host[2];
+    size_t map_bytes[2] = {0, 0}, map_fused_bytes = 0;
     ModelCtx ctx{};
     // options
     int math_fast = 1;
@@ -155,20 +155,51 @@ int check_ready(mppi_handle_t h) {
     return MPPI_OK;
 }
 
-void refresh_fused(mppi_handle_t h) {
+void refresh_fused(mppi_handle_t h, hipStream_t s) {
     h->ctx.fused = nullptr;
     if (h->cfg.model != MPPI_MODEL_RACING) return;
     const MapView &a = h->ctx.maps[0], &b = h->ctx.maps[1];
     if (!h->map_cells[0] || !h->map_cells[1]) return;
     if (a.nx != b.nx || a.ny != b.ny || a.cell != b.cell || a.ox != b.ox || a.oy != b.oy) return;
     const size_t n = (size_t)a.nx * a.ny;
-    std::vector<uint8_t> f(n);
-    for (size_t i = 0; i < n; ++i) f[i] = (uint8_t)(h->map_host[0][i] + h->map_host[1][i]);
-    if (h->map_fused) (void)hipFree(h->map_fused);
-    h->map_fused = nullptr;
-    if (hipMalloc(&h->map_fused, n) != hipSuccess) return;
-    if (hipMemcpy(h->map_fused, f.data(), n, hipMemcpyHostToDevice) != hipSuccess) return;
+    if (h->map_fused_bytes < n) {
+        if (h->map_fused) (void)hipFree(h->map_fused);
+        h->map_fused = nullptr; h->map_fused_bytes = 0;
+        if (hipMalloc(&h->map_fused, n) != hipSuccess) return;
+        h->map_fused_bytes = n;
+    }
+    hipLaunchKernelGGL(mppi::fuse_maps_kernel, dim3((unsigned)((n + mppi::BLOCK - 1) / mppi::BLOCK)), dim3(mppi::BLOCK),
+                       0, s, h->map_cells[0], h->map_cells[1], h->map_fused, n);
+    if (hipGetLastError() != hipSuccess) return;
     h->ctx.fused = h->map_fused;
+}
+
+// (re)allocate the grid of `slot` and fill in its geometry
+int prepare_map(mppi_handle_t h, int slot, int nx, int ny, float cell, float ox, float oy) {
+    if (!h || slot < 0 || slot > 1 || nx < 1 || ny < 1 || !(cell > 0.0f)) return fail(h, MPPI_E_INVALID, "bad map");
+    const size_t n = (size_t)nx * ny;
+    if (h->map_bytes[slot] < n) {
+        if (h->map_cells[slot]) { (void)hipFree(h->map_cells[slot]); h->map_cells[slot] = nullptr; h->map_bytes[slot] = 0; }
+        HIP_TRY(h, hipMalloc(&h->map_cells[slot], n));
+        h->map_bytes[slot] = n;
+    }
+    MapView& m = h->ctx.maps[slot];
+    m.cells = h->map_cells[slot];
+    m.nx = nx; m.ny = ny; m.cell = cell; m.ox = ox; m.oy = oy;
+    // Markstein division needs y = RN(1/cell) and a significand of cell that is not all ones.
+    uint32_t bits; std::memcpy(&bits, &cell, 4);
+    const bool all_ones = (bits & 0x7fffffu) == 0x7fffffu;
+    m.inv_cell = all_ones ? 0.0f : 1.0f / cell;  // host IEEE division: correctly rounded
+    return MPPI_OK;
+}
+
+// small integer table host -> device (map recipes); blocking, setup path only
+int upload_ints(mppi_handle_t h, const int32_t* src, size_t count, int32_t** dst) {
+    *dst = nullptr;
+    if (!count) return MPPI_OK;
+    HIP_TRY(h, hipMalloc(dst, sizeof(int32_t) * count));
+    HIP_TRY(h, hipMemcpy(*dst, src, sizeof(int32_t) * count, hipMemcpyHostToDevice));
+    return MPPI_OK;
 }
 
 }  // namespace
@@ -296,23 +327,67 @@ int mppi_set_model_params(mppi_handle_t h, const float* p, int n) {
 }
 
 int mppi_upload_map(mppi_handle_t h, int slot, const uint8_t* cells, int nx, int ny, float cell, float ox, float oy) {
-    if (!h || slot < 0 || slot > 1 || !cells || nx < 1 || ny < 1 || !(cell > 0.0f))
-        return fail(h, MPPI_E_INVALID, "bad map");
-    const size_t n = (size_t)nx * ny;
+    if (!h || !cells) return fail(h, MPPI_E_INVALID, "bad map");
+    const size_t n = (size_t)(nx > 0 ? nx : 0) * (ny > 0 ? ny : 0);
     for (size_t i = 0; i < n; ++i)
         if (cells[i] > 1) return fail(h, MPPI_E_INVALID, "map cells must be 0/1 occupancy");
-    if (h->map_cells[slot]) { (void)hipFree(h->map_cells[slot]); h->map_cells[slot] = nullptr; }
-    HIP_TRY(h, hipMalloc(&h->map_cells[slot], n));
+    if (int rc = prepare_map(h, slot, nx, ny, cell, ox, oy)) return rc;
     HIP_TRY(h, hipMemcpy(h->map_cells[slot], cells, n, hipMemcpyHostToDevice));
-    h->map_host[slot].assign(cells, cells + n);
-    MapView& m = h->ctx.maps[slot];
-    m.cells = h->map_cells[slot];
-    m.nx = nx; m.ny = ny; m.cell = cell; m.ox = ox; m.oy = oy;
-    // Markstein division needs y = RN(1/cell) and a significand of cell that is not all ones.
-    uint32_t bits; std::memcpy(&bits, &cell, 4);
-    const bool all_ones = (bits & 0x7fffffu) == 0x7fffffu;
-    m.inv_cell = all_ones ? 0.0f : 1.0f / cell;  // host IEEE division: correctly rounded
-    refresh_fused(h);
+    refresh_fused(h, nullptr);
+    HIP_TRY(h, hipStreamSynchronize(nullptr));
+    return MPPI_OK;
+}
+
+int mppi_build_obstacle_map(mppi_handle_t h, int slot, int nx, int ny, float cell, float ox, float oy,
+                            const int32_t* circles, int n_circles, const int32_t* rects, int n_rects, void* stream) {
+    if (!h || n_circles < 0 || n_rects < 0 || (n_circles && !circles) || (n_rects && !rects))
+        return fail(h, MPPI_E_INVALID, "bad obstacle list");
+    for (int c = 0; c < n_circles; ++c)
+        if (circles[3 * c + 2] < 0) return fail(h, MPPI_E_INVALID, "circle radius must be >= 0 cells");
+    if (int rc = prepare_map(h, slot, nx, ny, cell, ox, oy)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    int32_t *dc = nullptr, *dr = nullptr;
+    if (int rc = upload_ints(h, circles, (size_t)3 * n_circles, &dc)) return rc;
+    if (int rc = upload_ints(h, rects, (size_t)4 * n_rects, &dr)) { (void)hipFree(dc); return rc; }
+    hipLaunchKernelGGL(mppi::raster_obstacles_kernel, dim3((ny + mppi::BLOCK - 1) / mppi::BLOCK, nx), dim3(mppi::BLOCK), 0,
+                       s, h->map_cells[slot], nx, ny, dc, n_circles, dr, n_rects);
+    const hipError_t e = hipGetLastError();
+    refresh_fused(h, s);
+    const hipError_t e2 = hipStreamSynchronize(s);  // the recipe tables are freed below
+    (void)hipFree(dc); (void)hipFree(dr);
+    HIP_TRY(h, e);
+    HIP_TRY(h, e2);
+    return MPPI_OK;
+}
+
+int mppi_build_lane_map(mppi_handle_t h, int slot, int nx, int ny, float cell, float ox, float oy,
+                        const int32_t* seeds, int n_seeds, int64_t max_d2, void* stream) {
+    if (!h || n_seeds < 1 || !seeds || max_d2 < 0) return fail(h, MPPI_E_INVALID, "bad lane seeds");
+    if (int rc = prepare_map(h, slot, nx, ny, cell, ox, oy)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    int32_t* ds = nullptr;
+    if (int rc = upload_ints(h, seeds, (size_t)2 * n_seeds, &ds)) return rc;
+    hipLaunchKernelGGL(mppi::lane_map_kernel, dim3((ny + mppi::BLOCK - 1) / mppi::BLOCK, nx), dim3(mppi::BLOCK), 0, s,
+                       h->map_cells[slot], nx, ny, ds, n_seeds, max_d2);
+    const hipError_t e = hipGetLastError();
+    refresh_fused(h, s);
+    const hipError_t e2 = hipStreamSynchronize(s);
+    (void)hipFree(ds);
+    HIP_TRY(h, e);
+    HIP_TRY(h, e2);
+    return MPPI_OK;
+}
+
+int mppi_download_map(mppi_handle_t h, int slot, uint8_t* cells_host, int* nx, int* ny) {
+    if (!h || slot < 0 || slot > 1) return fail(h, MPPI_E_INVALID, "bad slot");
+    if (!h->map_cells[slot]) return fail(h, MPPI_E_STATE, "map slot is empty");
+    const MapView& m = h->ctx.maps[slot];
+    if (nx) *nx = m.nx;
+    if (ny) *ny = m.ny;
+    if (cells_host) {
+        HIP_TRY(h, hipDeviceSynchronize());
+        HIP_TRY(h, hipMemcpy(cells_host, h->map_cells[slot], (size_t)m.nx * m.ny, hipMemcpyDeviceToHost));
+    }
     return MPPI_OK;
 }
 

@@ -9,6 +9,10 @@
 #pragma once
 #include <stdint.h>
 
+#ifndef MPPI_PHILOX_ROUNDS
+#define MPPI_PHILOX_ROUNDS 10
+#endif
+
 namespace mppi {
 
 struct u32x4 {
@@ -18,7 +22,7 @@ struct u32x4 {
 __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                                uint32_t k1) {
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < MPPI_PHILOX_ROUNDS; ++r) {
         // one 32x32->64 multiply each (v_mad_u64_u32): integer multiplies are quarter rate on CDNA
         const uint64_t p0 = (uint64_t)0xD2511F53u * (uint64_t)c0;
         const uint64_t p1 = (uint64_t)0xCD9E8D57u * (uint64_t)c2;

@@ -16,6 +16,17 @@ from envs.obstacle_map_2d import _device, grid_lookup
 from pi_mpc.native import GridSpec
 
 
+def largest_square_within(max_distance: float) -> int:
+    """Largest integer k with float64 sqrt(k) <= max_distance: `edt <= max_distance` (lane_map_2d.py:80-82)
+    on a grid whose EDT values are sqrt(integer) becomes `d2 <= k`."""
+    k = int(max_distance * max_distance)
+    while np.sqrt(np.float64(k + 1)) <= max_distance:
+        k += 1
+    while k >= 0 and np.sqrt(np.float64(k)) > max_distance:
+        k -= 1
+    return k
+
+
 class LaneMap:
     def __init__(self, lane: np.ndarray, lane_width: float, map_size: Tuple[int, int] = (20, 20),
                  cell_size: float = 0.01, device=torch.device("cuda"), dtype=torch.float32) -> None:
@@ -36,13 +47,18 @@ class LaneMap:
         ok = (cx >= 0) & (cx < nx) & (cy >= 0) & (cy < ny)
         seeds[cx[ok], cy[ok]] = 0
         dist = distance_transform_edt(seeds)
-        self._map = np.where(dist <= (lane_width / 2) / cell_size, 0, 1)
+        max_distance = (lane_width / 2) / cell_size
+        self._map = np.where(dist <= max_distance, 0, 1)
+        # the same test on integer squared cell distances, for the device builder
+        self._seed_cells = np.unique(np.stack([cx[ok], cy[ok]], axis=1), axis=0).astype(np.int32)
+        self._max_d2 = largest_square_within(max_distance)
         self._map_torch = torch.tensor(self._map, device=self._device, dtype=self._dtype)
-        self._cells_u8 = np.ascontiguousarray(self._map != 0, dtype=np.uint8)
+        self._spec = GridSpec(np.ascontiguousarray(self._map != 0, dtype=np.uint8), float(cell_size),
+                              (float(self._cell_map_origin[0]), float(self._cell_map_origin[1])), 0,
+                              {"kind": "lane", "seeds": self._seed_cells, "max_d2": self._max_d2})
 
     def grid_spec(self) -> GridSpec:
-        return GridSpec(self._cells_u8, float(self._cell_size),
-                        (float(self._cell_map_origin[0]), float(self._cell_map_origin[1])), 0)
+        return self._spec
 
     def compute_cost(self, x: torch.Tensor) -> torch.Tensor:
         if x.device != self._device or x.dtype != self._dtype:

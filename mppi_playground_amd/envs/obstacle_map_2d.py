@@ -2,7 +2,7 @@
 
 Counterpart of the reference's src/envs/obstacle_map_2d.py (construction semantics :46-162,
 lookup :168-200, random placement :235-345), written for this build; pinned against the reference's
-maps by tests/test_envs_vs_golden.py.
+maps by tests/test_host_logic.py.
 """
 from __future__ import annotations
 
@@ -41,7 +41,9 @@ class ObstacleMap:
         self.circle_obs_list: List[Tuple[np.ndarray, float]] = []
         self.rectangle_obs_list: List[Tuple[np.ndarray, float, float]] = []
         self._version = 0
-        self._cells_u8 = None
+        self._spec = None
+        self._circle_cells: List[Tuple[int, int, int]] = []    # (ci, cj, r) in cells, for the device rasteriser
+        self._rect_cells: List[Tuple[int, int, int, int]] = []  # clipped (x0, x1, y0, y1)
 
     # -- rasterisers ---------------------------------------------------------------------------
     def add_circle_obstacle(self, center: np.ndarray, radius: float) -> None:
@@ -54,6 +56,7 @@ class ObstacleMap:
         xi = np.clip(c[0] + ii[inside], 0, self._map.shape[0] - 1)
         yi = np.clip(c[1] + jj[inside], 0, self._map.shape[1] - 1)
         self._map[xi, yi] = 1
+        self._circle_cells.append((int(c[0]), int(c[1]), int(r)))
         self.circle_obs_list.append((np.asarray(center, float), float(radius)))
         self._touch()
 
@@ -65,12 +68,13 @@ class ObstacleMap:
         x0, x1 = np.clip([c[0] - hw, c[0] + hw], 0, self._map.shape[0] - 1)
         y0, y1 = np.clip([c[1] - hh, c[1] + hh], 0, self._map.shape[1] - 1)
         self._map[x0:x1, y0:y1] = 1
+        self._rect_cells.append((int(x0), int(x1), int(y0), int(y1)))
         self.rectangle_obs_list.append((np.asarray(center, float), float(width), float(height)))
         self._touch()
 
     def _touch(self):
         self._version += 1
-        self._cells_u8 = None
+        self._spec = None
 
     # -- device views --------------------------------------------------------------------------
     def convert_to_torch(self) -> torch.Tensor:
@@ -78,11 +82,16 @@ class ObstacleMap:
         return self._map_torch
 
     def grid_spec(self) -> GridSpec:
-        """Plain host description for the native path (uploaded once per version)."""
-        if self._cells_u8 is None:
-            self._cells_u8 = np.ascontiguousarray(self._map != 0, dtype=np.uint8)
-        return GridSpec(self._cells_u8, float(self._cell_size),
-                        (float(self._cell_map_origin[0]), float(self._cell_map_origin[1])), self._version)
+        """Plain host description for the native path (cached per version; the solver rasterises the integer
+        recipe on the device, `cells` is the host-built twin)."""
+        if self._spec is None:
+            cells = np.ascontiguousarray(self._map != 0, dtype=np.uint8)
+            recipe = {"kind": "obstacles", "circles": np.asarray(self._circle_cells, np.int32).reshape(-1, 3),
+                      "rects": np.asarray(self._rect_cells, np.int32).reshape(-1, 4)}
+            self._spec = GridSpec(cells, float(self._cell_size),
+                                      (float(self._cell_map_origin[0]), float(self._cell_map_origin[1])),
+                                      self._version, recipe)
+        return self._spec
 
     def compute_cost(self, x: torch.Tensor) -> torch.Tensor:
         """x [B, L, 2] -> occupancy [B, L]; out of the grid counts as occupied."""

@@ -242,15 +242,40 @@ class MPPI(nn.Module):
         for slot, grid in enumerate(spec.get("maps", ())):
             key = (id(grid.cells), grid.version)
             if self._uploaded.get(slot) != key:
-                cells = np.ascontiguousarray(grid.cells, dtype=np.uint8)
-                self._h.call("mppi_upload_map", slot, cells.ctypes.data_as(C.c_void_p), cells.shape[0],
-                             cells.shape[1], float(grid.cell_size), float(grid.origin[0]), float(grid.origin[1]))
+                self._put_map(slot, grid)
                 self._uploaded[slot] = key
         ref = spec.get("ref_path")
         if ref is not None and ref is not self._ref_uploaded:  # re-upload only a NEW reference window
             r = np.ascontiguousarray(ref, dtype=np.float32)
             self._h.call("mppi_set_reference", r.ctypes.data_as(C.c_void_p), r.shape[0], self._stream())
             self._ref_uploaded = ref
+
+    def _put_map(self, slot: int, grid) -> None:
+        """Occupancy grid -> device slot: rasterised on the device from the integer recipe when the map
+        provides one (obstacle_map_2d.py:103-158, lane_map_2d.py:68-88), else uploaded as bytes."""
+        geom = (grid.cells.shape[0], grid.cells.shape[1], float(grid.cell_size), float(grid.origin[0]),
+                float(grid.origin[1]))
+        rec = getattr(grid, "recipe", None)
+        ip = lambda a: a.ctypes.data_as(C.c_void_p) if a.size else None  # noqa: E731
+        if rec and rec["kind"] == "obstacles":
+            circles = np.ascontiguousarray(rec["circles"], np.int32)
+            rects = np.ascontiguousarray(rec["rects"], np.int32)
+            self._h.call("mppi_build_obstacle_map", slot, *geom, ip(circles), len(circles), ip(rects), len(rects),
+                         self._stream())
+        elif rec and rec["kind"] == "lane" and len(rec["seeds"]):
+            seeds = np.ascontiguousarray(rec["seeds"], np.int32)
+            self._h.call("mppi_build_lane_map", slot, *geom, ip(seeds), len(seeds), int(rec["max_d2"]), self._stream())
+        else:
+            cells = np.ascontiguousarray(grid.cells, dtype=np.uint8)
+            self._h.call("mppi_upload_map", slot, cells.ctypes.data_as(C.c_void_p), *geom)
+
+    def device_map(self, slot: int) -> np.ndarray:
+        """The occupancy grid the kernels read (uint8 [nx, ny]) — inspection / tests."""
+        nx, ny = C.c_int(0), C.c_int(0)
+        self._h.call("mppi_download_map", slot, None, C.byref(nx), C.byref(ny))
+        out = np.empty((nx.value, ny.value), np.uint8)
+        self._h.call("mppi_download_map", slot, out.ctypes.data_as(C.c_void_p), None, None)
+        return out
 
     def inject_noise(self, eps: torch.Tensor) -> None:
         """Parity hook: use `eps` [N_local,T,dc] (already scaled by sigma) for the next solve instead of

@@ -34,6 +34,10 @@ class GridSpec:
     cell_size: float
     origin: tuple       # (ox, oy) cell index of world (0, 0)
     version: int = 0    # bump when cells change
+    # optional integer description the solver can rasterise on the device instead of uploading `cells`:
+    #   {"kind": "obstacles", "circles": int32[nc,3] (ci, cj, r cells), "rects": int32[nr,4] (x0, x1, y0, y1)}
+    #   {"kind": "lane", "seeds": int32[ns,2], "max_d2": int}
+    recipe: Optional[dict] = None
 
 
 def native_model(model: str, role: str, provider: Optional[Callable] = None):

@@ -206,3 +206,46 @@ def philox_normal(seed, solve_idx, first, n, T, dc, sigma):
     lib().oracle_philox_normal(int(seed), int(solve_idx), int(first), int(n), int(T), int(dc), _ptr(sigma),
                                _ptr(out))
     return out
+
+
+# ---- map construction (test oracle; literal restatement of the reference's host loops) -----------------------
+def obstacle_map_literal(nx, ny, cell_size, circles=(), rects=()):
+    """ObstacleMap.__init__ + add_circle_obstacle + add_rectangle_obstacle, cell by cell as the reference writes
+    them (src/envs/obstacle_map_2d.py:83-95,103-158).  circles: [(center(2,), radius)], rects: [(center, w, h)]
+    in metres.  Returns (uint8 [nx, ny], origin)."""
+    from math import ceil
+
+    grid = np.zeros((nx, ny), np.uint8)
+    origin = np.array([nx / 2, ny / 2]).astype(int)
+    for center, radius in circles:
+        c = np.round(np.asarray(center, float) / cell_size + origin).astype(int)
+        r = ceil(radius / cell_size)
+        for i in range(-r, r + 1):
+            for j in range(-r, r + 1):
+                if i ** 2 + j ** 2 <= r ** 2:
+                    grid[np.clip(c[0] + i, 0, nx - 1), np.clip(c[1] + j, 0, ny - 1)] = 1
+    for center, w, h in rects:
+        c = np.ceil(np.asarray(center, float) / cell_size + origin).astype(int)
+        wo, ho = ceil(w / cell_size), ceil(h / cell_size)
+        x0, x1 = c[0] - ceil(wo / 2), c[0] + ceil(wo / 2)
+        y0, y1 = c[1] - ceil(ho / 2), c[1] + ceil(ho / 2)
+        x0, x1 = np.clip(x0, 0, nx - 1), np.clip(x1, 0, nx - 1)
+        y0, y1 = np.clip(y0, 0, ny - 1), np.clip(y1, 0, ny - 1)
+        grid[x0:x1, y0:y1] = 1
+    return grid, origin
+
+
+def lane_map_literal(nx, ny, cell_size, lane, lane_width):
+    """LaneMap.__init__ + populate_map (src/envs/lane_map_2d.py:48-82): centre-line cells -> Euclidean distance
+    transform (scipy, as the reference) -> threshold.  Returns (uint8 [nx, ny], origin)."""
+    from scipy.ndimage import distance_transform_edt
+
+    grid = np.ones((nx, ny))
+    origin = np.array([nx // 2, ny // 2])
+    for x, y, _ in lane:
+        cx = int(round(x / cell_size)) + origin[0]
+        cy = int(round(y / cell_size)) + origin[1]
+        if 0 <= cx < nx and 0 <= cy < ny:
+            grid[cx, cy] = 0
+    dist = distance_transform_edt(grid)
+    return np.where(dist <= (lane_width / 2) / cell_size, 0, 1).astype(np.uint8), origin

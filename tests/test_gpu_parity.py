@@ -712,3 +712,82 @@ def test_racing_controller_closed_loop_smoke():
         top, tw = ctrl.get_top_samples(num_samples=300)
         assert top.shape == (300, 26, 4) and coll.shape[-1] == 26
     assert float(state[3]) > 0.5  # the car accelerates along the track
+
+
+# ------------------------------------------------------------------------------ map construction on the device
+def test_device_built_maps_are_bit_exact_with_reference_fixtures():
+    """raster_obstacles_kernel / lane_map_kernel (through mppi_build_*_map, the path the solver takes when a map
+    carries a recipe) against the reference's own 800x800 racing maps and 200x200 nav2d map."""
+    from helpers import nav2d_env_fixture, racing_env_fixture
+
+    solver, ctrl = make_solver("racing", 10, 64)
+    ctrl.set_reference(np.zeros((11, 4), np.float32))
+    solver.forward(torch.zeros(4))
+    e = racing_env_fixture()
+    assert np.array_equal(solver.device_map(0), e["obst"])
+    assert np.array_equal(solver.device_map(1), e["lane"])
+    solver, _ = make_solver("nav2d", 10, 64)
+    solver.forward(torch.tensor([-9.0, -9.0, 0.785]))
+    assert np.array_equal(solver.device_map(0), nav2d_env_fixture()["map"])
+
+
+def test_device_map_builders_clip_like_the_reference_loops():
+    """Obstacles sticking out of the grid (clipped onto border cells), degenerate radii, a centre line that
+    leaves the grid — against the literal restatement of the reference loops; and upload == build."""
+    _need_gpu()
+    from envs.lane_map_2d import LaneMap
+    from envs.obstacle_map_2d import ObstacleMap
+    from mppi_playground_amd import _capi
+
+    rng = np.random.default_rng(5)
+    f4 = C.c_float * 4
+    cfg = _capi.MppiConfig(model=_capi.MODEL_IDS["racing"], horizon=4, dim_state=4, dim_control=2, num_samples=64,
+                           sample_offset=0, inherit_count=64, u_min=f4(-1, -1, 0, 0), u_max=f4(1, 1, 0, 0),
+                           sigmas=f4(1, 1, 0, 0), seed=1, device=0)
+    h = _capi.Handle(cfg)
+    for trial, (metres, cell) in enumerate([(2, 0.05), (2, 0.04), (4, 0.1), (2, 0.025), (4, 0.05), (6, 0.1)]):
+        m = ObstacleMap(map_size=(metres, metres), cell_size=cell, device="cpu")
+        nx, ny = m._map.shape
+        size = metres / 2
+        circles = [(rng.uniform(-1.3 * size, 1.3 * size, 2), rng.uniform(0.2 * cell, 0.3 * size)) for _ in range(6)]
+        rects = [(rng.uniform(-1.3 * size, 1.3 * size, 2), rng.uniform(cell, 0.5 * size), rng.uniform(cell, 0.5 * size))
+                 for _ in range(5)]
+        for c, r in circles:
+            m.add_circle_obstacle(c, r)
+        for c, w, hh in rects:
+            m.add_rectangle_obstacle(c, w, hh)
+        lit, _ = orc.obstacle_map_literal(nx, ny, cell, circles, rects)
+        assert 0 < lit.sum() < lit.size
+        rec = m.grid_spec().recipe
+        ci, re_ = np.ascontiguousarray(rec["circles"]), np.ascontiguousarray(rec["rects"])
+        h.call("mppi_build_obstacle_map", 0, nx, ny, cell, float(nx // 2), float(ny // 2),
+               ci.ctypes.data_as(C.c_void_p), len(ci), re_.ctypes.data_as(C.c_void_p), len(re_), None)
+        out = np.empty((nx, ny), np.uint8)
+        h.call("mppi_download_map", 0, out.ctypes.data_as(C.c_void_p), None, None)
+        assert np.array_equal(out, lit), f"trial {trial}"
+
+        t = np.linspace(0, 2 * np.pi, 50)
+        lane = np.stack([1.1 * size * np.cos(t), 0.7 * size * np.sin(t) + 0.4 * size, t], axis=1)  # leaves the grid
+        width = float(rng.uniform(2 * cell, 0.5 * size))
+        lit, _ = orc.lane_map_literal(nx, ny, cell, lane, width)
+        lm = LaneMap(lane, lane_width=width, map_size=(metres, metres), cell_size=cell, device="cpu")
+        rec = lm.grid_spec().recipe
+        assert lm.grid_spec().cells.shape == (nx, ny)
+        seeds = np.ascontiguousarray(rec["seeds"])
+        h.call("mppi_build_lane_map", 1, nx, ny, cell, float(nx // 2), float(ny // 2),
+               seeds.ctypes.data_as(C.c_void_p), len(seeds), int(rec["max_d2"]), None)
+        h.call("mppi_download_map", 1, out.ctypes.data_as(C.c_void_p), None, None)
+        assert np.array_equal(out, lit), f"lane trial {trial}"
+
+    # byte upload and device build give the same grid; bad arguments are refused
+    h.call("mppi_upload_map", 1, lit.ctypes.data_as(C.c_void_p), nx, ny, 0.05, float(nx // 2), float(ny // 2))
+    h.call("mppi_download_map", 1, out.ctypes.data_as(C.c_void_p), None, None)
+    assert np.array_equal(out, lit)
+    with pytest.raises(_capi.MppiError):
+        h.call("mppi_build_lane_map", 1, nx, ny, 0.05, 0.0, 0.0, None, 0, 4, None)
+    with pytest.raises(_capi.MppiError):
+        h.call("mppi_build_obstacle_map", 2, nx, ny, 0.05, 0.0, 0.0, None, 0, None, 0, None)
+    bad = np.array([[1, 1, -2]], np.int32)
+    with pytest.raises(_capi.MppiError):
+        h.call("mppi_build_obstacle_map", 0, nx, ny, 0.05, 0.0, 0.0, bad.ctypes.data_as(C.c_void_p), 1, None, 0, None)
+    h.close()

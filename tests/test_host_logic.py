@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import CASES, ROOT, load, nav2d_env_fixture, oracle_problem, racing_env_fixture, rel_err
+from helpers import CASES, ROOT, load, nav2d_env_fixture, oracle_problem, orc, racing_env_fixture, rel_err
 from pi_mpc import _host
 
 
@@ -198,3 +198,75 @@ def test_fails_loudly_without_gpu():
     with pytest.raises(_capi.MppiError):
         MPPI(15, 100, 2, 1, pendulum_dynamics, pendulum_cost, torch.tensor([-2.0]), torch.tensor([2.0]),
              torch.tensor([1.0]), 1.0)
+
+
+# ------------------------------------------------------------------ map recipes (what the device rasterises)
+def _recipe_raster(nx, ny, recipe):
+    """numpy statement of the integer rules of raster_obstacles_kernel / lane_map_kernel (mppi_kernels.hpp)."""
+    ix, iy = np.meshgrid(np.arange(nx), np.arange(ny), indexing="ij")
+    if recipe["kind"] == "lane":
+        best = np.full((nx, ny), np.iinfo(np.int64).max)
+        for sx, sy in recipe["seeds"].astype(np.int64):
+            best = np.minimum(best, (ix - sx) ** 2 + (iy - sy) ** 2)
+        return (best > recipe["max_d2"]).astype(np.uint8)
+    big = 1 << 40
+    occ = np.zeros((nx, ny), bool)
+    for ci, cj, r in recipe["circles"].astype(np.int64):
+        lo_i, hi_i = np.where(ix == 0, -big, ix - ci), np.where(ix == nx - 1, big, ix - ci)
+        lo_j, hi_j = np.where(iy == 0, -big, iy - cj), np.where(iy == ny - 1, big, iy - cj)
+        i, j = np.minimum(np.maximum(0, lo_i), hi_i), np.minimum(np.maximum(0, lo_j), hi_j)
+        occ |= i * i + j * j <= r * r
+    for x0, x1, y0, y1 in recipe["rects"]:
+        occ |= (ix >= x0) & (ix < x1) & (iy >= y0) & (iy < y1)
+    return occ.astype(np.uint8)
+
+
+def test_map_recipes_reproduce_reference_maps(racing_env):
+    from envs.navigation_2d import Navigation2DEnv
+
+    e, n = racing_env_fixture(), nav2d_env_fixture()
+    spec = racing_env._obstacle_map.grid_spec()
+    assert np.array_equal(_recipe_raster(*spec.cells.shape, spec.recipe), e["obst"])
+    spec = Navigation2DEnv(device="cpu")._obstacle_map.grid_spec()
+    assert len(spec.recipe["rects"]) == 7 and len(spec.recipe["circles"]) == 7
+    assert np.array_equal(_recipe_raster(*spec.cells.shape, spec.recipe), n["map"])
+    # the lane rule on a crop around a stretch of the centre line (the full 800x800x3678 case runs on the GPU)
+    lane = racing_env._lane_map.grid_spec()
+    seeds, k = lane.recipe["seeds"], lane.recipe["max_d2"]
+    x0, y0 = seeds[:, 0].min(), int(np.median(seeds[:, 1]))
+    sl = (slice(x0, x0 + 90), slice(y0 - 60, y0 + 60))
+    near = seeds[(seeds[:, 0] < x0 + 90 + 40) & (np.abs(seeds[:, 1] - y0) < 100)]
+    crop = _recipe_raster(800, 800, {"kind": "lane", "seeds": near, "max_d2": k})[sl]
+    assert np.array_equal(crop, e["lane"][sl])
+
+
+def test_map_recipes_border_clipping_and_threshold():
+    """Discs and rectangles that stick out of the grid are clipped onto the border cells by the reference's
+    loops (obstacle_map_2d.py:118-123,146-156); the recipe rule must pile them up the same way."""
+    from envs.lane_map_2d import LaneMap, largest_square_within
+    from envs.obstacle_map_2d import ObstacleMap
+
+    circles = [(np.array([-0.95, 0.2]), 0.3), (np.array([0.9, -0.97]), 0.25), (np.array([1.4, 1.4]), 0.7),
+               (np.array([0.0, 0.0]), 0.04), (np.array([-3.0, 0.5]), 0.5)]
+    rects = [(np.array([0.9, 0.9]), 0.5, 0.3), (np.array([-1.2, -0.3]), 0.6, 0.2), (np.array([0.2, -0.4]), 0.11, 0.33)]
+    m = ObstacleMap(map_size=(2, 2), cell_size=0.05, device="cpu")
+    for c, r in circles:
+        m.add_circle_obstacle(c, r)
+    for c, w, h in rects:
+        m.add_rectangle_obstacle(c, w, h)
+    lit, origin = orc.obstacle_map_literal(40, 40, 0.05, circles, rects)
+    spec = m.grid_spec()
+    assert np.array_equal(spec.cells, lit) and tuple(origin) == spec.origin
+    assert np.array_equal(_recipe_raster(40, 40, spec.recipe), lit)
+
+    for md in (0.0, 0.5, 1.0, 25.999999, 26.0, 26.000001, np.sqrt(2.0), 2.5 ** 0.5, 1e3 + 0.5):
+        k = largest_square_within(md)
+        assert np.sqrt(np.float64(k)) <= md < np.sqrt(np.float64(k + 1))
+
+    t = np.linspace(0, 2 * np.pi, 40)
+    lane = np.stack([0.6 * np.cos(t), 0.5 * np.sin(t) + 0.45, t], axis=1)  # partly outside the 2 x 2 m grid
+    lm = LaneMap(lane, lane_width=0.33, map_size=(2, 2), cell_size=0.05, device="cpu")
+    lit, _ = orc.lane_map_literal(40, 40, 0.05, lane, 0.33)
+    spec = lm.grid_spec()
+    assert np.array_equal(spec.cells, lit)
+    assert np.array_equal(_recipe_raster(40, 40, spec.recipe), lit)
