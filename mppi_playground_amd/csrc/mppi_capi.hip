@@ -15,6 +15,10 @@
 
 using namespace mppi;
 
+// mppi_finalize folds the partial rows itself while the reductions publish at most this many (sparse softmax);
+// beyond it the multi-block summarize_kernel is cheaper than one block walking the rows.
+static constexpr int FOLD_IN_FINALIZE_MAX_ROWS = 64;
+
 struct MppiSolver {
     MppiConfig cfg{};
     Dims d{};
@@ -58,7 +62,10 @@ struct MppiSolver {
     int timing = 0;
     std::vector<hipEvent_t> ev_pool[4];  // per stage: start0, stop0, start1, stop1, ...
     size_t ev_used[4] = {0, 0, 0, 0};
-    int CH = 32, nchunks = 1, colsp = 128;
+    int GPW = 8, nchunks = 1, colsp = 128;  // reduce: float4 groups per wave, column chunks, padded row
+    bool summary_valid = false;             // summarize_kernel ran after the last reduce
+    int* live_hint = nullptr;               // mapped pinned: partial rows the last fold saw (host-side hint)
+    int* live_hint_dev = nullptr;
     std::string err;
 };
 
@@ -246,9 +253,10 @@ int mppi_create(const MppiConfig* cfg, mppi_handle_t* out) {
     for (int k = 0; k < MPPI_MAX_DIM_CONTROL; ++k) {
         d.u_min[k] = cfg->u_min[k]; d.u_max[k] = cfg->u_max[k]; d.sigma[k] = cfg->sigmas[k];
     }
-    h->CH = d.R <= 8 ? 8 : 32;
-    h->nchunks = (d.R + h->CH - 1) / h->CH;
-    h->colsp = h->nchunks * h->CH * 4;
+    h->GPW = d.R <= 32 ? 8 : 32;
+    const int chg = h->GPW * (BLOCK / WAVE);  // float4 groups per column chunk
+    h->nchunks = (d.R + chg - 1) / chg;
+    h->colsp = h->nchunks * chg * 4;
     *out = h;  // so that the caller can read the error and destroy on failure
     HIP_TRY(h, hipSetDevice(cfg->device));
     const size_t noise_bytes = (size_t)d.tiles * d.R * 64 * sizeof(float4);
@@ -271,6 +279,9 @@ int mppi_create(const MppiConfig* cfg, mppi_handle_t* out) {
     HIP_TRY(h, hipMalloc(&h->summary, sizeof(float) * (size_t)(MPPI_SUMMARY_HEAD + d.row)));
     HIP_TRY(h, hipMalloc(&h->stats_part, sizeof(float) * STATS_L * 3 * STATS_BLOCKS));
     HIP_TRY(h, hipHostMalloc((void**)&h->stats_host, sizeof(double) * (8 + STATS_L * 3), hipHostMallocMapped));
+    HIP_TRY(h, hipHostMalloc((void**)&h->live_hint, sizeof(int), hipHostMallocMapped));
+    *h->live_hint = 0;
+    HIP_TRY(h, hipHostGetDevicePointer((void**)&h->live_hint_dev, h->live_hint, 0));
     std::memset(&h->ctx, 0, sizeof(h->ctx));
     HIP_TRY(h, hipDeviceSynchronize());
     return MPPI_OK;
@@ -283,6 +294,7 @@ int mppi_destroy(mppi_handle_t h) {
     (void)hipFree(h->summary); (void)hipFree(h->map_cells[0]); (void)hipFree(h->map_cells[1]);
     (void)hipFree(h->map_fused); (void)hipFree(h->stats_part); (void)hipFree(h->noise_std);
     if (h->stats_host) (void)hipHostFree(h->stats_host);
+    if (h->live_hint) (void)hipHostFree(h->live_hint);
     for (int i = 0; i < MppiSolver::RING; ++i) {
         if (h->stage[i]) (void)hipHostFree(h->stage[i]);
         if (h->stage_ev[i]) (void)hipEventDestroy(h->stage_ev[i]);
@@ -599,26 +611,30 @@ int mppi_weights_reduce(mppi_handle_t h, float lambda, float* summary_out_dev, v
     // one wave per tile up to reduce_blocks blocks (dense weights need the parallelism; with sparse
     // weights most waves only run the phase-A check)
     int64_t blocks = std::min<int64_t>(h->reduce_blocks, (h->d.tiles + 3) / 4);
-    blocks = std::max<int64_t>(1, std::min<int64_t>(blocks, 2048));
+    blocks = std::max<int64_t>(1, std::min<int64_t>(blocks, REDUCE_MAX_BLOCKS));
     h->last_reduce_blocks = (int)blocks;
     const dim3 grid((unsigned)blocks, (unsigned)h->nchunks);
     const bool gen = h->noise_regen && !h->injected;
     if (!gen && !h->tiles_valid) return fail(h, MPPI_E_STATE, "no noise: call mppi_sample or mppi_inject_noise first");
     const unsigned* mk = h->min_key + h->min_slot;
-#define CALL_REDUCE(CHV, GENV)                                                                        \
-    hipLaunchKernelGGL((weights_reduce_kernel<CHV, GENV>), grid, dim3(BLOCK), 0, s, h->noise, h->mean, h->costs, mk, \
+#define CALL_REDUCE(GPWV, GENV)                                                                       \
+    hipLaunchKernelGGL((weights_reduce_kernel<GPWV, GENV>), grid, dim3(BLOCK), 0, s, h->noise, h->mean, h->costs, mk, \
                        h->partials, h->heads, h->d, h->gen, lambda)
-    if (h->CH == 8) { if (gen) CALL_REDUCE(8, true); else CALL_REDUCE(8, false); }
+    if (h->GPW == 8) { if (gen) CALL_REDUCE(8, true); else CALL_REDUCE(8, false); }
     else { if (gen) CALL_REDUCE(32, true); else CALL_REDUCE(32, false); }
 #undef CALL_REDUCE
     HIP_TRY(h, hipGetLastError());
-    if (summary_out_dev) {  // sharded use: the summary is needed before the collective
+    // Fold the published partial rows into the shard summary.  Sharded use needs the summary before the
+    // collective; otherwise mppi_finalize folds the rows itself when the previous solves published few of them
+    // (*live_hint, written by finalize_kernel to mapped host memory and read here without synchronising: it only
+    // steers this choice, both paths give the same summary).
+    h->summary_valid = false;
+    if (summary_out_dev || *(volatile int*)h->live_hint > FOLD_IN_FINALIZE_MAX_ROWS) {
         const unsigned sgrid = (unsigned)((h->colsp + SUM_COLS - 1) / SUM_COLS + 1);
         hipLaunchKernelGGL(summarize_kernel, dim3(sgrid), dim3(SUM_BLOCK), 0, s, h->partials, h->heads, mk, (int)blocks,
-                           h->colsp, h->d.row, h->summary);
+                           h->colsp, h->d.row, h->summary, summary_out_dev, h->live_hint_dev);
         HIP_TRY(h, hipGetLastError());
-        HIP_TRY(h, hipMemcpyAsync(summary_out_dev, h->summary, sizeof(float) * (size_t)(MPPI_SUMMARY_HEAD + h->d.row),
-                                  hipMemcpyDeviceToDevice, s));
+        h->summary_valid = true;
     }
     return MPPI_OK;
 }
@@ -631,34 +647,18 @@ int mppi_finalize(mppi_handle_t h, const float* summaries_dev, int num_shards, f
     if (!generic) { if (int rc = check_ready(h)) return rc; }
     hipStream_t s = (hipStream_t)stream;
     StageTimer tm(h, 3, s);
-    bool own = summaries_dev == nullptr;
-    if (own && h->last_reduce_blocks < 1) return fail(h, MPPI_E_STATE, "mppi_finalize before mppi_weights_reduce");
-    if (own) num_shards = 1;
+    if (!summaries_dev) {  // this handle's own reduction (mppi_weights_reduce)
+        if (h->last_reduce_blocks < 1) return fail(h, MPPI_E_STATE, "mppi_finalize before mppi_weights_reduce");
+        if (h->summary_valid) summaries_dev = h->summary;  // else the kernel folds the partial rows itself
+        num_shards = 1;
+    }
     const size_t shmem = sizeof(float) * ((size_t)2 * h->d.row + MPPI_SUMMARY_HEAD);
     const unsigned* mk = h->min_key + h->min_slot;
-    if (own && h->last_reduce_blocks > 128) {
-        // many partial rows (large N): fold them with the multi-block summarize kernel (4.4 us at 512 rows;
-        // the single finalize block would need ~11 us), then finalize from the summary
-        const unsigned sgrid = (unsigned)((h->colsp + SUM_COLS - 1) / SUM_COLS + 1);
-        hipLaunchKernelGGL(summarize_kernel, dim3(sgrid), dim3(SUM_BLOCK), 0, s, h->partials, h->heads, mk,
-                           h->last_reduce_blocks, h->colsp, h->d.row, h->summary);
-        HIP_TRY(h, hipGetLastError());
-        summaries_dev = h->summary;
-        own = false;
-    }
 #define CALL_FINALIZE(MODEL, FASTV)                                                                   \
-    do {                                                                                              \
-        if (own)                                                                                      \
-            hipLaunchKernelGGL((finalize_kernel<MODEL, FASTV, true>), dim3(1), dim3(FIN_BLOCK), shmem, s,        \
-                               (const float*)nullptr, 1, h->partials, h->heads, mk, h->last_reduce_blocks, h->colsp, \
-                               h->summary, lambda, h->d.row, h->d.T, h->x0_cur, store_mean ? h->mean : (float*)nullptr, \
-                               action_out, state_out, stats_out, h->ctx);                             \
-        else                                                                                          \
-            hipLaunchKernelGGL((finalize_kernel<MODEL, FASTV, false>), dim3(1), dim3(FIN_BLOCK), shmem, s,       \
-                               summaries_dev, num_shards, (const float*)nullptr, (const float*)nullptr, mk, 0, 0, \
-                               (float*)nullptr, lambda, h->d.row, h->d.T, h->x0_cur,                  \
-                               store_mean ? h->mean : (float*)nullptr, action_out, state_out, stats_out, h->ctx); \
-    } while (0)
+    hipLaunchKernelGGL((finalize_kernel<MODEL, FASTV>), dim3(1), dim3(FIN_BLOCK), shmem, s, summaries_dev, num_shards, \
+                       h->partials, h->heads, mk, h->last_reduce_blocks, h->colsp, h->summary, h->live_hint_dev,  \
+                       lambda, h->d.row, h->d.T, h->x0_cur, store_mean ? h->mean : (float*)nullptr, action_out,  \
+                       state_out, stats_out, h->ctx)
     MPPI_DISPATCH(h, CALL_FINALIZE);
 #undef CALL_FINALIZE
     HIP_TRY(h, hipGetLastError());

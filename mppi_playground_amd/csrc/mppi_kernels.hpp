@@ -309,13 +309,23 @@ __global__ __launch_bounds__(BLOCK) void rollout_cost_wave_kernel(const float* _
 
 // ------------------------------------------------------------------------------------------
 // Steps 5-6: e_i = exp((-c_i)/lambda - max_j(-c_j)/lambda) and A = sum_i e_i * clamp(mean + eps_i)
-// (mppi.py:376-384, un-normalised).  Each lane accumulates its own trajectories over the tiles its
-// wave owns in NACC registers; the 64 lanes are then combined through a padded LDS tile, 32
-// accumulators at a time (compact code: a fully unrolled register butterfly is ~40 KB of
-// straight-line instructions executed once per wave and ran instruction-fetch bound).  Tiles whose
-// 64 weights are all exactly zero are skipped without touching their noise (exact: they add 0).
-// partials layout: [gridDim.x][colsp] with colsp = gridDim.y * CH * 4; heads: [gridDim.x][4]
-template <int CH, bool GEN>  // float4 groups per column chunk (8 or 32)
+// (mppi.py:376-384, un-normalised) as per-block partial rows.
+//
+// Phase A (per wave): the costs of TPW tiles are loaded together (one memory latency instead of TPW in a
+// chain), turned into weights and a wave-uniform bitmask of the tiles that carry any weight; the weights of
+// those tiles are parked in LDS.  Tiles whose 64 weights are all exactly zero are never touched again
+// (exact: they add 0) — with a sharp softmax (racing, lambda = 1) that is all but a handful of tiles.
+// Phase B (per block): every live tile of the block is accumulated by ALL waves, wave w taking the float4
+// groups r = w, w+NW, ...: a single heavy tile is a 4x shorter dependent chain than one wave walking the whole
+// row, and each column is owned by exactly one wave, so no cross-wave sum is needed.  Each lane accumulates
+// its trajectory in GPW*4 registers; the 64 lanes are combined through a padded LDS tile, 32 accumulators at
+// a time (a fully unrolled register butterfly is ~40 KB of straight-line code executed once per wave and
+// ran instruction-fetch bound).
+// Blocks publish one partial row only if they saw a live tile (heads[b][3] is the flag); summarize_kernel
+// folds the published rows.
+// partials layout: [gridDim.x][colsp] with colsp = gridDim.y * NW * GPW * 4; heads: [gridDim.x][4].
+constexpr int REDUCE_MAX_BLOCKS = 2048;
+template <int GPW, bool GEN>  // float4 groups per wave and column chunk (8 or 32)
 __global__ __launch_bounds__(BLOCK) void weights_reduce_kernel(const float4* __restrict__ noise,
                                                                const float* __restrict__ mean,
                                                                const float* __restrict__ costs,
@@ -323,93 +333,102 @@ __global__ __launch_bounds__(BLOCK) void weights_reduce_kernel(const float4* __r
                                                                float* __restrict__ partials,
                                                                float* __restrict__ heads, Dims d, GenCtx gen,
                                                                float lambda) {
-    constexpr int NACC = CH * 4;
+    constexpr int NACC = GPW * 4;
     constexpr int NW = BLOCK / WAVE;
+    constexpr int CHG = NW * GPW;  // float4 groups per column chunk
+    constexpr int TPW = 8;
     __shared__ float s_red[NW][32][WAVE + 1];
-    __shared__ float s_cols[NW][NACC];
+    __shared__ float s_e[NW][TPW][WAVE];
+    __shared__ unsigned s_live[NW];
     __shared__ float s_head[NW][4];
     // this chunk's mean groups and an all-zero copy for samples that do not inherit the mean.  Read
-    // from LDS inside the tile loop (with an opaque offset) so that the compiler does not hoist 128
+    // from LDS inside the tile loop (with an opaque offset) so that the compiler does not hoist the
     // loop-invariant scalar loads into SGPRs: that spilled ~450 SGPRs in every wave's prologue.
-    __shared__ __attribute__((aligned(16))) float s_mean[2][NACC];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int r0 = blockIdx.y * CH;  // first float4 group of this column chunk
-    const int nr = min(CH, d.R - r0);
-    for (int j = threadIdx.x; j < NACC; j += BLOCK) {
+    __shared__ __attribute__((aligned(16))) float s_mean[2][CHG * 4];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: lives in an SGPR
+    const int r0 = blockIdx.y * CHG;  // first float4 group of this column chunk
+    for (int j = threadIdx.x; j < CHG * 4; j += BLOCK) {
         const int f = 4 * r0 + j;
         s_mean[0][j] = f < d.row ? mean[f] : 0.0f;
         s_mean[1][j] = 0.0f;
     }
-    __syncthreads();
     const float cmin = key_to_float(*min_key);
     const float xmax = (-cmin) / lambda;
     float acc[NACC];
 #pragma unroll
     for (int j = 0; j < NACC; ++j) acc[j] = 0.0f;
     float se = 0.0f, se2 = 0.0f, sec = 0.0f;
-    const int64_t wave_id = (int64_t)blockIdx.x * NW + wid;
     const int64_t nwaves = (int64_t)gridDim.x * NW;
-    // Phase A: the costs of TPW tiles are loaded together (one memory latency instead of TPW in a
-    // chain) and reduced to a wave-uniform bitmask of the tiles that carry any weight.
-    // Phase B: only those tiles are accumulated (their 64 costs are re-read from L2).
-    constexpr int TPW = 8;
-    bool any_live = false;  // wave-uniform
-    for (int64_t base = wave_id; base < d.tiles; base += nwaves * TPW) {
+    bool block_live = false;  // block-uniform
+    for (int64_t base0 = (int64_t)blockIdx.x * NW; base0 < d.tiles; base0 += nwaves * TPW) {
+        // ---- phase A: this wave's TPW tiles
         float cc[TPW];
 #pragma unroll
         for (int q = 0; q < TPW; ++q) {
-            const int64_t i = (base + q * nwaves) * 64 + lane;
+            const int64_t i = (base0 + wid + q * nwaves) * 64 + lane;
             cc[q] = (i < d.N) ? costs[i] : INFINITY;  // tiles past the end have i >= N as well
         }
         unsigned live = 0;
 #pragma unroll
         for (int q = 0; q < TPW; ++q) {
             const float e = expf((-cc[q]) / lambda - xmax);  // exp(-inf) = 0 for the padding lanes
-            live |= (__ballot(e != 0.0f) != 0ull ? 1u : 0u) << q;
-        }
-        any_live = any_live || live != 0u;
-        for (int q = 0; q < TPW; ++q) {
-            if (!((live >> q) & 1u)) continue;  // wave-uniform skip
-            const int64_t tile = base + q * nwaves;
-            const int64_t i = tile * 64 + lane;
-            float e = 0.0f, c = 0.0f;
-            if (i < d.N) {
-                c = costs[i];
-                e = expf((-c) / lambda - xmax);
+            const bool tile_live = __ballot(e != 0.0f) != 0ull;
+            live |= (tile_live ? 1u : 0u) << q;
+            if (tile_live) {  // wave-uniform
+                s_e[wid][q][lane] = e;
+                const float c = e != 0.0f ? cc[q] : 0.0f;  // (keeps 0 * inf out of the padding lanes)
+                se += e;
+                se2 = fmaf(e, e, se2);
+                sec = fmaf(e, c, sec);
             }
-            se += e;
-            se2 = fmaf(e, e, se2);
-            sec = fmaf(e, c, sec);
-            const uint64_t gi = (uint64_t)(d.sample_offset + i);
-            const bool inherit = (d.sample_offset + i) < d.inherit_count;
-            const float4* np = noise + (tile * d.R) * 64 + lane;
-            int moff = inherit ? 0 : NACC / 4;  // float4 offset of this lane's mean table
-            asm volatile("" : "+v"(moff));       // opaque: keeps the LDS reads inside the loop
-            const float4* mp = reinterpret_cast<const float4*>(&s_mean[0][0]) + moff;
-            int nrl = nr;
-            asm volatile("" : "+s"(nrl));        // opaque: keeps the 32 group predicates out of SGPRs
+        }
+        if (lane == 0) s_live[wid] = live;
+        __syncthreads();
+        // ---- phase B: the block's live tiles, this wave's groups
+        for (int w2 = 0; w2 < NW; ++w2) {
+            const unsigned lv = __builtin_amdgcn_readfirstlane(s_live[w2]);
+            if (lv == 0u) continue;
+            block_live = true;
+            for (int q = 0; q < TPW; ++q) {
+                if (!((lv >> q) & 1u)) continue;
+                const int64_t tile = base0 + w2 + q * nwaves;
+                const int64_t i = tile * 64 + lane;
+                const float e = s_e[w2][q][lane];
+                const uint64_t gi = (uint64_t)(d.sample_offset + i);
+                const bool inherit = (d.sample_offset + i) < d.inherit_count;
+                const float4* np = noise + (tile * d.R) * 64 + lane;
+                int moff = (inherit ? 0 : CHG) + wid;  // float4 offset of this lane's first mean group
+                asm volatile("" : "+v"(moff));          // opaque: keeps the LDS reads inside the loop
+                const float4* mp = reinterpret_cast<const float4*>(&s_mean[0][0]) + moff;
+                int nrl = d.R - r0 - wid;               // groups r0 + wid + NW*m with NW*m < nrl exist
+                asm volatile("" : "+s"(nrl));           // opaque: keeps the group predicates out of SGPRs
 #pragma unroll
-            for (int r = 0; r < CH; ++r) {
-                if (r < nrl) {
-                    const float4 n4 = noise_group<GEN>(np, r0 + r, gi, gen, d);
-                    const float4 m4 = mp[r];
-                    const float nv[4] = {n4.x, n4.y, n4.z, n4.w};
-                    const float mv[4] = {m4.x, m4.y, m4.z, m4.w};
-                    // (columns past the row length accumulate unused values; summarize drops them)
+                for (int m = 0; m < GPW; ++m) {
+                    if (NW * m < nrl) {
+                        const float4 n4 = noise_group<GEN>(np, r0 + wid + NW * m, gi, gen, d);
+                        const float4 m4 = mp[NW * m];
+                        const float nv[4] = {n4.x, n4.y, n4.z, n4.w};
+                        const float mv[4] = {m4.x, m4.y, m4.z, m4.w};
+                        // (columns past the row length accumulate unused values; the fold drops them)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int k = ctrl_index(j, d.dc);
-                        const float u = clampf(mv[j] + nv[j], d.u_min[k], d.u_max[k]);
-                        acc[4 * r + j] = fmaf(e, u, acc[4 * r + j]);
+                        for (int j = 0; j < 4; ++j) {
+                            const int k = ctrl_index(j, d.dc);
+                            const float u = clampf(mv[j] + nv[j], d.u_min[k], d.u_max[k]);
+                            acc[4 * m + j] = fmaf(e, u, acc[4 * m + j]);
+                        }
                     }
                 }
             }
         }
+        __syncthreads();  // s_e / s_live are rewritten by the next round
     }
     // cross-lane reduction, 32 accumulators per pass: every lane stores its 32 values as a column of
     // s_red[wid][j][lane]; lane l then sums row j = l & 31 over lanes [32*(l>>5), +32) (row stride 65
-    // floats: conflict-free), and the two halves are added with one shuffle.
-    if (any_live) {
+    // floats: conflict-free), and the two halves are added with one shuffle.  Accumulator 4*m + j of wave
+    // w is column 4*(r0 + w + NW*m) + j of the row.
+    const int colsp = gridDim.y * CHG * 4;
+    if (block_live) {
 #pragma unroll
         for (int p = 0; p < NACC / 32; ++p) {
 #pragma unroll
@@ -421,66 +440,99 @@ __global__ __launch_bounds__(BLOCK) void weights_reduce_kernel(const float4* __r
             for (int k = 0; k < 32; k += 4) { v0 += rowp[k]; v1 += rowp[k + 1]; v2 += rowp[k + 2]; v3 += rowp[k + 3]; }
             float v = (v0 + v1) + (v2 + v3);
             v += __shfl_xor(v, 32);
-            if (lane < 32) s_cols[wid][p * 32 + lane] = v;
+            if (lane < 32) {
+                const int a = p * 32 + lane;
+                const int col = 4 * (r0 + wid + NW * (a >> 2)) + (a & 3);
+                partials[(int64_t)blockIdx.x * colsp + col] = v;
+            }
             __builtin_amdgcn_wave_barrier();
         }
-    } else {  // every tile of this wave had weight exactly zero: its column sums are zero
-        for (int j = lane; j < NACC; j += WAVE) s_cols[wid][j] = 0.0f;
     }
     se = wave_sum(se);
     se2 = wave_sum(se2);
     sec = wave_sum(sec);
-    if (lane == 0) { s_head[wid][0] = se; s_head[wid][1] = se2; s_head[wid][2] = sec; s_head[wid][3] = 0.f; }
+    if (lane == 0) { s_head[wid][0] = se; s_head[wid][1] = se2; s_head[wid][2] = sec; }
     __syncthreads();
-    const int colsp = gridDim.y * NACC;
-    for (int cidx = threadIdx.x; cidx < NACC; cidx += BLOCK) {
-        float v = 0.0f;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) v += s_cols[w][cidx];
-        partials[(int64_t)blockIdx.x * colsp + blockIdx.y * NACC + cidx] = v;
-    }
     if (blockIdx.y == 0 && threadIdx.x < 4) {
-        float v = 0.0f;
+        float v = block_live ? 1.0f : 0.0f;
+        if (threadIdx.x < 3) {
+            v = 0.0f;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) v += s_head[w][threadIdx.x];
+            for (int w = 0; w < NW; ++w) v += s_head[w][threadIdx.x];
+        }
         heads[(int64_t)blockIdx.x * 4 + threadIdx.x] = v;
     }
 }
 
-// Sum the per-block partials into one shard summary {min c, sum e, sum e^2, sum e*c, A[row]}.
-// One block per 16 columns: thread (c = tid & 15, g = tid >> 4) sums rows g, g+16, ... of column
-// 16*blockIdx.x + c (64 B coalesced row segments), then the 16 row groups combine through LDS.  The
-// last block also folds the three scalar heads.  Deterministic (fixed order).
+// Ascending list of the blocks that published a partial row (heads[b][3] != 0), built by a whole block of
+// NT threads: per-wave ballots, wave counts through LDS, exclusive prefix.  Returns the list length.
+template <int NT>
+__device__ __forceinline__ int compact_live_rows(const float* __restrict__ heads, int nblocks,
+                                                 unsigned short* __restrict__ s_list, int* __restrict__ s_wcnt) {
+    constexpr int NWV = NT / WAVE;
+    constexpr int MAXCH = REDUCE_MAX_BLOCKS / NT;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int nch = (nblocks + NT - 1) / NT;
+    unsigned long long mine = 0ull;  // bit ch: this thread's block of chunk ch is live
+    for (int ch = 0; ch < nch; ++ch) {
+        const int bb = ch * NT + threadIdx.x;
+        const bool f = bb < nblocks && heads[(int64_t)bb * 4 + 3] != 0.0f;
+        const unsigned long long mask = __ballot(f);
+        if (f) mine |= 1ull << ch;
+        if (lane == 0) s_wcnt[ch * NWV + wv] = __popcll(mask);
+    }
+    __syncthreads();
+    int nlive = 0;
+    for (int ch = 0; ch < nch; ++ch) {
+        int off = 0;
+        for (int w = 0; w < nch * NWV; ++w) {
+            const int cnt = s_wcnt[w];
+            if (w < ch * NWV + wv) off += cnt;
+            if (ch == 0) nlive += cnt;
+        }
+        const bool f = (mine >> ch) & 1ull;
+        const unsigned long long mask = __ballot(f);
+        if (f) s_list[off + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)(ch * NT + threadIdx.x);
+    }
+    __syncthreads();
+    static_assert(MAXCH <= 64, "chunk bitmask");
+    return nlive;
+}
+
+// Sum the per-block partial rows into the shard summary {min c, sum e, sum e^2, sum e*c, A[row]}.  Only blocks
+// that saw a live tile published a row (heads[b][3]); every block of this kernel first compacts the ascending
+// list of those rows, then thread (c = tid & 15, g = tid >> 4) of block x sums list entries g, g+64, ... of
+// column 16x + c (64 B coalesced row segments, 8 loads in flight) and the 64 row groups combine through LDS.
+// The last block folds the three scalar heads.  Deterministic (fixed order).  With a sharp softmax the list
+// holds a handful of rows and the kernel is launch-latency only.
 constexpr int SUM_COLS = 16;
 constexpr int SUM_BLOCK = 1024;
 __global__ __launch_bounds__(SUM_BLOCK) void summarize_kernel(const float* __restrict__ partials,
                                                           const float* __restrict__ heads,
                                                           const unsigned* __restrict__ min_key, int nblocks,
-                                                          int colsp, int row, float* __restrict__ summary) {
-    __shared__ float s_part[SUM_BLOCK / SUM_COLS][SUM_COLS + 1];
-    const int c = threadIdx.x & (SUM_COLS - 1), g = threadIdx.x / SUM_COLS;
+                                                          int colsp, int row, float* __restrict__ summary,
+                                                          float* __restrict__ summary_copy,
+                                                          int* __restrict__ nlive_out) {
     constexpr int NG = SUM_BLOCK / SUM_COLS;
+    __shared__ float s_part[NG][SUM_COLS + 1];
+    __shared__ unsigned short s_list[REDUCE_MAX_BLOCKS];
+    __shared__ int s_wcnt[REDUCE_MAX_BLOCKS / WAVE];
+    const int nlive = compact_live_rows<SUM_BLOCK>(heads, nblocks, s_list, s_wcnt);
+    const int c = threadIdx.x & (SUM_COLS - 1), g = threadIdx.x / SUM_COLS;
     const bool head_block = blockIdx.x == gridDim.x - 1;
     float a[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) a[q] = 0.f;
-    if (!head_block) {
-        const int col = blockIdx.x * SUM_COLS + c;
-        if (col < colsp) {
-            for (int b = g; b < nblocks; b += 8 * NG) {  // 8 independent loads in flight per thread
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int bb = b + q * NG;
-                    if (bb < nblocks) a[q] += partials[(int64_t)bb * colsp + col];
-                }
-            }
-        }
-    } else if (c < 3) {
-        for (int b = g; b < nblocks; b += 8 * NG) {
+    const int col = blockIdx.x * SUM_COLS + c;
+    const bool active = head_block ? c < 3 : col < colsp;
+    const float* base = head_block ? heads + c : partials + col;
+    const int64_t ld = head_block ? 4 : colsp;
+    if (active) {
+        for (int k = g; k < nlive; k += 8 * NG) {  // 8 independent loads in flight per thread
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                const int bb = b + q * NG;
-                if (bb < nblocks) a[q] += heads[(int64_t)bb * 4 + c];
+                const int kk = k + q * NG;
+                if (kk < nlive) a[q] += base[(int64_t)s_list[kk] * ld];
             }
         }
     }
@@ -489,12 +541,21 @@ __global__ __launch_bounds__(SUM_BLOCK) void summarize_kernel(const float* __res
     if (threadIdx.x < SUM_COLS) {
         float v = 0.f;
         for (int q = 0; q < NG; ++q) v += s_part[q][threadIdx.x];
+        int dst = -1;
         if (!head_block) {
-            const int col = blockIdx.x * SUM_COLS + threadIdx.x;
-            if (col < row) summary[MPPI_SUMMARY_HEAD + col] = v;
+            const int cc = blockIdx.x * SUM_COLS + threadIdx.x;
+            if (cc < row) dst = MPPI_SUMMARY_HEAD + cc;
         } else {
-            if (threadIdx.x < 3) summary[1 + threadIdx.x] = v;
-            if (threadIdx.x == 3) summary[0] = key_to_float(*min_key);
+            if (threadIdx.x < 3) dst = 1 + threadIdx.x;
+            if (threadIdx.x == 3) {
+                dst = 0;
+                v = key_to_float(*min_key);
+                if (nlive_out) *nlive_out = nlive;
+            }
+        }
+        if (dst >= 0) {
+            summary[dst] = v;
+            if (summary_copy) summary_copy[dst] = v;
         }
     }
 }
@@ -533,19 +594,20 @@ __device__ __forceinline__ void rollout_states_checked(const float* __restrict__
 
 // Combine shard summaries, normalise, store the warm start, roll the result out with batch 1
 // (mppi.py:381-385,448-452,508-524).
-// OWN = true (single shard, few partial rows): the kernel first folds this handle's per-block
-// partials into the shard summary itself (FIN_BLOCK threads = 128 columns x 8 row groups, fixed order)
-// — no separate summarize launch; the summary is also written to `summary_out` for later readers.
-// OWN = false: `summaries` holds `num_shards` summary vectors (the all_gathered shards, or this
-// handle's own summary produced by summarize_kernel when there are many partial rows).
+// `summaries` != nullptr: `num_shards` summary vectors (the all_gathered shards, or this handle's own summary
+// from summarize_kernel).  `summaries` == nullptr: the kernel first folds this handle's published partial rows
+// itself (thread = 128 columns x 8 row groups over the live list, fixed order) — no summarize launch; with a
+// sharp softmax that is a handful of rows.  The summary is also written to `summary_out` for later readers and
+// the number of live rows to `nlive_out` (mapped host memory: the host's hint for the next solve).
 constexpr int FIN_BLOCK = 1024;
-template <int MODEL, bool FAST, bool OWN>
+template <int MODEL, bool FAST>
 __global__ __launch_bounds__(FIN_BLOCK) void finalize_kernel(const float* __restrict__ summaries, int num_shards,
                                                              const float* __restrict__ partials,
                                                              const float* __restrict__ heads,
                                                              const unsigned* __restrict__ min_key, int nblocks,
-                                                             int colsp, float* __restrict__ summary_out, float lambda,
-                                                             int row, int T, const float* __restrict__ x0,
+                                                             int colsp, float* __restrict__ summary_out,
+                                                             int* __restrict__ nlive_out, float lambda, int row, int T,
+                                                             const float* __restrict__ x0,
                                                              float* __restrict__ mean_store,
                                                              float* __restrict__ action_out,
                                                              float* __restrict__ state_out,
@@ -554,28 +616,32 @@ __global__ __launch_bounds__(FIN_BLOCK) void finalize_kernel(const float* __rest
     extern __shared__ __attribute__((aligned(16))) float s_fin[];  // [row] action, then [4 + row] own summary
     float* s_act = s_fin;
     float* s_sum = s_fin + row;
-    __shared__ float s_part[FIN_BLOCK / 128][128 + 1];
     const int stride = MPPI_SUMMARY_HEAD + row;
-    if (OWN) {
+    if (summaries == nullptr) {
         constexpr int NG = FIN_BLOCK / 128;
+        __shared__ float s_part[NG][128 + 1];
+        __shared__ unsigned short s_list[REDUCE_MAX_BLOCKS];
+        __shared__ int s_wcnt[REDUCE_MAX_BLOCKS / WAVE];
+        const int nlive = compact_live_rows<FIN_BLOCK>(heads, nblocks, s_list, s_wcnt);
         const int c = threadIdx.x & 127, g = threadIdx.x >> 7;
         for (int c0 = 0; c0 < row + 3; c0 += 128) {  // column chunks; the last 3 "columns" are the heads
             const int col = c0 + c;
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            float a[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a[q] = 0.f;
             if (col < row + 3) {
                 const bool is_head = col >= row;
                 const float* base = is_head ? heads + (col - row) : partials + col;
                 const int64_t ld = is_head ? 4 : colsp;
-                int bidx = g;
-                for (; bidx + 3 * NG < nblocks; bidx += 4 * NG) {
-                    a0 += base[(int64_t)bidx * ld];
-                    a1 += base[(int64_t)(bidx + NG) * ld];
-                    a2 += base[(int64_t)(bidx + 2 * NG) * ld];
-                    a3 += base[(int64_t)(bidx + 3 * NG) * ld];
+                for (int k = g; k < nlive; k += 8 * NG) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int kk = k + q * NG;
+                        if (kk < nlive) a[q] += base[(int64_t)s_list[kk] * ld];
+                    }
                 }
-                for (; bidx < nblocks; bidx += NG) a0 += base[(int64_t)bidx * ld];
             }
-            s_part[g][c] = (a0 + a1) + (a2 + a3);
+            s_part[g][c] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
             __syncthreads();
             if (threadIdx.x < 128 && col < row + 3) {
                 float v = 0.f;
@@ -590,6 +656,7 @@ __global__ __launch_bounds__(FIN_BLOCK) void finalize_kernel(const float* __rest
         if (threadIdx.x == 0) {
             s_sum[0] = key_to_float(*min_key);
             if (summary_out) summary_out[0] = s_sum[0];
+            if (nlive_out) *nlive_out = nlive;
         }
         __syncthreads();
         summaries = s_sum;  // (generic address space: LDS)
