@@ -138,8 +138,9 @@ def main():
                         "achieved_Ginst_per_s": k["valu_insts"] / t_roll / 1e9, "peak_Ginst_per_s": peak / 1e9,
                         "frac": k["valu_insts"] / t_roll / peak,
                         "measured_peak_Ginst_per_s": pc.get("valu_issue_ubench", {}).get("mul_add_Ginst_per_s"),
+                        "cycles_per_inst_per_simd_at_2p4GHz": 1024 * 2.4e9 * t_roll / k["valu_insts"],
                         "note": "wave64 VALU instructions (SQ_INSTS_VALU, rocprofv3) / live kernel time; the kernel "
-                                "is VALU-issue bound (2.97 cycles/instruction/SIMD measured), not HBM bound"}
+                                "is VALU-issue bound, not HBM bound (profiles/r01_experiments.md)"}
         except Exception:
             pass
         out = {
