@@ -206,6 +206,12 @@ int mppi_rollout_actions(mppi_handle_t h, const float* actions_dev, int k, float
 /* `_state_seq_batch[top_indices]` (mppi.py:481): re-roll the k local samples idx_dev[k] from the
  * resident noise instead of materialising S[N][T+1][ds] -> states_out_dev[k][T+1][ds]. */
 int mppi_rollout_samples(mppi_handle_t h, const int64_t* idx_dev, int k, float* states_out_dev, void* stream);
+/* get_top_samples (mppi.py:462-487) in one call: the k (<= 1024) samples of the last solve with the largest
+ * weight = the smallest cost (radix select on the device), sorted by descending weight, their state
+ * trajectories re-rolled around the mean that solve sampled (states_out_dev [k][T+1][ds]) and their softmax
+ * weights softmax(-c/lambda)_i (weights_out_dev [k]).  lambda = the temperature of that solve.  Unsharded
+ * handles only (a shard sees its own samples). */
+int mppi_top_samples(mppi_handle_t h, int k, float lambda, float* states_out_dev, float* weights_out_dev, void* stream);
 
 /* Tuning knobs (not in the reference): "math" 0 = library sin/cos/tan/fmod/div, 1 = range-checked
  * fast paths (default); "noise_regen" (see mppi_sample); "mapping" 0 = lane per trajectory (default), 1 =

@@ -45,6 +45,11 @@ struct MppiSolver {
     bool tiles_valid = false;      // the noise tiles hold the current solve's noise
     bool injected = false;         // ... because it was injected (cannot be regenerated)
     float* mean = nullptr;
+    float* mean_used = nullptr;      // the mean the last rollout sampled around (snapshot taken by the rollout kernel)
+    float* solve_stats = nullptr;    // {min c, sum e, sum e^2, sum e*c} over all shards of the last finalize
+    unsigned* topk_hist = nullptr;   // [3][TOPK_BINS] + 2 counters, kept zeroed between calls
+    TopkSel* topk_sel = nullptr;     // [3]
+    unsigned long long* topk_cand = nullptr;  // [TOPK_MAX]
     float* ref = nullptr;
     int ref_cap = 0;
     float* partials = nullptr;
@@ -273,6 +278,14 @@ int mppi_create(const MppiConfig* cfg, mppi_handle_t* out) {
     d.dc = md.dc;
     HIP_TRY(h, hipMalloc(&h->mean, sizeof(float) * (size_t)d.row));
     HIP_TRY(h, hipMemset(h->mean, 0, sizeof(float) * (size_t)d.row));  // mppi.py:157
+    HIP_TRY(h, hipMalloc(&h->mean_used, sizeof(float) * (size_t)d.row));
+    HIP_TRY(h, hipMemset(h->mean_used, 0, sizeof(float) * (size_t)d.row));
+    HIP_TRY(h, hipMalloc(&h->solve_stats, sizeof(float) * 4));
+    HIP_TRY(h, hipMemset(h->solve_stats, 0, sizeof(float) * 4));
+    HIP_TRY(h, hipMalloc(&h->topk_hist, sizeof(unsigned) * (3 * TOPK_BINS + 2)));
+    HIP_TRY(h, hipMemset(h->topk_hist, 0, sizeof(unsigned) * (3 * TOPK_BINS + 2)));
+    HIP_TRY(h, hipMalloc(&h->topk_sel, sizeof(TopkSel) * 3));
+    HIP_TRY(h, hipMalloc(&h->topk_cand, sizeof(unsigned long long) * TOPK_MAX));
     const int max_blocks = 2048;
     HIP_TRY(h, hipMalloc(&h->partials, sizeof(float) * (size_t)max_blocks * h->colsp));
     HIP_TRY(h, hipMalloc(&h->heads, sizeof(float) * (size_t)max_blocks * 4));
@@ -290,7 +303,8 @@ int mppi_create(const MppiConfig* cfg, mppi_handle_t* out) {
 int mppi_destroy(mppi_handle_t h) {
     if (!h) return MPPI_E_INVALID;
     (void)hipFree(h->noise); (void)hipFree(h->costs); (void)hipFree(h->min_key); (void)hipFree(h->x0);
-    (void)hipFree(h->mean); (void)hipFree(h->ref); (void)hipFree(h->partials); (void)hipFree(h->heads);
+    (void)hipFree(h->mean); (void)hipFree(h->mean_used); (void)hipFree(h->solve_stats); (void)hipFree(h->topk_hist);
+    (void)hipFree(h->topk_sel); (void)hipFree(h->topk_cand); (void)hipFree(h->ref); (void)hipFree(h->partials); (void)hipFree(h->heads);
     (void)hipFree(h->summary); (void)hipFree(h->map_cells[0]); (void)hipFree(h->map_cells[1]);
     (void)hipFree(h->map_fused); (void)hipFree(h->stats_part); (void)hipFree(h->noise_std);
     if (h->stats_host) (void)hipHostFree(h->stats_host);
@@ -540,6 +554,7 @@ int mppi_rollout_cost(mppi_handle_t h, void* stream) {
         const dim3 cgrid((unsigned)h->d.tiles, (unsigned)((h->d.row + CONV_COLS - 1) / CONV_COLS));
         hipLaunchKernelGGL(export_kernel, cgrid, dim3(BLOCK), 0, s, h->noise, h->mean, h->noise_std, (float*)nullptr, h->d);
         HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipMemcpyAsync(h->mean_used, h->mean, sizeof(float) * (size_t)h->d.row, hipMemcpyDeviceToDevice, s));
         StageTimer tmw(h, 1, s);
         h->min_slot ^= 1;
         unsigned* mkw = h->min_key + h->min_slot;
@@ -569,10 +584,10 @@ int mppi_rollout_cost(mppi_handle_t h, void* stream) {
         constexpr bool UCV = FASTV;  /* the FAST kernels exist in the u_in_bounds form only (see use_fast) */ \
         if (gen)                                                                                      \
             hipLaunchKernelGGL((rollout_cost_kernel<MODEL, FASTV, true, UCV>), dim3(grid), dim3(BLOCK), shmem, s, \
-                               h->noise, h->mean, h->x0_cur, h->costs, mk, mk_next, h->d, h->gen, h->ctx); \
+                               h->noise, h->mean, h->x0_cur, h->costs, mk, mk_next, h->mean_used, h->d, h->gen, h->ctx); \
         else                                                                                          \
             hipLaunchKernelGGL((rollout_cost_kernel<MODEL, FASTV, false, UCV>), dim3(grid), dim3(BLOCK), shmem, s, \
-                               h->noise, h->mean, h->x0_cur, h->costs, mk, mk_next, h->d, h->gen, h->ctx); \
+                               h->noise, h->mean, h->x0_cur, h->costs, mk, mk_next, h->mean_used, h->d, h->gen, h->ctx); \
     } while (0)
     MPPI_DISPATCH(h, CALL_ROLLOUT);
 #undef CALL_ROLLOUT
@@ -658,7 +673,7 @@ int mppi_finalize(mppi_handle_t h, const float* summaries_dev, int num_shards, f
     hipLaunchKernelGGL((finalize_kernel<MODEL, FASTV>), dim3(1), dim3(FIN_BLOCK), shmem, s, summaries_dev, num_shards, \
                        h->partials, h->heads, mk, h->last_reduce_blocks, h->colsp, h->summary, h->live_hint_dev,  \
                        lambda, h->d.row, h->d.T, h->x0_cur, store_mean ? h->mean : (float*)nullptr, action_out,  \
-                       state_out, stats_out, h->ctx)
+                       state_out, stats_out, h->solve_stats, h->ctx)
     MPPI_DISPATCH(h, CALL_FINALIZE);
 #undef CALL_FINALIZE
     HIP_TRY(h, hipGetLastError());
@@ -735,10 +750,37 @@ int mppi_rollout_samples(mppi_handle_t h, const int64_t* idx_dev, int k, float* 
     if (int rc = need_tiles(h, s)) return rc;
     const unsigned grid = (unsigned)((k + WAVE - 1) / WAVE);
 #define CALL_RS(MODEL, FASTV)                                                                         \
-    hipLaunchKernelGGL((rollout_samples_kernel<MODEL, FASTV>), dim3(grid), dim3(WAVE), 0, s, h->noise, h->mean, \
+    hipLaunchKernelGGL((rollout_samples_kernel<MODEL, FASTV>), dim3(grid), dim3(WAVE), 0, s, h->noise, h->mean_used, \
                        idx_dev, k, h->x0_cur, states_out, h->d, h->ctx)
     MPPI_DISPATCH(h, CALL_RS);
 #undef CALL_RS
+    HIP_TRY(h, hipGetLastError());
+    return MPPI_OK;
+}
+
+int mppi_top_samples(mppi_handle_t h, int k, float lambda, float* states_out, float* weights_out, void* stream) {
+    if (!h || !states_out || !weights_out || !(lambda > 0.0f)) return fail(h, MPPI_E_INVALID, "bad top_samples arguments");
+    if (k < 1 || k > TOPK_MAX || k > h->d.N) return fail(h, MPPI_E_INVALID, "top_samples: need 1 <= k <= min(1024, num_samples)");
+    if (h->d.N >= ((int64_t)1 << 32)) return fail(h, MPPI_E_INVALID, "top_samples: num_samples must be < 2^32");
+    if (int rc = check_ready(h)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const bool gen = h->noise_regen && !h->injected;
+    if (!gen && !h->tiles_valid) return fail(h, MPPI_E_STATE, "no noise: solve first");
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((h->d.N + BLOCK * 8 - 1) / (BLOCK * 8), 1024));
+    unsigned* hist = h->topk_hist;
+    unsigned* counters = h->topk_hist + 3 * TOPK_BINS;
+    hipLaunchKernelGGL(topk_hist_kernel<0>, dim3(grid), dim3(BLOCK), 0, s, h->costs, h->d.N, (unsigned)k, hist, h->topk_sel);
+    hipLaunchKernelGGL(topk_hist_kernel<1>, dim3(grid), dim3(BLOCK), 0, s, h->costs, h->d.N, (unsigned)k, hist, h->topk_sel);
+    hipLaunchKernelGGL(topk_hist_kernel<2>, dim3(grid), dim3(BLOCK), 0, s, h->costs, h->d.N, (unsigned)k, hist, h->topk_sel);
+    hipLaunchKernelGGL(topk_collect_kernel, dim3(grid), dim3(BLOCK), 0, s, h->costs, h->d.N, (unsigned)k, hist, h->topk_sel,
+                       h->topk_cand, counters);
+    HIP_TRY(h, hipGetLastError());
+#define CALL_TOPK(MODEL, FASTV)                                                                       \
+    hipLaunchKernelGGL((topk_rollout_kernel<MODEL, FASTV>), dim3(1), dim3(TOPK_MAX), 0, s, h->topk_cand, k, h->costs, \
+                       h->noise, gen, h->mean_used, h->x0_cur, h->solve_stats, lambda, states_out, weights_out, hist, \
+                       counters, h->d, h->gen, h->ctx)
+    MPPI_DISPATCH(h, CALL_TOPK);
+#undef CALL_TOPK
     HIP_TRY(h, hipGetLastError());
     return MPPI_OK;
 }

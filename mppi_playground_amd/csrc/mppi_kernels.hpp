@@ -186,7 +186,8 @@ __global__ __launch_bounds__(BLOCK) MPPI_ROLLOUT_ATTR void rollout_cost_kernel(c
                                                              const float* __restrict__ x0,
                                                              float* __restrict__ costs,
                                                              unsigned* __restrict__ min_key,
-                                                             unsigned* __restrict__ next_min_key, Dims d, GenCtx gen,
+                                                             unsigned* __restrict__ next_min_key,
+                                                             float* __restrict__ mean_used, Dims d, GenCtx gen,
                                                              ModelCtx ctx) {
     using M = ModelT<MODEL, FAST>;
     __shared__ float s_min[BLOCK / WAVE];
@@ -195,8 +196,11 @@ __global__ __launch_bounds__(BLOCK) MPPI_ROLLOUT_ATTR void rollout_cost_kernel(c
     float4* s_mean4 = reinterpret_cast<float4*>(s_dyn);
     float* s_ktab = s_dyn + 8 * d.R;
     for (int f = threadIdx.x; f < 4 * d.R; f += BLOCK) {
-        s_dyn[f] = f < d.row ? mean[f] : 0.0f;
+        const float m = f < d.row ? mean[f] : 0.0f;
+        s_dyn[f] = m;
         s_dyn[4 * d.R + f] = 0.0f;
+        // the mean this solve samples around outlives the warm-start update (get_top_samples re-rolls with it)
+        if (blockIdx.x == 0 && f < d.row) mean_used[f] = m;
     }
     for (int f = threadIdx.x; f < d.T * M::KROW; f += BLOCK) s_ktab[f] = ctx.ref[f];
     __syncthreads();
@@ -611,7 +615,8 @@ __global__ __launch_bounds__(FIN_BLOCK) void finalize_kernel(const float* __rest
                                                              float* __restrict__ mean_store,
                                                              float* __restrict__ action_out,
                                                              float* __restrict__ state_out,
-                                                             float* __restrict__ stats_out, ModelCtx ctx) {
+                                                             float* __restrict__ stats_out,
+                                                             float* __restrict__ stats_keep, ModelCtx ctx) {
     constexpr int DC = ModelT<MODEL, FAST>::DC;
     extern __shared__ __attribute__((aligned(16))) float s_fin[];  // [row] action, then [4 + row] own summary
     float* s_act = s_fin;
@@ -688,8 +693,9 @@ __global__ __launch_bounds__(FIN_BLOCK) void finalize_kernel(const float* __rest
         if (action_out) action_out[cidx] = a;
         if (mean_store) mean_store[cidx] = a;
     }
-    if (threadIdx.x == 0 && stats_out) {
-        stats_out[0] = cmin; stats_out[1] = se; stats_out[2] = se2; stats_out[3] = sec;
+    if (threadIdx.x == 0) {
+        if (stats_out) { stats_out[0] = cmin; stats_out[1] = se; stats_out[2] = se2; stats_out[3] = sec; }
+        stats_keep[0] = cmin; stats_keep[1] = se; stats_keep[2] = se2; stats_keep[3] = sec;
     }
     __syncthreads();
     if (threadIdx.x == 0 && state_out) {
@@ -866,6 +872,175 @@ __global__ __launch_bounds__(WAVE) void rollout_samples_kernel(const float4* __r
             const int f = t * DC + kk;
             const float e = np[(int64_t)(f >> 2) * 256 + (f & 3)];
             const float m = inherit ? mean[f] : 0.0f;
+            u[kk] = clampf(m + e, d.u_min[kk], d.u_max[kk]);
+        }
+    });
+}
+
+// ------------------------------------------------------------------------------------------
+// get_top_samples (mppi.py:462-487) on the device: the k largest weights are the k smallest costs.
+// Radix select on the order-preserving cost keys (11 + 11 + 10 bits): three histogram passes over costs[N]
+// (LDS histograms merged into a global one; passes 1 and 2 count only keys under the prefix chosen so far, which
+// every block re-derives from the previous histogram), a collect pass that gathers the keys below the k-th key
+// plus as many ties as are needed, and one block that sorts the k candidates by (key, index) — the order does
+// not depend on the atomics that gathered them — and re-rolls their trajectories from the regenerated (or
+// resident) noise around the mean the solve sampled.  State trajectories S[N,T+1,ds] are never materialised.
+constexpr int TOPK_BINS = 2048;
+constexpr int TOPK_MAX = 1024;
+struct TopkSel { unsigned prefix, krem; };  // high bits selected so far; how many keys to take under that prefix
+__device__ __forceinline__ constexpr int topk_shift(int pass) { return pass == 0 ? 21 : pass == 1 ? 10 : 0; }
+__device__ __forceinline__ constexpr int topk_bits(int pass) { return pass == 2 ? 10 : 11; }
+
+// Block-wide (BLOCK threads): the bin whose cumulative count first reaches krem, and the count below that bin.
+__device__ __forceinline__ void topk_pick(const unsigned* __restrict__ hist, int nbins, unsigned krem,
+                                          unsigned* __restrict__ s_scan /*[BLOCK + 2]*/, unsigned& bin,
+                                          unsigned& below) {
+    const int per = (nbins + BLOCK - 1) / BLOCK;
+    const int b0 = threadIdx.x * per;
+    unsigned loc = 0;
+    for (int b = b0; b < min(b0 + per, nbins); ++b) loc += hist[b];
+    s_scan[threadIdx.x] = loc;
+    __syncthreads();
+    if (threadIdx.x < WAVE) {  // exclusive scan of the BLOCK partial sums by one wave (BLOCK / WAVE each)
+        constexpr int PER = BLOCK / WAVE;
+        unsigned v[PER], sum = 0;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) { v[q] = s_scan[threadIdx.x * PER + q]; sum += v[q]; }
+        unsigned incl = sum;
+#pragma unroll
+        for (int m = 1; m < WAVE; m <<= 1) {
+            const unsigned o = __shfl_up(incl, m);
+            if ((int)threadIdx.x >= m) incl += o;
+        }
+        unsigned run = incl - sum;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) { s_scan[threadIdx.x * PER + q] = run; run += v[q]; }
+    }
+    __syncthreads();
+    const unsigned excl = s_scan[threadIdx.x];
+    __syncthreads();
+    if (excl < krem && krem <= excl + loc) {  // exactly one thread (loc > 0 there)
+        unsigned run = excl;
+        for (int b = b0; b < min(b0 + per, nbins); ++b) {
+            const unsigned hcount = hist[b];
+            if (krem <= run + hcount) { s_scan[BLOCK] = (unsigned)b; s_scan[BLOCK + 1] = run; break; }
+            run += hcount;
+        }
+    }
+    __syncthreads();
+    bin = s_scan[BLOCK];
+    below = s_scan[BLOCK + 1];
+}
+
+// prefix/krem entering pass PASS (derived from the histogram of pass PASS-1); block 0 records it in sel[PASS-1]
+template <int PASS>
+__device__ __forceinline__ TopkSel topk_enter(const unsigned* __restrict__ hist, TopkSel* __restrict__ sel, unsigned k,
+                                              unsigned* __restrict__ s_scan) {
+    TopkSel cur{0u, k};
+    if (PASS > 0) {
+        if (PASS > 1) cur = sel[PASS - 2];
+        unsigned bin, below;
+        topk_pick(hist + (PASS - 1) * TOPK_BINS, 1 << topk_bits(PASS - 1), cur.krem, s_scan, bin, below);
+        cur.prefix = (cur.prefix << topk_bits(PASS - 1)) | bin;
+        cur.krem -= below;
+        if (blockIdx.x == 0 && threadIdx.x == 0) sel[PASS - 1] = cur;
+    }
+    return cur;
+}
+
+template <int PASS>
+__global__ __launch_bounds__(BLOCK) void topk_hist_kernel(const float* __restrict__ costs, int64_t N, unsigned k,
+                                                          unsigned* __restrict__ hist, TopkSel* __restrict__ sel) {
+    __shared__ unsigned s_hist[TOPK_BINS];
+    __shared__ unsigned s_scan[BLOCK + 2];
+    constexpr int NB = 1 << topk_bits(PASS);
+    for (int b = threadIdx.x; b < NB; b += BLOCK) s_hist[b] = 0u;
+    const TopkSel cur = topk_enter<PASS>(hist, sel, k, s_scan);
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < N; i += (int64_t)gridDim.x * BLOCK) {
+        const unsigned key = float_to_key(costs[i]);
+        if (PASS == 0 || (key >> (topk_shift(PASS) + topk_bits(PASS))) == cur.prefix)
+            atomicAdd(&s_hist[(key >> topk_shift(PASS)) & (NB - 1)], 1u);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < NB; b += BLOCK)
+        if (s_hist[b]) atomicAdd(&hist[PASS * TOPK_BINS + b], s_hist[b]);
+}
+
+// cand[j] = (key << 32) | index for the k selected samples (unordered); counters = {#below, #ties taken}
+__global__ __launch_bounds__(BLOCK) void topk_collect_kernel(const float* __restrict__ costs, int64_t N, unsigned k,
+                                                             const unsigned* __restrict__ hist,
+                                                             TopkSel* __restrict__ sel,
+                                                             unsigned long long* __restrict__ cand,
+                                                             unsigned* __restrict__ counters) {
+    __shared__ unsigned s_scan[BLOCK + 2];
+    const TopkSel cur = topk_enter<3>(hist, sel, k, s_scan);  // prefix = the k-th smallest key, krem = ties to take
+    const unsigned nbelow = k - cur.krem;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < N; i += (int64_t)gridDim.x * BLOCK) {
+        const unsigned key = float_to_key(costs[i]);
+        if (key < cur.prefix) {
+            const unsigned slot = atomicAdd(&counters[0], 1u);
+            cand[slot] = ((unsigned long long)key << 32) | (unsigned long long)i;
+        } else if (key == cur.prefix) {
+            const unsigned t = atomicAdd(&counters[1], 1u);
+            if (t < cur.krem) cand[nbelow + t] = ((unsigned long long)key << 32) | (unsigned long long)i;
+        }
+    }
+}
+
+template <int MODEL, bool FAST>
+__global__ __launch_bounds__(TOPK_MAX) void topk_rollout_kernel(const unsigned long long* __restrict__ cand, int k,
+                                                                const float* __restrict__ costs,
+                                                                const float4* __restrict__ noise, bool gen_noise,
+                                                                const float* __restrict__ mean,
+                                                                const float* __restrict__ x0,
+                                                                const float* __restrict__ stats, float lambda,
+                                                                float* __restrict__ states,
+                                                                float* __restrict__ weights,
+                                                                unsigned* __restrict__ hist,
+                                                                unsigned* __restrict__ counters, Dims d, GenCtx gen,
+                                                                ModelCtx ctx) {
+    constexpr int DS = ModelT<MODEL, FAST>::DS, DC = ModelT<MODEL, FAST>::DC;
+    __shared__ unsigned long long s_key[TOPK_MAX];
+    s_key[threadIdx.x] = (int)threadIdx.x < k ? cand[threadIdx.x] : ~0ull;
+    // leave the select state clean for the next call
+    for (int b = threadIdx.x; b < 3 * TOPK_BINS; b += TOPK_MAX) hist[b] = 0u;
+    if (threadIdx.x < 2) counters[threadIdx.x] = 0u;
+    __syncthreads();
+    for (int size = 2; size <= TOPK_MAX; size <<= 1) {  // bitonic sort, ascending (key, index)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            const int j = threadIdx.x ^ stride;
+            if (j > (int)threadIdx.x) {
+                const unsigned long long a = s_key[threadIdx.x], b = s_key[j];
+                const bool up = (threadIdx.x & size) == 0;
+                if ((a > b) == up) { s_key[threadIdx.x] = b; s_key[j] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    const int q = threadIdx.x;
+    if (q >= k) return;
+    const int64_t i = (int64_t)(s_key[q] & 0xFFFFFFFFull);
+    const float c = costs[i];
+    weights[q] = expf((-c) / lambda - (-stats[0]) / lambda) / stats[1];  // softmax(-c/lambda)_i (mppi.py:376)
+    const uint64_t gi = (uint64_t)(d.sample_offset + i);
+    const bool inherit = (d.sample_offset + i) < d.inherit_count;
+    const float4* np = noise + ((i >> 6) * d.R) * 64 + (i & 63);
+    float* out = states + (int64_t)q * (d.T + 1) * DS;
+    int have = -1;
+    float grp[4] = {0.f, 0.f, 0.f, 0.f};
+    rollout_states_checked<MODEL, FAST>(x0, d.T, ctx, out, [&](int t, float* u) {
+#pragma unroll
+        for (int kk = 0; kk < DC; ++kk) {
+            const int f = t * DC + kk;
+            if ((f >> 2) != have) {
+                have = f >> 2;
+                const float4 n4 = gen_noise ? gen_noise4(gi, have, gen, d) : np[(int64_t)have * 64];
+                grp[0] = n4.x; grp[1] = n4.y; grp[2] = n4.z; grp[3] = n4.w;
+            }
+            const float m = inherit ? mean[f] : 0.0f;
+            const int c4 = f & 3;
+            const float e = c4 == 0 ? grp[0] : c4 == 1 ? grp[1] : c4 == 2 ? grp[2] : grp[3];
             u[kk] = clampf(m + e, d.u_min[kk], d.u_max[kk]);
         }
     });

@@ -545,24 +545,24 @@ class MPPI(nn.Module):
     # ------------------------------------------------------------------ queries
     def get_top_samples(self, num_samples: int) -> Tuple[torch.Tensor, torch.Tensor]:
         """Top-weighted trajectories of the last solve (src/pi_mpc/mppi.py:462-487).  The N state
-        trajectories are not kept in HBM; the k winners are re-rolled from the resident noise."""
+        trajectories are not kept in HBM: the k winners are selected on the device (largest weight =
+        smallest cost) and re-rolled from the noise of that solve around the mean it sampled."""
         assert num_samples <= self._num_samples
         if self._world > 1:
             raise NotImplementedError("get_top_samples on a sharded solver")
-        w = self._weights
-        top = torch.topk(w, num_samples)
         if self._model is None:  # the generic path keeps _state_seq_batch like the reference
+            top = torch.topk(self._weights, num_samples)
             order = torch.argsort(top.values, descending=True)
             return self._state_seq_batch_buf[top.indices][order], top.values[order]
-        idx = top.indices.to(torch.int64).contiguous()
         out = torch.empty(num_samples, self._horizon + 1, self._dim_state, device=self._device, dtype=self._dtype)
         st = self._stream()
-        # the rollouts must use the mean the solve sampled around, not the freshly stored warm start
-        cur = torch.empty(self._horizon, self._dim_control, device=self._device, dtype=self._dtype)
-        self._h.call("mppi_get_mean", _ptr(cur), 1, st)
-        self._h.call("mppi_set_mean", _ptr(self._mean_of_last_solve), 1, st)
+        if num_samples <= 1024:  # one library call: radix select + sort + re-roll + weights
+            w = torch.empty(num_samples, device=self._device, dtype=self._dtype)
+            self._h.call("mppi_top_samples", num_samples, float(self._last_lambda), _ptr(out), _ptr(w), st)
+            return out, w
+        top = torch.topk(self._weights, num_samples)
+        idx = top.indices.to(torch.int64).contiguous()
         self._h.call("mppi_rollout_samples", _ptr(idx), num_samples, _ptr(out), st)
-        self._h.call("mppi_set_mean", _ptr(cur), 1, st)
         order = torch.argsort(top.values, descending=True)
         return out[order], top.values[order]
 

@@ -205,6 +205,39 @@ def test_top_samples_match_reference():
     assert rel_err(ts.cpu().numpy(), g["top8_states_0"]) < TOL
 
 
+@pytest.mark.parametrize("N,k,lam", [(1000, 1, 1.0), (4096, 300, 50.0), (777, 777, 500.0), (1 << 20, 300, 1.0),
+                                     (1 << 20, 1024, 2000.0)])
+def test_device_top_k_selects_the_smallest_costs(N, k, lam):
+    """mppi_top_samples (radix select + sort + re-roll on the device) against a host sort of the same costs,
+    the softmax weights, and the index-driven re-roll path; twice, to check the select state is left clean."""
+    solver, ctrl = make_solver("racing", 50, N, lambda_=lam)
+    env = _envs["racing"]
+    x0 = env._robot_state.clone()
+    ref, _ = ctrl.calc_ref_trajectory(x0, env.racing_center_path, 0, 50, DL=0.1, lookahead_distance=3,
+                                      reference_path_interval=0.85)
+    ctrl.set_reference(ref)
+    for _ in range(2):
+        solver.forward(x0)
+        ts, tw = solver.get_top_samples(k)
+        costs = solver._costs.cpu().numpy()
+        order = np.lexsort((np.arange(N), costs))[:k]  # ascending cost, then index
+        x = (-costs.astype(np.float64)) / lam
+        w_all = np.exp(x - x.max())
+        w_all /= w_all.sum()
+        got_w = tw.cpu().numpy()
+        assert got_w.shape == (k,) and np.all(np.diff(got_w) <= 0)
+        assert np.abs(got_w - w_all[order]).max() <= 2e-5 * w_all.max()
+        # the same samples re-rolled through the index path (noise tiles materialised on demand): identical
+        out2 = torch.empty_like(ts)
+        idx = torch.from_numpy(order.astype(np.int64)).to(ts.device)
+        solver._h.call("mppi_rollout_samples", idx.data_ptr(), k, out2.data_ptr(), solver._stream())
+        tie_free = len(np.unique(costs[order])) == k and (k == N or costs[order][-1] < np.partition(costs, k)[k])
+        if tie_free:
+            assert torch.equal(ts, out2)
+        assert ts.shape == (k, 51, 4) and torch.isfinite(ts).all()
+        assert torch.equal(ts[:, 0, :], x0.to(ts.device).expand(k, 4))
+
+
 @pytest.mark.parametrize("model,T,N,expl", [("pendulum", 1, 5, 0.0), ("pendulum", 2, 64, 0.5), ("pendulum", 7, 65, 1.0),
                                             ("racing", 1, 3, 0.0), ("racing", 3, 130, 0.3), ("nav2d", 2, 1, 0.0),
                                             ("cartpole", 5, 63, 0.0), ("mountaincar", 9, 200, 0.9)])
