@@ -698,12 +698,22 @@ __global__ __launch_bounds__(FIN_BLOCK) void finalize_kernel(const float* __rest
         stats_keep[0] = cmin; stats_keep[1] = se; stats_keep[2] = se2; stats_keep[3] = sec;
     }
     __syncthreads();
-    if (threadIdx.x == 0 && state_out) {
-        rollout_states_checked<MODEL, FAST>(x0, T, ctx, state_out, [&](int t, float* u) {
+    if (!state_out) return;
+    const auto getu = [&](int t, float* u) {
 #pragma unroll
-            for (int k = 0; k < DC; ++k) u[k] = s_act[t * DC + k];
-        });
+        for (int k = 0; k < DC; ++k) u[k] = s_act[t * DC + k];
+    };
+    if constexpr (MODEL == MPPI_MODEL_RACING && FAST) {
+        if (T <= 63) {  // the serial part of the batch-1 rollout shrinks to the heading/speed recurrences
+            if (threadIdx.x >= WAVE) return;
+            bool bad = false;
+            ModelT<MODEL, FAST>::rollout_wave(ctx, x0, s_act, T, state_out, bad);
+            if (__ballot(bad) != 0ull && threadIdx.x == 0)  // left a fast-path validity range: library math
+                (void)rollout_states<MODEL, false>(x0, T, ctx, state_out, getu);
+            return;
+        }
     }
+    if (threadIdx.x == 0) rollout_states_checked<MODEL, FAST>(x0, T, ctx, state_out, getu);
 }
 
 // Softmax statistics of the cost vector for one temperature — the device half of the auto-lambda

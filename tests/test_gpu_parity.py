@@ -824,3 +824,31 @@ def test_device_map_builders_clip_like_the_reference_loops():
     with pytest.raises(_capi.MppiError):
         h.call("mppi_build_obstacle_map", 0, nx, ny, 0.05, 0.0, 0.0, bad.ctypes.data_as(C.c_void_p), 1, None, 0, None)
     h.close()
+
+
+def test_wave_parallel_batch1_rollout_is_bit_identical_to_the_serial_one():
+    """finalize_kernel<racing, fast> spreads the batch-1 rollout over a wave (Model::rollout_wave); the states must
+    equal, bit for bit, the lane-serial rollout of the same actions (mppi_rollout_actions), along a closed loop
+    that visits many headings / speeds and with actions outside the bounds."""
+    solver, ctrl = make_solver("racing", 50, 2048, lambda_=20.0)
+    env = _envs["racing"]
+    state = env.reset()
+    ctrl.current_path_index = 0
+    for tick in range(40):
+        a, s = ctrl.update(state, env.racing_center_path)
+        s2 = torch.empty_like(s)
+        solver._h.call("mppi_rollout_actions", a.data_ptr(), 1, s2.data_ptr(), solver._stream())
+        assert torch.equal(s, s2), f"tick {tick}"
+        state, _ = env.step(a[0, :])
+    # actions beyond the bounds and a heading just inside the wrap
+    solver2, ctrl2 = make_solver("racing", 50, 256, lambda_=1e6)
+    ctrl2.set_reference(np.zeros((51, 4), np.float32))
+    x0 = torch.tensor([39.0, -39.5, 3.1415, 7.9])
+    solver2.set_warm_start(np.tile(np.array([[3.0, -0.3]], np.float32), (50, 1)))
+    a, s = solver2.forward(x0)
+    s2 = torch.empty_like(s)
+    solver2._h.call("mppi_rollout_actions", a.data_ptr(), 1, s2.data_ptr(), solver2._stream())
+    assert torch.equal(s, s2)
+    P = oracle_problem("racing", 1, 50)
+    ref = P.rollout_single(x0.numpy(), a.cpu().numpy())
+    assert rel_err(s.cpu().numpy()[0], ref) < TOL
