@@ -60,8 +60,14 @@ def main():
     if args.gpus > 1 or world > 1:
         assert world == args.gpus, f"launch with torch.distributed.run --nproc-per-node {args.gpus}"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # MPPI_BENCH_BACKEND=gloo + MPPI_BENCH_ONE_DEVICE=1: dry run of the multi-rank path on a 1-GPU box
+        backend = os.environ.get("MPPI_BENCH_BACKEND", "nccl")
+        dev = 0 if os.environ.get("MPPI_BENCH_ONE_DEVICE") else local_rank
+        torch.cuda.set_device(dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
 
