@@ -1,9 +1,9 @@
 #!/bin/bash
-# A/B of two builds of the library on the same box: default vs $1 (path), interleaved
+# A/B of builds of the library on the same box, interleaved: BENCH_ARGS="..." scripts/gpu_ab.sh lib1.so lib2.so ...
 mkdir -p gpurun_out
 for rep in 1 2 3; do
-for lib in "" "$1"; do
-  MPPI_HIP_LIB=${lib:+$PWD/$lib} timeout 300 python bench.py --steps 300 --warmup 30 --no-cpu-baseline --timing 2 2>/dev/null | python -c "
+for lib in "" "$@"; do
+  MPPI_HIP_LIB=${lib:+$PWD/$lib} timeout 300 python bench.py --steps 300 --warmup 30 --no-cpu-baseline --timing 2 ${BENCH_ARGS:-} 2>/dev/null | python -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
