@@ -196,6 +196,12 @@ int mppi_softmax_stats(mppi_handle_t h, float lambda, double* out5_host, void* s
  * {sum e, sum e^2, sum e*c} per lambda (each relative to this shard's min c).  Lets the ESSPS
  * bracketing search probe a whole grid of lambdas per round trip.  Synchronises. */
 int mppi_softmax_stats_multi(mppi_handle_t h, const float* lambdas_host, int count, double* out_host, void* stream);
+/* ESSPS (mppi.py:351-370): lambda in [lam_min, lam_max] with ESS(lambda) = target_ess (end-point rules of
+ * mppi.py:361-364), searched on the host from two 32-temperature passes of mppi_softmax_stats_multi and an
+ * inverse cubic interpolation (within ~1e-7 relative of scipy's brentq on the same statistics).  Unsharded
+ * handles; synchronises twice. */
+int mppi_essps_lambda(mppi_handle_t h, double target_ess, double lam_min, double lam_max, double* lambda_out_host,
+                      void* stream);
 
 /* `_weights` (mppi.py:376) for this shard given the GLOBAL {min c, sum e}: w_out_dev[N]. */
 int mppi_weights(mppi_handle_t h, float lambda, float cmin_global, float sum_e_global, float* w_out_dev,

@@ -720,6 +720,55 @@ int mppi_softmax_stats_multi(mppi_handle_t h, const float* lambdas_host, int cou
     return MPPI_OK;
 }
 
+// ESSPS temperature (mppi.py:351-370,559-566): the root of ESS(lambda) = target on [lam_min, lam_max] with the
+// reference's end-point rules, found on the host from device statistics — two 32-point geometric grids
+// (mppi_softmax_stats_multi: one pass over the costs each) and an inverse cubic interpolation in
+// (ESS, log lambda).  Same algorithm as pi_mpc/_host.py::essps_lambda_grid (which sharded solvers use, with an
+// all_gather per grid); kept in the library so that the single-GPU solve has no interpreter work per probe.
+int mppi_essps_lambda(mppi_handle_t h, double target_ess, double lam_min, double lam_max, double* lambda_out,
+                      void* stream) {
+    if (!h || !lambda_out || !(lam_min > 0.0) || !(lam_max > lam_min) || !(target_ess > 0.0))
+        return fail(h, MPPI_E_INVALID, "bad essps arguments");
+    constexpr int P = STATS_L;
+    double grid[P], ess[P], raw[P * 3];
+    float lamf[P];
+    double lo = lam_min, hi = lam_max;
+    int i = 1;
+    for (int rnd = 0; rnd < 2; ++rnd) {
+        const double llo = std::log(lo), lhi = std::log(hi);
+        for (int j = 0; j < P; ++j) grid[j] = std::exp(llo + (lhi - llo) * (double)j / (double)(P - 1));
+        grid[0] = lo; grid[P - 1] = hi;
+        for (int j = 0; j < P; ++j) lamf[j] = (float)grid[j];
+        if (int rc = mppi_softmax_stats_multi(h, lamf, P, raw, stream)) return rc;
+        for (int j = 0; j < P; ++j) ess[j] = raw[3 * j] * raw[3 * j] / raw[3 * j + 1];
+        if (rnd == 0) {  // mppi.py:361-364
+            if (target_ess <= ess[0]) { *lambda_out = lam_min; return MPPI_OK; }
+            if (target_ess >= ess[P - 1]) { *lambda_out = lam_max; return MPPI_OK; }
+        }
+        i = P - 1;
+        for (int j = 0; j < P; ++j) if (ess[j] >= target_ess) { i = j; break; }
+        if (i < 1) i = 1;
+        lo = grid[i - 1]; hi = grid[i];
+    }
+    const int j0 = std::min(std::max(i - 2, 0), P - 4);
+    bool increasing = true;
+    for (int a = 0; a < 3; ++a) increasing = increasing && ess[j0 + a + 1] > ess[j0 + a];
+    if (increasing) {  // Lagrange form of log(lambda) as a function of ESS, at ESS = target
+        double x = 0.0;
+        for (int a = 0; a < 4; ++a) {
+            double w = 1.0;
+            for (int b = 0; b < 4; ++b)
+                if (b != a) w *= (target_ess - ess[j0 + b]) / (ess[j0 + a] - ess[j0 + b]);
+            x += w * std::log(grid[j0 + a]);
+        }
+        const double lam = std::exp(x);
+        if (lam >= lo && lam <= hi) { *lambda_out = lam; return MPPI_OK; }
+    }
+    const double e0 = ess[i - 1], e1 = ess[i];
+    *lambda_out = (e1 == e0) ? 0.5 * (lo + hi) : lo + (hi - lo) * (target_ess - e0) / (e1 - e0);
+    return MPPI_OK;
+}
+
 int mppi_weights(mppi_handle_t h, float lambda, float cmin, float sum_e, float* w_out, void* stream) {
     if (!h || !w_out || !(lambda > 0.0f)) return fail(h, MPPI_E_INVALID, "bad weights arguments");
     const unsigned grid = (unsigned)((h->d.N + BLOCK - 1) / BLOCK);

@@ -355,6 +355,11 @@ class MPPI(nn.Module):
             self._lambda = (_host.lbps_lambda_stats(self._softmax_stats, self._lbps_delta, self._lambda_min,
                                                     self._lambda_max) if on_dev else
                             _host.lbps_lambda(costs_host, self._lbps_delta, self._lambda_min, self._lambda_max))
+        elif self._auto_lambda == "ESSPS" and on_dev and self._essps_search == "grid" and self._world == 1:
+            lam_out = C.c_double(0.0)  # the whole search inside the library (same algorithm as essps_lambda_grid)
+            h.call("mppi_essps_lambda", float(self._essps_target_ess), float(self._lambda_min),
+                   float(self._lambda_max), C.byref(lam_out), st)
+            self._lambda = lam_out.value
         elif self._auto_lambda == "ESSPS":
             self._lambda = ((_host.essps_lambda_grid(self._ess_grid, self._essps_target_ess, self._lambda_min,
                                                      self._lambda_max) if self._essps_search == "grid" else

@@ -599,6 +599,10 @@ def test_device_softmax_stats_drive_the_same_temperature(lam_mode):
         sg, _ = make_solver("nav2d", T, N, lambda_="ESSPS", essps_search="grid")
         sg.forward(torch.tensor([-9.0, -9.0, 0.785]))
         assert abs(sb._last_lambda - sg._last_lambda) <= 1e-6 * sb._last_lambda
+        # the library's own search (mppi_essps_lambda, what forward() used) == the host statement of it
+        from pi_mpc import _host
+        lam_py = _host.essps_lambda_grid(sg._ess_grid, sg._essps_target_ess, sg._lambda_min, sg._lambda_max)
+        assert abs(lam_py - sg._last_lambda) <= 1e-9 * lam_py
         ess = sg._ess_grid([sg._last_lambda])[0]
         assert abs(ess - N / 10) <= 1e-4 * N / 10
     assert rel_err(outs[0][1], outs[1][1]) < 20 * tol
