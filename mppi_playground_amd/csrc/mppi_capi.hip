@@ -58,8 +58,9 @@ struct MppiSolver {
     float* stats_part = nullptr;     // [STATS_BLOCKS][max(4, STATS_L*3)]
     double* stats_host = nullptr;    // mapped pinned [8 + STATS_L*3]
     uint8_t* map_cells[2] = {nullptr, nullptr};
-    uint8_t* map_fused = nullptr;
-    size_t map_bytes[2] = {0, 0}, map_fused_bytes = 0;
+    uint8_t* map_pad = nullptr;      // padded (and, for racing, summed) grid of the FAST lookup
+    size_t map_bytes[2] = {0, 0}, map_pad_bytes = 0;
+    bool params_set = false;
     ModelCtx ctx{};
     // options
     int math_fast = 1;
@@ -148,10 +149,11 @@ bool use_fast(mppi_handle_t h);
 bool use_fast(mppi_handle_t h) {
     if (!h->math_fast) return false;
     const int m = h->cfg.model;
-    if (m == MPPI_MODEL_NAV2D) return h->ctx.maps[0].inv_cell != 0.0f && h->ctx.wrap_safe != 0 && h->ctx.u_in_bounds != 0;
+    if (m == MPPI_MODEL_NAV2D)
+        return h->ctx.maps[0].inv_cell != 0.0f && h->ctx.pad != nullptr && h->ctx.wrap_safe != 0 && h->ctx.u_in_bounds != 0;
     if (m == MPPI_MODEL_GOALZONE) return h->ctx.wrap_safe != 0 && h->ctx.u_in_bounds != 0;
     if (m == MPPI_MODEL_RACING)
-        return h->ctx.wrap_safe != 0 && h->ctx.u_in_bounds != 0 && h->ctx.maps[0].inv_cell != 0.0f && h->ctx.fused != nullptr && h->ctx.tan_small != 0 && h->ctx.inv_L != 0.0f;
+        return h->ctx.wrap_safe != 0 && h->ctx.u_in_bounds != 0 && h->ctx.maps[0].inv_cell != 0.0f && h->ctx.pad != nullptr && h->ctx.tan_small != 0 && h->ctx.inv_L != 0.0f;
     return true;
 }
 
@@ -167,23 +169,35 @@ int check_ready(mppi_handle_t h) {
     return MPPI_OK;
 }
 
-void refresh_fused(mppi_handle_t h, hipStream_t s) {
-    h->ctx.fused = nullptr;
-    if (h->cfg.model != MPPI_MODEL_RACING) return;
+// (Re)build the padded grid of the FAST lookup when the maps and the model parameters allow it; otherwise
+// ctx.pad stays null and the FAST=false kernels (bounds-tested lookups) are dispatched.
+void refresh_pad(mppi_handle_t h, hipStream_t s) {
+    h->ctx.pad = nullptr;
+    h->ctx.pad_stride = 0;
+    const int model = h->cfg.model;
+    const bool racing = model == MPPI_MODEL_RACING;
+    if (!racing && model != MPPI_MODEL_NAV2D) return;
+    if (!h->params_set || !h->map_cells[0] || (racing && !h->map_cells[1])) return;
     const MapView &a = h->ctx.maps[0], &b = h->ctx.maps[1];
-    if (!h->map_cells[0] || !h->map_cells[1]) return;
-    if (a.nx != b.nx || a.ny != b.ny || a.cell != b.cell || a.ox != b.ox || a.oy != b.oy) return;
-    const size_t n = (size_t)a.nx * a.ny;
-    if (h->map_fused_bytes < n) {
-        if (h->map_fused) (void)hipFree(h->map_fused);
-        h->map_fused = nullptr; h->map_fused_bytes = 0;
-        if (hipMalloc(&h->map_fused, n) != hipSuccess) return;
-        h->map_fused_bytes = n;
+    if (racing && (a.nx != b.nx || a.ny != b.ny || a.cell != b.cell || a.ox != b.ox || a.oy != b.oy)) return;
+    const float* P = h->ctx.P;
+    const float xlo = P[racing ? MPPI_RP_XLO : MPPI_NP_XLO], xhi = P[racing ? MPPI_RP_XHI : MPPI_NP_XHI];
+    const float ylo = P[racing ? MPPI_RP_YLO : MPPI_NP_YLO], yhi = P[racing ? MPPI_RP_YHI : MPPI_NP_YHI];
+    uint32_t koff = 0;
+    if (!pad_map_plan(a, xlo, xhi, ylo, yhi, koff)) return;
+    const size_t n = (size_t)(a.nx + 1) * (a.ny + 1);
+    if (h->map_pad_bytes < n) {
+        if (h->map_pad) (void)hipFree(h->map_pad);
+        h->map_pad = nullptr; h->map_pad_bytes = 0;
+        if (hipMalloc(&h->map_pad, n) != hipSuccess) return;
+        h->map_pad_bytes = n;
     }
-    hipLaunchKernelGGL(mppi::fuse_maps_kernel, dim3((unsigned)((n + mppi::BLOCK - 1) / mppi::BLOCK)), dim3(mppi::BLOCK),
-                       0, s, h->map_cells[0], h->map_cells[1], h->map_fused, n);
+    hipLaunchKernelGGL(pad_map_kernel, dim3((unsigned)((a.ny + 1 + BLOCK - 1) / BLOCK), (unsigned)(a.nx + 1)), dim3(BLOCK), 0, s,
+                       h->map_cells[0], racing ? h->map_cells[1] : (const uint8_t*)nullptr, a.nx, a.ny,
+                       (uint8_t)(racing ? 2 : 1), h->map_pad);
     if (hipGetLastError() != hipSuccess) return;
-    h->ctx.fused = h->map_fused;
+    h->ctx.pad = reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(h->map_pad) - (uintptr_t)koff);
+    h->ctx.pad_stride = a.ny + 1;
 }
 
 // (re)allocate the grid of `slot` and fill in its geometry
@@ -306,7 +320,7 @@ int mppi_destroy(mppi_handle_t h) {
     (void)hipFree(h->mean); (void)hipFree(h->mean_used); (void)hipFree(h->solve_stats); (void)hipFree(h->topk_hist);
     (void)hipFree(h->topk_sel); (void)hipFree(h->topk_cand); (void)hipFree(h->ref); (void)hipFree(h->partials); (void)hipFree(h->heads);
     (void)hipFree(h->summary); (void)hipFree(h->map_cells[0]); (void)hipFree(h->map_cells[1]);
-    (void)hipFree(h->map_fused); (void)hipFree(h->stats_part); (void)hipFree(h->noise_std);
+    (void)hipFree(h->map_pad); (void)hipFree(h->stats_part); (void)hipFree(h->noise_std);
     if (h->stats_host) (void)hipHostFree(h->stats_host);
     if (h->live_hint) (void)hipHostFree(h->live_hint);
     for (int i = 0; i < MppiSolver::RING; ++i) {
@@ -349,6 +363,9 @@ int mppi_set_model_params(mppi_handle_t h, const float* p, int n) {
         uint32_t bits; std::memcpy(&bits, &L, 4);
         h->ctx.inv_L = (L > 0.0f && (bits & 0x7fffffu) != 0x7fffffu) ? 1.0f / L : 0.0f;
     }
+    h->params_set = true;
+    refresh_pad(h, nullptr);  // the padded grid depends on the position clamp limits
+    if (hipStreamSynchronize(nullptr) != hipSuccess) return fail(h, MPPI_E_HIP, "padded grid construction failed");
     return MPPI_OK;
 }
 
@@ -359,7 +376,7 @@ int mppi_upload_map(mppi_handle_t h, int slot, const uint8_t* cells, int nx, int
         if (cells[i] > 1) return fail(h, MPPI_E_INVALID, "map cells must be 0/1 occupancy");
     if (int rc = prepare_map(h, slot, nx, ny, cell, ox, oy)) return rc;
     HIP_TRY(h, hipMemcpy(h->map_cells[slot], cells, n, hipMemcpyHostToDevice));
-    refresh_fused(h, nullptr);
+    refresh_pad(h, nullptr);
     HIP_TRY(h, hipStreamSynchronize(nullptr));
     return MPPI_OK;
 }
@@ -378,7 +395,7 @@ int mppi_build_obstacle_map(mppi_handle_t h, int slot, int nx, int ny, float cel
     hipLaunchKernelGGL(mppi::raster_obstacles_kernel, dim3((ny + mppi::BLOCK - 1) / mppi::BLOCK, nx), dim3(mppi::BLOCK), 0,
                        s, h->map_cells[slot], nx, ny, dc, n_circles, dr, n_rects);
     const hipError_t e = hipGetLastError();
-    refresh_fused(h, s);
+    refresh_pad(h, s);
     const hipError_t e2 = hipStreamSynchronize(s);  // the recipe tables are freed below
     (void)hipFree(dc); (void)hipFree(dr);
     HIP_TRY(h, e);
@@ -396,7 +413,7 @@ int mppi_build_lane_map(mppi_handle_t h, int slot, int nx, int ny, float cell, f
     hipLaunchKernelGGL(mppi::lane_map_kernel, dim3((ny + mppi::BLOCK - 1) / mppi::BLOCK, nx), dim3(mppi::BLOCK), 0, s,
                        h->map_cells[slot], nx, ny, ds, n_seeds, max_d2);
     const hipError_t e = hipGetLastError();
-    refresh_fused(h, s);
+    refresh_pad(h, s);
     const hipError_t e2 = hipStreamSynchronize(s);
     (void)hipFree(ds);
     HIP_TRY(h, e);

@@ -114,7 +114,7 @@ __device__ __forceinline__ float trajectory_cost(const float4* __restrict__ np, 
     float s[DS], pu[DC], pl[DC];
 #pragma unroll
     for (int j = 0; j < DS; ++j) s[j] = x0[j];
-    if (FAST) M::check_state(s, bad);
+    if (FAST) M::check_state(ctx, s, bad);
     // clamp bounds live in VGPRs: v_med3_f32 takes one SGPR operand only, and the compiler would
     // otherwise re-materialise the second bound with a v_mov in every step
     float lo[DC], hi[DC];
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(BLOCK) void rollout_cost_wave_kernel(const float* _
             float s[DS];
 #pragma unroll
             for (int j = 0; j < DS; ++j) s[j] = x0[j];
-            if (FAST) M::check_state(s, bad);
+            if (FAST) M::check_state(ctx, s, bad);
             for (int t = 0; t < d.T; ++t) {
                 float u[DC], sn[DS], ss[DS];
 #pragma unroll
@@ -575,7 +575,7 @@ __device__ __forceinline__ bool rollout_states(const float* __restrict__ x0, int
     float s[DS];
 #pragma unroll
     for (int j = 0; j < DS; ++j) s[j] = x0[j];
-    if (FAST) M::check_state(s, bad);
+    if (FAST) M::check_state(ctx, s, bad);
     for (int t = 0; t < T; ++t) {
         float u[DC], sn[DS], ss[DS];
         getu(t, u);
@@ -1173,11 +1173,20 @@ __global__ __launch_bounds__(BLOCK) void lane_map_kernel(uint8_t* __restrict__ c
     if (iy < ny) cells[(size_t)ix * ny + iy] = (best <= max_d2) ? 0 : 1;
 }
 
-// racing: obstacle + lane occupancy summed per cell (0..2) so the cost does one gather instead of two
-__global__ __launch_bounds__(BLOCK) void fuse_maps_kernel(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
-                                                          uint8_t* __restrict__ out, size_t n) {
-    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i < n) out[i] = (uint8_t)(a[i] + b[i]);
+// The grid of the FAST lookup (occ_lookup_pad): a (nx+1) x (ny+1) copy of the occupancy grid — for racing the
+// obstacle and lane grids summed per cell (0..2), one gather instead of two — whose extra row and column hold
+// the out-of-bounds value.
+__global__ __launch_bounds__(BLOCK) void pad_map_kernel(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
+                                                        int nx, int ny, uint8_t oob, uint8_t* __restrict__ out) {
+    const int iy = blockIdx.x * BLOCK + threadIdx.x;
+    const int ix = blockIdx.y;
+    if (iy > ny) return;
+    uint8_t v = oob;
+    if (ix < nx && iy < ny) {
+        v = a[(size_t)ix * ny + iy];
+        if (b) v = (uint8_t)(v + b[(size_t)ix * ny + iy]);
+    }
+    out[(size_t)ix * (ny + 1) + iy] = v;
 }
 
 }  // namespace mppi

@@ -32,7 +32,7 @@ constexpr float PI_F = 3.14159274f;      // (float)torch.pi
 constexpr float TWO_PI_F = 6.28318548f;  // (float)(2*torch.pi)
 
 struct MapView {
-    const uint8_t* cells;  // [nx][ny] occupancy 0/1 (or 0..2 when fused)
+    const uint8_t* cells;  // [nx][ny] occupancy 0/1
     int32_t nx, ny;
     float cell, inv_cell;  // inv_cell = RN(1/cell) for the Markstein division
     float ox, oy;
@@ -41,7 +41,11 @@ struct MapView {
 struct ModelCtx {
     float P[MPPI_MAX_PARAMS];
     MapView maps[2];
-    const uint8_t* fused;  // racing: obstacle+lane summed (0..2) when both maps share geometry
+    // FAST racing / nav2d: the occupancy grid(s) copied into one (nx+1) x (ny+1) grid whose extra row and
+    // column hold the out-of-bounds value (racing: obstacle + lane summed, 0..2), addressed without any
+    // bounds test (see occ_lookup_pad); `pad` is the grid's base minus the constant the index trick adds.
+    const uint8_t* pad;
+    int32_t pad_stride;    // ny + 1
     const float* ref;      // racing: [rows][8] = x, y, yaw, v, sin(yaw), cos(yaw), 0, 0
     int32_t ref_rows;
     int32_t tan_small;     // steer bounds within [-0.25, 0.25]: polynomial tan is valid
@@ -49,6 +53,19 @@ struct ModelCtx {
     int32_t u_in_bounds;   // the solver's [u_min, u_max] lies inside the model's own action clamp
     int32_t wrap_safe;     // per-step heading increments are < pi: wrapped angles stay in the narrow range
 };
+
+// Host-side plan of the padded grid.  The models clamp positions to [xlo, xhi] x [ylo, yhi]; if every index
+// round(p/cell + origin) reachable under that clamp lies in [0, nx] x [0, ny], the lookup needs no bounds test.
+// koff = the constant (mod 2^32) that occ_lookup_pad's index carries; returns false when the plan does not apply.
+inline bool pad_map_plan(const MapView& m, float xlo, float xhi, float ylo, float yhi, uint32_t& koff) {
+    if (!(m.cell > 0.0f) || m.nx < 1 || m.ny < 1 || m.nx >= (1 << 20) || m.ny >= (1 << 20)) return false;
+    const float ix0 = rintf(xlo / m.cell + m.ox), ix1 = rintf(xhi / m.cell + m.ox);  // IEEE division = the
+    const float iy0 = rintf(ylo / m.cell + m.oy), iy1 = rintf(yhi / m.cell + m.oy);  // device's Markstein quotient
+    if (!(ix0 >= 0.0f && ix1 <= (float)m.nx && iy0 >= 0.0f && iy1 <= (float)m.ny)) return false;
+    const uint64_t k = 0x400000ull * (uint64_t)(m.ny + 1) + 0x4B400000ull;
+    koff = (uint32_t)k;
+    return (uint64_t)koff + (uint64_t)(m.nx + 1) * (uint64_t)(m.ny + 1) < (1ull << 32);
+}
 
 // torch.clamp(x, lo, hi) = min(max(x, lo), hi).  On the device this is one v_med3_f32 (identical for
 // lo <= hi and non-NaN x; NaN inputs are outside the contract).

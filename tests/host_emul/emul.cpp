@@ -19,7 +19,7 @@ static float walk(const float* eps_row, const float* mean, const float* x0, int 
     constexpr int DS = M::DS, DC = M::DC;
     float s[DS], pu[DC], pl[DC];
     for (int j = 0; j < DS; ++j) s[j] = x0[j];
-    if (FAST) M::check_state(s, bad);
+    if (FAST) M::check_state(ctx, s, bad);
     for (int k = 0; k < DC; ++k) pu[k] = pl[k] = 0.f;
     float acc = 0.f;
     for (int t = 0; t < T; ++t) {
@@ -76,10 +76,21 @@ int emul_rollout_cost(int model, int fast, int N, int T, int threshold, const fl
         m.cells = mp[sidx]; m.nx = map_dims[0]; m.ny = map_dims[1];
         m.cell = map_geom[0]; m.inv_cell = 1.0f / m.cell; m.ox = map_geom[1]; m.oy = map_geom[2];
     }
-    if (map0 && map1) {
-        fused.resize((size_t)map_dims[0] * map_dims[1]);
-        for (size_t i = 0; i < fused.size(); ++i) fused[i] = map0[i] + map1[i];
-        ctx.fused = fused.data();
+    if (map0 && (model == MPPI_MODEL_RACING ? map1 != nullptr : model == MPPI_MODEL_NAV2D)) {
+        // the padded grid of the FAST lookup, planned exactly like the C ABI does (pad_map_plan)
+        const bool racing = model == MPPI_MODEL_RACING;
+        const float* P = ctx.P;
+        const float xlo = P[racing ? MPPI_RP_XLO : MPPI_NP_XLO], xhi = P[racing ? MPPI_RP_XHI : MPPI_NP_XHI];
+        const float ylo = P[racing ? MPPI_RP_YLO : MPPI_NP_YLO], yhi = P[racing ? MPPI_RP_YHI : MPPI_NP_YHI];
+        uint32_t koff = 0;
+        if (!pad_map_plan(ctx.maps[0], xlo, xhi, ylo, yhi, koff)) return -2;
+        const int nx = map_dims[0], ny = map_dims[1];
+        fused.assign((size_t)(nx + 1) * (ny + 1), racing ? 2 : 1);
+        for (int ix = 0; ix < nx; ++ix)
+            for (int iy = 0; iy < ny; ++iy)
+                fused[(size_t)ix * (ny + 1) + iy] = map0[(size_t)ix * ny + iy] + (racing ? map1[(size_t)ix * ny + iy] : 0);
+        ctx.pad = reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(fused.data()) - (uintptr_t)koff);
+        ctx.pad_stride = ny + 1;
     }
     if (ref) {
         ref8.resize((size_t)ref_rows * 8);
