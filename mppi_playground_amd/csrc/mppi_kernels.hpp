@@ -150,16 +150,35 @@ __device__ __forceinline__ float trajectory_cost(const float4* __restrict__ np, 
     };
     // groups that lie completely inside the horizon: SPG steps each, no per-step bound checks
     const int full = d.T / SPG;
-    for (int r = 0; r < full; ++r) {
-        const int rn = min(r + 1, d.R - 1);
-        const float4 en = noise_group<GEN>(np, rn, gi, gen, d);
-        const float4 m4n = mean4[rn];
-        const float ev[4] = {e.x, e.y, e.z, e.w};
-        const float mv[4] = {m4.x, m4.y, m4.z, m4.w};
+    if (GEN) {
+        for (int r = 0; r < full; ++r) {
+            const int rn = min(r + 1, d.R - 1);
+            const float4 en = noise_group<GEN>(np, rn, gi, gen, d);  // independent chain, interleaved with the steps
+            const float4 m4n = mean4[rn];
+            const float ev[4] = {e.x, e.y, e.z, e.w};
+            const float mv[4] = {m4.x, m4.y, m4.z, m4.w};
 #pragma unroll
-        for (int g = 0; g < SPG; ++g) one_step(ev + g * DC, mv + g * DC);
-        e = en;
-        m4 = m4n;
+            for (int g = 0; g < SPG; ++g) one_step(ev + g * DC, mv + g * DC);
+            e = en;
+            m4 = m4n;
+        }
+    } else {
+        // Tiles: loads return in order (one vmcnt), so the first map gather consumed after a noise load also
+        // waits for that load.  Keep two groups in flight and issue the load of group r+2 at the very END of
+        // iteration r (pinned by a fake dependency on the iteration's result): it then has most of iteration r+1 to arrive.
+        float4 e1 = noise_group<GEN>(np, min(1, d.R - 1), gi, gen, d);
+        for (int r = 0; r < full; ++r) {
+            const float4 m4n = mean4[min(r + 1, d.R - 1)];
+            const float ev[4] = {e.x, e.y, e.z, e.w};
+            const float mv[4] = {m4.x, m4.y, m4.z, m4.w};
+#pragma unroll
+            for (int g = 0; g < SPG; ++g) one_step(ev + g * DC, mv + g * DC);
+            e = e1;
+            m4 = m4n;
+            const float4* nptr = np + (int64_t)min(r + 2, d.R - 1) * 64;
+            asm volatile("" : "+v"(nptr) : "v"(acc));  // the address "depends" on this iteration's last cost
+            e1 = *nptr;
+        }
     }
     if (t < d.T) {  // ragged last group (T*dc not a multiple of 4)
         const float ev[4] = {e.x, e.y, e.z, e.w};
