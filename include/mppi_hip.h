@@ -215,9 +215,19 @@ int mppi_rollout_samples(mppi_handle_t h, const int64_t* idx_dev, int k, float* 
 /* get_top_samples (mppi.py:462-487) in one call: the k (<= 1024) samples of the last solve with the largest
  * weight = the smallest cost (radix select on the device), sorted by descending weight, their state
  * trajectories re-rolled around the mean that solve sampled (states_out_dev [k][T+1][ds]) and their softmax
- * weights softmax(-c/lambda)_i (weights_out_dev [k]).  lambda = the temperature of that solve.  Unsharded
- * handles only (a shard sees its own samples). */
+ * weights softmax(-c/lambda)_i (weights_out_dev [k]).  lambda = the temperature of that solve.  On a shard this
+ * ranks the shard's own samples (weights still use the global normalisation); see the two calls below. */
 int mppi_top_samples(mppi_handle_t h, int k, float lambda, float* states_out_dev, float* weights_out_dev, void* stream);
+/* The two halves of mppi_top_samples for sharded solvers.  A candidate is (cost key << 32) | GLOBAL sample index; the
+ * key is an order-preserving bijection of the fp32 cost, so candidates of all shards can be merged by sorting the
+ * 64-bit words ascending, and — the device noise being a function of the global index — any rank can then weigh
+ * and re-roll the k winners:
+ *   mppi_top_candidates:     this shard's k smallest costs -> cand_out_dev[k] (unordered)
+ *   mppi_rollout_candidates: k merged candidates -> states_out_dev[k][T+1][ds], weights_out_dev[k], sorted by
+ *                            descending weight (needs regenerated noise: option "noise_regen" = 1, no injection). */
+int mppi_top_candidates(mppi_handle_t h, int k, uint64_t* cand_out_dev, void* stream);
+int mppi_rollout_candidates(mppi_handle_t h, const uint64_t* cand_dev, int k, float lambda, float* states_out_dev,
+                            float* weights_out_dev, void* stream);
 
 /* Tuning knobs (not in the reference): "math" 0 = library sin/cos/tan/fmod/div, 1 = range-checked
  * fast paths (default); "noise_regen" (see mppi_sample); "mapping" 0 = lane per trajectory (default), 1 =

@@ -824,31 +824,66 @@ int mppi_rollout_samples(mppi_handle_t h, const int64_t* idx_dev, int k, float* 
     return MPPI_OK;
 }
 
-int mppi_top_samples(mppi_handle_t h, int k, float lambda, float* states_out, float* weights_out, void* stream) {
-    if (!h || !states_out || !weights_out || !(lambda > 0.0f)) return fail(h, MPPI_E_INVALID, "bad top_samples arguments");
-    if (k < 1 || k > TOPK_MAX || k > h->d.N) return fail(h, MPPI_E_INVALID, "top_samples: need 1 <= k <= min(1024, num_samples)");
-    if (h->d.N >= ((int64_t)1 << 32)) return fail(h, MPPI_E_INVALID, "top_samples: num_samples must be < 2^32");
-    if (int rc = check_ready(h)) return rc;
-    hipStream_t s = (hipStream_t)stream;
-    const bool gen = h->noise_regen && !h->injected;
-    if (!gen && !h->tiles_valid) return fail(h, MPPI_E_STATE, "no noise: solve first");
+// radix select of this handle's k smallest costs -> h->topk_cand (unordered, global indices)
+static int topk_select(mppi_handle_t h, int k, hipStream_t s) {
+    if (k < 1 || k > TOPK_MAX || k > h->d.N) return fail(h, MPPI_E_INVALID, "top samples: need 1 <= k <= min(1024, num_samples)");
+    if (h->d.sample_offset + h->d.N >= ((int64_t)1 << 32)) return fail(h, MPPI_E_INVALID, "top samples: global sample indices must be < 2^32");
     const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((h->d.N + BLOCK * 8 - 1) / (BLOCK * 8), 1024));
     unsigned* hist = h->topk_hist;
     unsigned* counters = h->topk_hist + 3 * TOPK_BINS;
     hipLaunchKernelGGL(topk_hist_kernel<0>, dim3(grid), dim3(BLOCK), 0, s, h->costs, h->d.N, (unsigned)k, hist, h->topk_sel);
     hipLaunchKernelGGL(topk_hist_kernel<1>, dim3(grid), dim3(BLOCK), 0, s, h->costs, h->d.N, (unsigned)k, hist, h->topk_sel);
     hipLaunchKernelGGL(topk_hist_kernel<2>, dim3(grid), dim3(BLOCK), 0, s, h->costs, h->d.N, (unsigned)k, hist, h->topk_sel);
-    hipLaunchKernelGGL(topk_collect_kernel, dim3(grid), dim3(BLOCK), 0, s, h->costs, h->d.N, (unsigned)k, hist, h->topk_sel,
-                       h->topk_cand, counters);
+    hipLaunchKernelGGL(topk_collect_kernel, dim3(grid), dim3(BLOCK), 0, s, h->costs, h->d.N, (unsigned)k, h->d.sample_offset,
+                       hist, h->topk_sel, h->topk_cand, counters);
     HIP_TRY(h, hipGetLastError());
+    return MPPI_OK;
+}
+
+// sort k candidates, weigh and re-roll them; `clean` also resets the select state (after topk_select)
+static int topk_rollout(mppi_handle_t h, const unsigned long long* cand, int k, float lambda, float* states_out,
+                        float* weights_out, bool clean, bool need_local, hipStream_t s) {
+    const bool gen = h->noise_regen && !h->injected;
+    if (!gen && !h->tiles_valid) return fail(h, MPPI_E_STATE, "no noise: solve first");
+    if (!gen && !need_local)
+        return fail(h, MPPI_E_STATE, "candidates of other shards can only be re-rolled from regenerated noise (noise_regen = 1, no injection)");
+    unsigned* hist = clean ? h->topk_hist : nullptr;
+    unsigned* counters = clean ? h->topk_hist + 3 * TOPK_BINS : nullptr;
 #define CALL_TOPK(MODEL, FASTV)                                                                       \
-    hipLaunchKernelGGL((topk_rollout_kernel<MODEL, FASTV>), dim3(1), dim3(TOPK_MAX), 0, s, h->topk_cand, k, h->costs, \
-                       h->noise, gen, h->mean_used, h->x0_cur, h->solve_stats, lambda, states_out, weights_out, hist, \
-                       counters, h->d, h->gen, h->ctx)
+    hipLaunchKernelGGL((topk_rollout_kernel<MODEL, FASTV>), dim3(1), dim3(TOPK_MAX), 0, s, cand, k, h->noise, gen,  \
+                       h->mean_used, h->x0_cur, h->solve_stats, lambda, states_out, weights_out, hist, counters,  \
+                       h->d, h->gen, h->ctx)
     MPPI_DISPATCH(h, CALL_TOPK);
 #undef CALL_TOPK
     HIP_TRY(h, hipGetLastError());
     return MPPI_OK;
+}
+
+int mppi_top_samples(mppi_handle_t h, int k, float lambda, float* states_out, float* weights_out, void* stream) {
+    if (!h || !states_out || !weights_out || !(lambda > 0.0f)) return fail(h, MPPI_E_INVALID, "bad top_samples arguments");
+    if (int rc = check_ready(h)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if (int rc = topk_select(h, k, s)) return rc;
+    return topk_rollout(h, h->topk_cand, k, lambda, states_out, weights_out, true, true, s);
+}
+
+int mppi_top_candidates(mppi_handle_t h, int k, uint64_t* cand_out_dev, void* stream) {
+    if (!h || !cand_out_dev) return fail(h, MPPI_E_INVALID, "bad top_candidates arguments");
+    hipStream_t s = (hipStream_t)stream;
+    if (int rc = topk_select(h, k, s)) return rc;
+    HIP_TRY(h, hipMemcpyAsync(cand_out_dev, h->topk_cand, sizeof(uint64_t) * (size_t)k, hipMemcpyDeviceToDevice, s));
+    // leave the select state clean for the next call
+    HIP_TRY(h, hipMemsetAsync(h->topk_hist, 0, sizeof(unsigned) * (3 * TOPK_BINS + 2), s));
+    return MPPI_OK;
+}
+
+int mppi_rollout_candidates(mppi_handle_t h, const uint64_t* cand_dev, int k, float lambda, float* states_out,
+                            float* weights_out, void* stream) {
+    if (!h || !cand_dev || !states_out || !weights_out || !(lambda > 0.0f) || k < 1 || k > TOPK_MAX)
+        return fail(h, MPPI_E_INVALID, "bad rollout_candidates arguments");
+    if (int rc = check_ready(h)) return rc;
+    return topk_rollout(h, reinterpret_cast<const unsigned long long*>(cand_dev), k, lambda, states_out, weights_out, false,
+                        false, (hipStream_t)stream);
 }
 
 int mppi_set_option(mppi_handle_t h, const char* key, int64_t value) {

@@ -996,8 +996,11 @@ __global__ __launch_bounds__(BLOCK) void topk_hist_kernel(const float* __restric
         if (s_hist[b]) atomicAdd(&hist[PASS * TOPK_BINS + b], s_hist[b]);
 }
 
-// cand[j] = (key << 32) | index for the k selected samples (unordered); counters = {#below, #ties taken}
+// cand[j] = (key << 32) | GLOBAL sample index for the k selected samples (unordered); counters = {#below, #ties taken}.
+// The key is the cost itself (order-preserving bijection), so a candidate is self-contained: any rank can weigh and
+// re-roll it without the owner's cost vector.
 __global__ __launch_bounds__(BLOCK) void topk_collect_kernel(const float* __restrict__ costs, int64_t N, unsigned k,
+                                                             int64_t sample_offset,
                                                              const unsigned* __restrict__ hist,
                                                              TopkSel* __restrict__ sel,
                                                              unsigned long long* __restrict__ cand,
@@ -1009,17 +1012,16 @@ __global__ __launch_bounds__(BLOCK) void topk_collect_kernel(const float* __rest
         const unsigned key = float_to_key(costs[i]);
         if (key < cur.prefix) {
             const unsigned slot = atomicAdd(&counters[0], 1u);
-            cand[slot] = ((unsigned long long)key << 32) | (unsigned long long)i;
+            cand[slot] = ((unsigned long long)key << 32) | (unsigned long long)(sample_offset + i);
         } else if (key == cur.prefix) {
             const unsigned t = atomicAdd(&counters[1], 1u);
-            if (t < cur.krem) cand[nbelow + t] = ((unsigned long long)key << 32) | (unsigned long long)i;
+            if (t < cur.krem) cand[nbelow + t] = ((unsigned long long)key << 32) | (unsigned long long)(sample_offset + i);
         }
     }
 }
 
 template <int MODEL, bool FAST>
 __global__ __launch_bounds__(TOPK_MAX) void topk_rollout_kernel(const unsigned long long* __restrict__ cand, int k,
-                                                                const float* __restrict__ costs,
                                                                 const float4* __restrict__ noise, bool gen_noise,
                                                                 const float* __restrict__ mean,
                                                                 const float* __restrict__ x0,
@@ -1032,9 +1034,10 @@ __global__ __launch_bounds__(TOPK_MAX) void topk_rollout_kernel(const unsigned l
     constexpr int DS = ModelT<MODEL, FAST>::DS, DC = ModelT<MODEL, FAST>::DC;
     __shared__ unsigned long long s_key[TOPK_MAX];
     s_key[threadIdx.x] = (int)threadIdx.x < k ? cand[threadIdx.x] : ~0ull;
-    // leave the select state clean for the next call
-    for (int b = threadIdx.x; b < 3 * TOPK_BINS; b += TOPK_MAX) hist[b] = 0u;
-    if (threadIdx.x < 2) counters[threadIdx.x] = 0u;
+    if (hist) {  // leave the select state clean for the next call
+        for (int b = threadIdx.x; b < 3 * TOPK_BINS; b += TOPK_MAX) hist[b] = 0u;
+        if (threadIdx.x < 2) counters[threadIdx.x] = 0u;
+    }
     __syncthreads();
     for (int size = 2; size <= TOPK_MAX; size <<= 1) {  // bitonic sort, ascending (key, index)
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
@@ -1049,11 +1052,11 @@ __global__ __launch_bounds__(TOPK_MAX) void topk_rollout_kernel(const unsigned l
     }
     const int q = threadIdx.x;
     if (q >= k) return;
-    const int64_t i = (int64_t)(s_key[q] & 0xFFFFFFFFull);
-    const float c = costs[i];
+    const uint64_t gi = s_key[q] & 0xFFFFFFFFull;            // global sample index
+    const float c = key_to_float((unsigned)(s_key[q] >> 32));  // its cost
     weights[q] = expf((-c) / lambda - (-stats[0]) / lambda) / stats[1];  // softmax(-c/lambda)_i (mppi.py:376)
-    const uint64_t gi = (uint64_t)(d.sample_offset + i);
-    const bool inherit = (d.sample_offset + i) < d.inherit_count;
+    const bool inherit = (int64_t)gi < d.inherit_count;
+    const int64_t i = (int64_t)gi - d.sample_offset;  // local index: only meaningful when the tiles are read
     const float4* np = noise + ((i >> 6) * d.R) * 64 + (i & 63);
     float* out = states + (int64_t)q * (d.T + 1) * DS;
     int have = -1;

@@ -554,7 +554,7 @@ class MPPI(nn.Module):
         smallest cost) and re-rolled from the noise of that solve around the mean it sampled."""
         assert num_samples <= self._num_samples
         if self._world > 1:
-            raise NotImplementedError("get_top_samples on a sharded solver")
+            return self._top_samples_sharded(num_samples)
         if self._model is None:  # the generic path keeps _state_seq_batch like the reference
             top = torch.topk(self._weights, num_samples)
             order = torch.argsort(top.values, descending=True)
@@ -570,6 +570,26 @@ class MPPI(nn.Module):
         self._h.call("mppi_rollout_samples", _ptr(idx), num_samples, _ptr(out), st)
         order = torch.argsort(top.values, descending=True)
         return out[order], top.values[order]
+
+    def _top_samples_sharded(self, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Sharded get_top_samples: every rank selects its k best candidates ((cost key << 32) | global index), one
+        all_gather merges them, and — the device noise being a function of the global sample index — every rank
+        re-rolls the k global winners itself: all ranks return the same tensors."""
+        import torch.distributed as dist
+
+        if self._model is None or k > 1024 or k > self._local_samples:
+            raise NotImplementedError("sharded get_top_samples: native models, k <= min(1024, samples per rank)")
+        st = self._stream()
+        mine = torch.empty(k, dtype=torch.int64, device=self._device)  # uint64 bit patterns
+        self._h.call("mppi_top_candidates", k, _ptr(mine), st)
+        allc = torch.empty(self._world * k, dtype=torch.int64, device=self._device)
+        dist.all_gather_into_tensor(allc, mine, group=self._pg)
+        flip = torch.tensor(-(1 << 63), dtype=torch.int64, device=self._device)  # unsigned order through a signed sort
+        best = (torch.sort(allc ^ flip).values[:k] ^ flip).contiguous()
+        out = torch.empty(k, self._horizon + 1, self._dim_state, device=self._device, dtype=self._dtype)
+        w = torch.empty(k, device=self._device, dtype=self._dtype)
+        self._h.call("mppi_rollout_candidates", _ptr(best), k, float(self._last_lambda), _ptr(out), _ptr(w), st)
+        return out, w
 
     def get_samples_from_posterior(self, optimal_solution: torch.Tensor, state: torch.Tensor,
                                    num_samples: int) -> Tuple[torch.Tensor, torch.Tensor]:

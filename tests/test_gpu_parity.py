@@ -457,7 +457,9 @@ def _sharded_worker(rank, world, port, q):
         a1, s1 = solver.forward(x0)
         a2, s2 = solver.forward(x0)
         st = solver.last_stats()
-        q.put((rank, a1.cpu().numpy(), s1.cpu().numpy(), a2.cpu().numpy(), st["sum_e"], st["cmin"]))
+        ts, tw = solver.get_top_samples(24)  # sharded: candidates merged across ranks, re-rolled on every rank
+        q.put((rank, a1.cpu().numpy(), s1.cpu().numpy(), a2.cpu().numpy(), st["sum_e"], st["cmin"],
+               ts.cpu().numpy(), tw.cpu().numpy()))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -489,6 +491,12 @@ def test_two_rank_sharded_solver_matches_single():
     ctrl.set_reference(ref)
     a1, s1 = single.forward(x0)
     a2, _ = single.forward(x0)
+    ts, tw = single.get_top_samples(24)
+    for r in res:  # the sharded top samples are the unsharded ones (same global indices, same noise; the warm
+        # start they are rolled around differs in the last bits between the sharded and the single combine)
+        assert rel_err(r[6], ts.cpu().numpy()) < 1e-5
+        assert rel_err(r[7], tw.cpu().numpy()) < 1e-5
+    assert np.array_equal(res[0][6], res[1][6]) and np.array_equal(res[0][7], res[1][7])
     for r in res:  # every rank ends up with the same, correct answer
         assert rel_err(r[1], a1.cpu().numpy()) < 2e-6 and rel_err(r[2], s1.cpu().numpy()) < 2e-6
         assert rel_err(r[3], a2.cpu().numpy()) < 4e-6
