@@ -1,27 +1,34 @@
-"""2-D navigation (counterpart of the reference's example/navigation2d.py, rendering removed)."""
+"""Drive the unicycle of Navigation2DEnv to its goal with the MI355X MPPI solver (no rendering).
+
+Same public calls as the reference's navigation example — env plugin callables into MPPI(...), one solve per
+tick, the first action applied to the env — written as a small report instead of a video."""
+import time
+
 import torch
 
-import _common  # noqa: F401
+import _common  # noqa: F401  (puts mppi_playground_amd on the path)
 from envs.navigation_2d import Navigation2DEnv
 from pi_mpc.mppi import MPPI
 
+SETTINGS = dict(horizon=30, num_samples=3000, dim_state=3, dim_control=2, lambda_="ESSPS")
 
-def main(max_steps: int = 500):
-    env = Navigation2DEnv()
-    solver = MPPI(horizon=30, num_samples=3000, dim_state=3, dim_control=2, dynamics=env.dynamics,
-                  cost_func=env.cost_function, u_min=env.u_min, u_max=env.u_max, sigmas=torch.tensor([0.5, 0.5]),
-                  lambda_="ESSPS")
-    state = env.reset()
-    for i in range(max_steps):
-        action_seq, state_seq = solver.forward(state=state)
-        state, is_goal_reached = env.step(action_seq[0, :])
-        is_collisions = env.collision_check(state=state_seq)
-        top_samples, top_weights = solver.get_top_samples(num_samples=300)
-        if is_goal_reached:
-            print(f"Goal Reached! ({i + 1} steps, collisions along the way: {int(is_collisions.sum())})")
+
+def run(tick_limit: int = 500, shown_rollouts: int = 300) -> bool:
+    world = Navigation2DEnv()
+    mppi = MPPI(dynamics=world.dynamics, cost_func=world.cost_function, u_min=world.u_min, u_max=world.u_max,
+                sigmas=torch.tensor([0.5, 0.5]), **SETTINGS)
+    pose, arrived, hits, t0 = world.reset(), False, 0, time.perf_counter()
+    for tick in range(1, tick_limit + 1):
+        plan, predicted = mppi(pose)
+        pose, arrived = world.step(plan[0])
+        hits += int(world.collision_check(state=predicted).sum())
+        mppi.get_top_samples(num_samples=shown_rollouts)  # what the reference draws every tick
+        if arrived:
+            print(f"Goal Reached! ({tick} steps, collisions along the way: {hits})")
             break
-    print("final state", state.tolist())
+    print(f"final state {pose.tolist()}  ({(time.perf_counter() - t0) / tick * 1e3:.2f} ms per tick)")
+    return bool(arrived)
 
 
 if __name__ == "__main__":
-    main()
+    run()
