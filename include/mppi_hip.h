@@ -185,6 +185,13 @@ int mppi_weights_reduce(mppi_handle_t h, float lambda, float* summary_out_dev, v
  * sum e*c} (global); any output may be NULL. */
 int mppi_finalize(mppi_handle_t h, const float* summaries_dev, int num_shards, float lambda, int store_mean,
                   float* action_out_dev, float* state_seq_out_dev, float* stats_out_dev, void* stream);
+/* Step 7 inside mppi_finalize (mppi.py:423-443,598-620): Savitzky-Golay smoothing of [history(T-1); a(T)] per control
+ * dimension (symmetric-flip padding, valid cross-correlation, keep the last T), applied whenever mppi_finalize is
+ * called with store_mean != 0; the smoothed sequence is what is returned, stored as the warm start and rolled out,
+ * and its first row is shifted into the history.  coeffs_host [window] = first row of pinv(vander) (mppi.py:568-596);
+ * history_host [T-1][dc] or NULL (keep / zeros).  window = 0 switches the filter off.  T*dc <= 1024. */
+int mppi_set_sg_filter(mppi_handle_t h, const float* coeffs_host, int window, const float* history_host);
+int mppi_get_sg_history(mppi_handle_t h, float* history_host);
 
 /* Device half of the automatic temperature searches (`_compute_ess`, `_lbps_objective`,
  * `_essps_objective`, the MPO dual; mppi.py:341-370,387-398,526-566): softmax statistics of this

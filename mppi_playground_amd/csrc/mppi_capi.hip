@@ -50,6 +50,9 @@ struct MppiSolver {
     unsigned* topk_hist = nullptr;   // [3][TOPK_BINS] + 2 counters, kept zeroed between calls
     TopkSel* topk_sel = nullptr;     // [3]
     unsigned long long* topk_cand = nullptr;  // [TOPK_MAX]
+    float* sg_coeffs = nullptr;      // Savitzky-Golay taps (device), window sg_window (0 = filter off)
+    float* sg_history = nullptr;     // [T-1][dc] `_actions_history_for_sg` (mppi.py:160-166,441-443)
+    int sg_window = 0;
     float* ref = nullptr;
     int ref_cap = 0;
     float* partials = nullptr;
@@ -318,7 +321,8 @@ int mppi_destroy(mppi_handle_t h) {
     if (!h) return MPPI_E_INVALID;
     (void)hipFree(h->noise); (void)hipFree(h->costs); (void)hipFree(h->min_key); (void)hipFree(h->x0);
     (void)hipFree(h->mean); (void)hipFree(h->mean_used); (void)hipFree(h->solve_stats); (void)hipFree(h->topk_hist);
-    (void)hipFree(h->topk_sel); (void)hipFree(h->topk_cand); (void)hipFree(h->ref); (void)hipFree(h->partials); (void)hipFree(h->heads);
+    (void)hipFree(h->topk_sel); (void)hipFree(h->topk_cand); (void)hipFree(h->sg_coeffs); (void)hipFree(h->sg_history);
+    (void)hipFree(h->ref); (void)hipFree(h->partials); (void)hipFree(h->heads);
     (void)hipFree(h->summary); (void)hipFree(h->map_cells[0]); (void)hipFree(h->map_cells[1]);
     (void)hipFree(h->map_pad); (void)hipFree(h->stats_part); (void)hipFree(h->noise_std);
     if (h->stats_host) (void)hipHostFree(h->stats_host);
@@ -684,16 +688,48 @@ int mppi_finalize(mppi_handle_t h, const float* summaries_dev, int num_shards, f
         if (h->summary_valid) summaries_dev = h->summary;  // else the kernel folds the partial rows itself
         num_shards = 1;
     }
-    const size_t shmem = sizeof(float) * ((size_t)2 * h->d.row + MPPI_SUMMARY_HEAD);
+    // the filter replaces the stored warm start, so it only runs when this call stores it (mppi.py:441-452)
+    const SgFilter sg{h->sg_coeffs, h->sg_history, (store_mean && h->sg_window > 0) ? h->sg_window : 0};
+    const size_t shmem = sizeof(float) * ((size_t)2 * h->d.row + MPPI_SUMMARY_HEAD +
+                                          (sg.window ? (size_t)(2 * h->d.T - 1 + 2 * (sg.window / 2)) * h->dc : 0));
     const unsigned* mk = h->min_key + h->min_slot;
 #define CALL_FINALIZE(MODEL, FASTV)                                                                   \
     hipLaunchKernelGGL((finalize_kernel<MODEL, FASTV>), dim3(1), dim3(FIN_BLOCK), shmem, s, summaries_dev, num_shards, \
                        h->partials, h->heads, mk, h->last_reduce_blocks, h->colsp, h->summary, h->live_hint_dev,  \
                        lambda, h->d.row, h->d.T, h->x0_cur, store_mean ? h->mean : (float*)nullptr, action_out,  \
-                       state_out, stats_out, h->solve_stats, h->ctx)
+                       state_out, stats_out, h->solve_stats, sg, h->ctx)
     MPPI_DISPATCH(h, CALL_FINALIZE);
 #undef CALL_FINALIZE
     HIP_TRY(h, hipGetLastError());
+    return MPPI_OK;
+}
+
+// Savitzky-Golay smoothing of the solution inside mppi_finalize (step 7, mppi.py:423-443): taps = first row of
+// pinv(vander) computed by the caller (mppi.py:568-596), history = `_actions_history_for_sg`.
+int mppi_set_sg_filter(mppi_handle_t h, const float* coeffs_host, int window, const float* history_host) {
+    if (!h || window < 0) return fail(h, MPPI_E_INVALID, "bad sg filter arguments");
+    if (window == 0) { h->sg_window = 0; return MPPI_OK; }
+    if (!coeffs_host || window % 2 == 0 || window > 255) return fail(h, MPPI_E_INVALID, "sg window must be odd and <= 255");
+    if (h->d.row > FIN_BLOCK) return fail(h, MPPI_E_INVALID, "sg filter on the device supports T*dim_control <= 1024");
+    if (window / 2 > 2 * h->d.T - 1) return fail(h, MPPI_E_INVALID, "sg window too wide for the horizon");
+    const size_t hist_floats = (size_t)std::max(h->d.T - 1, 1) * h->dc;
+    if (!h->sg_coeffs) HIP_TRY(h, hipMalloc(&h->sg_coeffs, sizeof(float) * 256));
+    if (!h->sg_history) {
+        HIP_TRY(h, hipMalloc(&h->sg_history, sizeof(float) * hist_floats));
+        HIP_TRY(h, hipMemset(h->sg_history, 0, sizeof(float) * hist_floats));
+    }
+    HIP_TRY(h, hipMemcpy(h->sg_coeffs, coeffs_host, sizeof(float) * (size_t)window, hipMemcpyHostToDevice));
+    if (history_host)
+        HIP_TRY(h, hipMemcpy(h->sg_history, history_host, sizeof(float) * (size_t)(h->d.T - 1) * h->dc, hipMemcpyHostToDevice));
+    h->sg_window = window;
+    return MPPI_OK;
+}
+
+int mppi_get_sg_history(mppi_handle_t h, float* history_host) {
+    if (!h || !history_host) return fail(h, MPPI_E_INVALID, "null");
+    if (!h->sg_history) return fail(h, MPPI_E_STATE, "sg filter not set");
+    HIP_TRY(h, hipDeviceSynchronize());
+    HIP_TRY(h, hipMemcpy(history_host, h->sg_history, sizeof(float) * (size_t)(h->d.T - 1) * h->dc, hipMemcpyDeviceToHost));
     return MPPI_OK;
 }
 

@@ -27,6 +27,12 @@ struct Dims {
 };
 
 // Identity of the noise of one solve: eps[i][t][k] is a pure function of (seed, solve, global i, t, k).
+struct SgFilter {       // device half of the Savitzky-Golay step (window == 0: off)
+    const float* coeffs;  // [window]
+    float* history;       // [T-1][dc], updated by finalize_kernel
+    int window;
+};
+
 struct GenCtx {
     uint32_t seed_lo, seed_hi, solve_idx;
 };
@@ -635,11 +641,14 @@ __global__ __launch_bounds__(FIN_BLOCK) void finalize_kernel(const float* __rest
                                                              float* __restrict__ action_out,
                                                              float* __restrict__ state_out,
                                                              float* __restrict__ stats_out,
-                                                             float* __restrict__ stats_keep, ModelCtx ctx) {
+                                                             float* __restrict__ stats_keep, SgFilter sg,
+                                                             ModelCtx ctx) {
     constexpr int DC = ModelT<MODEL, FAST>::DC;
-    extern __shared__ __attribute__((aligned(16))) float s_fin[];  // [row] action, then [4 + row] own summary
+    // [row] action, [4 + row] own summary, then (SG filter) [(2T-1+2*(w/2))*dc] padded sequence
+    extern __shared__ __attribute__((aligned(16))) float s_fin[];
     float* s_act = s_fin;
     float* s_sum = s_fin + row;
+    float* s_yp = s_fin + 2 * row + MPPI_SUMMARY_HEAD;
     const int stride = MPPI_SUMMARY_HEAD + row;
     if (summaries == nullptr) {
         constexpr int NG = FIN_BLOCK / 128;
@@ -709,14 +718,52 @@ __global__ __launch_bounds__(FIN_BLOCK) void finalize_kernel(const float* __rest
         }
         a = a / se;
         s_act[cidx] = a;
-        if (action_out) action_out[cidx] = a;
-        if (mean_store) mean_store[cidx] = a;
+        if (sg.window == 0) {
+            if (action_out) action_out[cidx] = a;
+            if (mean_store) mean_store[cidx] = a;
+        }
     }
     if (threadIdx.x == 0) {
         if (stats_out) { stats_out[0] = cmin; stats_out[1] = se; stats_out[2] = se2; stats_out[3] = sec; }
         stats_keep[0] = cmin; stats_keep[1] = se; stats_keep[2] = se2; stats_keep[3] = sec;
     }
     __syncthreads();
+    if (sg.window > 0) {
+        // Step 7 (mppi.py:423-443,598-620): Savitzky-Golay smoothing of [history(T-1); a(T)] per control dimension,
+        // symmetric-flip padding by w/2, valid cross-correlation accumulated tap by tap in fp32 (the operation
+        // order of the host statement in pi_mpc/_host.py), keep the last T; then shift a'[0] into the history.
+        const int dcn = row / T, p = sg.window / 2, n = 2 * T - 1;
+        for (int idx = threadIdx.x; idx < n * dcn; idx += FIN_BLOCK) {
+            const int i = idx / dcn, k = idx - i * dcn;
+            s_yp[(p + i) * dcn + k] = i < T - 1 ? sg.history[i * dcn + k] : s_act[(i - (T - 1)) * dcn + k];
+        }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < p * dcn; idx += FIN_BLOCK) {
+            const int j = idx / dcn, k = idx - j * dcn;
+            s_yp[(p - 1 - j) * dcn + k] = s_yp[(p + j) * dcn + k];                  // front: y[p-1], ..., y[0]
+            s_yp[(p + n + j) * dcn + k] = s_yp[(p + n - 1 - j) * dcn + k];          // back:  y[n-1], ..., y[n-p]
+        }
+        __syncthreads();
+        float filt = 0.0f;
+        const int cidx = threadIdx.x;  // row <= FIN_BLOCK is checked on the host for the filter
+        if (cidx < row) {
+            const int t = cidx / dcn, k = cidx - t * dcn;
+            for (int j = 0; j < sg.window; ++j) filt = filt + s_yp[(T - 1 + t + j) * dcn + k] * sg.coeffs[j];
+        }
+        __syncthreads();
+        if (cidx < row) {
+            s_act[cidx] = filt;
+            if (action_out) action_out[cidx] = filt;
+            if (mean_store) mean_store[cidx] = filt;
+        }
+        for (int idx = threadIdx.x; idx < (T - 1) * dcn; idx += FIN_BLOCK) {  // history <- [history[1:]; a'[0]]
+            const int i = idx / dcn, k = idx - i * dcn;
+            sg.history[idx] = i < T - 2 ? s_yp[(p + i + 1) * dcn + k] : 0.0f;
+        }
+        __syncthreads();
+        if (threadIdx.x < dcn && T >= 2) sg.history[(T - 2) * dcn + threadIdx.x] = s_act[threadIdx.x];
+        __syncthreads();
+    }
     if (!state_out) return;
     const auto getu = [&](int t, float* u) {
 #pragma unroll

@@ -63,6 +63,7 @@ class MPPI(nn.Module):
         process_group=None,
         auto_lambda_stats: str = "device",
         essps_search: str = "grid",
+        sg_filter: str = "device",
     ) -> None:
         """Arguments up to `seed` are the reference's (src/pi_mpc/mppi.py:24-47).
 
@@ -113,6 +114,8 @@ class MPPI(nn.Module):
         if essps_search not in ("grid", "brentq"):
             raise ValueError("essps_search must be 'grid' or 'brentq'")
         self._essps_search = essps_search
+        assert sg_filter in ("device", "host")
+        self._sg_on_device = sg_filter == "device"
         if noise_source not in ("philox", "torch_cpu"):
             raise ValueError("noise_source must be 'philox' or 'torch_cpu'")
         self._noise_source = noise_source
@@ -171,7 +174,10 @@ class MPPI(nn.Module):
 
         # ---- Savitzky-Golay (src/pi_mpc/mppi.py:160-165); raises ValueError like the reference
         self._coeffs = _host.savitzky_golay_coeffs(sg_window_size, sg_poly_order)
-        self._actions_history_for_sg = np.zeros((horizon - 1, dim_control), np.float32)
+        self._sg_history_host = np.zeros((horizon - 1, dim_control), np.float32)
+        # the device filter holds one thread per element of the action sequence and needs T >= 2
+        self._sg_on_device = (self._sg_on_device and use_sg_filter and horizon >= 2
+                              and horizon * dim_control <= 1024)
 
         # ---- device handle
         cfg = _capi.MppiConfig()
@@ -187,6 +193,8 @@ class MPPI(nn.Module):
         cfg.seed = self._seed
         cfg.device = self._device.index
         self._h = _capi.Handle(cfg)
+        if self._sg_on_device:  # step 7 runs inside mppi_finalize (taps computed above, history zero)
+            self._h.call("mppi_set_sg_filter", self._coeffs.ctypes.data_as(C.c_void_p), int(len(self._coeffs)), None)
         self._uploaded = {}  # slot -> (id(cells), version)
         self._ref_uploaded = None
         self._x0_keep = None
@@ -291,7 +299,7 @@ class MPPI(nn.Module):
         self._h.call("mppi_set_mean", _ptr(m), 1, self._stream())
         torch.cuda.current_stream(self._device).synchronize()
         if sg_history is not None:
-            self._actions_history_for_sg = np.asarray(sg_history, np.float32).copy()
+            self._actions_history_for_sg = np.asarray(sg_history, np.float32)
 
     def stage_times_ms(self) -> Dict[str, float]:
         """Mean device time per stage since the last call (needs set_option('timing', 1))."""
@@ -310,6 +318,25 @@ class MPPI(nn.Module):
                                                 dtype=self._dtype)
         self._h.call("mppi_set_mean", _ptr(self._previous_action_seq), 1, self._stream())
         self._actions_history_for_sg = np.zeros((self._horizon - 1, self._dim_control), np.float32)
+
+    @property
+    def _actions_history_for_sg(self) -> np.ndarray:
+        """The last T-1 applied (filtered) first actions (src/pi_mpc/mppi.py:166,441-443); lives on the device
+        when the filter runs there."""
+        if self._sg_on_device:
+            out = np.empty((self._horizon - 1, self._dim_control), np.float32)
+            self._h.call("mppi_get_sg_history", out.ctypes.data_as(C.c_void_p))
+            return out
+        return self._sg_history_host
+
+    @_actions_history_for_sg.setter
+    def _actions_history_for_sg(self, value) -> None:
+        hist = np.ascontiguousarray(value, dtype=np.float32).reshape(self._horizon - 1, self._dim_control).copy()
+        if self._sg_on_device:
+            self._h.call("mppi_set_sg_filter", self._coeffs.ctypes.data_as(C.c_void_p), int(len(self._coeffs)),
+                         hist.ctypes.data_as(C.c_void_p))
+        else:
+            self._sg_history_host = hist
 
     # ------------------------------------------------------------------ forward
     def forward(self, state: torch.Tensor, info: Dict = {}) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -378,7 +405,7 @@ class MPPI(nn.Module):
             summaries, nsh = all_gather_summaries(self._summary, self._pg), self._world
 
         # Steps 6-8: normalise, warm start, batch-1 rollout (src/pi_mpc/mppi.py:381-385,448-452)
-        use_sg = self._use_sg_filter
+        use_sg = self._use_sg_filter and not self._sg_on_device  # host round trip only for sg_filter="host"
         # fresh output tensors every solve (the kernel writes straight into what is returned)
         self._action_out = torch.empty(self._horizon, self._dim_control, device=self._device, dtype=self._dtype)
         self._state_out = torch.empty(1, self._horizon + 1, self._dim_state, device=self._device, dtype=self._dtype)

@@ -864,3 +864,24 @@ def test_wave_parallel_batch1_rollout_is_bit_identical_to_the_serial_one():
     P = oracle_problem("racing", 1, 50)
     ref = P.rollout_single(x0.numpy(), a.cpu().numpy())
     assert rel_err(s.cpu().numpy()[0], ref) < TOL
+
+
+def test_device_sg_filter_equals_the_host_statement():
+    """Step 7 inside finalize_kernel (sg_filter="device", default) against the host numpy statement of the reference's
+    filter (sg_filter="host"): same taps, same accumulation order -> identical actions, states and history, over a
+    closed loop that fills the history; also a wider window and two control dimensions."""
+    for model, T, N, kw in (("cartpole", 64, 1024, dict()), ("cartpole", 12, 256, dict(sg_window_size=9, sg_poly_order=4)),
+                            ("nav2d", 30, 512, dict(sg_window_size=7, sg_poly_order=2))):
+        dev, _ = make_solver(model, T, N, lambda_=1.0, use_sg_filter=True, **kw)
+        host, _ = make_solver(model, T, N, lambda_=1.0, use_sg_filter=True, sg_filter="host", **kw)
+        assert dev._sg_on_device and not host._sg_on_device
+        x = torch.tensor([0.01, 0.0, 0.02, 0.0]) if model == "cartpole" else torch.tensor([-9.0, -9.0, 0.785])
+        for tick in range(8):
+            a_d, s_d = dev.forward(x)
+            a_h, s_h = host.forward(x)
+            assert torch.equal(a_d, a_h), f"{model} tick {tick}"
+            assert torch.equal(s_d, s_h)
+            assert np.array_equal(dev._actions_history_for_sg, host._actions_history_for_sg)
+            x = s_d[0, 1].clone()
+        dev.reset()
+        assert not dev._actions_history_for_sg.any()
