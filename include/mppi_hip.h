@@ -236,6 +236,26 @@ int mppi_top_candidates(mppi_handle_t h, int k, uint64_t* cand_out_dev, void* st
 int mppi_rollout_candidates(mppi_handle_t h, const uint64_t* cand_dev, int k, float lambda, float* states_out_dev,
                             float* weights_out_dev, void* stream);
 
+/* Peer-to-peer exchange of the shard summaries (one process per GPU, same node): instead of an all_gather between
+ * mppi_weights_reduce and mppi_finalize, every rank stores its 4+T*dc summary straight into all peers' exchange
+ * buffers (fine-grained device memory shared through HIP IPC, 8-byte {value, sequence} cells so that data and
+ * readiness arrive in one store) and mppi_finalize polls its own buffer.
+ *   mppi_p2p_alloc    allocate this rank's buffer, return its 64-byte IPC handle (exchange the handles of all
+ *                     ranks with any host-side collective)
+ *   mppi_p2p_connect  map the peers' buffers: handles_host [world][64] and the ranks' HIP device ordinals
+ *                     peer_devices_host [world], both in rank order; refuses (MPPI_E_STATE) unless every peer device
+ *                     is visible and hipDeviceCanAccessPeer says it is directly addressable
+ *   mppi_p2p_exchange one stand-alone exchange (self-test): data_dev [4+T*dc] -> gathered_out_dev [world][4+T*dc];
+ *                     MPPI_E_STATE if a poll timed out (~20 s).  Synchronises.
+ *   option "exchange_p2p" = 1: mppi_weights_reduce publishes the summary to the peers, and mppi_finalize called with
+ *                     summaries_dev = NULL combines all `world` shards from the buffer.  Every rank must issue the
+ *                     same sequence of reduce / exchange calls.
+ *   mppi_p2p_error    1 once any poll on this handle timed out (results of that solve are void). */
+int mppi_p2p_alloc(mppi_handle_t h, int world, int rank, void* ipc_handle_out64);
+int mppi_p2p_connect(mppi_handle_t h, const void* ipc_handles_host, const int32_t* peer_devices_host);
+int mppi_p2p_exchange(mppi_handle_t h, const float* data_dev, float* gathered_out_dev, void* stream);
+int mppi_p2p_error(mppi_handle_t h);
+
 /* Tuning knobs (not in the reference): "math" 0 = library sin/cos/tan/fmod/div, 1 = range-checked
  * fast paths (default); "noise_regen" (see mppi_sample); "mapping" 0 = lane per trajectory (default), 1 =
  * the north star's literal wavefront-per-trajectory rollout (comparison only, ~20x slower); "reduce_blocks" grid of the weighted

@@ -26,7 +26,7 @@ SYMBOLS = [
     "mppi_download_map", "mppi_set_reference", "mppi_set_mean", "mppi_get_mean",
     "mppi_set_state", "mppi_bind_state", "mppi_sample", "mppi_inject_noise", "mppi_export_noise", "mppi_rollout_cost",
     "mppi_get_costs", "mppi_set_costs", "mppi_weights_reduce", "mppi_finalize", "mppi_set_sg_filter", "mppi_get_sg_history", "mppi_softmax_stats", "mppi_softmax_stats_multi", "mppi_essps_lambda", "mppi_weights",
-    "mppi_rollout_actions", "mppi_rollout_samples", "mppi_top_samples", "mppi_top_candidates", "mppi_rollout_candidates", "mppi_set_option", "mppi_get_timing",
+    "mppi_p2p_alloc", "mppi_p2p_connect", "mppi_p2p_exchange", "mppi_p2p_error", "mppi_rollout_actions", "mppi_rollout_samples", "mppi_top_samples", "mppi_top_candidates", "mppi_rollout_candidates", "mppi_set_option", "mppi_get_timing",
 ]
 
 
@@ -67,6 +67,10 @@ def load():
     lib.mppi_build_obstacle_map.argtypes = [vp, i32, i32, i32, f32, f32, f32, vp, i32, vp, i32, vp]
     lib.mppi_build_lane_map.argtypes = [vp, i32, i32, i32, f32, f32, f32, vp, i32, C.c_int64, vp]
     lib.mppi_download_map.argtypes = [vp, i32, vp, vp, vp]
+    lib.mppi_p2p_alloc.argtypes = [vp, i32, i32, vp]
+    lib.mppi_p2p_connect.argtypes = [vp, vp, vp]
+    lib.mppi_p2p_exchange.argtypes = [vp, vp, vp, vp]
+    lib.mppi_p2p_error.argtypes = [vp]
     lib.mppi_set_sg_filter.argtypes = [vp, vp, i32, vp]
     lib.mppi_get_sg_history.argtypes = [vp, vp]
     lib.mppi_top_samples.argtypes = [vp, i32, f32, vp, vp, vp]

@@ -50,6 +50,15 @@ struct MppiSolver {
     unsigned* topk_hist = nullptr;   // [3][TOPK_BINS] + 2 counters, kept zeroed between calls
     TopkSel* topk_sel = nullptr;     // [3]
     unsigned long long* topk_cand = nullptr;  // [TOPK_MAX]
+    // peer-to-peer exchange of the shard summaries (mppi_p2p_*): off unless connected and enabled
+    unsigned long long* p2p_local = nullptr;       // this rank's exchange buffer (fine-grained, IPC-exported)
+    unsigned long long** p2p_peers_dev = nullptr;  // device array [world] of every rank's buffer as mapped here
+    std::vector<void*> p2p_opened;                 // peer mappings to close
+    int* p2p_error = nullptr;                      // mapped pinned flag raised by a timed-out poll
+    int* p2p_error_dev = nullptr;
+    int p2p_world = 0, p2p_rank = 0, p2p_lenp = 0;
+    unsigned p2p_seq = 0;
+    bool p2p_connected = false, p2p_enabled = false;
     float* sg_coeffs = nullptr;      // Savitzky-Golay taps (device), window sg_window (0 = filter off)
     float* sg_history = nullptr;     // [T-1][dc] `_actions_history_for_sg` (mppi.py:160-166,441-443)
     int sg_window = 0;
@@ -231,6 +240,10 @@ int upload_ints(mppi_handle_t h, const int32_t* src, size_t count, int32_t** dst
     return MPPI_OK;
 }
 
+P2pCtx p2p_ctx(mppi_handle_t h) {
+    return P2pCtx{h->p2p_peers_dev, h->p2p_local, h->p2p_error_dev, h->p2p_world, h->p2p_rank, h->p2p_lenp, h->p2p_seq};
+}
+
 }  // namespace
 
 extern "C" {
@@ -327,6 +340,9 @@ int mppi_destroy(mppi_handle_t h) {
     (void)hipFree(h->map_pad); (void)hipFree(h->stats_part); (void)hipFree(h->noise_std);
     if (h->stats_host) (void)hipHostFree(h->stats_host);
     if (h->live_hint) (void)hipHostFree(h->live_hint);
+    for (void* pm : h->p2p_opened) (void)hipIpcCloseMemHandle(pm);
+    (void)hipFree(h->p2p_local); (void)hipFree(h->p2p_peers_dev);
+    if (h->p2p_error) (void)hipHostFree(h->p2p_error);
     for (int i = 0; i < MppiSolver::RING; ++i) {
         if (h->stage[i]) (void)hipHostFree(h->stage[i]);
         if (h->stage_ev[i]) (void)hipEventDestroy(h->stage_ev[i]);
@@ -665,12 +681,18 @@ int mppi_weights_reduce(mppi_handle_t h, float lambda, float* summary_out_dev, v
     // (*live_hint, written by finalize_kernel to mapped host memory and read here without synchronising: it only
     // steers this choice, both paths give the same summary).
     h->summary_valid = false;
-    if (summary_out_dev || *(volatile int*)h->live_hint > FOLD_IN_FINALIZE_MAX_ROWS) {
+    if (summary_out_dev || h->p2p_enabled || *(volatile int*)h->live_hint > FOLD_IN_FINALIZE_MAX_ROWS) {
         const unsigned sgrid = (unsigned)((h->colsp + SUM_COLS - 1) / SUM_COLS + 1);
         hipLaunchKernelGGL(summarize_kernel, dim3(sgrid), dim3(SUM_BLOCK), 0, s, h->partials, h->heads, mk, (int)blocks,
                            h->colsp, h->d.row, h->summary, summary_out_dev, h->live_hint_dev);
         HIP_TRY(h, hipGetLastError());
         h->summary_valid = true;
+    }
+    if (h->p2p_enabled) {  // hand the summary to every peer (and to this rank's own slot)
+        ++h->p2p_seq;
+        if (h->p2p_seq == 0) h->p2p_seq = 1;
+        hipLaunchKernelGGL(p2p_publish_kernel, dim3(1), dim3(BLOCK), 0, s, h->summary, MPPI_SUMMARY_HEAD + h->d.row, p2p_ctx(h));
+        HIP_TRY(h, hipGetLastError());
     }
     return MPPI_OK;
 }
@@ -683,21 +705,28 @@ int mppi_finalize(mppi_handle_t h, const float* summaries_dev, int num_shards, f
     if (!generic) { if (int rc = check_ready(h)) return rc; }
     hipStream_t s = (hipStream_t)stream;
     StageTimer tm(h, 3, s);
+    P2pCtx p2p{};  // seq == 0: off
     if (!summaries_dev) {  // this handle's own reduction (mppi_weights_reduce)
         if (h->last_reduce_blocks < 1) return fail(h, MPPI_E_STATE, "mppi_finalize before mppi_weights_reduce");
-        if (h->summary_valid) summaries_dev = h->summary;  // else the kernel folds the partial rows itself
-        num_shards = 1;
+        if (h->p2p_enabled) {
+            p2p = p2p_ctx(h);  // all shards' summaries of this solve, through the exchange buffer
+            num_shards = h->p2p_world;
+        } else {
+            if (h->summary_valid) summaries_dev = h->summary;  // else the kernel folds the partial rows itself
+            num_shards = 1;
+        }
     }
     // the filter replaces the stored warm start, so it only runs when this call stores it (mppi.py:441-452)
     const SgFilter sg{h->sg_coeffs, h->sg_history, (store_mean && h->sg_window > 0) ? h->sg_window : 0};
-    const size_t shmem = sizeof(float) * ((size_t)2 * h->d.row + MPPI_SUMMARY_HEAD +
+    const size_t shmem = sizeof(float) * ((size_t)h->d.row + (size_t)(p2p.seq ? p2p.world : 1) * (h->d.row + MPPI_SUMMARY_HEAD) +
                                           (sg.window ? (size_t)(2 * h->d.T - 1 + 2 * (sg.window / 2)) * h->dc : 0));
+    if (shmem > 64 * 1024) return fail(h, MPPI_E_INVALID, "finalize: horizon too long for the exchange / filter staging");
     const unsigned* mk = h->min_key + h->min_slot;
 #define CALL_FINALIZE(MODEL, FASTV)                                                                   \
     hipLaunchKernelGGL((finalize_kernel<MODEL, FASTV>), dim3(1), dim3(FIN_BLOCK), shmem, s, summaries_dev, num_shards, \
                        h->partials, h->heads, mk, h->last_reduce_blocks, h->colsp, h->summary, h->live_hint_dev,  \
                        lambda, h->d.row, h->d.T, h->x0_cur, store_mean ? h->mean : (float*)nullptr, action_out,  \
-                       state_out, stats_out, h->solve_stats, sg, h->ctx)
+                       state_out, stats_out, h->solve_stats, sg, p2p, h->ctx)
     MPPI_DISPATCH(h, CALL_FINALIZE);
 #undef CALL_FINALIZE
     HIP_TRY(h, hipGetLastError());
@@ -922,6 +951,74 @@ int mppi_rollout_candidates(mppi_handle_t h, const uint64_t* cand_dev, int k, fl
                         false, (hipStream_t)stream);
 }
 
+// ---- peer-to-peer exchange of the shard summaries (sharded solves; see P2pCtx in mppi_kernels.hpp)
+int mppi_p2p_alloc(mppi_handle_t h, int world, int rank, void* ipc_handle_out64) {
+    if (!h || !ipc_handle_out64 || world < 2 || world > 64 || rank < 0 || rank >= world)
+        return fail(h, MPPI_E_INVALID, "bad p2p arguments");
+    if (h->p2p_local) return fail(h, MPPI_E_STATE, "p2p buffer already allocated");
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "ipc handle size");
+    h->p2p_world = world; h->p2p_rank = rank;
+    h->p2p_lenp = ((MPPI_SUMMARY_HEAD + h->d.row + 15) / 16) * 16;
+    const size_t bytes = sizeof(unsigned long long) * 2 * (size_t)world * h->p2p_lenp;
+    HIP_TRY(h, hipExtMallocWithFlags((void**)&h->p2p_local, bytes, hipDeviceMallocFinegrained));
+    HIP_TRY(h, hipMemset(h->p2p_local, 0, bytes));
+    HIP_TRY(h, hipDeviceSynchronize());
+    HIP_TRY(h, hipHostMalloc((void**)&h->p2p_error, sizeof(int), hipHostMallocMapped));
+    *h->p2p_error = 0;
+    HIP_TRY(h, hipHostGetDevicePointer((void**)&h->p2p_error_dev, h->p2p_error, 0));
+    HIP_TRY(h, hipIpcGetMemHandle(reinterpret_cast<hipIpcMemHandle_t*>(ipc_handle_out64), h->p2p_local));
+    return MPPI_OK;
+}
+
+int mppi_p2p_connect(mppi_handle_t h, const void* ipc_handles_world_x64, const int32_t* peer_devices) {
+    if (!h || !ipc_handles_world_x64 || !peer_devices) return fail(h, MPPI_E_INVALID, "bad p2p arguments");
+    if (!h->p2p_local || h->p2p_connected) return fail(h, MPPI_E_STATE, "p2p: allocate first, connect once");
+    // every peer GPU must be directly addressable from this one (xGMI / PCIe peer access) before any store goes out
+    int ndev = 0;
+    HIP_TRY(h, hipGetDeviceCount(&ndev));
+    for (int w = 0; w < h->p2p_world; ++w) {
+        const int pd = peer_devices[w];
+        if (w == h->p2p_rank || pd == h->cfg.device) continue;
+        if (pd < 0 || pd >= ndev) return fail(h, MPPI_E_STATE, "p2p: a peer's device is not visible to this process");
+        int can = 0;
+        HIP_TRY(h, hipDeviceCanAccessPeer(&can, h->cfg.device, pd));
+        if (!can) return fail(h, MPPI_E_STATE, "p2p: no peer access to a rank's device");
+    }
+    std::vector<unsigned long long*> peers((size_t)h->p2p_world, nullptr);
+    const hipIpcMemHandle_t* hs = reinterpret_cast<const hipIpcMemHandle_t*>(ipc_handles_world_x64);
+    for (int w = 0; w < h->p2p_world; ++w) {
+        if (w == h->p2p_rank) { peers[w] = h->p2p_local; continue; }
+        void* pm = nullptr;
+        HIP_TRY(h, hipIpcOpenMemHandle(&pm, hs[w], hipIpcMemLazyEnablePeerAccess));
+        h->p2p_opened.push_back(pm);
+        peers[w] = static_cast<unsigned long long*>(pm);
+    }
+    HIP_TRY(h, hipMalloc(&h->p2p_peers_dev, sizeof(unsigned long long*) * (size_t)h->p2p_world));
+    HIP_TRY(h, hipMemcpy(h->p2p_peers_dev, peers.data(), sizeof(unsigned long long*) * (size_t)h->p2p_world, hipMemcpyHostToDevice));
+    h->p2p_connected = true;
+    return MPPI_OK;
+}
+
+// One exchange of `data_dev` [4 + T*dc] outside a solve (self-test; every rank must call it the same number of
+// times): gathered_out_dev [world][4 + T*dc].  Returns MPPI_E_STATE when a poll timed out.  Synchronises.
+int mppi_p2p_exchange(mppi_handle_t h, const float* data_dev, float* gathered_out_dev, void* stream) {
+    if (!h || !data_dev || !gathered_out_dev) return fail(h, MPPI_E_INVALID, "bad p2p arguments");
+    if (!h->p2p_connected) return fail(h, MPPI_E_STATE, "p2p: not connected");
+    hipStream_t s = (hipStream_t)stream;
+    ++h->p2p_seq;
+    if (h->p2p_seq == 0) h->p2p_seq = 1;
+    const int len = MPPI_SUMMARY_HEAD + h->d.row;
+    hipLaunchKernelGGL(p2p_publish_kernel, dim3(1), dim3(BLOCK), 0, s, data_dev, len, p2p_ctx(h));
+    hipLaunchKernelGGL(p2p_collect_kernel, dim3(1), dim3(BLOCK), 0, s, p2p_ctx(h), len, gathered_out_dev);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipStreamSynchronize(s));
+    if (*(volatile int*)h->p2p_error) return fail(h, MPPI_E_STATE, "p2p exchange timed out");
+    return MPPI_OK;
+}
+
+// 1 if a poll of the exchange buffer ever timed out on this handle (read without synchronising)
+int mppi_p2p_error(mppi_handle_t h) { return (h && h->p2p_error) ? *(volatile int*)h->p2p_error : 0; }
+
 int mppi_set_option(mppi_handle_t h, const char* key, int64_t value) {
     if (!h || !key) return MPPI_E_INVALID;
     const std::string k(key);
@@ -929,6 +1026,11 @@ int mppi_set_option(mppi_handle_t h, const char* key, int64_t value) {
     if (k == "reduce_blocks") { h->reduce_blocks = (int)std::max<int64_t>(1, std::min<int64_t>(value, 2048)); return MPPI_OK; }
     if (k == "timing") { h->timing = (int)value; return MPPI_OK; }
     if (k == "mapping") { h->mapping = value ? 1 : 0; return MPPI_OK; }
+    if (k == "exchange_p2p") {  // sharded solves: summaries travel through the peer-to-peer buffer, no collective
+        if (value && !h->p2p_connected) return fail(h, MPPI_E_STATE, "exchange_p2p: call mppi_p2p_alloc / mppi_p2p_connect first");
+        h->p2p_enabled = value != 0;
+        return MPPI_OK;
+    }
     if (k == "noise_regen") { h->noise_regen = value ? 1 : 0; h->tiles_valid = h->tiles_valid && h->injected; return MPPI_OK; }
     return fail(h, MPPI_E_INVALID, "unknown option " + k);
 }

@@ -621,6 +621,62 @@ __device__ __forceinline__ void rollout_states_checked(const float* __restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// One-shot peer-to-peer exchange of the shard summaries (the sharded solve's only exchange) without a collective
+// launch: every rank stores its summary straight into all peers' exchange buffers over xGMI and the consumer
+// polls its own buffer.  Cells are 8 bytes {fp32 value, 32-bit sequence number} written with ONE store, so data and
+// "ready" flag cannot be seen apart (the idea of RCCL's low-latency protocol): no fence ordering is relied on.
+// Buffer of rank r (fine-grained device memory, IPC-mapped into every peer): cells[2][W][lenp]; solve `seq` uses
+// parity seq & 1 — a rank can be at most one solve ahead of the slowest one, because its next finalize needs
+// everybody's summary of that solve.
+struct P2pCtx {
+    unsigned long long* const* peers;  // [W] base of every rank's buffer as mapped here (device array)
+    unsigned long long* local;         // this rank's buffer
+    int* error;                        // mapped host flag: set when a poll timed out
+    int world, rank, lenp;
+    unsigned seq;                      // 0 = exchange off
+};
+
+__device__ __forceinline__ void p2p_store(unsigned long long* p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ unsigned long long p2p_load(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ __launch_bounds__(BLOCK) void p2p_publish_kernel(const float* __restrict__ summary, int len, P2pCtx x) {
+    const size_t slot = ((size_t)(x.seq & 1u) * x.world + x.rank) * x.lenp;
+    for (int j = threadIdx.x; j < len; j += BLOCK) {
+        const unsigned long long cell = ((unsigned long long)x.seq << 32) | (unsigned long long)__float_as_uint(summary[j]);
+        for (int w = 0; w < x.world; ++w) p2p_store(x.peers[w] + slot + j, cell);
+    }
+}
+
+// Block-wide: wait for the `len` cells of every rank of solve x.seq and unpack them to out[w * stride + j].
+// Polls give up after ~20 s of wall clock (100 MHz counter) and raise *x.error; the caller's results are then void.
+template <int NT>
+__device__ __forceinline__ void p2p_collect(const P2pCtx& x, int len, float* __restrict__ out, int stride) {
+    const long long t0 = wall_clock64();
+    for (int idx = threadIdx.x; idx < x.world * len; idx += NT) {
+        const int w = idx / len, j = idx - w * len;
+        const unsigned long long* cellp = x.local + ((size_t)(x.seq & 1u) * x.world + w) * x.lenp + j;
+        unsigned long long cell = p2p_load(cellp);
+        unsigned spins = 0;
+        while ((unsigned)(cell >> 32) != x.seq) {
+            if ((++spins & 1023u) == 0u && wall_clock64() - t0 > 2000000000ll) { *x.error = 1; break; }
+            __builtin_amdgcn_s_sleep(2);
+            cell = p2p_load(cellp);
+        }
+        out[w * stride + j] = __uint_as_float((unsigned)cell);
+    }
+    __syncthreads();
+}
+
+// self-test / generic use: collect into a plain device array [W][len]
+__global__ __launch_bounds__(BLOCK) void p2p_collect_kernel(P2pCtx x, int len, float* __restrict__ out) {
+    p2p_collect<BLOCK>(x, len, out, len);
+}
+
 // Combine shard summaries, normalise, store the warm start, roll the result out with batch 1
 // (mppi.py:381-385,448-452,508-524).
 // `summaries` != nullptr: `num_shards` summary vectors (the all_gathered shards, or this handle's own summary
@@ -642,15 +698,19 @@ __global__ __launch_bounds__(FIN_BLOCK) void finalize_kernel(const float* __rest
                                                              float* __restrict__ state_out,
                                                              float* __restrict__ stats_out,
                                                              float* __restrict__ stats_keep, SgFilter sg,
-                                                             ModelCtx ctx) {
+                                                             P2pCtx p2p, ModelCtx ctx) {
     constexpr int DC = ModelT<MODEL, FAST>::DC;
-    // [row] action, [4 + row] own summary, then (SG filter) [(2T-1+2*(w/2))*dc] padded sequence
+    // [row] action, [max(1, W) * (4 + row)] own / collected summaries, then (SG filter) [(2T-1+2*(w/2))*dc]
     extern __shared__ __attribute__((aligned(16))) float s_fin[];
+    const int stride = MPPI_SUMMARY_HEAD + row;
     float* s_act = s_fin;
     float* s_sum = s_fin + row;
-    float* s_yp = s_fin + 2 * row + MPPI_SUMMARY_HEAD;
-    const int stride = MPPI_SUMMARY_HEAD + row;
-    if (summaries == nullptr) {
+    float* s_yp = s_sum + (p2p.seq ? p2p.world : 1) * stride;
+    if (p2p.seq) {  // the shards' summaries arrive through the peer-to-peer exchange buffer
+        p2p_collect<FIN_BLOCK>(p2p, stride, s_sum, stride);
+        summaries = s_sum;
+        num_shards = p2p.world;
+    } else if (summaries == nullptr) {
         constexpr int NG = FIN_BLOCK / 128;
         __shared__ float s_part[NG][128 + 1];
         __shared__ unsigned short s_list[REDUCE_MAX_BLOCKS];

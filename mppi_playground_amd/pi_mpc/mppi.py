@@ -216,6 +216,9 @@ class MPPI(nn.Module):
         self._stats = torch.zeros(4, device=self._device, dtype=dtype)
         self._summary = torch.zeros(_capi.SUMMARY_HEAD + T * dcn, device=self._device, dtype=dtype)
         self._gathered = None
+        self._p2p = False
+        if self._world > 1:
+            self._setup_exchange()
         self._previous_action_seq = torch.zeros(T, dcn, device=self._device, dtype=dtype)
         self._last_lambda = None
         self._injected = None
@@ -284,6 +287,62 @@ class MPPI(nn.Module):
         out = np.empty((nx.value, ny.value), np.uint8)
         self._h.call("mppi_download_map", slot, out.ctypes.data_as(C.c_void_p), None, None)
         return out
+
+    def _setup_exchange(self) -> None:
+        """Pick the per-solve exchange of a sharded solver.  MPPI_EXCHANGE = "nccl": one all_gather per solve
+        (torch.distributed);  "auto" (default): try the library's peer-to-peer buffer exchange (mppi_p2p_*: no
+        collective launch on the critical path), verify it with a few pattern exchanges, and use it only if
+        EVERY rank succeeded — otherwise all ranks fall back to the all_gather together;  "p2p": as auto, but raise
+        instead of falling back."""
+        import os
+
+        import torch.distributed as dist
+
+        mode = os.environ.get("MPPI_EXCHANGE", "auto").lower()
+        if mode == "nccl":
+            return
+        W, r, length = self._world, self._rank, int(self._summary.numel())
+
+        def all_ok(ok: bool) -> bool:  # agreement point: every rank takes the same branch afterwards
+            t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self._device)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self._pg)
+            return bool(int(t.item()))
+
+        why = ""
+        handle = (C.c_ubyte * 64)()
+        ok = True
+        try:
+            self._h.call("mppi_p2p_alloc", W, r, handle)
+        except _capi.MppiError as e:
+            ok, why = False, str(e)
+        if all_ok(ok):
+            # 64 handle bytes + this rank's device ordinal
+            mine = torch.tensor(list(bytes(handle)) + [int(self._device.index)], dtype=torch.uint8, device=self._device)
+            allh = torch.empty(W * 65, dtype=torch.uint8, device=self._device)
+            dist.all_gather_into_tensor(allh, mine, group=self._pg)
+            rows = allh.cpu().numpy().reshape(W, 65)
+            blob = (C.c_ubyte * (64 * W)).from_buffer_copy(rows[:, :64].tobytes())
+            devs = (C.c_int32 * W)(*[int(v) for v in rows[:, 64]])
+            try:
+                self._h.call("mppi_p2p_connect", blob, devs)
+            except _capi.MppiError as e:
+                ok, why = False, str(e)
+            if all_ok(ok):
+                try:  # pattern exchanges: rank w sends 1000*w + j + round
+                    base = torch.arange(length, device=self._device, dtype=torch.float32)
+                    got = torch.empty(W, length, device=self._device, dtype=torch.float32)
+                    for rnd in range(3):
+                        self._h.call("mppi_p2p_exchange", _ptr(base + (1000.0 * r + rnd)), _ptr(got), self._stream())
+                        want = base[None, :] + (1000.0 * torch.arange(W, device=self._device)[:, None] + rnd)
+                        ok = ok and bool(torch.equal(got, want))
+                except _capi.MppiError as e:
+                    ok, why = False, str(e)
+                if all_ok(ok):
+                    self._h.call("mppi_set_option", b"exchange_p2p", 1)
+                    self._p2p = True
+                    return
+        if mode == "p2p":
+            raise _capi.MppiError("MPPI_EXCHANGE=p2p: the peer-to-peer exchange is not usable here: " + (why or "self-test mismatch"))
 
     def inject_noise(self, eps: torch.Tensor) -> None:
         """Parity hook: use `eps` [N_local,T,dc] (already scaled by sigma) for the next solve instead of
@@ -399,10 +458,16 @@ class MPPI(nn.Module):
 
         # Steps 5-6: weights + weighted mean (src/pi_mpc/mppi.py:376-385)
         sharded = self._world > 1
-        h.call("mppi_weights_reduce", lam, _ptr(self._summary) if sharded else None, st)
         summaries, nsh = None, 1
-        if sharded:  # the only exchange of the solve: 4+T*dc floats per rank over RCCL/xGMI
-            summaries, nsh = all_gather_summaries(self._summary, self._pg), self._world
+        if self._p2p:  # the shard summaries travel through the peer-to-peer buffers: no collective launch
+            if h.lib.mppi_p2p_error(h.h):
+                raise _capi.MppiError("peer-to-peer exchange timed out on an earlier solve (a rank is missing or stalled)")
+            h.call("mppi_weights_reduce", lam, None, st)
+            nsh = self._world
+        else:
+            h.call("mppi_weights_reduce", lam, _ptr(self._summary) if sharded else None, st)
+            if sharded:  # the only exchange of the solve: 4+T*dc floats per rank over RCCL/xGMI
+                summaries, nsh = all_gather_summaries(self._summary, self._pg), self._world
 
         # Steps 6-8: normalise, warm start, batch-1 rollout (src/pi_mpc/mppi.py:381-385,448-452)
         use_sg = self._use_sg_filter and not self._sg_on_device  # host round trip only for sg_filter="host"

@@ -438,17 +438,19 @@ def test_shard_invariance_and_combine():
     assert abs(st[1] - stats_full["sum_e"]) <= 1e-5 * stats_full["sum_e"]
 
 
-def _sharded_worker(rank, world, port, q):
+def _sharded_worker(rank, world, port, q, exchange="nccl"):
     import os
 
     import torch.distributed as dist
 
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ["MPPI_EXCHANGE"] = exchange
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import mppi_playground_amd  # noqa: F401
 
         solver, ctrl = make_solver("racing", 50, 8192, lambda_=5000.0, shard_samples=True)
+        assert solver._p2p == (exchange == "p2p")
         env = _envs["racing"]
         x0 = env._robot_state.clone()
         ref, _ = ctrl.calc_ref_trajectory(x0, env.racing_center_path, 0, 50, DL=0.1, lookahead_distance=3,
@@ -458,16 +460,20 @@ def _sharded_worker(rank, world, port, q):
         a2, s2 = solver.forward(x0)
         st = solver.last_stats()
         ts, tw = solver.get_top_samples(24)  # sharded: candidates merged across ranks, re-rolled on every rank
+        for _ in range(50):  # many back-to-back solves: the exchange buffers alternate, ranks drift apart freely
+            a3, _ = solver.forward(x0)
         q.put((rank, a1.cpu().numpy(), s1.cpu().numpy(), a2.cpu().numpy(), st["sum_e"], st["cmin"],
-               ts.cpu().numpy(), tw.cpu().numpy()))
+               ts.cpu().numpy(), tw.cpu().numpy(), a3.cpu().numpy()))
         dist.barrier()
     finally:
         dist.destroy_process_group()
 
 
-def test_two_rank_sharded_solver_matches_single():
-    """The whole sharded forward() (shard_samples=True, one all_gather of the 4+T*dc summary per solve)
-    with two ranks — both on this GPU, gloo instead of RCCL — against the unsharded solver."""
+@pytest.mark.parametrize("exchange", ["nccl", "p2p"])
+def test_two_rank_sharded_solver_matches_single(exchange):
+    """The whole sharded forward() (shard_samples=True) with two ranks — both on this GPU, gloo instead of RCCL —
+    against the unsharded solver; exchange = one all_gather of the 4+T*dc summary per solve, or the library's
+    peer-to-peer buffer exchange (IPC-mapped fine-grained buffers, polled by finalize_kernel)."""
     _need_gpu()
     import socket
 
@@ -476,7 +482,7 @@ def test_two_rank_sharded_solver_matches_single():
     sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q, exchange)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=180) for _ in range(2)], key=lambda r: r[0])
@@ -497,6 +503,11 @@ def test_two_rank_sharded_solver_matches_single():
         assert rel_err(r[6], ts.cpu().numpy()) < 1e-5
         assert rel_err(r[7], tw.cpu().numpy()) < 1e-5
     assert np.array_equal(res[0][6], res[1][6]) and np.array_equal(res[0][7], res[1][7])
+    for _ in range(50):
+        a3, _ = single.forward(x0)
+    for r in res:
+        assert rel_err(r[8], a3.cpu().numpy()) < 5e-3  # 52 warm-started solves amplify the last-bit differences of the combine
+    assert np.array_equal(res[0][8], res[1][8])
     for r in res:  # every rank ends up with the same, correct answer
         assert rel_err(r[1], a1.cpu().numpy()) < 2e-6 and rel_err(r[2], s1.cpu().numpy()) < 2e-6
         assert rel_err(r[3], a2.cpu().numpy()) < 4e-6

@@ -181,7 +181,7 @@ def test_capi_exports_every_declared_symbol():
 
     _build.build()
     hdr = open(os.path.join(ROOT, "include", "mppi_hip.h")).read()
-    declared = set(re.findall(r"\b(mppi_[a-z_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(mppi_[a-z0-9_]+)\s*\(", hdr))
     assert declared == set(_capi.SYMBOLS)
     lib = ctypes.CDLL(_capi.LIB_PATH)
     for name in declared:
