@@ -158,7 +158,8 @@ def main():
                        "num_samples_per_gpu": N_local, "num_samples_total": N_total, "horizon": T,
                        "lambda": 1.0, "noise": "device philox4x32-10 (" + ("regenerated in registers" if args.noise_regen else "materialised tiles") + ")", "math": "fast" if args.math else "library",
                        "mapping": "lane-per-trajectory" if not args.mapping else "wavefront-per-trajectory",
-                       "sharding": f"num_samples x{world}" if world > 1 else "none"},
+                       "sharding": f"num_samples x{world}" if world > 1 else "none",
+                       "exchange": ("peer-to-peer buffers" if solver._p2p else "all_gather") if world > 1 else "none"},
             "solves_per_sec": solves_per_s,
             "roofline": {"bound": "hbm", "kernel": "rollout_cost_kernel<racing>", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
