@@ -462,8 +462,15 @@ def _sharded_worker(rank, world, port, q, exchange="nccl"):
         ts, tw = solver.get_top_samples(24)  # sharded: candidates merged across ranks, re-rolled on every rank
         for _ in range(50):  # many back-to-back solves: the exchange buffers alternate, ranks drift apart freely
             a3, _ = solver.forward(x0)
+        # a second model on the same ranks: nav2d with an exploration split and the ESSPS search (sharded
+        # statistics: one all_gather per 32-temperature grid)
+        nav, _ = make_solver("nav2d", 30, 4096, lambda_="ESSPS", exploration=0.25, shard_samples=True)
+        xn = torch.tensor([-9.0, -9.0, 0.785])
+        nav.forward(xn)
+        an, sn = nav.forward(xn)
         q.put((rank, a1.cpu().numpy(), s1.cpu().numpy(), a2.cpu().numpy(), st["sum_e"], st["cmin"],
-               ts.cpu().numpy(), tw.cpu().numpy(), a3.cpu().numpy()))
+               ts.cpu().numpy(), tw.cpu().numpy(), a3.cpu().numpy(), an.cpu().numpy(), sn.cpu().numpy(),
+               nav._last_lambda))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -508,6 +515,14 @@ def test_two_rank_sharded_solver_matches_single(exchange):
     for r in res:
         assert rel_err(r[8], a3.cpu().numpy()) < 5e-3  # 52 warm-started solves amplify the last-bit differences of the combine
     assert np.array_equal(res[0][8], res[1][8])
+    nav, _ = make_solver("nav2d", 30, 4096, lambda_="ESSPS", exploration=0.25)
+    xn = torch.tensor([-9.0, -9.0, 0.785])
+    nav.forward(xn)
+    an, sn = nav.forward(xn)
+    for r in res:
+        assert abs(r[11] - nav._last_lambda) <= 1e-5 * nav._last_lambda
+        assert rel_err(r[9], an.cpu().numpy()) < 2e-5 and rel_err(r[10], sn.cpu().numpy()) < 2e-5
+    assert np.array_equal(res[0][9], res[1][9]) and res[0][11] == res[1][11]
     for r in res:  # every rank ends up with the same, correct answer
         assert rel_err(r[1], a1.cpu().numpy()) < 2e-6 and rel_err(r[2], s1.cpu().numpy()) < 2e-6
         assert rel_err(r[3], a2.cpu().numpy()) < 4e-6
