@@ -6,7 +6,7 @@ lambda=1.0 (BASELINE configs[2] = C3; with --gpus G it is C4: G*N samples sharde
 scaling, one all_gather of 4+T*dc floats per solve).  A "step" is one MPPI solve = one pass of the hot
 path: sample -> rollout+cost -> weights+reduce -> finalize, with every input resident in HBM.
 
-    python bench.py --gpus 1 --steps 50 --warmup 10
+    python bench.py --gpus 1 --steps 200 --warmup 20
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \\
         --master-port 29500 bench.py --gpus 8 --steps 50 --warmup 10
 
@@ -32,8 +32,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--samples", type=int, default=1 << 20, help="samples per GPU")
     ap.add_argument("--horizon", type=int, default=50)
     ap.add_argument("--math", type=int, default=1, help="1 = fast-path math (default), 0 = library math")
@@ -91,6 +91,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # set-up, before the contract's W warm-up steps: bring the device out of its idle power state (the first
+    # ~20 ms of load run at lower clocks) so that short --warmup values do not time the clock ramp
+    for _ in range(200):
+        solver.forward(x0)
+    sync()
     for _ in range(args.warmup):
         solver.forward(x0)
     sync()
