@@ -6,11 +6,11 @@ Same constructor, `forward(state, info={}) -> (action_seq[T,dc], state_seq[1,T+1
 `dynamics` / `cost_func` callables are the plugin surface (pi_mpc/native.py explains how the shipped
 models are recognised without changing the call site).
 
-Device work per solve (native models): sample -> rollout+cost -> weights+reduce -> finalize, four
-kernel launches on torch's current stream with no host synchronisation when lambda is fixed and the
-Savitzky-Golay filter is off.  Auto-lambda (ESSPS/LBPS/MPO) and the SG filter stay on the host as in
-the reference.  There is NO CPU fallback: without the built extension or without a GPU the
-constructor raises.
+Device work per solve (native models): rollout+cost (the noise is regenerated in registers) ->
+weights+reduce -> finalize (fold, normalise, Savitzky-Golay step if enabled, warm start, batch-1 rollout):
+three kernel launches on torch's current stream with no host synchronisation when lambda is fixed.  The
+auto-lambda searches (ESSPS/LBPS/MPO) are host code as in the reference, fed by softmax statistics reduced on
+the device.  There is NO CPU fallback: without the built extension or without a GPU the constructor raises.
 """
 from __future__ import annotations
 
@@ -74,12 +74,17 @@ class MPPI(nn.Module):
             auto_lambda_stats: "device" (default) evaluates the softmax sums of the ESSPS/LBPS/MPO searches
                 on the GPU (mppi_softmax_stats; the root-finders stay on the host), "host" copies
                 costs[N] to the CPU and evaluates them in numpy like the reference does.
-            essps_search: with device statistics, "grid" (default) brackets the ESSPS root with 32 lambdas
-                per pass over the costs (4 round trips), "brentq" probes one lambda at a time like the
-                reference's scipy call; both return the same root (to ~1e-9).
+            essps_search: with device statistics, "grid" (default) brackets the ESSPS root with two
+                32-temperature geometric grids (one pass over the costs each) and an inverse cubic
+                interpolation, "brentq" probes one lambda at a time like the reference's scipy call; both
+                return the same root (to ~1e-7 relative).
+            sg_filter: "device" (default) runs the Savitzky-Golay step inside the finalize kernel
+                (bit-identical to the host statement), "host" keeps the reference's numpy-style round trip.
             shard_samples: treat `num_samples` as the GLOBAL sample count and let this rank own the
                 contiguous block rank*N/W .. (rank+1)*N/W of it (torch.distributed must be
-                initialised); one all_gather of 4+T*dc floats per solve combines the shards.
+                initialised); the 4+T*dc-float shard summaries are exchanged once per solve — through
+                peer-to-peer buffers when the start-up self-test passes on every rank, else with one
+                all_gather (environment variable MPPI_EXCHANGE = auto | p2p | nccl).
         """
         super().__init__()
         assert u_min.shape == (dim_control,)
