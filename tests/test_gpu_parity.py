@@ -240,7 +240,9 @@ def test_device_top_k_selects_the_smallest_costs(N, k, lam):
 
 @pytest.mark.parametrize("model,T,N,expl", [("pendulum", 1, 5, 0.0), ("pendulum", 2, 64, 0.5), ("pendulum", 7, 65, 1.0),
                                             ("racing", 1, 3, 0.0), ("racing", 3, 130, 0.3), ("nav2d", 2, 1, 0.0),
-                                            ("cartpole", 5, 63, 0.0), ("mountaincar", 9, 200, 0.9)])
+                                            ("cartpole", 5, 63, 0.0), ("mountaincar", 9, 200, 0.9),
+                                            # long rows: 32 groups per wave (T*dc > 128), two column chunks (> 512)
+                                            ("racing", 80, 300, 0.2), ("nav2d", 300, 130, 0.1)])
 def test_edge_sizes_against_oracle(model, T, N, expl):
     """Ragged shapes: horizons shorter than one float4 group, sample counts that are not a multiple of 64
     (or smaller than a wave), exploration splits that fall inside a tile, all against the oracle."""
