@@ -913,3 +913,26 @@ def test_device_sg_filter_equals_the_host_statement():
             x = s_d[0, 1].clone()
         dev.reset()
         assert not dev._actions_history_for_sg.any()
+
+
+def test_reset_and_posterior_samples():
+    """reset() (mppi.py:212-221) zeroes the warm start; get_samples_from_posterior (mppi.py:489-506) returns
+    N(a, Sigma) action sequences (unclamped) and their batch rollouts — each checked against the oracle's rollout."""
+    solver, _ = make_solver("nav2d", 20, 512, lambda_=1.0)
+    x0 = torch.tensor([-9.0, -9.0, 0.785])
+    a, _ = solver.forward(x0)
+    assert float(a.abs().max()) > 0
+    samples, states = solver.get_samples_from_posterior(a, x0, 16)
+    assert samples.shape == (16, 20, 2) and states.shape == (16, 21, 3)
+    spread = (samples - a[None]).std(dim=0).mean(dim=0).cpu().numpy()
+    assert np.all(np.abs(spread - np.array([0.5, 0.5])) < 0.2)  # sigma = 0.5 per control, 16 x 20 draws
+    P = oracle_problem("nav2d", 1, 20)
+    for i in range(16):
+        ref = P.rollout_single(x0.numpy(), samples[i].cpu().numpy())
+        assert rel_err(states[i].cpu().numpy(), ref) < TOL
+    solver.reset()
+    h = (C.c_float * 40)()
+    solver._h.call("mppi_get_mean", h, 0, solver._stream())
+    assert not any(h) and not solver._previous_action_seq.any()
+    a2, _ = solver.forward(x0)  # solving again from a zero warm start works
+    assert torch.isfinite(a2).all()
