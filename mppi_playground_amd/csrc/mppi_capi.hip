@@ -681,18 +681,18 @@ int mppi_weights_reduce(mppi_handle_t h, float lambda, float* summary_out_dev, v
     // (*live_hint, written by finalize_kernel to mapped host memory and read here without synchronising: it only
     // steers this choice, both paths give the same summary).
     h->summary_valid = false;
+    P2pCtx p2p{};
+    if (h->p2p_enabled) {  // summarize_kernel also hands the summary to every peer (and to this rank's own slot)
+        ++h->p2p_seq;
+        if (h->p2p_seq == 0) h->p2p_seq = 1;
+        p2p = p2p_ctx(h);
+    }
     if (summary_out_dev || h->p2p_enabled || *(volatile int*)h->live_hint > FOLD_IN_FINALIZE_MAX_ROWS) {
         const unsigned sgrid = (unsigned)((h->colsp + SUM_COLS - 1) / SUM_COLS + 1);
         hipLaunchKernelGGL(summarize_kernel, dim3(sgrid), dim3(SUM_BLOCK), 0, s, h->partials, h->heads, mk, (int)blocks,
-                           h->colsp, h->d.row, h->summary, summary_out_dev, h->live_hint_dev);
+                           h->colsp, h->d.row, h->summary, summary_out_dev, h->live_hint_dev, p2p);
         HIP_TRY(h, hipGetLastError());
         h->summary_valid = true;
-    }
-    if (h->p2p_enabled) {  // hand the summary to every peer (and to this rank's own slot)
-        ++h->p2p_seq;
-        if (h->p2p_seq == 0) h->p2p_seq = 1;
-        hipLaunchKernelGGL(p2p_publish_kernel, dim3(1), dim3(BLOCK), 0, s, h->summary, MPPI_SUMMARY_HEAD + h->d.row, p2p_ctx(h));
-        HIP_TRY(h, hipGetLastError());
     }
     return MPPI_OK;
 }

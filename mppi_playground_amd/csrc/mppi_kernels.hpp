@@ -493,6 +493,29 @@ __global__ __launch_bounds__(BLOCK) void weights_reduce_kernel(const float4* __r
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// One-shot peer-to-peer exchange of the shard summaries (the sharded solve's only exchange) without a collective
+// launch: every rank stores its summary straight into all peers' exchange buffers over xGMI and the consumer
+// polls its own buffer.  Cells are 8 bytes {fp32 value, 32-bit sequence number} written with ONE store, so data and
+// "ready" flag cannot be seen apart (the idea of RCCL's low-latency protocol): no fence ordering is relied on.
+// Buffer of rank r (fine-grained device memory, IPC-mapped into every peer): cells[2][W][lenp]; solve `seq` uses
+// parity seq & 1 — a rank can be at most one solve ahead of the slowest one, because its next finalize needs
+// everybody's summary of that solve.
+struct P2pCtx {
+    unsigned long long* const* peers;  // [W] base of every rank's buffer as mapped here (device array)
+    unsigned long long* local;         // this rank's buffer
+    int* error;                        // mapped host flag: set when a poll timed out
+    int world, rank, lenp;
+    unsigned seq;                      // 0 = exchange off
+};
+
+__device__ __forceinline__ void p2p_store(unsigned long long* p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ unsigned long long p2p_load(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // Ascending list of the blocks that published a partial row (heads[b][3] != 0), built by a whole block of
 // NT threads: per-wave ballots, wave counts through LDS, exclusive prefix.  Returns the list length.
 template <int NT>
@@ -541,7 +564,7 @@ __global__ __launch_bounds__(SUM_BLOCK) void summarize_kernel(const float* __res
                                                           const unsigned* __restrict__ min_key, int nblocks,
                                                           int colsp, int row, float* __restrict__ summary,
                                                           float* __restrict__ summary_copy,
-                                                          int* __restrict__ nlive_out) {
+                                                          int* __restrict__ nlive_out, P2pCtx p2p) {
     constexpr int NG = SUM_BLOCK / SUM_COLS;
     __shared__ float s_part[NG][SUM_COLS + 1];
     __shared__ unsigned short s_list[REDUCE_MAX_BLOCKS];
@@ -585,6 +608,11 @@ __global__ __launch_bounds__(SUM_BLOCK) void summarize_kernel(const float* __res
         if (dst >= 0) {
             summary[dst] = v;
             if (summary_copy) summary_copy[dst] = v;
+            if (p2p.seq) {  // cells are self-contained: every block hands its own columns to the peers right away
+                const size_t slot = ((size_t)(p2p.seq & 1u) * p2p.world + p2p.rank) * p2p.lenp + dst;
+                const unsigned long long cell = ((unsigned long long)p2p.seq << 32) | (unsigned long long)__float_as_uint(v);
+                for (int w = 0; w < p2p.world; ++w) p2p_store(p2p.peers[w] + slot, cell);
+            }
         }
     }
 }
@@ -619,29 +647,6 @@ __device__ __forceinline__ void rollout_states_checked(const float* __restrict__
     if (FAST) {
         if (bad) (void)rollout_states<MODEL, false>(x0, T, ctx, out, getu);
     }
-}
-
-// ------------------------------------------------------------------------------------------
-// One-shot peer-to-peer exchange of the shard summaries (the sharded solve's only exchange) without a collective
-// launch: every rank stores its summary straight into all peers' exchange buffers over xGMI and the consumer
-// polls its own buffer.  Cells are 8 bytes {fp32 value, 32-bit sequence number} written with ONE store, so data and
-// "ready" flag cannot be seen apart (the idea of RCCL's low-latency protocol): no fence ordering is relied on.
-// Buffer of rank r (fine-grained device memory, IPC-mapped into every peer): cells[2][W][lenp]; solve `seq` uses
-// parity seq & 1 — a rank can be at most one solve ahead of the slowest one, because its next finalize needs
-// everybody's summary of that solve.
-struct P2pCtx {
-    unsigned long long* const* peers;  // [W] base of every rank's buffer as mapped here (device array)
-    unsigned long long* local;         // this rank's buffer
-    int* error;                        // mapped host flag: set when a poll timed out
-    int world, rank, lenp;
-    unsigned seq;                      // 0 = exchange off
-};
-
-__device__ __forceinline__ void p2p_store(unsigned long long* p, unsigned long long v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-__device__ __forceinline__ unsigned long long p2p_load(const unsigned long long* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 __global__ __launch_bounds__(BLOCK) void p2p_publish_kernel(const float* __restrict__ summary, int len, P2pCtx x) {
