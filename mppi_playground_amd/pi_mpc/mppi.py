@@ -229,6 +229,7 @@ class MPPI(nn.Module):
         self._injected = None
         self._mean_of_last_solve = self._previous_action_seq
         self._state_seq_batch_buf = None
+        self._perturbed_action_seqs_buf = None
         self._x0_tensor = None
 
     # ------------------------------------------------------------------ helpers
@@ -514,7 +515,7 @@ class MPPI(nn.Module):
         # mean of this solve (it is replaced by mppi_finalize)
         U = torch.empty(N, T, self._dim_control, device=self._device, dtype=self._dtype)
         self._h.call("mppi_export_noise", None, _ptr(U), self._stream())
-        self._perturbed_action_seqs = U
+        self._perturbed_action_seqs_buf = U
         S = self._state_seq_batch_buf
         if S is None or S.shape[0] != N:
             S = self._state_seq_batch_buf = torch.zeros(N, T + 1, self._dim_state, device=self._device,
@@ -630,6 +631,26 @@ class MPPI(nn.Module):
                         dtype=self._dtype)
         self._h.call("mppi_export_noise", _ptr(e), None, self._stream())
         return e
+
+    @property
+    def _perturbed_action_seqs(self) -> torch.Tensor:
+        """clamp(mean + eps) of the last solve, [N,T,dc] (src/pi_mpc/mppi.py:266-275): kept by the generic path,
+        rebuilt on demand from the solve's noise and the mean it sampled around for the native models."""
+        if self._model is None:
+            return self._perturbed_action_seqs_buf
+        return self._perturbed_actions_for(self._mean_of_last_solve)
+
+    @property
+    def _state_seq_batch(self) -> torch.Tensor:
+        """All N state trajectories of the last solve, [N,T+1,ds] (src/pi_mpc/mppi.py:280-286).  The native
+        path never stores them (856 MB at N = 2^20, T = 50): they are re-rolled on demand."""
+        if self._model is None:
+            return self._state_seq_batch_buf
+        n = self._local_samples
+        out = torch.empty(n, self._horizon + 1, self._dim_state, device=self._device, dtype=self._dtype)
+        idx = torch.arange(n, device=self._device, dtype=torch.int64)
+        self._h.call("mppi_rollout_samples", _ptr(idx), n, _ptr(out), self._stream())
+        return out
 
     def _perturbed_actions_for(self, mean: torch.Tensor) -> torch.Tensor:
         """clamp(mean + eps) for the resident noise with an explicit mean (the mean of the LAST solve

@@ -271,6 +271,10 @@ def test_edge_sizes_against_oracle(model, T, N, expl):
         assert rel_err(a.cpu().numpy(), P.weighted_actions(w, mean, eps)) < TOL
         assert rel_err(s.cpu().numpy()[0], P.rollout_single(x0, a.cpu().numpy())) < TOL
         assert np.array_equal(solver._perturbed_actions_for(torch.from_numpy(mean).cuda()).cpu().numpy(), r["U"])
+        if k == 0:  # the reference's per-sample buffers, rebuilt on demand (U bit-exact, S to tolerance)
+            assert np.array_equal(solver._perturbed_action_seqs.cpu().numpy(), r["U"])
+            S = P.rollout_cost(x0, mean, eps, want_S=True)["S"]
+            assert solver._state_seq_batch.shape == S.shape and rel_err(solver._state_seq_batch.cpu().numpy(), S) < TOL
         k8 = min(8, N)
         ts, tw = solver.get_top_samples(k8)
         assert ts.shape == (k8, T + 1, P.ds) and rel_err(tw.cpu().numpy(), np.sort(w)[::-1][:k8]) < TOL
