@@ -1040,3 +1040,38 @@ def test_randomised_model_parameters_against_oracle(seed):
         a_or = P.weighted_actions(w, mean, eps)
         assert rel_err(a, a_or) < TOL, (model, math)
         assert rel_err(s, P.rollout_single(x0, a)) < TOL, (model, math)
+
+
+@pytest.mark.parametrize("model", ["pendulum", "cartpole", "mountaincar", "mjcartpole", "goalzone"])
+def test_extreme_initial_states_against_oracle(model):
+    """Initial states far outside the nominal ranges (many turns of angle, states at or beyond the model's clamps,
+    huge velocities): every fast path either covers them exactly or flags the lane for the library-math redo."""
+    rng = np.random.default_rng(7)
+    T, N = 25, 192
+    cases = {
+        "pendulum": [[3.0, 0.1], [150.0, -3.0], [-199.0, 8.0], [250.0, 1.0], [-9.9e4, 7.9], [1.2e5, -8.0], [0.0, 100.0]],
+        "cartpole": [[0.0, 0.0, 0.1, 0.0], [2.4, 5.0, 190.0, -7.0], [-30.0, -20.0, -250.0, 30.0], [0.0, 0.0, 3.1415927, 0.0],
+                     [1.0, 0.0, 1e4, 2.0]],
+        "mountaincar": [[-0.5, 0.0], [-1.2, -0.07], [0.6, 0.07], [-1.5, 0.3], [0.45, 0.0]],
+        "mjcartpole": [[0.0, 0.0, 0.05, 0.0], [3.0, 4.0, 170.0, -9.0], [-5.0, 0.0, -230.0, 40.0], [0.1, 0.2, 5e3, 0.0]],
+        "goalzone": [[0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0], [4.0, -3.0, 3.1, 0.5, -0.5, 1.0, 0.0],
+                     [-12.0, 15.0, -3.14159, 0.0, 0.0, 0.0, 1.0], [2.0, 2.0, 100.0, 0.3, 0.2, 0.0, 0.0]],
+    }[model]
+    solver, _ = make_solver(model, T, N, lambda_=2.0)
+    P = oracle_problem(model, N, T)
+    for x0 in cases:
+        x0 = np.asarray(x0, np.float32)
+        mean = (rng.standard_normal((T, P.dc)) * 0.3).astype(np.float32)
+        eps = (rng.standard_normal((N, T, P.dc)) * np.asarray(MODEL_CFG[model]["sigmas"])).astype(np.float32)
+        solver.set_warm_start(mean)
+        solver.inject_noise(torch.from_numpy(eps))
+        a, s = solver.forward(torch.from_numpy(x0))
+        c = solver._costs.cpu().numpy()
+        r = P.rollout_cost(x0, mean, eps, want_margin=True)
+        assert np.all(np.isfinite(c)), x0
+        scale = max(np.abs(r["costs"]).max(), 1e-30)
+        # (angles of hundreds of radians carry ulps of 1e-5 rad: 1e-4 is the conditioning of these cases, not a precision claim)
+        assert np.abs(c - r["costs"]).max() <= 1e-4 * scale, (model, x0.tolist(), np.abs(c - r["costs"]).max() / scale)
+        w, _ = orc.softmax_weights(c, 2.0)
+        assert rel_err(a.cpu().numpy(), P.weighted_actions(w, mean, eps)) < TOL
+        assert rel_err(s.cpu().numpy()[0], P.rollout_single(x0, a.cpu().numpy())) < 1e-4
