@@ -1075,3 +1075,29 @@ def test_extreme_initial_states_against_oracle(model):
         w, _ = orc.softmax_weights(c, 2.0)
         assert rel_err(a.cpu().numpy(), P.weighted_actions(w, mean, eps)) < TOL
         assert rel_err(s.cpu().numpy()[0], P.rollout_single(x0, a.cpu().numpy())) < 1e-4
+
+
+def test_top_samples_with_tied_costs():
+    """Radix select when many costs are bit-identical: all equal, two plateaus with the k-th rank inside a plateau,
+    and negative / zero costs (key order across the sign)."""
+    solver, _ = make_solver("pendulum", 10, 4096, lambda_=1.0)
+    x0 = torch.tensor([1.0, 0.0])
+    solver.forward(x0)
+    st = solver._stream()
+    for costs, k in ((np.full(4096, 5.0, np.float32), 300),
+                     (np.where(np.arange(4096) % 3 == 0, 1.0, 2.0).astype(np.float32), 1000),
+                     (np.concatenate([np.full(100, -3.0), np.zeros(100), -np.zeros(100), np.linspace(0.5, 9, 3796)]).astype(np.float32), 250)):
+        c = torch.from_numpy(costs).cuda()
+        solver._h.call("mppi_set_costs", c.data_ptr(), 1, st)
+        solver._h.call("mppi_weights_reduce", 1.0, None, st)   # refreshes the statistics the weights are normalised with
+        a = torch.empty(10, 1, device="cuda")
+        solver._h.call("mppi_finalize", None, 1, 1.0, 0, a.data_ptr(), None, None, st)
+        out = torch.empty(k, 11, 2, device="cuda")
+        w = torch.empty(k, device="cuda")
+        solver._h.call("mppi_top_samples", k, 1.0, out.data_ptr(), w.data_ptr(), st)
+        x = -costs.astype(np.float64)
+        ref_w = np.exp(x - x.max())
+        ref_w /= ref_w.sum()
+        want = np.sort(ref_w)[::-1][:k]
+        assert rel_err(w.cpu().numpy(), want) < TOL and torch.isfinite(out).all()
+        assert torch.equal(out[:, 0, :], x0.cuda().expand(k, 2))
