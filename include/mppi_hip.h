@@ -179,7 +179,8 @@ int mppi_set_costs(mppi_handle_t h, const float* src, int on_device, void* strea
  * (the handle keeps its own copy). */
 int mppi_weights_reduce(mppi_handle_t h, float lambda, float* summary_out_dev, void* stream);
 /* Combine `num_shards` summaries (device array [num_shards][MPPI_SUMMARY_HEAD + T*dc]; NULL = this
- * handle's own, num_shards = 1), form action_seq = A / sum e (mppi.py:381-385), optionally store it
+ * handle's own, num_shards = 1 — or, with option "exchange_p2p", the summaries of all ranks from the
+ * peer-to-peer buffer), form action_seq = A / sum e (mppi.py:381-385), optionally store it
  * as the next warm start (mppi.py:452), and roll it out with batch 1 (mppi.py:448-449,508-524).
  * action_out_dev [T][dc], state_seq_out_dev [T+1][ds], stats_out_dev [4] = {min c, sum e, sum e^2,
  * sum e*c} (global); any output may be NULL. */
