@@ -76,7 +76,8 @@ enum { MPPI_GP_VMIN = 0, MPPI_GP_VMAX, MPPI_GP_WMIN, MPPI_GP_WMAX, MPPI_GP_DT, M
 
 #define MPPI_MAX_PARAMS 32
 #define MPPI_MAX_DIM_STATE 8
-#define MPPI_MAX_DIM_CONTROL 4
+#define MPPI_MAX_DIM_CONTROL 4          /* controls held by MppiConfig (all native models have 1 or 2)       */
+#define MPPI_MAX_DIM_CONTROL_GENERIC 64 /* MPPI_MODEL_GENERIC: any dim_control up to this (mppi.py:96-98)    */
 #define MPPI_SUMMARY_HEAD 4 /* {min cost, sum e, sum e^2, sum e*c} */
 
 /* Constructor arguments that reach the device path (MPPI.__init__, mppi.py:24-47,109-121). */
@@ -84,7 +85,7 @@ typedef struct MppiConfig {
     int32_t model;          /* MPPI_MODEL_*                                                     */
     int32_t horizon;        /* T                                                                */
     int32_t dim_state;      /* must match the model (any value >= 1 for MPPI_MODEL_GENERIC)     */
-    int32_t dim_control;    /* must match the model (1, 2 or 4 for GENERIC; pad 3 to 4)         */
+    int32_t dim_control;    /* must match the model (1..MPPI_MAX_DIM_CONTROL_GENERIC for GENERIC) */
     int64_t num_samples;    /* N held by THIS handle (= the local shard when sharded)           */
     int64_t sample_offset;  /* global index of local sample 0 (0 when not sharded)              */
     int64_t inherit_count;  /* global threshold int(N_global*(1-exploration)), mppi.py:266      */
@@ -107,6 +108,12 @@ const char* mppi_last_error(mppi_handle_t h);
  * RNG-stream side effect; callers that mirror the torch CPU stream draw it themselves). */
 int mppi_create(const MppiConfig* cfg, mppi_handle_t* out);
 int mppi_destroy(mppi_handle_t h);
+/* `u_min`, `u_max`, `sigmas` constructor tensors (mppi.py:32-34,96-98,109-121) as host arrays of n = dim_control
+ * values: replaces the bounds / noise scales taken from MppiConfig.  REQUIRED once, before the first sample, for
+ * generic handles with dim_control > MPPI_MAX_DIM_CONTROL (the config arrays hold four); native models accept it
+ * only before mppi_set_model_params.  Synchronises. */
+int mppi_set_control_limits(mppi_handle_t h, const float* u_min_host, const float* u_max_host, const float* sigmas_host,
+                            int n);
 
 /* Model constants (closures' Python constants / env attributes).  params: MPPI_RP_* or MPPI_NP_*
  * layout; models without parameters accept n == 0. */
@@ -145,8 +152,11 @@ int mppi_set_mean(mppi_handle_t h, const float* mean, int on_device, void* strea
 int mppi_get_mean(mppi_handle_t h, float* mean_out, int on_device, void* stream);
 /* forward(state) argument (mppi.py:247-253), dim_state floats (copied). */
 int mppi_set_state(mppi_handle_t h, const float* x0, int on_device, void* stream);
-/* Zero-copy variant: the kernels read the state from the caller's device buffer, which must stay
- * valid and unmodified until the work enqueued up to the next mppi_set_state/mppi_bind_state ran. */
+/* Zero-copy variant: the kernels of THIS solve (mppi_rollout_cost, mppi_finalize) read the state from the caller's
+ * device buffer, which must stay valid and unmodified until that enqueued work ran.  mppi_rollout_cost snapshots the
+ * state into the handle, and every later re-roll of that solve's samples (mppi_rollout_samples, mppi_top_samples,
+ * mppi_rollout_candidates) starts from the snapshot — like the reference, whose `_state_seq_batch` is stored
+ * (mppi.py:280-286,481) — so the caller may reuse or overwrite its buffer once the solve's kernels ran. */
 int mppi_bind_state(mppi_handle_t h, const float* x0_dev);
 
 /* Step 1 — `_noise_distribution.rsample` (mppi.py:261-263): eps ~ N(0, diag(sigma^2)) from the
@@ -210,13 +220,33 @@ int mppi_softmax_stats_multi(mppi_handle_t h, const float* lambdas_host, int cou
  * handles; synchronises twice. */
 int mppi_essps_lambda(mppi_handle_t h, double target_ess, double lam_min, double lam_max, double* lambda_out_host,
                       void* stream);
+/* LBPS (mppi.py:341-349,534-557): argmin over [lam_min, lam_max] of -(E_w[-c] - (max c - min c) * sqrt((1-delta)/delta)
+ * / sqrt(ESS)), searched on the host with Brent's bounded minimiser (scipy minimize_scalar(method="bounded"): xatol
+ * 1e-5, at most 500 evaluations); every probe is one mppi_softmax_stats round trip.  Unsharded handles; synchronises. */
+int mppi_lbps_lambda(mppi_handle_t h, double delta, double lam_min, double lam_max, double* lambda_out_host, void* stream);
+/* MPO (mppi.py:191-200,387-398): the dual variable log T and its Adam moments live in the handle.
+ *   mppi_mpo_reset  log T = log(lambda0), moments cleared; epsilon = the KL bound (0.1), lr = Adam step (0.2)
+ *   mppi_mpo_step   one Adam step on loss = softplus(logT) * (epsilon + logsumexp(-c / softplus(logT))) over the LAST
+ *                   solve's costs; *lambda_out_host = exp(logT), the temperature of the NEXT solve.  Synchronises.
+ *   mppi_mpo_state  out4_host = {log T, first moment, second moment, step count}. */
+int mppi_mpo_reset(mppi_handle_t h, double lambda0, double epsilon, double lr);
+int mppi_mpo_step(mppi_handle_t h, double* lambda_out_host, void* stream);
+int mppi_mpo_state(mppi_handle_t h, double* out4_host);
 
 /* `_weights` (mppi.py:376) for this shard given the GLOBAL {min c, sum e}: w_out_dev[N]. */
 int mppi_weights(mppi_handle_t h, float lambda, float cmin_global, float sum_e_global, float* w_out_dev,
                  void* stream);
-/* `_states_prediction` (mppi.py:508-524) for k action sequences actions_dev[k][T][dc] ->
- * states_out_dev[k][T+1][ds] (step 8 after host-side smoothing; get_samples_from_posterior). */
-int mppi_rollout_actions(mppi_handle_t h, const float* actions_dev, int k, float* states_out_dev, void* stream);
+/* `_states_prediction(state, action_seqs)` (mppi.py:508-524) for k action sequences actions_dev[k][T][dc] ->
+ * states_out_dev[k][T+1][ds] (step 8 after host-side smoothing; get_samples_from_posterior).  x0_dev = the start
+ * state [ds] (device), or NULL for the state of the current solve; an explicit state does not disturb the solver. */
+int mppi_rollout_actions(mppi_handle_t h, const float* actions_dev, int k, const float* x0_dev, float* states_out_dev,
+                         void* stream);
+/* get_samples_from_posterior, sampling half (mppi.py:489-503): samples_out_dev[k][T][dc] = loc_dev[T][dc] + eps with
+ * eps ~ N(0, diag(sigma^2)) (unclamped, like MultivariateNormal(loc).sample()) from the device Philox stream at the
+ * RESERVED solve index `solve_idx` (counter = (sample, float4 group, solve_idx): the call consumes the solver's
+ * stream the way the reference's draw consumes torch's generator; sharding does not change the samples). */
+int mppi_sample_posterior(mppi_handle_t h, uint32_t solve_idx, const float* loc_dev, int k, float* samples_out_dev,
+                          void* stream);
 /* `_state_seq_batch[top_indices]` (mppi.py:481): re-roll the k local samples idx_dev[k] from the
  * resident noise instead of materialising S[N][T+1][ds] -> states_out_dev[k][T+1][ds]. */
 int mppi_rollout_samples(mppi_handle_t h, const int64_t* idx_dev, int k, float* states_out_dev, void* stream);

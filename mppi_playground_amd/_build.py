@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libmppi_hip.so")
 SOURCES = ["mppi_capi.hip"]
-DEPS = ["mppi_capi.hip", "mppi_kernels.hpp", "mppi_models.hpp", "philox.hpp", os.path.join("..", "..", "include", "mppi_hip.h")]
+HEADER = os.path.join(HERE, "..", "include", "mppi_hip.h")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-slp-vectorize",
          "-fhip-fp32-correctly-rounded-divide-sqrt"]
 
@@ -21,11 +21,18 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found: the HIP extension cannot be built")
 
 
+def deps() -> list:
+    """Everything the library is compiled from: every .hip / .hpp / .inc under csrc/ (mppi_models.inc holds all the
+    model arithmetic and is included twice by mppi_models.hpp) plus the public header."""
+    out = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".hpp", ".inc", ".h"))]
+    return out + [HEADER]
+
+
 def stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
+    return any(os.path.getmtime(d) > t for d in deps())
 
 
 def build(force: bool = False, verbose: bool = False) -> str:

@@ -13,7 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MPPI_HIP_LIB") or os.path.join(_HERE, "csrc", "libmppi_hip.so")
 
 MODEL_GENERIC = -1
-MAX_DIM_CONTROL = 4
+MAX_DIM_CONTROL = 4           # controls held by MppiConfig
+MAX_DIM_CONTROL_GENERIC = 64  # opaque callables: any dim_control up to this
 MODEL_IDS = {"pendulum": 0, "cartpole": 1, "mountaincar": 2, "nav2d": 3, "racing": 4, "mjcartpole": 5, "goalzone": 6}
 MODEL_DIMS = {"pendulum": (2, 1), "cartpole": (4, 1), "mountaincar": (2, 1), "nav2d": (3, 2), "racing": (4, 2),
               "mjcartpole": (4, 1), "goalzone": (7, 2)}
@@ -21,11 +22,11 @@ SUMMARY_HEAD = 4
 
 # every symbol include/mppi_hip.h declares
 SYMBOLS = [
-    "mppi_version", "mppi_device_count", "mppi_last_error", "mppi_create", "mppi_destroy",
+    "mppi_version", "mppi_device_count", "mppi_last_error", "mppi_create", "mppi_destroy", "mppi_set_control_limits",
     "mppi_set_model_params", "mppi_upload_map", "mppi_build_obstacle_map", "mppi_build_lane_map",
     "mppi_download_map", "mppi_set_reference", "mppi_set_mean", "mppi_get_mean",
     "mppi_set_state", "mppi_bind_state", "mppi_sample", "mppi_inject_noise", "mppi_export_noise", "mppi_rollout_cost",
-    "mppi_get_costs", "mppi_set_costs", "mppi_weights_reduce", "mppi_finalize", "mppi_set_sg_filter", "mppi_get_sg_history", "mppi_softmax_stats", "mppi_softmax_stats_multi", "mppi_essps_lambda", "mppi_weights",
+    "mppi_get_costs", "mppi_set_costs", "mppi_weights_reduce", "mppi_finalize", "mppi_set_sg_filter", "mppi_get_sg_history", "mppi_softmax_stats", "mppi_softmax_stats_multi", "mppi_essps_lambda", "mppi_lbps_lambda", "mppi_mpo_reset", "mppi_mpo_step", "mppi_mpo_state", "mppi_weights", "mppi_sample_posterior",
     "mppi_p2p_alloc", "mppi_p2p_connect", "mppi_p2p_exchange", "mppi_p2p_error", "mppi_rollout_actions", "mppi_rollout_samples", "mppi_top_samples", "mppi_top_candidates", "mppi_rollout_candidates", "mppi_set_option", "mppi_get_timing",
 ]
 
@@ -77,6 +78,12 @@ def load():
     lib.mppi_top_candidates.argtypes = [vp, i32, vp, vp]
     lib.mppi_rollout_candidates.argtypes = [vp, vp, i32, f32, vp, vp, vp]
     lib.mppi_essps_lambda.argtypes = [vp, C.c_double, C.c_double, C.c_double, vp, vp]
+    lib.mppi_lbps_lambda.argtypes = [vp, C.c_double, C.c_double, C.c_double, vp, vp]
+    lib.mppi_mpo_reset.argtypes = [vp, C.c_double, C.c_double, C.c_double]
+    lib.mppi_mpo_step.argtypes = [vp, vp, vp]
+    lib.mppi_mpo_state.argtypes = [vp, vp]
+    lib.mppi_set_control_limits.argtypes = [vp, vp, vp, vp, i32]
+    lib.mppi_sample_posterior.argtypes = [vp, u32, vp, i32, vp, vp]
     lib.mppi_set_reference.argtypes = [vp, vp, i32, vp]
     lib.mppi_set_mean.argtypes = [vp, vp, i32, vp]
     lib.mppi_get_mean.argtypes = [vp, vp, i32, vp]
@@ -93,7 +100,7 @@ def load():
     lib.mppi_softmax_stats.argtypes = [vp, f32, vp, vp]
     lib.mppi_softmax_stats_multi.argtypes = [vp, vp, i32, vp, vp]
     lib.mppi_weights.argtypes = [vp, f32, f32, f32, vp, vp]
-    lib.mppi_rollout_actions.argtypes = [vp, vp, i32, vp, vp]
+    lib.mppi_rollout_actions.argtypes = [vp, vp, i32, vp, vp, vp]
     lib.mppi_rollout_samples.argtypes = [vp, vp, i32, vp, vp]
     lib.mppi_set_option.argtypes = [vp, C.c_char_p, i64]
     lib.mppi_get_timing.argtypes = [vp, vp]

@@ -1,0 +1,202 @@
+// host_search.hpp — the scalar halves of the automatic temperature rules (ESSPS / LBPS / MPO,
+// src/pi_mpc/mppi.py:341-370,387-398,526-566 of the reference), as host C++ over softmax statistics that the
+// device reduces (mppi_softmax_stats / mppi_softmax_stats_multi).  Pure C++17, no HIP: mppi_capi.hip calls
+// these with device-backed statistics callbacks, tests/host_emul compiles the same header with g++ and checks
+// it against scipy / the numpy statements in pi_mpc/_host.py on a machine without a GPU.
+//
+// The reference runs scipy.optimize.brentq (ESSPS) and scipy.optimize.minimize_scalar(method="bounded")
+// (LBPS) and one torch.optim.Adam step (MPO); scipy 1.15.3 and torch are third-party dependencies of the
+// reference (uv.lock), so their published algorithms are restated here:
+//   * bounded scalar minimisation = Brent's fmin (Brent 1973, ch. 5; Forsythe, Malcolm & Moler 1977 "FMIN"),
+//     golden-section steps with parabolic interpolation, termination |x - xm| <= 2*tol1 - (b-a)/2 with
+//     tol1 = sqrt(eps)*|x| + xatol/3 — scipy's `_minimize_scalar_bounded` uses xatol = 1e-5, maxiter = 500;
+//   * Adam (Kingma & Ba 2015) with bias correction in torch's operation order, lr 0.2, betas (0.9, 0.999),
+//     eps 1e-8, scalar parameter in fp32.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+
+namespace mppi {
+namespace host {
+
+struct SoftmaxStats {  // of softmax(-c/lambda) over all samples, e_i = exp(-(c_i - cmin)/lambda)
+    double cmin, cmax, se, se2, sec;
+    double ess() const { return se * se / se2; }
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// Brent's bounded minimiser.  f: double -> double (may fail: returns false), minimum of f on [x1, x2].
+// Returns false if an evaluation failed.
+template <class F>
+bool fminbound(F&& f, double x1, double x2, double xatol, int maxiter, double& xmin, int* nfev = nullptr) {
+    const double sqrt_eps = std::sqrt(2.2e-16);
+    const double golden_mean = 0.5 * (3.0 - std::sqrt(5.0));
+    double a = x1, b = x2;
+    double fulc = a + golden_mean * (b - a);
+    double nfc = fulc, xf = fulc;
+    double rat = 0.0, e = 0.0;
+    double x = xf, fx = 0.0;
+    if (!f(x, fx)) return false;
+    int num = 1;
+    double fu = INFINITY;
+    double ffulc = fx, fnfc = fx;
+    double xm = 0.5 * (a + b);
+    double tol1 = sqrt_eps * std::fabs(xf) + xatol / 3.0;
+    double tol2 = 2.0 * tol1;
+    while (std::fabs(xf - xm) > (tol2 - 0.5 * (b - a))) {
+        bool golden = true;
+        if (std::fabs(e) > tol1) {  // try a parabolic step through (fulc, nfc, xf)
+            golden = false;
+            double r = (xf - nfc) * (fx - ffulc);
+            double q = (xf - fulc) * (fx - fnfc);
+            double p = (xf - fulc) * q - (xf - nfc) * r;
+            q = 2.0 * (q - r);
+            if (q > 0.0) p = -p;
+            q = std::fabs(q);
+            r = e;
+            e = rat;
+            if (std::fabs(p) < std::fabs(0.5 * q * r) && p > q * (a - xf) && p < q * (b - xf)) {
+                rat = p / q;
+                x = xf + rat;
+                if ((x - a) < tol2 || (b - x) < tol2) {  // too close to an end point: step tol1 towards the middle
+                    const double d = xm - xf;
+                    const double si = (d > 0.0 ? 1.0 : (d < 0.0 ? -1.0 : 0.0)) + (d == 0.0 ? 1.0 : 0.0);
+                    rat = tol1 * si;
+                }
+            } else {
+                golden = true;
+            }
+        }
+        if (golden) {
+            e = (xf >= xm) ? a - xf : b - xf;
+            rat = golden_mean * e;
+        }
+        const double si = (rat > 0.0 ? 1.0 : (rat < 0.0 ? -1.0 : 0.0)) + (rat == 0.0 ? 1.0 : 0.0);
+        x = xf + si * std::max(std::fabs(rat), tol1);
+        if (!f(x, fu)) return false;
+        ++num;
+        if (fu <= fx) {
+            if (x >= xf) a = xf; else b = xf;
+            fulc = nfc; ffulc = fnfc;
+            nfc = xf; fnfc = fx;
+            xf = x; fx = fu;
+        } else {
+            if (x < xf) a = x; else b = x;
+            if (fu <= fnfc || nfc == xf) {
+                fulc = nfc; ffulc = fnfc;
+                nfc = x; fnfc = fu;
+            } else if (fu <= ffulc || fulc == xf || fulc == nfc) {
+                fulc = x; ffulc = fu;
+            }
+        }
+        xm = 0.5 * (a + b);
+        tol1 = sqrt_eps * std::fabs(xf) + xatol / 3.0;
+        tol2 = 2.0 * tol1;
+        if (num >= maxiter) break;
+    }
+    xmin = xf;
+    if (nfev) *nfev = num;
+    return true;
+}
+
+// LBPS objective (mppi.py:534-557): -(E_w[-c] - range * sqrt((1-delta)/delta) / sqrt(ESS)).
+inline double lbps_objective(const SoftmaxStats& st, double delta) {
+    const double expected_return = -st.sec / st.se;
+    const double penalty = (st.cmax - st.cmin) * std::sqrt((1.0 - delta) / delta) / std::sqrt(st.ess());
+    return -(expected_return - penalty);
+}
+
+// LBPS temperature (mppi.py:341-349): bounded minimisation of the objective over [lam_min, lam_max].
+// stats(lambda, SoftmaxStats&) -> bool evaluates the softmax sums (one device round trip per probe).
+template <class S>
+bool lbps_lambda(S&& stats, double delta, double lam_min, double lam_max, double& lam, int* nfev = nullptr) {
+    return fminbound(
+        [&](double l, double& out) {
+            SoftmaxStats st{};
+            if (!stats(l, st)) return false;
+            out = lbps_objective(st, delta);
+            return true;
+        },
+        lam_min, lam_max, 1e-5, 500, lam, nfev);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// ESSPS (mppi.py:351-370,559-566): the root of ESS(lambda) = target on [lam_min, lam_max] with the reference's
+// end-point rules, from `rounds` geometric grids of P temperatures (ess_grid(lams[P], ess_out[P]) -> bool is ONE
+// pass over the costs on the device) and an inverse cubic interpolation in (ESS, log lambda).  Same algorithm as
+// pi_mpc/_host.py::essps_lambda_grid (within ~1e-7 relative of scipy's brentq on the same statistics).
+template <int P, class G>
+bool essps_lambda(G&& ess_grid, double target_ess, double lam_min, double lam_max, double& lam_out) {
+    static_assert(P >= 4, "grid too small for the cubic");
+    double grid[P], ess[P];
+    double lo = lam_min, hi = lam_max;
+    int i = 1;
+    for (int rnd = 0; rnd < 2; ++rnd) {
+        const double llo = std::log(lo), lhi = std::log(hi);
+        for (int j = 0; j < P; ++j) grid[j] = std::exp(llo + (lhi - llo) * (double)j / (double)(P - 1));
+        grid[0] = lo; grid[P - 1] = hi;
+        if (!ess_grid(grid, ess)) return false;
+        if (rnd == 0) {  // mppi.py:361-364
+            if (target_ess <= ess[0]) { lam_out = lam_min; return true; }
+            if (target_ess >= ess[P - 1]) { lam_out = lam_max; return true; }
+        }
+        i = P - 1;
+        for (int j = 0; j < P; ++j) if (ess[j] >= target_ess) { i = j; break; }
+        if (i < 1) i = 1;
+        lo = grid[i - 1]; hi = grid[i];
+    }
+    const int j0 = std::min(std::max(i - 2, 0), P - 4);
+    bool increasing = true;
+    for (int a = 0; a < 3; ++a) increasing = increasing && ess[j0 + a + 1] > ess[j0 + a];
+    if (increasing) {  // Lagrange form of log(lambda) as a function of ESS, at ESS = target
+        double x = 0.0;
+        for (int a = 0; a < 4; ++a) {
+            double w = 1.0;
+            for (int b = 0; b < 4; ++b)
+                if (b != a) w *= (target_ess - ess[j0 + b]) / (ess[j0 + a] - ess[j0 + b]);
+            x += w * std::log(grid[j0 + a]);
+        }
+        const double lam = std::exp(x);
+        if (lam >= lo && lam <= hi) { lam_out = lam; return true; }
+    }
+    const double e0 = ess[i - 1], e1 = ess[i];
+    lam_out = (e1 == e0) ? 0.5 * (lo + hi) : lo + (hi - lo) * (target_ess - e0) / (e1 - e0);
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// MPO temperature (mppi.py:191-200,387-398): one Adam(lr) step per solve on
+//   loss(logT) = T * (epsilon + logsumexp(-c / T)),  T = softplus(logT),  then lambda = exp(logT)   (B-Q12)
+// with the gradient written out: dL/dT = epsilon + LSE + E_w[c] / T, dT/dlogT = sigmoid(logT).  Scalars are
+// kept in fp32 where torch keeps them in fp32 (parameter, gradient, both moments).
+struct MpoState {
+    float log_temperature = 0.0f, m = 0.0f, v = 0.0f;
+    int32_t t = 0;
+    double epsilon = 0.1, lr = 0.2;
+    double temperature() const { return std::log1p(std::exp((double)log_temperature)); }  // softplus(logT)
+};
+inline void mpo_reset(MpoState& s, double lam0, double epsilon, double lr) {
+    s = MpoState{};
+    s.log_temperature = (float)std::log(lam0);
+    s.epsilon = epsilon; s.lr = lr;
+}
+// `st` = the softmax statistics at lambda = s.temperature().  Returns the new lambda = exp(logT).
+inline double mpo_step(MpoState& s, const SoftmaxStats& st) {
+    const double b1 = 0.9, b2 = 0.999, adam_eps = 1e-8;
+    const double lt = (double)s.log_temperature, T = s.temperature();
+    const double lse = -st.cmin / T + std::log(st.se);
+    const double wc = st.sec / st.se;
+    const double dL_dT = s.epsilon + lse + wc / T;
+    const float g = (float)(dL_dT * (1.0 / (1.0 + std::exp(-lt))));
+    s.t += 1;
+    s.m = (float)(b1 * (double)s.m + (1.0 - b1) * (double)g);
+    s.v = (float)(b2 * (double)s.v + (1.0 - b2) * (double)g * (double)g);
+    const double bc1 = 1.0 - std::pow(b1, (double)s.t), bc2 = 1.0 - std::pow(b2, (double)s.t);
+    const double denom = std::sqrt((double)s.v) / std::sqrt(bc2) + adam_eps;
+    s.log_temperature = (float)(lt - (s.lr / bc1) * (double)s.m / denom);
+    return (double)std::exp(s.log_temperature);  // np.exp of the fp32 scalar: fp32 result
+}
+
+}  // namespace host
+}  // namespace mppi

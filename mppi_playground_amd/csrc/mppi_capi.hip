@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../include/mppi_hip.h"
+#include "host_search.hpp"
 #include "mppi_kernels.hpp"
 
 using namespace mppi;
@@ -30,6 +31,11 @@ struct MppiSolver {
     int min_slot = 0;
     float* x0 = nullptr;           // owned copy of the state ...
     const float* x0_cur = nullptr; // ... or a borrowed device pointer (mppi_bind_state)
+    float* x0_used = nullptr;      // the state the last rollout started from (snapshot taken by the rollout kernel)
+    // generic handles whose dim_control is not 1, 2 or 4: per-column {sigma, lo, hi}[4R] table (see gen_noise4)
+    float* coltab = nullptr;
+    bool wide = false, limits_set = true;
+    mppi::host::MpoState mpo{};    // MPO temperature dual (mppi_mpo_*)
     // pinned staging ring for small host -> device uploads without a stream synchronisation
     static constexpr int RING = 8;
     float* stage[RING] = {};
@@ -240,6 +246,19 @@ int upload_ints(mppi_handle_t h, const int32_t* src, size_t count, int32_t** dst
     return MPPI_OK;
 }
 
+// dynamic LDS of finalize_kernel: [row] action, [W][4 + row] summaries, the Savitzky-Golay staging and — when the
+// kernel folds the partial rows itself — [64][row + 3] group sums (see finalize_kernel)
+size_t finalize_lds_floats(mppi_handle_t h, int world, int sg_window, bool fold) {
+    return (size_t)h->d.row + (size_t)world * (h->d.row + MPPI_SUMMARY_HEAD) +
+           (sg_window ? (size_t)(2 * h->d.T - 1 + 2 * (sg_window / 2)) * h->dc : 0) +
+           (fold ? (size_t)(SUM_BLOCK / SUM_COLS) * (h->d.row + 3) : 0);
+}
+// Short rows fold inside finalize_kernel (sparse softmax: no summarize launch); rows whose group sums do not fit the
+// 64 KiB of LDS always take summarize_kernel.  A static property of the handle: the choice never depends on timing.
+bool fold_fits(mppi_handle_t h) {
+    return finalize_lds_floats(h, 1, 255 /* widest filter */, true) * sizeof(float) <= 64 * 1024;
+}
+
 P2pCtx p2p_ctx(mppi_handle_t h) {
     return P2pCtx{h->p2p_peers_dev, h->p2p_local, h->p2p_error_dev, h->p2p_world, h->p2p_rank, h->p2p_lenp, h->p2p_seq};
 }
@@ -263,8 +282,8 @@ int mppi_create(const MppiConfig* cfg, mppi_handle_t* out) {
     *out = nullptr;
     ModelDims md{};
     if (cfg->model == MPPI_MODEL_GENERIC) {
-        // the lane-major rows need 4 % dim_control == 0 (callers pad 3 controls to 4 with sigma = 0)
-        if (cfg->dim_state < 1 || (cfg->dim_control != 1 && cfg->dim_control != 2 && cfg->dim_control != 4))
+        // any control dimension: 1, 2 and 4 index the launch constants, every other value the per-column table
+        if (cfg->dim_state < 1 || cfg->dim_control < 1 || cfg->dim_control > MPPI_MAX_DIM_CONTROL_GENERIC)
             return MPPI_E_INVALID;
         md = {cfg->dim_state, cfg->dim_control};
     } else {
@@ -288,6 +307,7 @@ int mppi_create(const MppiConfig* cfg, mppi_handle_t* out) {
     for (int k = 0; k < MPPI_MAX_DIM_CONTROL; ++k) {
         d.u_min[k] = cfg->u_min[k]; d.u_max[k] = cfg->u_max[k]; d.sigma[k] = cfg->sigmas[k];
     }
+    h->wide = cfg->model == MPPI_MODEL_GENERIC && md.dc != 1 && md.dc != 2 && md.dc != 4;
     h->GPW = d.R <= 32 ? 8 : 32;
     const int chg = h->GPW * (BLOCK / WAVE);  // float4 groups per column chunk
     h->nchunks = (d.R + chg - 1) / chg;
@@ -304,6 +324,8 @@ int mppi_create(const MppiConfig* cfg, mppi_handle_t* out) {
     HIP_TRY(h, hipMalloc(&h->x0, sizeof(float) * x0_floats));
     HIP_TRY(h, hipMemset(h->x0, 0, sizeof(float) * x0_floats));
     h->x0_cur = h->x0;
+    HIP_TRY(h, hipMalloc(&h->x0_used, sizeof(float) * x0_floats));
+    HIP_TRY(h, hipMemset(h->x0_used, 0, sizeof(float) * x0_floats));
     h->gen = GenCtx{(uint32_t)cfg->seed, (uint32_t)(cfg->seed >> 32), 0u};
     d.dc = md.dc;
     HIP_TRY(h, hipMalloc(&h->mean, sizeof(float) * (size_t)d.row));
@@ -326,13 +348,49 @@ int mppi_create(const MppiConfig* cfg, mppi_handle_t* out) {
     *h->live_hint = 0;
     HIP_TRY(h, hipHostGetDevicePointer((void**)&h->live_hint_dev, h->live_hint, 0));
     std::memset(&h->ctx, 0, sizeof(h->ctx));
+    mppi::host::mpo_reset(h->mpo, 1.0, 0.1, 0.2);  // mppi.py:191-200
+    if (h->wide) {
+        HIP_TRY(h, hipMalloc(&h->coltab, sizeof(float) * 12 * (size_t)d.R));
+        h->limits_set = false;
+        if (md.dc <= MPPI_MAX_DIM_CONTROL)  // the config arrays hold all of it (dim_control = 3)
+            if (int rc = mppi_set_control_limits(h, cfg->u_min, cfg->u_max, cfg->sigmas, md.dc)) return rc;
+    }
     HIP_TRY(h, hipDeviceSynchronize());
+    return MPPI_OK;
+}
+
+// u_min / u_max / sigmas of all dim_control controls (host arrays).  Required once for generic handles with more
+// than MPPI_MAX_DIM_CONTROL controls (the config arrays hold four); replaces the bounds of any handle.  Synchronises.
+int mppi_set_control_limits(mppi_handle_t h, const float* u_min, const float* u_max, const float* sigmas, int n) {
+    if (!h || !u_min || !u_max || !sigmas || n != h->dc) return fail(h, MPPI_E_INVALID, "control limits: need dim_control values each");
+    for (int k = 0; k < n; ++k)
+        if (!(u_min[k] <= u_max[k]) || !(sigmas[k] >= 0.0f)) return fail(h, MPPI_E_INVALID, "control limits: need u_min <= u_max, sigma >= 0");
+    if (h->cfg.model != MPPI_MODEL_GENERIC && h->params_set)  // the fast-path preconditions were derived from the old bounds
+        return fail(h, MPPI_E_STATE, "control limits of a native model must be set before its parameters");
+    Dims& d = h->d;
+    for (int k = 0; k < std::min(n, (int)MPPI_MAX_DIM_CONTROL); ++k) {
+        d.u_min[k] = h->cfg.u_min[k] = u_min[k];
+        d.u_max[k] = h->cfg.u_max[k] = u_max[k];
+        d.sigma[k] = h->cfg.sigmas[k] = sigmas[k];
+    }
+    if (h->wide) {
+        const size_t C = 4 * (size_t)d.R;
+        std::vector<float> tab(3 * C, 0.0f);
+        for (int f = 0; f < d.row; ++f) {
+            tab[f] = sigmas[f % n]; tab[C + f] = u_min[f % n]; tab[2 * C + f] = u_max[f % n];
+        }
+        HIP_TRY(h, hipDeviceSynchronize());
+        HIP_TRY(h, hipMemcpy(h->coltab, tab.data(), sizeof(float) * tab.size(), hipMemcpyHostToDevice));
+        h->limits_set = true;
+        h->tiles_valid = h->tiles_valid && h->injected;
+    }
     return MPPI_OK;
 }
 
 int mppi_destroy(mppi_handle_t h) {
     if (!h) return MPPI_E_INVALID;
     (void)hipFree(h->noise); (void)hipFree(h->costs); (void)hipFree(h->min_key); (void)hipFree(h->x0);
+    (void)hipFree(h->x0_used); (void)hipFree(h->coltab);
     (void)hipFree(h->mean); (void)hipFree(h->mean_used); (void)hipFree(h->solve_stats); (void)hipFree(h->topk_hist);
     (void)hipFree(h->topk_sel); (void)hipFree(h->topk_cand); (void)hipFree(h->sg_coeffs); (void)hipFree(h->sg_history);
     (void)hipFree(h->ref); (void)hipFree(h->partials); (void)hipFree(h->heads);
@@ -537,7 +595,9 @@ int mppi_bind_state(mppi_handle_t h, const float* x0_dev) {
 
 static int materialize_tiles(mppi_handle_t h, hipStream_t s) {
     const unsigned grid = (unsigned)((h->d.tiles + 3) / 4);
-    hipLaunchKernelGGL(sample_kernel, dim3(grid), dim3(BLOCK), 0, s, h->noise, h->d, h->gen);
+    if (!h->limits_set) return fail(h, MPPI_E_STATE, "dim_control > 4: call mppi_set_control_limits first");
+    if (h->wide) hipLaunchKernelGGL(sample_kernel<true>, dim3(grid), dim3(BLOCK), 0, s, h->noise, h->d, h->gen, h->coltab);
+    else hipLaunchKernelGGL(sample_kernel<false>, dim3(grid), dim3(BLOCK), 0, s, h->noise, h->d, h->gen, (const float*)nullptr);
     HIP_TRY(h, hipGetLastError());
     h->tiles_valid = true;
     return MPPI_OK;
@@ -549,7 +609,7 @@ int mppi_sample(mppi_handle_t h, uint32_t solve_idx, void* stream) {
     h->gen.solve_idx = solve_idx;
     h->injected = false;
     h->tiles_valid = false;
-    if (h->noise_regen) return MPPI_OK;  // consumers regenerate eps(seed, solve, i, t, k) in registers
+    if (h->noise_regen && !h->wide) return MPPI_OK;  // consumers regenerate eps(seed, solve, i, t, k) in registers
     StageTimer tm(h, 0, s);
     return materialize_tiles(h, s);
 }
@@ -576,7 +636,8 @@ int mppi_export_noise(mppi_handle_t h, float* eps_out, float* act_out, void* str
     hipStream_t s = (hipStream_t)stream;
     if (int rc = need_tiles(h, s)) return rc;
     const dim3 grid((unsigned)h->d.tiles, (unsigned)((h->d.row + CONV_COLS - 1) / CONV_COLS));
-    hipLaunchKernelGGL(export_kernel, grid, dim3(BLOCK), 0, s, h->noise, h->mean, eps_out, act_out, h->d);
+    hipLaunchKernelGGL(export_kernel, grid, dim3(BLOCK), 0, s, h->noise, h->mean, eps_out, act_out, h->d,
+                       h->wide ? h->coltab : (const float*)nullptr);
     HIP_TRY(h, hipGetLastError());
     return MPPI_OK;
 }
@@ -589,9 +650,11 @@ int mppi_rollout_cost(mppi_handle_t h, void* stream) {
         if (!h->noise_std) HIP_TRY(h, hipMalloc(&h->noise_std, sizeof(float) * (size_t)h->d.N * h->d.row));
         if (int rc = need_tiles(h, s)) return rc;
         const dim3 cgrid((unsigned)h->d.tiles, (unsigned)((h->d.row + CONV_COLS - 1) / CONV_COLS));
-        hipLaunchKernelGGL(export_kernel, cgrid, dim3(BLOCK), 0, s, h->noise, h->mean, h->noise_std, (float*)nullptr, h->d);
+        hipLaunchKernelGGL(export_kernel, cgrid, dim3(BLOCK), 0, s, h->noise, h->mean, h->noise_std, (float*)nullptr, h->d,
+                           (const float*)nullptr);
         HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipMemcpyAsync(h->mean_used, h->mean, sizeof(float) * (size_t)h->d.row, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(h, hipMemcpyAsync(h->x0_used, h->x0_cur, sizeof(float) * (size_t)h->ds, hipMemcpyDeviceToDevice, s));
         StageTimer tmw(h, 1, s);
         h->min_slot ^= 1;
         unsigned* mkw = h->min_key + h->min_slot;
@@ -621,10 +684,10 @@ int mppi_rollout_cost(mppi_handle_t h, void* stream) {
         constexpr bool UCV = FASTV;  /* the FAST kernels exist in the u_in_bounds form only (see use_fast) */ \
         if (gen)                                                                                      \
             hipLaunchKernelGGL((rollout_cost_kernel<MODEL, FASTV, true, UCV>), dim3(grid), dim3(BLOCK), shmem, s, \
-                               h->noise, h->mean, h->x0_cur, h->costs, mk, mk_next, h->mean_used, h->d, h->gen, h->ctx); \
+                               h->noise, h->mean, h->x0_cur, h->costs, mk, mk_next, h->mean_used, h->x0_used, h->d, h->gen, h->ctx); \
         else                                                                                          \
             hipLaunchKernelGGL((rollout_cost_kernel<MODEL, FASTV, false, UCV>), dim3(grid), dim3(BLOCK), shmem, s, \
-                               h->noise, h->mean, h->x0_cur, h->costs, mk, mk_next, h->mean_used, h->d, h->gen, h->ctx); \
+                               h->noise, h->mean, h->x0_cur, h->costs, mk, mk_next, h->mean_used, h->x0_used, h->d, h->gen, h->ctx); \
     } while (0)
     MPPI_DISPATCH(h, CALL_ROLLOUT);
 #undef CALL_ROLLOUT
@@ -666,20 +729,21 @@ int mppi_weights_reduce(mppi_handle_t h, float lambda, float* summary_out_dev, v
     blocks = std::max<int64_t>(1, std::min<int64_t>(blocks, REDUCE_MAX_BLOCKS));
     h->last_reduce_blocks = (int)blocks;
     const dim3 grid((unsigned)blocks, (unsigned)h->nchunks);
-    const bool gen = h->noise_regen && !h->injected;
+    const bool gen = h->noise_regen && !h->injected && !h->wide;
     if (!gen && !h->tiles_valid) return fail(h, MPPI_E_STATE, "no noise: call mppi_sample or mppi_inject_noise first");
     const unsigned* mk = h->min_key + h->min_slot;
-#define CALL_REDUCE(GPWV, GENV)                                                                       \
-    hipLaunchKernelGGL((weights_reduce_kernel<GPWV, GENV>), grid, dim3(BLOCK), 0, s, h->noise, h->mean, h->costs, mk, \
-                       h->partials, h->heads, h->d, h->gen, lambda)
-    if (h->GPW == 8) { if (gen) CALL_REDUCE(8, true); else CALL_REDUCE(8, false); }
-    else { if (gen) CALL_REDUCE(32, true); else CALL_REDUCE(32, false); }
+#define CALL_REDUCE(GPWV, GENV, WIDEV)                                                                \
+    hipLaunchKernelGGL((weights_reduce_kernel<GPWV, GENV, WIDEV>), grid, dim3(BLOCK), 0, s, h->noise, h->mean, h->costs, mk, \
+                       h->partials, h->heads, h->d, h->gen, lambda, (const float*)h->coltab)
+    if (h->wide) { if (h->GPW == 8) CALL_REDUCE(8, false, true); else CALL_REDUCE(32, false, true); }
+    else if (h->GPW == 8) { if (gen) CALL_REDUCE(8, true, false); else CALL_REDUCE(8, false, false); }
+    else { if (gen) CALL_REDUCE(32, true, false); else CALL_REDUCE(32, false, false); }
 #undef CALL_REDUCE
     HIP_TRY(h, hipGetLastError());
     // Fold the published partial rows into the shard summary.  Sharded use needs the summary before the
     // collective; otherwise mppi_finalize folds the rows itself when the previous solves published few of them
     // (*live_hint, written by finalize_kernel to mapped host memory and read here without synchronising: it only
-    // steers this choice, both paths give the same summary).
+    // steers this choice: both folds use the same summation tree, so the summary is bit-identical either way).
     h->summary_valid = false;
     P2pCtx p2p{};
     if (h->p2p_enabled) {  // summarize_kernel also hands the summary to every peer (and to this rank's own slot)
@@ -687,7 +751,7 @@ int mppi_weights_reduce(mppi_handle_t h, float lambda, float* summary_out_dev, v
         if (h->p2p_seq == 0) h->p2p_seq = 1;
         p2p = p2p_ctx(h);
     }
-    if (summary_out_dev || h->p2p_enabled || *(volatile int*)h->live_hint > FOLD_IN_FINALIZE_MAX_ROWS) {
+    if (summary_out_dev || h->p2p_enabled || !fold_fits(h) || *(volatile int*)h->live_hint > FOLD_IN_FINALIZE_MAX_ROWS) {
         const unsigned sgrid = (unsigned)((h->colsp + SUM_COLS - 1) / SUM_COLS + 1);
         hipLaunchKernelGGL(summarize_kernel, dim3(sgrid), dim3(SUM_BLOCK), 0, s, h->partials, h->heads, mk, (int)blocks,
                            h->colsp, h->d.row, h->summary, summary_out_dev, h->live_hint_dev, p2p);
@@ -718,8 +782,8 @@ int mppi_finalize(mppi_handle_t h, const float* summaries_dev, int num_shards, f
     }
     // the filter replaces the stored warm start, so it only runs when this call stores it (mppi.py:441-452)
     const SgFilter sg{h->sg_coeffs, h->sg_history, (store_mean && h->sg_window > 0) ? h->sg_window : 0};
-    const size_t shmem = sizeof(float) * ((size_t)h->d.row + (size_t)(p2p.seq ? p2p.world : 1) * (h->d.row + MPPI_SUMMARY_HEAD) +
-                                          (sg.window ? (size_t)(2 * h->d.T - 1 + 2 * (sg.window / 2)) * h->dc : 0));
+    const bool fold_here = !summaries_dev && !p2p.seq;  // the kernel folds the partial rows itself
+    const size_t shmem = finalize_lds_floats(h, p2p.seq ? p2p.world : 1, sg.window, fold_here) * sizeof(float);
     if (shmem > 64 * 1024) return fail(h, MPPI_E_INVALID, "finalize: horizon too long for the exchange / filter staging");
     const unsigned* mk = h->min_key + h->min_slot;
 #define CALL_FINALIZE(MODEL, FASTV)                                                                   \
@@ -805,49 +869,87 @@ int mppi_softmax_stats_multi(mppi_handle_t h, const float* lambdas_host, int cou
 // ESSPS temperature (mppi.py:351-370,559-566): the root of ESS(lambda) = target on [lam_min, lam_max] with the
 // reference's end-point rules, found on the host from device statistics — two 32-point geometric grids
 // (mppi_softmax_stats_multi: one pass over the costs each) and an inverse cubic interpolation in
-// (ESS, log lambda).  Same algorithm as pi_mpc/_host.py::essps_lambda_grid (which sharded solvers use, with an
-// all_gather per grid); kept in the library so that the single-GPU solve has no interpreter work per probe.
+// (ESS, log lambda): host::essps_lambda in host_search.hpp.  Same algorithm as pi_mpc/_host.py::essps_lambda_grid
+// (which sharded solvers use, with an all_gather per grid); kept in the library so that the single-GPU solve has no
+// interpreter work per probe.
 int mppi_essps_lambda(mppi_handle_t h, double target_ess, double lam_min, double lam_max, double* lambda_out,
                       void* stream) {
     if (!h || !lambda_out || !(lam_min > 0.0) || !(lam_max > lam_min) || !(target_ess > 0.0))
         return fail(h, MPPI_E_INVALID, "bad essps arguments");
     constexpr int P = STATS_L;
-    double grid[P], ess[P], raw[P * 3];
-    float lamf[P];
-    double lo = lam_min, hi = lam_max;
-    int i = 1;
-    for (int rnd = 0; rnd < 2; ++rnd) {
-        const double llo = std::log(lo), lhi = std::log(hi);
-        for (int j = 0; j < P; ++j) grid[j] = std::exp(llo + (lhi - llo) * (double)j / (double)(P - 1));
-        grid[0] = lo; grid[P - 1] = hi;
-        for (int j = 0; j < P; ++j) lamf[j] = (float)grid[j];
-        if (int rc = mppi_softmax_stats_multi(h, lamf, P, raw, stream)) return rc;
-        for (int j = 0; j < P; ++j) ess[j] = raw[3 * j] * raw[3 * j] / raw[3 * j + 1];
-        if (rnd == 0) {  // mppi.py:361-364
-            if (target_ess <= ess[0]) { *lambda_out = lam_min; return MPPI_OK; }
-            if (target_ess >= ess[P - 1]) { *lambda_out = lam_max; return MPPI_OK; }
-        }
-        i = P - 1;
-        for (int j = 0; j < P; ++j) if (ess[j] >= target_ess) { i = j; break; }
-        if (i < 1) i = 1;
-        lo = grid[i - 1]; hi = grid[i];
-    }
-    const int j0 = std::min(std::max(i - 2, 0), P - 4);
-    bool increasing = true;
-    for (int a = 0; a < 3; ++a) increasing = increasing && ess[j0 + a + 1] > ess[j0 + a];
-    if (increasing) {  // Lagrange form of log(lambda) as a function of ESS, at ESS = target
-        double x = 0.0;
-        for (int a = 0; a < 4; ++a) {
-            double w = 1.0;
-            for (int b = 0; b < 4; ++b)
-                if (b != a) w *= (target_ess - ess[j0 + b]) / (ess[j0 + a] - ess[j0 + b]);
-            x += w * std::log(grid[j0 + a]);
-        }
-        const double lam = std::exp(x);
-        if (lam >= lo && lam <= hi) { *lambda_out = lam; return MPPI_OK; }
-    }
-    const double e0 = ess[i - 1], e1 = ess[i];
-    *lambda_out = (e1 == e0) ? 0.5 * (lo + hi) : lo + (hi - lo) * (target_ess - e0) / (e1 - e0);
+    int rc = MPPI_OK;
+    const bool ok = mppi::host::essps_lambda<P>(
+        [&](const double* grid, double* ess) {
+            float lamf[P];
+            double raw[P * 3];
+            for (int j = 0; j < P; ++j) lamf[j] = (float)grid[j];
+            rc = mppi_softmax_stats_multi(h, lamf, P, raw, stream);
+            if (rc) return false;
+            for (int j = 0; j < P; ++j) ess[j] = raw[3 * j] * raw[3 * j] / raw[3 * j + 1];
+            return true;
+        },
+        target_ess, lam_min, lam_max, *lambda_out);
+    return ok ? MPPI_OK : rc;
+}
+
+// LBPS temperature (mppi.py:341-349,534-557): scipy's bounded Brent minimiser (host::fminbound, xatol 1e-5) of the
+// lower-bound objective over [lam_min, lam_max]; every probe is one mppi_softmax_stats round trip (two tiny launches
+// + a 40-byte read-back through mapped host memory), with no interpreter in the loop.  Unsharded handles; synchronises.
+int mppi_lbps_lambda(mppi_handle_t h, double delta, double lam_min, double lam_max, double* lambda_out, void* stream) {
+    if (!h || !lambda_out || !(lam_min > 0.0) || !(lam_max > lam_min) || !(delta > 0.0) || !(delta < 1.0))
+        return fail(h, MPPI_E_INVALID, "bad lbps arguments");
+    int rc = MPPI_OK;
+    const bool ok = mppi::host::lbps_lambda(
+        [&](double lam, mppi::host::SoftmaxStats& st) {
+            double o[5];
+            rc = mppi_softmax_stats(h, (float)lam, o, stream);
+            if (rc) return false;
+            st = mppi::host::SoftmaxStats{o[0], o[1], o[2], o[3], o[4]};
+            return true;
+        },
+        delta, lam_min, lam_max, *lambda_out);
+    return ok ? MPPI_OK : rc;
+}
+
+// MPO temperature (mppi.py:191-200,387-398): the dual variable log T and its Adam moments live in the handle.
+int mppi_mpo_reset(mppi_handle_t h, double lambda0, double epsilon, double lr) {
+    if (!h || !(lambda0 > 0.0) || !(lr > 0.0)) return fail(h, MPPI_E_INVALID, "bad mpo arguments");
+    mppi::host::mpo_reset(h->mpo, lambda0, epsilon, lr);
+    return MPPI_OK;
+}
+// One Adam step of the dual on the last solve's costs (statistics at softplus(logT): one mppi_softmax_stats round
+// trip), lambda_out = exp(logT) = the temperature of the NEXT solve.  Unsharded handles; synchronises.
+int mppi_mpo_step(mppi_handle_t h, double* lambda_out, void* stream) {
+    if (!h || !lambda_out) return fail(h, MPPI_E_INVALID, "null");
+    double o[5];
+    if (int rc = mppi_softmax_stats(h, (float)h->mpo.temperature(), o, stream)) return rc;
+    *lambda_out = mppi::host::mpo_step(h->mpo, mppi::host::SoftmaxStats{o[0], o[1], o[2], o[3], o[4]});
+    return MPPI_OK;
+}
+// {log T, first moment, second moment, step count} of the dual (inspection / tests).
+int mppi_mpo_state(mppi_handle_t h, double* out4_host) {
+    if (!h || !out4_host) return fail(h, MPPI_E_INVALID, "null");
+    out4_host[0] = h->mpo.log_temperature; out4_host[1] = h->mpo.m; out4_host[2] = h->mpo.v; out4_host[3] = h->mpo.t;
+    return MPPI_OK;
+}
+
+// get_samples_from_posterior, the sampling half (mppi.py:489-503): k unclamped action sequences
+// loc + eps, eps ~ N(0, diag(sigma^2)) from the Philox stream of the RESERVED solve index `solve_idx` (callers advance
+// their solve counter: the draw consumes the stream like the reference's global generator).  Roll them out with
+// mppi_rollout_actions(x0_dev = the posterior's state).
+int mppi_sample_posterior(mppi_handle_t h, uint32_t solve_idx, const float* loc_dev, int k, float* samples_out_dev,
+                          void* stream) {
+    if (!h || !loc_dev || !samples_out_dev || k < 1) return fail(h, MPPI_E_INVALID, "bad sample_posterior arguments");
+    if (!h->limits_set) return fail(h, MPPI_E_STATE, "dim_control > 4: call mppi_set_control_limits first");
+    const GenCtx g{h->gen.seed_lo, h->gen.seed_hi, solve_idx};
+    const unsigned grid = (unsigned)(((int64_t)k * h->d.R + BLOCK - 1) / BLOCK);
+    if (h->wide)
+        hipLaunchKernelGGL(posterior_sample_kernel<true>, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, loc_dev, k,
+                           samples_out_dev, h->d, g, (const float*)h->coltab);
+    else
+        hipLaunchKernelGGL(posterior_sample_kernel<false>, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, loc_dev, k,
+                           samples_out_dev, h->d, g, (const float*)nullptr);
+    HIP_TRY(h, hipGetLastError());
     return MPPI_OK;
 }
 
@@ -860,14 +962,16 @@ int mppi_weights(mppi_handle_t h, float lambda, float cmin, float sum_e, float* 
     return MPPI_OK;
 }
 
-int mppi_rollout_actions(mppi_handle_t h, const float* actions_dev, int k, float* states_out, void* stream) {
+int mppi_rollout_actions(mppi_handle_t h, const float* actions_dev, int k, const float* x0_dev, float* states_out,
+                         void* stream) {
     if (!h || !actions_dev || !states_out || k < 1) return fail(h, MPPI_E_INVALID, "bad rollout_actions arguments");
     if (int rc = check_ready(h)) return rc;
     hipStream_t s = (hipStream_t)stream;
+    const float* x0 = x0_dev ? x0_dev : h->x0_cur;  // an explicit start state leaves the solver's own untouched
     const unsigned grid = (unsigned)((k + WAVE - 1) / WAVE);
 #define CALL_RA(MODEL, FASTV)                                                                         \
     hipLaunchKernelGGL((rollout_actions_kernel<MODEL, FASTV>), dim3(grid), dim3(WAVE), 0, s, actions_dev, k, h->d.T, \
-                       h->x0_cur, states_out, h->ctx)
+                       x0, states_out, h->ctx)
     MPPI_DISPATCH(h, CALL_RA);
 #undef CALL_RA
     HIP_TRY(h, hipGetLastError());
@@ -882,7 +986,7 @@ int mppi_rollout_samples(mppi_handle_t h, const int64_t* idx_dev, int k, float* 
     const unsigned grid = (unsigned)((k + WAVE - 1) / WAVE);
 #define CALL_RS(MODEL, FASTV)                                                                         \
     hipLaunchKernelGGL((rollout_samples_kernel<MODEL, FASTV>), dim3(grid), dim3(WAVE), 0, s, h->noise, h->mean_used, \
-                       idx_dev, k, h->x0_cur, states_out, h->d, h->ctx)
+                       idx_dev, k, h->x0_used, states_out, h->d, h->ctx)
     MPPI_DISPATCH(h, CALL_RS);
 #undef CALL_RS
     HIP_TRY(h, hipGetLastError());
@@ -916,7 +1020,7 @@ static int topk_rollout(mppi_handle_t h, const unsigned long long* cand, int k, 
     unsigned* counters = clean ? h->topk_hist + 3 * TOPK_BINS : nullptr;
 #define CALL_TOPK(MODEL, FASTV)                                                                       \
     hipLaunchKernelGGL((topk_rollout_kernel<MODEL, FASTV>), dim3(1), dim3(TOPK_MAX), 0, s, cand, k, h->noise, gen,  \
-                       h->mean_used, h->x0_cur, h->solve_stats, lambda, states_out, weights_out, hist, counters,  \
+                       h->mean_used, h->x0_used, h->solve_stats, lambda, states_out, weights_out, hist, counters,  \
                        h->d, h->gen, h->ctx)
     MPPI_DISPATCH(h, CALL_TOPK);
 #undef CALL_TOPK

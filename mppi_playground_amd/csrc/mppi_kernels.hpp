@@ -67,25 +67,52 @@ __device__ __forceinline__ float wave_sum(float v) {
 // group r of global sample gi.  It is used by sample_kernel (materialise the lane-major tiles) and,
 // in "regen" mode, directly by the rollout and reduction kernels, which then never touch HBM for
 // the noise (Philox + Box-Muller is ~25 VALU per normal, cheaper than a 16 B/lane HBM round trip).
-__device__ __forceinline__ float4 gen_noise4(uint64_t gi, int r, const GenCtx& g, const Dims& d) {
+// WIDE (generic handles whose dim_control is not 1, 2 or 4): the control index of a flat column depends on the
+// group, so sigma / bounds come from the per-column table `coltab` = {sigma[4R], lo[4R], hi[4R]} (built on the host,
+// zeros past the row) instead of the launch constants in Dims.
+template <bool WIDE = false>
+__device__ __forceinline__ float4 gen_noise4(uint64_t gi, int r, const GenCtx& g, const Dims& d,
+                                             const float* __restrict__ sig_cols = nullptr) {
     const u32x4 x = philox4x32_10((uint32_t)gi, (uint32_t)(gi >> 32), (uint32_t)r, g.solve_idx, g.seed_lo, g.seed_hi);
     float z[4];
     box_muller(x.x, x.y, z[0], z[1]);
     box_muller(x.z, x.w, z[2], z[3]);
     // columns past the row length (row % 4 != 0) carry unused values: no consumer reads them
 #pragma unroll
-    for (int j = 0; j < 4; ++j) z[j] *= d.sigma[ctrl_index(j, d.dc)];
+    for (int j = 0; j < 4; ++j) z[j] *= WIDE ? sig_cols[4 * r + j] : d.sigma[ctrl_index(j, d.dc)];
     return make_float4(z[0], z[1], z[2], z[3]);
 }
 
 // HBM-write bound: 16 B per lane per Philox call, one 1 KiB store per wave instruction.
-__global__ __launch_bounds__(BLOCK) void sample_kernel(float4* __restrict__ noise, Dims d, GenCtx g) {
+template <bool WIDE>
+__global__ __launch_bounds__(BLOCK) void sample_kernel(float4* __restrict__ noise, Dims d, GenCtx g,
+                                                       const float* __restrict__ coltab) {
     const int lane = threadIdx.x & 63;
     const int64_t tile = (int64_t)blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6);
     if (tile >= d.tiles) return;
     const uint64_t gi = (uint64_t)(d.sample_offset + tile * 64 + lane);
     float4* out = noise + tile * d.R * 64 + lane;
-    for (int r = 0; r < d.R; ++r) out[(int64_t)r * 64] = gen_noise4(gi, r, g, d);
+    for (int r = 0; r < d.R; ++r) out[(int64_t)r * 64] = gen_noise4<WIDE>(gi, r, g, d, coltab);
+}
+
+// get_samples_from_posterior (mppi.py:489-506): samples[q][f] = loc[f] + eps_q[f] with eps ~ N(0, diag(sigma^2)) from
+// the Philox stream of a solve index RESERVED for this call (counter = (q, group, solve_idx): the draw advances the
+// solver's stream exactly like a forward() would, and every shard draws the same k samples).  Unclamped, like the
+// reference's MultivariateNormal(loc=optimal_solution).sample().  One thread per (sample, float4 group).
+template <bool WIDE>
+__global__ __launch_bounds__(BLOCK) void posterior_sample_kernel(const float* __restrict__ loc, int k,
+                                                                 float* __restrict__ samples, Dims d, GenCtx g,
+                                                                 const float* __restrict__ coltab) {
+    const int64_t idx = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (idx >= (int64_t)k * d.R) return;
+    const int q = (int)(idx / d.R), r = (int)(idx - (int64_t)q * d.R);
+    const float4 n4 = gen_noise4<WIDE>((uint64_t)q, r, g, d, coltab);
+    const float nv[4] = {n4.x, n4.y, n4.z, n4.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int f = 4 * r + j;
+        if (f < d.row) samples[(int64_t)q * d.row + f] = loc[f] + nv[j];
+    }
 }
 
 // One float4 group of a lane's noise row: from the tiles (GEN=false) or regenerated (GEN=true).
@@ -212,10 +239,14 @@ __global__ __launch_bounds__(BLOCK) MPPI_ROLLOUT_ATTR void rollout_cost_kernel(c
                                                              float* __restrict__ costs,
                                                              unsigned* __restrict__ min_key,
                                                              unsigned* __restrict__ next_min_key,
-                                                             float* __restrict__ mean_used, Dims d, GenCtx gen,
+                                                             float* __restrict__ mean_used,
+                                                             float* __restrict__ x0_used, Dims d, GenCtx gen,
                                                              ModelCtx ctx) {
     using M = ModelT<MODEL, FAST>;
     __shared__ float s_min[BLOCK / WAVE];
+    // the state this solve starts from outlives the caller's buffer (mppi_bind_state is zero-copy): later
+    // re-rolls of this solve's samples (get_top_samples, _state_seq_batch) read the snapshot
+    if (blockIdx.x == 0 && threadIdx.x < M::DS) x0_used[threadIdx.x] = x0[threadIdx.x];
     // [4*R] mean groups, [4*R] zeros (samples that do not inherit the mean), then [T*KROW] step rows
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];
     float4* s_mean4 = reinterpret_cast<float4*>(s_dyn);
@@ -354,14 +385,16 @@ __global__ __launch_bounds__(BLOCK) void rollout_cost_wave_kernel(const float* _
 // folds the published rows.
 // partials layout: [gridDim.x][colsp] with colsp = gridDim.y * NW * GPW * 4; heads: [gridDim.x][4].
 constexpr int REDUCE_MAX_BLOCKS = 2048;
-template <int GPW, bool GEN>  // float4 groups per wave and column chunk (8 or 32)
+// WIDE: per-column clamp bounds from `coltab` (see gen_noise4) staged in LDS next to the mean; tiles only (GEN = false).
+template <int GPW, bool GEN, bool WIDE = false>  // GPW: float4 groups per wave and column chunk (8 or 32)
 __global__ __launch_bounds__(BLOCK) void weights_reduce_kernel(const float4* __restrict__ noise,
                                                                const float* __restrict__ mean,
                                                                const float* __restrict__ costs,
                                                                const unsigned* __restrict__ min_key,
                                                                float* __restrict__ partials,
                                                                float* __restrict__ heads, Dims d, GenCtx gen,
-                                                               float lambda) {
+                                                               float lambda, const float* __restrict__ coltab) {
+    static_assert(!(GEN && WIDE), "wide control rows are reduced from the materialised tiles");
     constexpr int NACC = GPW * 4;
     constexpr int NW = BLOCK / WAVE;
     constexpr int CHG = NW * GPW;  // float4 groups per column chunk
@@ -374,6 +407,7 @@ __global__ __launch_bounds__(BLOCK) void weights_reduce_kernel(const float4* __r
     // from LDS inside the tile loop (with an opaque offset) so that the compiler does not hoist the
     // loop-invariant scalar loads into SGPRs: that spilled ~450 SGPRs in every wave's prologue.
     __shared__ __attribute__((aligned(16))) float s_mean[2][CHG * 4];
+    __shared__ __attribute__((aligned(16))) float s_bnd[2][WIDE ? CHG * 4 : 4];  // WIDE: lo / hi of this chunk's columns
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: lives in an SGPR
     const int r0 = blockIdx.y * CHG;  // first float4 group of this column chunk
@@ -381,6 +415,10 @@ __global__ __launch_bounds__(BLOCK) void weights_reduce_kernel(const float4* __r
         const int f = 4 * r0 + j;
         s_mean[0][j] = f < d.row ? mean[f] : 0.0f;
         s_mean[1][j] = 0.0f;
+        if (WIDE) {
+            s_bnd[0][j] = f < d.row ? coltab[4 * d.R + f] : 0.0f;
+            s_bnd[1][j] = f < d.row ? coltab[8 * d.R + f] : 0.0f;
+        }
     }
     const float cmin = key_to_float(*min_key);
     const float xmax = (-cmin) / lambda;
@@ -442,8 +480,14 @@ __global__ __launch_bounds__(BLOCK) void weights_reduce_kernel(const float4* __r
                         // (columns past the row length accumulate unused values; the fold drops them)
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            const int k = ctrl_index(j, d.dc);
-                            const float u = clampf(mv[j] + nv[j], d.u_min[k], d.u_max[k]);
+                            float u;
+                            if (WIDE) {
+                                const int cj = 4 * (wid + NW * m) + j;  // column inside this chunk
+                                u = clampf(mv[j] + nv[j], s_bnd[0][cj], s_bnd[1][cj]);
+                            } else {
+                                const int k = ctrl_index(j, d.dc);
+                                u = clampf(mv[j] + nv[j], d.u_min[k], d.u_max[k]);
+                            }
                             acc[4 * m + j] = fmaf(e, u, acc[4 * m + j]);
                         }
                     }
@@ -660,7 +704,8 @@ __global__ __launch_bounds__(BLOCK) void p2p_publish_kernel(const float* __restr
 // Block-wide: wait for the `len` cells of every rank of solve x.seq and unpack them to out[w * stride + j].
 // Polls give up after ~20 s of wall clock (100 MHz counter) and raise *x.error; the caller's results are then void.
 template <int NT>
-__device__ __forceinline__ void p2p_collect(const P2pCtx& x, int len, float* __restrict__ out, int stride) {
+__device__ __forceinline__ void p2p_collect(const P2pCtx& x, int len, float* __restrict__ out, int stride,
+                                            int* __restrict__ s_timed_out = nullptr) {
     const long long t0 = wall_clock64();
     for (int idx = threadIdx.x; idx < x.world * len; idx += NT) {
         const int w = idx / len, j = idx - w * len;
@@ -668,7 +713,11 @@ __device__ __forceinline__ void p2p_collect(const P2pCtx& x, int len, float* __r
         unsigned long long cell = p2p_load(cellp);
         unsigned spins = 0;
         while ((unsigned)(cell >> 32) != x.seq) {
-            if ((++spins & 1023u) == 0u && wall_clock64() - t0 > 2000000000ll) { *x.error = 1; break; }
+            if ((++spins & 1023u) == 0u && wall_clock64() - t0 > 2000000000ll) {
+                *x.error = 1;
+                if (s_timed_out) *s_timed_out = 1;  // (LDS) the block voids this solve's outputs
+                break;
+            }
             __builtin_amdgcn_s_sleep(2);
             cell = p2p_load(cellp);
         }
@@ -686,9 +735,12 @@ __global__ __launch_bounds__(BLOCK) void p2p_collect_kernel(P2pCtx x, int len, f
 // (mppi.py:381-385,448-452,508-524).
 // `summaries` != nullptr: `num_shards` summary vectors (the all_gathered shards, or this handle's own summary
 // from summarize_kernel).  `summaries` == nullptr: the kernel first folds this handle's published partial rows
-// itself (thread = 128 columns x 8 row groups over the live list, fixed order) — no summarize launch; with a
-// sharp softmax that is a handful of rows.  The summary is also written to `summary_out` for later readers and
-// the number of live rows to `nlive_out` (mapped host memory: the host's hint for the next solve).
+// itself — no summarize launch; with a sharp softmax that is a handful of rows.  The fold uses summarize_kernel's
+// summation tree (64 row groups x 8 interleaved accumulators per column over the ascending live list, then the
+// groups in order), so the summary is bit-identical whichever of the two paths the host picks.  The summary is
+// also written to `summary_out` for later readers and the number of live rows to `nlive_out` (mapped host memory:
+// the host's hint for the next solve).  A timed-out peer-to-peer poll voids the outputs (NaN) instead of
+// returning a partial combine.
 constexpr int FIN_BLOCK = 1024;
 template <int MODEL, bool FAST>
 __global__ __launch_bounds__(FIN_BLOCK) void finalize_kernel(const float* __restrict__ summaries, int num_shards,
@@ -712,44 +764,52 @@ __global__ __launch_bounds__(FIN_BLOCK) void finalize_kernel(const float* __rest
     float* s_sum = s_fin + row;
     float* s_yp = s_sum + (p2p.seq ? p2p.world : 1) * stride;
     if (p2p.seq) {  // the shards' summaries arrive through the peer-to-peer exchange buffer
-        p2p_collect<FIN_BLOCK>(p2p, stride, s_sum, stride);
+        __shared__ int s_timed_out;
+        if (threadIdx.x == 0) s_timed_out = 0;
+        __syncthreads();
+        p2p_collect<FIN_BLOCK>(p2p, stride, s_sum, stride, &s_timed_out);
+        if (s_timed_out) {  // a rank is missing or stalled: no partial answer leaves this kernel
+            const float nanv = __uint_as_float(0x7fc00000u);
+            constexpr int DSN = ModelT<MODEL, FAST>::DS;
+            for (int c = threadIdx.x; c < row; c += FIN_BLOCK) if (action_out) action_out[c] = nanv;
+            for (int c = threadIdx.x; c < (T + 1) * DSN; c += FIN_BLOCK) if (state_out) state_out[c] = nanv;
+            if (threadIdx.x < 4 && stats_out) stats_out[threadIdx.x] = nanv;
+            return;
+        }
         summaries = s_sum;
         num_shards = p2p.world;
     } else if (summaries == nullptr) {
-        constexpr int NG = FIN_BLOCK / 128;
-        __shared__ float s_part[NG][128 + 1];
+        constexpr int NG = SUM_BLOCK / SUM_COLS;  // 64 row groups: summarize_kernel's tree
         __shared__ unsigned short s_list[REDUCE_MAX_BLOCKS];
         __shared__ int s_wcnt[REDUCE_MAX_BLOCKS / WAVE];
         const int nlive = compact_live_rows<FIN_BLOCK>(heads, nblocks, s_list, s_wcnt);
-        const int c = threadIdx.x & 127, g = threadIdx.x >> 7;
-        for (int c0 = 0; c0 < row + 3; c0 += 128) {  // column chunks; the last 3 "columns" are the heads
-            const int col = c0 + c;
+        const int ncols = row + 3;  // the last 3 "columns" are the heads
+        // [NG][ncols] group sums, behind the filter staging (the host sizes the dynamic LDS for it)
+        float* s_fold = s_yp + (sg.window ? (2 * T - 1 + 2 * (sg.window / 2)) * (row / T) : 0);
+        for (int p = threadIdx.x; p < NG * ncols; p += FIN_BLOCK) {
+            const int g = p / ncols, col = p - g * ncols;  // consecutive lanes: consecutive columns of one row
+            const bool is_head = col >= row;
+            const float* base = is_head ? heads + (col - row) : partials + col;
+            const int64_t ld = is_head ? 4 : colsp;
             float a[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) a[q] = 0.f;
-            if (col < row + 3) {
-                const bool is_head = col >= row;
-                const float* base = is_head ? heads + (col - row) : partials + col;
-                const int64_t ld = is_head ? 4 : colsp;
-                for (int k = g; k < nlive; k += 8 * NG) {
+            for (int k = g; k < nlive; k += 8 * NG) {
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const int kk = k + q * NG;
-                        if (kk < nlive) a[q] += base[(int64_t)s_list[kk] * ld];
-                    }
+                for (int q = 0; q < 8; ++q) {
+                    const int kk = k + q * NG;
+                    if (kk < nlive) a[q] += base[(int64_t)s_list[kk] * ld];
                 }
             }
-            s_part[g][c] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
-            __syncthreads();
-            if (threadIdx.x < 128 && col < row + 3) {
-                float v = 0.f;
-#pragma unroll
-                for (int q = 0; q < NG; ++q) v += s_part[q][threadIdx.x];
-                const int dst = col < row ? MPPI_SUMMARY_HEAD + col : 1 + (col - row);
-                s_sum[dst] = v;
-                if (summary_out) summary_out[dst] = v;
-            }
-            __syncthreads();
+            s_fold[p] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+        }
+        __syncthreads();
+        for (int col = threadIdx.x; col < ncols; col += FIN_BLOCK) {
+            float v = 0.f;
+            for (int q = 0; q < NG; ++q) v += s_fold[q * ncols + col];
+            const int dst = col < row ? MPPI_SUMMARY_HEAD + col : 1 + (col - row);
+            s_sum[dst] = v;
+            if (summary_out) summary_out[dst] = v;
         }
         if (threadIdx.x == 0) {
             s_sum[0] = key_to_float(*min_key);
@@ -1220,7 +1280,8 @@ __global__ __launch_bounds__(BLOCK) void inject_kernel(const float* __restrict__
 
 __global__ __launch_bounds__(BLOCK) void export_kernel(const float4* __restrict__ noise,
                                                        const float* __restrict__ mean, float* __restrict__ eps_out,
-                                                       float* __restrict__ act_out, Dims d) {
+                                                       float* __restrict__ act_out, Dims d,
+                                                       const float* __restrict__ coltab /* wide rows, else null */) {
     __shared__ float tilebuf[64][CONV_COLS + 1];
     const int64_t tile = blockIdx.x;
     const int c0 = blockIdx.y * CONV_COLS;
@@ -1242,9 +1303,11 @@ __global__ __launch_bounds__(BLOCK) void export_kernel(const float4* __restrict_
             if (eps_out) eps_out[i * d.row + f] = e;
             if (act_out) {
                 const bool inherit = (d.sample_offset + i) < d.inherit_count;
-                const int k = f % dc;
                 const float m = inherit ? mean[f] : 0.0f;
-                act_out[i * d.row + f] = clampf(m + e, d.u_min[k], d.u_max[k]);
+                float lo, hi;
+                if (coltab) { lo = coltab[4 * d.R + f]; hi = coltab[8 * d.R + f]; }
+                else { const int k = f % dc; lo = d.u_min[k]; hi = d.u_max[k]; }
+                act_out[i * d.row + f] = clampf(m + e, lo, hi);
             }
         }
     }

@@ -82,9 +82,14 @@ class MPPI(nn.Module):
                 (bit-identical to the host statement), "host" keeps the reference's numpy-style round trip.
             shard_samples: treat `num_samples` as the GLOBAL sample count and let this rank own the
                 contiguous block rank*N/W .. (rank+1)*N/W of it (torch.distributed must be
-                initialised); the 4+T*dc-float shard summaries are exchanged once per solve — through
-                peer-to-peer buffers when the start-up self-test passes on every rank, else with one
-                all_gather (environment variable MPPI_EXCHANGE = auto | p2p | nccl).
+                initialised); the 4+T*dc-float shard summaries are exchanged once per solve with one RCCL
+                all_gather (default), or through the library's peer-to-peer buffers (environment variable
+                MPPI_EXCHANGE = nccl | p2p | auto; "auto" takes the buffers when their start-up self-test passes
+                on every rank and falls back to the all_gather otherwise).
+
+        `device`: the hot path exists on MI355X only.  The reference falls back to the CPU silently when CUDA is
+        unavailable or another device is asked for (src/pi_mpc/mppi.py:102-105); this class raises instead — a
+        CPU device is refused, a "cuda" device (with or without an index) selects that GPU.
         """
         super().__init__()
         assert u_min.shape == (dim_control,)
@@ -92,11 +97,15 @@ class MPPI(nn.Module):
         assert sigmas.shape == (dim_control,)
         if dtype != torch.float32:
             raise ValueError("the HIP path computes in float32 (the reference default dtype)")
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise ValueError(f"device={dev}: this MPPI runs its hot path on MI355X only; there is no CPU path "
+                             "(the reference's silent CPU fallback, src/pi_mpc/mppi.py:102-105, is not reproduced)")
         if not torch.cuda.is_available():
             raise _capi.MppiError("no GPU visible: this MPPI runs its hot path on MI355X only "
                                   "(no CPU fallback)")
         _capi.load()  # fail loudly if the extension is missing
-        self._device = torch.device("cuda", torch.cuda.current_device())
+        self._device = torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
         self._dtype = dtype
 
         self._horizon = horizon
@@ -153,10 +162,8 @@ class MPPI(nn.Module):
             # T-step loops run the user's callables on GPU tensors exactly like the reference
             self._model = None
             self._cost_tag = self._cost_owner = self._dyn_tag = self._dyn_owner = None
-            if dim_control not in (1, 2, 4):
-                # the lane-major noise rows hold whole float4 groups per step (every shipped example has
-                # 1 or 2 controls)
-                raise NotImplementedError("the HIP path supports dim_control in {1, 2, 4}")
+            if not 1 <= dim_control <= _capi.MAX_DIM_CONTROL_GENERIC:
+                raise ValueError(f"dim_control must be in 1..{_capi.MAX_DIM_CONTROL_GENERIC}")
 
         # ---- auto lambda (src/pi_mpc/mppi.py:183-210)
         self._lambda: float | str = lambda_
@@ -167,7 +174,7 @@ class MPPI(nn.Module):
         if self._lambda == "MPO":
             self._auto_lambda = "MPO"
             self._lambda = 1.0
-            self._mpo = _host.MpoTemperature(1.0, 0.1, 0.2)
+            self._mpo = _host.MpoTemperature(1.0, 0.1, 0.2)  # host statement (sharded / host statistics)
         elif self._lambda == "LBPS":
             self._auto_lambda = "LBPS"
         elif self._lambda == "ESSPS":
@@ -191,13 +198,21 @@ class MPPI(nn.Module):
         cfg.num_samples = self._local_samples
         cfg.sample_offset = self._sample_offset
         cfg.inherit_count = int(num_samples * (1 - exploration))  # src/pi_mpc/mppi.py:266
-        for k in range(dim_control):
+        for k in range(min(dim_control, _capi.MAX_DIM_CONTROL)):
             cfg.u_min[k] = float(u_min[k])
             cfg.u_max[k] = float(u_max[k])
             cfg.sigmas[k] = float(sigmas[k])
         cfg.seed = self._seed
         cfg.device = self._device.index
         self._h = _capi.Handle(cfg)
+        if dim_control > _capi.MAX_DIM_CONTROL:  # the config holds four controls: hand over the full vectors
+            f = lambda t: (C.c_float * dim_control)(*[float(v) for v in t])  # noqa: E731
+            self._h.call("mppi_set_control_limits", f(u_min), f(u_max), f(sigmas), dim_control)
+        # the LBPS search and the MPO step run inside the library (no interpreter work per probe) whenever the
+        # statistics come from this device alone; sharded solvers combine the shards' statistics in Python
+        self._search_in_library = auto_lambda_stats == "device" and self._world == 1
+        if self._auto_lambda == "MPO":
+            self._h.call("mppi_mpo_reset", 1.0, 0.1, 0.2)  # mppi.py:191-200
         if self._sg_on_device:  # step 7 runs inside mppi_finalize (taps computed above, history zero)
             self._h.call("mppi_set_sg_filter", self._coeffs.ctypes.data_as(C.c_void_p), int(len(self._coeffs)), None)
         self._uploaded = {}  # slot -> (id(cells), version)
@@ -295,16 +310,19 @@ class MPPI(nn.Module):
         return out
 
     def _setup_exchange(self) -> None:
-        """Pick the per-solve exchange of a sharded solver.  MPPI_EXCHANGE = "nccl": one all_gather per solve
-        (torch.distributed);  "auto" (default): try the library's peer-to-peer buffer exchange (mppi_p2p_*: no
+        """Pick the per-solve exchange of a sharded solver.  MPPI_EXCHANGE = "nccl" (default): one RCCL all_gather
+        per solve (torch.distributed);  "auto": try the library's peer-to-peer buffer exchange (mppi_p2p_*: no
         collective launch on the critical path), verify it with a few pattern exchanges, and use it only if
         EVERY rank succeeded — otherwise all ranks fall back to the all_gather together;  "p2p": as auto, but raise
-        instead of falling back."""
+        instead of falling back.  The all_gather is the default because the buffer exchange has only been measured
+        between processes sharing one device."""
         import os
 
         import torch.distributed as dist
 
-        mode = os.environ.get("MPPI_EXCHANGE", "auto").lower()
+        mode = os.environ.get("MPPI_EXCHANGE", "nccl").lower()
+        if mode not in ("nccl", "p2p", "auto"):
+            raise ValueError("MPPI_EXCHANGE must be nccl, p2p or auto")
         if mode == "nccl":
             return
         W, r, length = self._world, self._rank, int(self._summary.numel())
@@ -409,7 +427,8 @@ class MPPI(nn.Module):
         assert state.shape == (self._dim_state,)
         h, st = self._h, self._stream()
         if torch.is_tensor(state) and state.is_cuda:
-            # zero-copy: the kernels read the caller's tensor (kept alive until the next solve)
+            # zero-copy: this solve's kernels read the caller's tensor (kept alive until the next solve); the rollout
+            # kernel snapshots it, so later re-rolls (get_top_samples, _state_seq_batch) do not depend on it
             self._x0_keep = state.detach().to(self._device, self._dtype).contiguous()
             h.call("mppi_bind_state", _ptr(self._x0_keep))
         else:
@@ -443,7 +462,12 @@ class MPPI(nn.Module):
         on_dev = self._auto_lambda_stats == "device"
         if self._auto_lambda is not None and not on_dev:
             costs_host = self._gather_costs_host()
-        if self._auto_lambda == "LBPS":
+        if self._auto_lambda == "LBPS" and self._search_in_library:
+            lam_out = C.c_double(0.0)  # bounded Brent inside the library (same algorithm as scipy's, host C++)
+            h.call("mppi_lbps_lambda", float(self._lbps_delta), float(self._lambda_min), float(self._lambda_max),
+                   C.byref(lam_out), st)
+            self._lambda = lam_out.value
+        elif self._auto_lambda == "LBPS":
             self._lambda = (_host.lbps_lambda_stats(self._softmax_stats, self._lbps_delta, self._lambda_min,
                                                     self._lambda_max) if on_dev else
                             _host.lbps_lambda(costs_host, self._lbps_delta, self._lambda_min, self._lambda_max))
@@ -485,8 +509,13 @@ class MPPI(nn.Module):
                _ptr(self._state_out) if (native and not use_sg) else None, _ptr(self._stats), st)
 
         if self._auto_lambda == "MPO":  # after the weights, affects the next solve (mppi.py:387-398)
-            self._lambda = (self._mpo.step_from_stats(self._softmax_stats(self._mpo.temperature())) if on_dev
-                            else self._mpo.step(costs_host))
+            if self._search_in_library:
+                lam_out = C.c_double(0.0)
+                h.call("mppi_mpo_step", C.byref(lam_out), st)
+                self._lambda = lam_out.value
+            else:
+                self._lambda = (self._mpo.step_from_stats(self._softmax_stats(self._mpo.temperature())) if on_dev
+                                else self._mpo.step(costs_host))
 
         if use_sg:  # Step 7 on the host (src/pi_mpc/mppi.py:423-443)
             a = self._action_out.cpu().numpy()
@@ -494,7 +523,7 @@ class MPPI(nn.Module):
             self._action_out.copy_(torch.from_numpy(a))
             h.call("mppi_set_mean", _ptr(self._action_out), 1, st)
             if native:
-                h.call("mppi_rollout_actions", _ptr(self._action_out), 1, _ptr(self._state_out), st)
+                h.call("mppi_rollout_actions", _ptr(self._action_out), 1, None, _ptr(self._state_out), st)
             first = a[0]
             self._actions_history_for_sg = np.concatenate([self._actions_history_for_sg[1:], first[None, :]])
         if not native:  # Step 8 with the user's dynamics (src/pi_mpc/mppi.py:448-449,508-524)
@@ -586,8 +615,10 @@ class MPPI(nn.Module):
             dist.all_gather_into_tensor(allv, mine, group=self._pg)
             a = allv.view(self._world, -1).cpu().numpy()
             cm, st = a[:, 0], a[:, 1:].reshape(self._world, L, 3)
-            x = (-cm.astype(np.float32))[:, None] / lams[None, :]          # [W, L] fp32 like the kernel
-            f = np.exp(x.astype(np.float64) - x.max(axis=0, keepdims=True))
+            # every shard's sums are relative to ITS minimum, e = exp((cmin_w - c) / lam) (stats_multi_partial_kernel):
+            # rescale by exp((cmin - cmin_w) / lam), difference first, in float64 — rounding the two quotients
+            # separately would put ulp(cmin / lam) into the exponent
+            f = np.exp((cm.min() - cm)[:, None] * (1.0 / lams.astype(np.float64))[None, :])
             se, se2 = (f * st[:, :, 0]).sum(0), (f * f * st[:, :, 1]).sum(0)
         return se * se / se2
 
@@ -711,20 +742,33 @@ class MPPI(nn.Module):
 
     def get_samples_from_posterior(self, optimal_solution: torch.Tensor, state: torch.Tensor,
                                    num_samples: int) -> Tuple[torch.Tensor, torch.Tensor]:
-        """N(optimal_solution, Sigma) samples and their rollouts (src/pi_mpc/mppi.py:489-506)."""
+        """N(optimal_solution, Sigma) samples (unclamped) and their rollouts (src/pi_mpc/mppi.py:489-506).
+
+        The draw comes from the SOLVER'S noise stream, like the reference's MultivariateNormal.sample() on torch's
+        global generator: in "torch_cpu" mode the next [k,T,dc] normals of the solver's CPU generator (so an
+        identically seeded reference run sees the same samples and the same noise in the following solve), otherwise
+        the Philox stream at the next solve index, which this call consumes.  The solver's own state is untouched:
+        a later get_top_samples still describes the last solve."""
         assert num_samples <= self._num_samples
-        g = torch.Generator(device="cpu")
-        g.manual_seed(self._seed + 7919 * self._solve_idx)
-        eps = torch.randn(num_samples, self._horizon, self._dim_control, generator=g) * self._sigmas.cpu()
-        samples = (optimal_solution.to(self._device) + eps.to(self._device)).contiguous()
-        if self._model is None:
-            x0g = torch.as_tensor(state, dtype=torch.float32).to(self._device)
-            return samples, self._states_prediction(x0g, samples)
+        k, T, dc = num_samples, self._horizon, self._dim_control
         st = self._stream()
-        x0 = torch.as_tensor(state, dtype=torch.float32).to(self._device).contiguous()
-        self._h.call("mppi_set_state", _ptr(x0), 1, st)
-        out = torch.empty(num_samples, self._horizon + 1, self._dim_state, device=self._device, dtype=self._dtype)
-        self._h.call("mppi_rollout_actions", _ptr(samples), num_samples, _ptr(out), st)
+        loc = torch.as_tensor(optimal_solution, dtype=self._dtype).to(self._device).contiguous()
+        assert loc.shape == (T, dc)
+        if self._noise_source == "torch_cpu":
+            eps = torch.randn(k, T, dc, generator=self._cpu_gen, dtype=torch.float32) * self._sigmas.cpu()
+            samples = (loc + eps.to(self._device)).contiguous()
+        else:
+            samples = torch.empty(k, T, dc, device=self._device, dtype=self._dtype)
+            self._h.call("mppi_sample_posterior", self._solve_idx, _ptr(loc), k, _ptr(samples), st)
+            self._solve_idx += 1
+        x0 = torch.as_tensor(np.asarray(state) if not torch.is_tensor(state) else state).to(
+            self._device, self._dtype).contiguous()
+        assert x0.shape == (self._dim_state,)
+        if self._model is None:
+            return samples, self._states_prediction(x0, samples)
+        out = torch.empty(k, T + 1, self._dim_state, device=self._device, dtype=self._dtype)
+        self._h.call("mppi_rollout_actions", _ptr(samples), k, _ptr(x0), _ptr(out), st)
+        self._posterior_keep = (x0, samples)  # alive until the enqueued kernels ran
         return samples, out
 
     # ------------------------------------------------------------------ diagnostics

@@ -47,3 +47,52 @@ def rollout_cost(model_id, fast, x0, mean, eps, u_min, u_max, threshold, params=
                                  0 if r is None else r.shape[0], _p(costs), _p(bad), _p(S))
     assert rc == 0
     return costs, bad, S
+
+
+_SEARCH_SO = os.path.join(_HERE, "libsearch.so")
+_search = None
+
+
+def search_lib():
+    """Host build of csrc/host_search.hpp (the library's LBPS / ESSPS / MPO searches) over plain cost arrays."""
+    global _search
+    if _search is None:
+        src = os.path.join(_HERE, "search.cpp")
+        hdr = os.path.join(_HERE, "..", "..", "mppi_playground_amd", "csrc", "host_search.hpp")
+        if (not os.path.exists(_SEARCH_SO)
+                or os.path.getmtime(_SEARCH_SO) < max(os.path.getmtime(src), os.path.getmtime(hdr))):
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", _SEARCH_SO, src])
+        _search = C.CDLL(_SEARCH_SO)
+        d, vp, i = C.c_double, C.c_void_p, C.c_int
+        _search.search_lbps.argtypes = [vp, i, d, d, d, vp, vp]
+        _search.search_fminbound_poly.argtypes = [d, d, d, d, d, vp, vp]
+        _search.search_essps.argtypes = [vp, i, d, d, d, vp]
+        _search.search_mpo.argtypes = [vp, i, i, d, d, d, vp]
+    return _search
+
+
+def lbps(costs, delta, lo, hi):
+    c = np.ascontiguousarray(costs, np.float32)
+    out, nf = C.c_double(0), C.c_int(0)
+    assert search_lib().search_lbps(_p(c), len(c), delta, lo, hi, C.byref(out), C.byref(nf)) == 0
+    return out.value, nf.value
+
+
+def fminbound_poly(a, b, c, lo, hi):
+    out, nf = C.c_double(0), C.c_int(0)
+    assert search_lib().search_fminbound_poly(a, b, c, lo, hi, C.byref(out), C.byref(nf)) == 0
+    return out.value, nf.value
+
+
+def essps(costs, target, lo, hi):
+    c = np.ascontiguousarray(costs, np.float32)
+    out = C.c_double(0)
+    assert search_lib().search_essps(_p(c), len(c), target, lo, hi, C.byref(out)) == 0
+    return out.value
+
+
+def mpo(cost_rows, lam0=1.0, epsilon=0.1, lr=0.2):
+    c = np.ascontiguousarray(cost_rows, np.float32)
+    out = np.zeros(c.shape[0], np.float64)
+    assert search_lib().search_mpo(_p(c), c.shape[1], c.shape[0], lam0, epsilon, lr, _p(out)) == 0
+    return out

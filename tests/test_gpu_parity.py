@@ -882,7 +882,7 @@ def test_wave_parallel_batch1_rollout_is_bit_identical_to_the_serial_one():
     for tick in range(40):
         a, s = ctrl.update(state, env.racing_center_path)
         s2 = torch.empty_like(s)
-        solver._h.call("mppi_rollout_actions", a.data_ptr(), 1, s2.data_ptr(), solver._stream())
+        solver._h.call("mppi_rollout_actions", a.data_ptr(), 1, None, s2.data_ptr(), solver._stream())
         assert torch.equal(s, s2), f"tick {tick}"
         state, _ = env.step(a[0, :])
     # actions beyond the bounds and a heading just inside the wrap
@@ -892,7 +892,7 @@ def test_wave_parallel_batch1_rollout_is_bit_identical_to_the_serial_one():
     solver2.set_warm_start(np.tile(np.array([[3.0, -0.3]], np.float32), (50, 1)))
     a, s = solver2.forward(x0)
     s2 = torch.empty_like(s)
-    solver2._h.call("mppi_rollout_actions", a.data_ptr(), 1, s2.data_ptr(), solver2._stream())
+    solver2._h.call("mppi_rollout_actions", a.data_ptr(), 1, None, s2.data_ptr(), solver2._stream())
     assert torch.equal(s, s2)
     P = oracle_problem("racing", 1, 50)
     ref = P.rollout_single(x0.numpy(), a.cpu().numpy())

@@ -270,3 +270,50 @@ def test_map_recipes_border_clipping_and_threshold():
     spec = lm.grid_spec()
     assert np.array_equal(spec.cells, lit)
     assert np.array_equal(_recipe_raster(40, 40, spec.recipe), lit)
+
+
+# ------------------------------------------------------------------ the library's own searches (csrc/host_search.hpp)
+def test_library_bounded_minimiser_is_scipys():
+    """host::fminbound (what mppi_lbps_lambda runs) against scipy.optimize.minimize_scalar(method="bounded") on the
+    same objectives: same minimiser, same number of function evaluations (the same published algorithm, step by
+    step), including minima at an end point and objectives with several local minima."""
+    import emul
+    from scipy.optimize import minimize_scalar
+
+    rng = np.random.default_rng(3)
+    for trial in range(40):
+        a, b, c = rng.uniform(-2, 12), rng.uniform(0, 0.9), rng.uniform(0.1, 6)
+        lo, hi = 0.01, 10.0
+        f = lambda x: (x - a) ** 2 * (1.0 + b * np.sin(c * x)) + 0.1 * x  # noqa: E731
+        res = minimize_scalar(f, bounds=(lo, hi), method="bounded")
+        x, nfev = emul.fminbound_poly(a, b, c, lo, hi)
+        assert nfev == res.nfev, (trial, nfev, res.nfev)
+        assert abs(x - res.x) <= 1e-12 * max(1.0, abs(res.x)), (trial, x, res.x)
+
+
+def test_library_searches_match_reference_fixtures():
+    """LBPS / ESSPS / MPO as the library computes them (host C++ over softmax statistics) on the reference's own
+    cost vectors -> the reference's lambdas (same tolerances as the numpy statements in pi_mpc/_host.py)."""
+    import emul
+
+    g = load("pendulum_T15_N256_lbps")
+    for k in range(3):
+        c = g[f"costs_{k}"]
+        lam, nfev = emul.lbps(c, 0.01, 0.01, 10.0)
+        assert abs(lam - float(g[f"lambda_{k}"])) <= 1e-3 * float(g[f"lambda_{k}"])
+        assert abs(lam - _host.lbps_lambda_stats(_np_stats(c), 0.01, 0.01, 10.0)) <= 1e-4 * lam
+        assert 5 <= nfev <= 60
+    for name in ("pendulum_T50_N1000_essps", "nav2d_T50_N512_essps", "cartpole_T64_N1024_essps_sg"):
+        g, cfg = load(name), CASES[name]
+        for k in range(3):
+            lam = emul.essps(g[f"costs_{k}"], cfg["N"] / 10, 0.01, 10.0)
+            assert abs(lam - float(g[f"lambda_{k}"])) <= 1e-5 * float(g[f"lambda_{k}"])
+    # end-point rules of mppi.py:361-364
+    c = load("pendulum_T50_N1000_essps")["costs_0"]
+    assert emul.essps(c, 1.0, 0.01, 10.0) == 0.01 and emul.essps(c, 999.99, 0.01, 10.0) == 10.0
+    g = load("pendulum_T15_N256_mpo")
+    lams = emul.mpo(np.stack([g[f"costs_{k}"] for k in range(3)]))
+    m = _host.MpoTemperature()
+    for k in range(3):
+        assert abs(lams[k] - float(g[f"lambda_{k}"])) <= 2e-4 * float(g[f"lambda_{k}"])
+        assert abs(lams[k] - m.step(g[f"costs_{k}"])) <= 2e-6 * lams[k]
