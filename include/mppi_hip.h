@@ -290,7 +290,9 @@ int mppi_p2p_error(mppi_handle_t h);
 /* Tuning knobs (not in the reference): "math" 0 = library sin/cos/tan/fmod/div, 1 = range-checked
  * fast paths (default); "noise_regen" (see mppi_sample); "mapping" 0 = lane per trajectory (default), 1 =
  * the north star's literal wavefront-per-trajectory rollout (comparison only, ~20x slower); "reduce_blocks" grid of the weighted
- * reduction; "timing" (see mppi_get_timing). */
+ * reduction; "fold_path" who sums the reduction's partial rows: 0 = by the live-row count of earlier solves (default),
+ * 1 = inside mppi_finalize whenever the rows fit its LDS, 2 = always the separate summarize kernel (both use the same
+ * summation tree: results are bit-identical); "timing" (see mppi_get_timing). */
 int mppi_set_option(mppi_handle_t h, const char* key, int64_t value);
 /* Device time per stage from HIP event pairs recorded on the caller's stream around every stage call
  * since the last drain (no host synchronisation while recording): out[0..3] = mean ms of

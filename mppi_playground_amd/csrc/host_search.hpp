@@ -168,13 +168,17 @@ bool essps_lambda(G&& ess_grid, double target_ess, double lam_min, double lam_ma
 // ---------------------------------------------------------------------------------------------------------
 // MPO temperature (mppi.py:191-200,387-398): one Adam(lr) step per solve on
 //   loss(logT) = T * (epsilon + logsumexp(-c / T)),  T = softplus(logT),  then lambda = exp(logT)   (B-Q12)
-// with the gradient written out: dL/dT = epsilon + LSE + E_w[c] / T, dT/dlogT = sigmoid(logT).  Scalars are
-// kept in fp32 where torch keeps them in fp32 (parameter, gradient, both moments).
+// with the gradient written out: dL/dT = epsilon + LSE + E_w[c] / T, dT/dlogT = sigmoid(logT).  The two large terms
+// cancel (|LSE| ~ |c|/T against |dL/dT| ~ 1), so WHERE the reference rounds to fp32 decides the result: its autograd
+// keeps LSE as an fp32 scalar and forms the backward pass's weights as exp(x_i - fl32(LSE)), which sum to
+// exp(LSE - fl32(LSE)) instead of 1.  Both roundings are reproduced (lse32, scale): the same formula in float64 is
+// 2-10 % of the gradient away from the reference on nav2d costs, this statement ~1e-4.  Same arithmetic as
+// pi_mpc/_host.py::MpoTemperature.  Scalars are fp32 where torch keeps them in fp32 (parameter, gradient, moments).
 struct MpoState {
     float log_temperature = 0.0f, m = 0.0f, v = 0.0f;
     int32_t t = 0;
     double epsilon = 0.1, lr = 0.2;
-    double temperature() const { return std::log1p(std::exp((double)log_temperature)); }  // softplus(logT)
+    float temperature() const { return (float)std::log1p(std::exp((double)log_temperature)); }  // softplus(logT), fp32
 };
 inline void mpo_reset(MpoState& s, double lam0, double epsilon, double lr) {
     s = MpoState{};
@@ -184,11 +188,13 @@ inline void mpo_reset(MpoState& s, double lam0, double epsilon, double lr) {
 // `st` = the softmax statistics at lambda = s.temperature().  Returns the new lambda = exp(logT).
 inline double mpo_step(MpoState& s, const SoftmaxStats& st) {
     const double b1 = 0.9, b2 = 0.999, adam_eps = 1e-8;
-    const double lt = (double)s.log_temperature, T = s.temperature();
-    const double lse = -st.cmin / T + std::log(st.se);
-    const double wc = st.sec / st.se;
-    const double dL_dT = s.epsilon + lse + wc / T;
-    const float g = (float)(dL_dT * (1.0 / (1.0 + std::exp(-lt))));
+    const double lt = (double)s.log_temperature;
+    const float T = s.temperature();
+    const float xmax32 = (-(float)st.cmin) / T;
+    const float lse32 = xmax32 + (float)std::log((double)(float)st.se);
+    const double scale = std::exp((double)xmax32 - (double)lse32);
+    const float dL_dT = ((float)s.epsilon + lse32) + (float)(scale * st.sec / (double)T);
+    const float g = (float)((double)dL_dT * (1.0 / (1.0 + std::exp(-lt))));
     s.t += 1;
     s.m = (float)(b1 * (double)s.m + (1.0 - b1) * (double)g);
     s.v = (float)(b2 * (double)s.v + (1.0 - b2) * (double)g * (double)g);

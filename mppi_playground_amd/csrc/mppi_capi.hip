@@ -90,6 +90,7 @@ struct MppiSolver {
     bool summary_valid = false;             // summarize_kernel ran after the last reduce
     int* live_hint = nullptr;               // mapped pinned: partial rows the last fold saw (host-side hint)
     int* live_hint_dev = nullptr;
+    int fold_mode = 0;                      // 0: choose by the hint; 1: fold inside finalize when it fits; 2: always summarize
     std::string err;
 };
 
@@ -751,7 +752,8 @@ int mppi_weights_reduce(mppi_handle_t h, float lambda, float* summary_out_dev, v
         if (h->p2p_seq == 0) h->p2p_seq = 1;
         p2p = p2p_ctx(h);
     }
-    if (summary_out_dev || h->p2p_enabled || !fold_fits(h) || *(volatile int*)h->live_hint > FOLD_IN_FINALIZE_MAX_ROWS) {
+    const bool many_rows = h->fold_mode == 0 ? *(volatile int*)h->live_hint > FOLD_IN_FINALIZE_MAX_ROWS : h->fold_mode == 2;
+    if (summary_out_dev || h->p2p_enabled || !fold_fits(h) || many_rows) {
         const unsigned sgrid = (unsigned)((h->colsp + SUM_COLS - 1) / SUM_COLS + 1);
         hipLaunchKernelGGL(summarize_kernel, dim3(sgrid), dim3(SUM_BLOCK), 0, s, h->partials, h->heads, mk, (int)blocks,
                            h->colsp, h->d.row, h->summary, summary_out_dev, h->live_hint_dev, p2p);
@@ -1130,6 +1132,7 @@ int mppi_set_option(mppi_handle_t h, const char* key, int64_t value) {
     if (k == "reduce_blocks") { h->reduce_blocks = (int)std::max<int64_t>(1, std::min<int64_t>(value, 2048)); return MPPI_OK; }
     if (k == "timing") { h->timing = (int)value; return MPPI_OK; }
     if (k == "mapping") { h->mapping = value ? 1 : 0; return MPPI_OK; }
+    if (k == "fold_path") { h->fold_mode = (value >= 0 && value <= 2) ? (int)value : 0; return MPPI_OK; }
     if (k == "exchange_p2p") {  // sharded solves: summaries travel through the peer-to-peer buffer, no collective
         if (value && !h->p2p_connected) return fail(h, MPPI_E_STATE, "exchange_p2p: call mppi_p2p_alloc / mppi_p2p_connect first");
         h->p2p_enabled = value != 0;

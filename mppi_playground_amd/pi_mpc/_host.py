@@ -128,6 +128,11 @@ class MpoTemperature:
     per solve on loss = softplus(logT) * (eps + logsumexp(-c / softplus(logT))), then
     lambda = exp(logT).  The gradient is written out instead of using autograd:
       dL/dT = eps + LSE + (sum_i w_i c_i) / T,   dT/dlogT = sigmoid(logT).
+    The two large terms cancel (|LSE| ~ |c|/T against |dL/dT| ~ 1), so WHERE the reference rounds to fp32 decides
+    the result: its autograd keeps LSE as an fp32 scalar and forms the weights of the backward pass as
+    exp(x_i - fl32(LSE)) — they sum to exp(LSE - fl32(LSE)), not to 1.  Both roundings are reproduced here
+    (`lse32`, `scale`); evaluating the same formula in float64 differs from the reference by 2-10 % of the gradient
+    on nav2d costs (c ~ 770, T ~ 0.8), this statement by ~1e-4.
     """
 
     def __init__(self, lam0: float = 1.0, epsilon: float = 0.1, lr: float = 0.2):
@@ -139,30 +144,32 @@ class MpoTemperature:
         self.t = 0
 
     def temperature(self) -> float:
-        """softplus(logT): the temperature inside the dual (not the lambda used for the weights)."""
-        return math.log1p(math.exp(float(self.log_temperature)))
+        """softplus(logT) as the fp32 scalar of the dual (not the lambda used for the weights)."""
+        return float(F32(math.log1p(math.exp(float(self.log_temperature)))))
 
     def step(self, costs: np.ndarray) -> float:
-        T = self.temperature()
-        x = (-costs.astype(np.float64)) / T
-        mx = x.max()
-        e = np.exp(x - mx)
-        se = e.sum()
-        return self.step_from_sums(mx + math.log(se), float((e * costs).sum() / se))
+        T = F32(self.temperature())
+        c = costs.astype(F32)
+        x = ((-c) / T).astype(np.float64)  # fp32 quotients, like the device statistics
+        e = np.exp(x - x.max())
+        return self.step_from_sums(float(c.min()), float(e.sum()), float((e * c).sum()))
 
     def step_from_stats(self, st) -> float:
         """`st` = softmax statistics at lambda = self.temperature()."""
-        T = self.temperature()
-        return self.step_from_sums(-st["cmin"] / T + math.log(st["se"]), st["sec"] / st["se"])
+        return self.step_from_sums(st["cmin"], st["se"], st["sec"])
 
-    def step_from_sums(self, lse: float, wc: float) -> float:
+    def step_from_sums(self, cmin: float, se: float, sec: float) -> float:
+        """cmin, se = sum e_i, sec = sum e_i c_i with e_i = exp((-c_i)/T - (-cmin)/T), T = self.temperature()."""
         lt = float(self.log_temperature)
-        T = self.temperature()
-        dL_dT = self.epsilon + lse + wc / T
-        g = F32(dL_dT * (1.0 / (1.0 + math.exp(-lt))))
+        T = F32(self.temperature())
+        xmax32 = F32(-F32(cmin)) / T
+        lse32 = F32(xmax32 + F32(math.log(F32(se))))           # torch.logsumexp keeps an fp32 scalar
+        scale = math.exp(float(xmax32) - float(lse32))          # what the backward pass's fp32 weights sum to / se
+        dL_dT = F32(F32(F32(self.epsilon) + lse32) + F32(scale * sec / float(T)))
+        g = F32(float(dL_dT) * (1.0 / (1.0 + math.exp(-lt))))
         self.t += 1
-        self.m = F32(self.b1 * self.m + (1 - self.b1) * g)
-        self.v = F32(self.b2 * self.v + (1 - self.b2) * g * g)
+        self.m = F32(self.b1 * float(self.m) + (1 - self.b1) * float(g))
+        self.v = F32(self.b2 * float(self.v) + (1 - self.b2) * float(g) * float(g))
         bc1 = 1 - self.b1 ** self.t
         bc2 = 1 - self.b2 ** self.t
         denom = math.sqrt(float(self.v)) / math.sqrt(bc2) + self.eps

@@ -7,7 +7,10 @@ inputs/outputs of ``pi_mpc.mppi.MPPI.forward`` for the five shipped models into 
 bytecode) is written into the fixtures: they hold arrays only.
 
 Usage (container only; the GPU box has no /root/reference):
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py            # everything
+    python tests/golden/make_golden.py round2     # only the cases added in round 2 (dense softmax at N = 4096,
+                                                  # racing / nav2d with SG, exploration, LBPS, MPO, ESSPS end point,
+                                                  # get_samples_from_posterior between two solves)
 
 Recipe follows SURVEY.md Appendix C: stub the UI-only imports (moviepy, fire,
 gymnasium), run with cwd=/root/reference (racing_env.py:47-49 opens a relative CSV),
@@ -93,9 +96,20 @@ class Recorder:
         return c
 
 
-def run_case(name, make_solver, x0, K, next_state, keep_S, before_solve=None):
-    """Run K closed-loop solves and dump everything the parity tests need."""
+ONLY_ROUND2 = len(sys.argv) > 1 and sys.argv[1] == "round2"
+ROUND2 = set()  # names registered with round2=True
+
+
+def run_case(name, make_solver, x0, K, next_state, keep_S, before_solve=None, round2=False, posterior_after=None):
+    """Run K closed-loop solves and dump everything the parity tests need.  posterior_after = (k, n): call
+    get_samples_from_posterior(action_seq_k, state, n) right after solve k (mppi.py:489-506) and record it — the draw
+    comes from the same global generator, so the noise of solve k+1 pins the stream position."""
     import torch
+
+    if round2:
+        ROUND2.add(name)
+    if ONLY_ROUND2 and not round2:
+        return
 
     solver, rec, extra = make_solver()
     N, T = solver._num_samples, solver._horizon
@@ -132,6 +146,11 @@ def run_case(name, make_solver, x0, K, next_state, keep_S, before_solve=None):
             ts, tw = solver.get_top_samples(8)
             d["top8_states_0"] = ts.numpy().copy()
             d["top8_weights_0"] = tw.detach().numpy().copy()
+        if posterior_after is not None and posterior_after[0] == k:
+            ps, pst = solver.get_samples_from_posterior(a, state.clone(), posterior_after[1])
+            d["posterior_after"] = np.int64(k)
+            d["posterior_samples"] = ps.detach().numpy().copy()
+            d["posterior_states"] = pst.detach().numpy().copy()
         state = next_state(state, a, s)
     d["K"] = np.int64(K)
     path = os.path.join(OUT, name + ".npz")
@@ -214,7 +233,8 @@ def main():
                             np.array(gz._danger_zone.center) - gz._pos]).astype(np.float32)
     gz_extra = {"goal": np.asarray(gz._goal, np.float64), "center": np.asarray(gz._danger_zone.center, np.float64),
                 "radius": np.float64(gz._danger_zone.radius), "x0": gz_x0}
-    np.savez_compressed(os.path.join(OUT, "goalzone_env.npz"), **gz_extra)
+    if not ONLY_ROUND2:
+        np.savez_compressed(os.path.join(OUT, "goalzone_env.npz"), **gz_extra)
 
     def goalzone(**kw):
         def make():
@@ -259,7 +279,8 @@ def main():
 
         return make
 
-    np.savez_compressed(os.path.join(OUT, "nav2d_env.npz"), **nav_extra)
+    if not ONLY_ROUND2:
+        np.savez_compressed(os.path.join(OUT, "nav2d_env.npz"), **nav_extra)
 
     x0_nav = nav_env._robot_state.numpy().copy()
     run_case("nav2d_T50_N512_essps", nav(horizon=50, num_samples=512, lambda_="ESSPS"),
@@ -267,6 +288,18 @@ def main():
     run_case("nav2d_T30_N256_fixed_explore", nav(horizon=30, num_samples=256, lambda_=1.0,
                                                  exploration=0.25),
              x0_nav, 3, pred_next, keep_S=True)
+    # round 2: dense softmax at N = 4096, the other temperature rules, SG, the posterior draw
+    run_case("nav2d_T30_N4096_essps", nav(horizon=30, num_samples=4096, lambda_="ESSPS"), x0_nav, 2, pred_next,
+             keep_S=False, round2=True)
+    run_case("nav2d_T30_N512_lbps", nav(horizon=30, num_samples=512, lambda_="LBPS"), x0_nav, 3, pred_next,
+             keep_S=False, round2=True)
+    run_case("nav2d_T30_N512_mpo", nav(horizon=30, num_samples=512, lambda_="MPO"), x0_nav, 3, pred_next,
+             keep_S=False, round2=True)
+    run_case("nav2d_T30_N512_sg", nav(horizon=30, num_samples=512, lambda_=5.0, use_sg_filter=True,
+                                      sg_window_size=7, sg_poly_order=2), x0_nav, 3, pred_next, keep_S=False,
+             round2=True)
+    run_case("nav2d_T20_N256_posterior", nav(horizon=20, num_samples=256, lambda_=5.0), x0_nav, 3, pred_next,
+             keep_S=False, round2=True, posterior_after=(0, 16))
 
     # ------------------------------------------------------------ racing
     import racing as racing_example  # example/racing.py (fire stubbed)
@@ -296,10 +329,13 @@ def main():
 
     cp64, _, _ = make_csv_paths("src/envs/circuit_generator/circuit.csv")
     racing_extra["center_path_f64"] = cp64
-    np.savez_compressed(os.path.join(OUT, "racing_env.npz"), **racing_extra)
+    if not ONLY_ROUND2:
+        np.savez_compressed(os.path.join(OUT, "racing_env.npz"), **racing_extra)
 
-    def racing_case(name, T, N, K, keep_S):
+    def racing_case(name, T, N, K, keep_S, lambda_=1.0, round2=False, **kw):
         ctrl_box = {}
+        if ONLY_ROUND2 and not round2:
+            return
 
         def make():
             ctrl = racing_example.racing_controller(env, debug=False, device=cpu)
@@ -307,8 +343,8 @@ def main():
             rec = Recorder(ctrl.cost_function)
             ctrl.solver = MPPI(horizon=T, num_samples=N, dim_state=4, dim_control=2,
                                dynamics=env.dynamics, cost_func=rec, u_min=env.u_min,
-                               u_max=env.u_max, sigmas=torch.tensor([0.5, 0.1]), lambda_=1.0,
-                               device=cpu)
+                               u_max=env.u_max, sigmas=torch.tensor([0.5, 0.1]), lambda_=lambda_,
+                               device=cpu, **kw)
             ctrl_box["c"] = ctrl
             return ctrl.solver, rec, {}
 
@@ -327,11 +363,19 @@ def main():
             u = torch.clamp(a[0], env.u_min, env.u_max)
             return env.dynamics(state.unsqueeze(0), u.unsqueeze(0)).squeeze(0).detach().clone()
 
-        run_case(name, make, env._robot_state.numpy().copy(), K, nxt, keep_S, before_solve=before)
+        run_case(name, make, env._robot_state.numpy().copy(), K, nxt, keep_S, before_solve=before, round2=round2)
 
     racing_case("racing_T50_N512_fixed", 50, 512, 3, keep_S=False)
     racing_case("racing_T25_N256_fixed", 25, 256, 3, keep_S=True)
+    # round 2: a dense softmax at the example's sample count, exploration + SG, ESSPS end point
+    racing_case("racing_T25_N4096_dense", 25, 4096, 3, keep_S=False, lambda_=500.0, round2=True)
+    racing_case("racing_T25_N512_explore_sg", 25, 512, 3, keep_S=False, lambda_=200.0, round2=True,
+                exploration=0.25, use_sg_filter=True)
+    racing_case("racing_T25_N1024_essps", 25, 1024, 2, keep_S=False, lambda_="ESSPS", round2=True)
 
+    if ONLY_ROUND2:
+        print("done (round-2 cases only):", sorted(ROUND2))
+        return
     # ------------------------------------------------------------ torch-CPU RNG stream
     rng = {}
     for seed in (0, 42):

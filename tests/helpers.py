@@ -29,7 +29,26 @@ CASES = {
     "racing_T25_N256_fixed": dict(model="racing", T=25, N=256, lambda_=1.0),
     "mjcartpole_T50_N256_fixed": dict(model="mjcartpole", T=50, N=256, lambda_=1.0),
     "goalzone_T30_N256_fixed": dict(model="goalzone", T=30, N=256, lambda_=1.0),
+    # round 2: dense softmax at N = 4096, racing / nav2d with SG + exploration, the other
+    # temperature rules on nav2d, ESSPS running into lambda_max, a posterior draw between two solves
+    "racing_T25_N4096_dense": dict(model="racing", T=25, N=4096, lambda_=500.0),
+    "racing_T25_N512_explore_sg": dict(model="racing", T=25, N=512, lambda_=200.0, exploration=0.25,
+                                       use_sg_filter=True),
+    "racing_T25_N1024_essps": dict(model="racing", T=25, N=1024, lambda_="ESSPS"),
+    "nav2d_T30_N4096_essps": dict(model="nav2d", T=30, N=4096, lambda_="ESSPS"),
+    "nav2d_T30_N512_lbps": dict(model="nav2d", T=30, N=512, lambda_="LBPS"),
+    "nav2d_T30_N512_mpo": dict(model="nav2d", T=30, N=512, lambda_="MPO"),
+    "nav2d_T30_N512_sg": dict(model="nav2d", T=30, N=512, lambda_=5.0, use_sg_filter=True, sg_window_size=7,
+                              sg_poly_order=2),
+    "nav2d_T20_N256_posterior": dict(model="nav2d", T=20, N=256, lambda_=5.0),
 }
+SOLVER_KW = ("exploration", "use_sg_filter", "sg_window_size", "sg_poly_order")  # ctor kwargs a case may carry
+
+
+def sg_coeffs(cfg):
+    from pi_mpc import _host
+
+    return _host.savitzky_golay_coeffs(cfg.get("sg_window_size", 5), cfg.get("sg_poly_order", 3))
 
 MODEL_CFG = {
     "pendulum": dict(u_min=[-2.0], u_max=[2.0], sigmas=[1.0]),
@@ -107,3 +126,24 @@ def rel_err(a, b):
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
     return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-30))
+
+
+def lbps_objective64(costs, lam, delta=0.01):
+    """The LBPS objective (src/pi_mpc/mppi.py:534-557) in float64 — the yardstick for a temperature found on the
+    reference's fp32, noise-flat objective: two minimisers are "the same" when this differs by a few fp32 ulps."""
+    c = np.asarray(costs, np.float64)
+    x = -c / lam
+    e = np.exp(x - x.max())
+    w = e / e.sum()
+    ess = 1.0 / np.sum(w * w)
+    return float(-(-np.sum(w * c) - (c.max() - c.min()) * np.sqrt((1 - delta) / delta) / np.sqrt(ess)))
+
+
+def same_lbps_minimum(costs, lam, lam_ref, delta=0.01):
+    """LBPS temperatures agree: within 1e-3 relative, or — where the fp32 objective is flat to its own rounding noise
+    (nav2d: 1e-8 relative over a 1 % change of lambda) — within 2 % AND no worse than the reference's own lambda by
+    more than 4 fp32 ulps of the float64 objective."""
+    if abs(lam - lam_ref) <= 1e-3 * lam_ref:
+        return True
+    f, f_ref = lbps_objective64(costs, lam, delta), lbps_objective64(costs, lam_ref, delta)
+    return abs(lam - lam_ref) <= 2e-2 * lam_ref and f - f_ref <= 4 * float(np.finfo(np.float32).eps) * abs(f_ref)

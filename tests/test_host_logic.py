@@ -9,7 +9,8 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import CASES, ROOT, load, nav2d_env_fixture, oracle_problem, orc, racing_env_fixture, rel_err
+from helpers import (CASES, ROOT, load, nav2d_env_fixture, oracle_problem, orc, racing_env_fixture, rel_err,
+                     same_lbps_minimum)
 from pi_mpc import _host
 
 
@@ -21,21 +22,24 @@ def test_essps_lambda(name):
         assert abs(lam - float(g[f"lambda_{k}"])) <= 1e-5 * float(g[f"lambda_{k}"])
 
 
-def test_lbps_lambda():
+@pytest.mark.parametrize("name", ["pendulum_T15_N256_lbps", "nav2d_T30_N512_lbps"])
+def test_lbps_lambda(name):
     # the bounded scalar minimiser stops at xatol=1e-5 on a flat, fp32-noisy objective
-    g = load("pendulum_T15_N256_lbps")
+    g = load(name)
     for k in range(3):
         lam = _host.lbps_lambda(g[f"costs_{k}"], 0.01, 0.01, 10.0)
-        assert abs(lam - float(g[f"lambda_{k}"])) <= 1e-3 * float(g[f"lambda_{k}"])
+        assert same_lbps_minimum(g[f"costs_{k}"], lam, float(g[f"lambda_{k}"]))
 
 
-def test_mpo_temperature():
-    # the reference's fp32 autograd gradient cancels ~600 against ~600 (|g| ~ 1): 2e-4 is its noise
-    g = load("pendulum_T15_N256_mpo")
+@pytest.mark.parametrize("name", ["pendulum_T15_N256_mpo", "nav2d_T30_N512_mpo"])
+def test_mpo_temperature(name):
+    # the reference's fp32 autograd gradient cancels ~1000 against ~1000 (|g| ~ 1); with its two fp32 roundings of the
+    # log-sum-exp reproduced (see MpoTemperature) three chained Adam steps agree to ~1e-5
+    g = load(name)
     m = _host.MpoTemperature()
     for k in range(3):
         lam = m.step(g[f"costs_{k}"])
-        assert abs(lam - float(g[f"lambda_{k}"])) <= 2e-4 * float(g[f"lambda_{k}"])
+        assert abs(lam - float(g[f"lambda_{k}"])) <= 3e-5 * float(g[f"lambda_{k}"])
 
 
 def _np_stats(costs):
@@ -296,24 +300,27 @@ def test_library_searches_match_reference_fixtures():
     cost vectors -> the reference's lambdas (same tolerances as the numpy statements in pi_mpc/_host.py)."""
     import emul
 
-    g = load("pendulum_T15_N256_lbps")
-    for k in range(3):
-        c = g[f"costs_{k}"]
-        lam, nfev = emul.lbps(c, 0.01, 0.01, 10.0)
-        assert abs(lam - float(g[f"lambda_{k}"])) <= 1e-3 * float(g[f"lambda_{k}"])
-        assert abs(lam - _host.lbps_lambda_stats(_np_stats(c), 0.01, 0.01, 10.0)) <= 1e-4 * lam
-        assert 5 <= nfev <= 60
-    for name in ("pendulum_T50_N1000_essps", "nav2d_T50_N512_essps", "cartpole_T64_N1024_essps_sg"):
-        g, cfg = load(name), CASES[name]
+    for name in ("pendulum_T15_N256_lbps", "nav2d_T30_N512_lbps"):
+        g = load(name)
         for k in range(3):
+            c = g[f"costs_{k}"]
+            lam, nfev = emul.lbps(c, 0.01, 0.01, 10.0)
+            assert same_lbps_minimum(c, lam, float(g[f"lambda_{k}"]))
+            assert same_lbps_minimum(c, lam, _host.lbps_lambda_stats(_np_stats(c), 0.01, 0.01, 10.0))
+            assert 5 <= nfev <= 60
+    for name in ("pendulum_T50_N1000_essps", "nav2d_T50_N512_essps", "cartpole_T64_N1024_essps_sg",
+                 "nav2d_T30_N4096_essps", "racing_T25_N1024_essps"):
+        g, cfg = load(name), CASES[name]
+        for k in range(int(g["K"])):
             lam = emul.essps(g[f"costs_{k}"], cfg["N"] / 10, 0.01, 10.0)
             assert abs(lam - float(g[f"lambda_{k}"])) <= 1e-5 * float(g[f"lambda_{k}"])
     # end-point rules of mppi.py:361-364
     c = load("pendulum_T50_N1000_essps")["costs_0"]
     assert emul.essps(c, 1.0, 0.01, 10.0) == 0.01 and emul.essps(c, 999.99, 0.01, 10.0) == 10.0
-    g = load("pendulum_T15_N256_mpo")
-    lams = emul.mpo(np.stack([g[f"costs_{k}"] for k in range(3)]))
-    m = _host.MpoTemperature()
-    for k in range(3):
-        assert abs(lams[k] - float(g[f"lambda_{k}"])) <= 2e-4 * float(g[f"lambda_{k}"])
-        assert abs(lams[k] - m.step(g[f"costs_{k}"])) <= 2e-6 * lams[k]
+    for name in ("pendulum_T15_N256_mpo", "nav2d_T30_N512_mpo"):
+        g = load(name)
+        lams = emul.mpo(np.stack([g[f"costs_{k}"] for k in range(3)]))
+        m = _host.MpoTemperature()
+        for k in range(3):
+            assert abs(lams[k] - float(g[f"lambda_{k}"])) <= 3e-5 * float(g[f"lambda_{k}"])
+            assert abs(lams[k] - m.step(g[f"costs_{k}"])) <= 2e-6 * lams[k]

@@ -4,7 +4,7 @@ Appendix D); observed ~2e-7."""
 import numpy as np
 import pytest
 
-from helpers import CASES, load, oracle_problem, orc, racing_env_fixture, nav2d_env_fixture, rel_err
+from helpers import CASES, load, oracle_problem, orc, racing_env_fixture, nav2d_env_fixture, rel_err, sg_coeffs
 
 TOL = 1e-5
 
@@ -42,8 +42,11 @@ def test_weights_action_state_seq(name):
         w, st = orc.softmax_weights(g[f"costs_{k}"], lam)
         assert rel_err(w, g[f"weights_{k}"]) < TOL
         a = P.weighted_actions(g[f"weights_{k}"], g[f"mean_in_{k}"], g[f"eps_{k}"])
-        if not cfg.get("use_sg_filter"):
-            assert rel_err(a, g[f"action_seq_{k}"]) < TOL
+        if cfg.get("use_sg_filter"):  # step 7 (mppi.py:423-443) with the fixture's own history
+            from pi_mpc import _host
+
+            a = _host.sg_filter_sequence(g[f"sg_hist_in_{k}"], a, sg_coeffs(cfg))
+        assert rel_err(a, g[f"action_seq_{k}"]) < TOL
         s = P.rollout_single(g[f"x0_{k}"], g[f"action_seq_{k}"])
         assert rel_err(s, g[f"state_seq_{k}"][0]) < TOL
 
@@ -92,3 +95,21 @@ def test_philox_restatement_statistics():
     # counter-based: a shard starting at 1000 reproduces rows 1000.. of the full draw
     part = orc.philox_normal(42, 1, 1000, 64, 50, 2, [0.5, 0.1])
     assert np.array_equal(part, eps[1000:1064])
+
+
+def test_posterior_samples_roll_out_through_the_oracle():
+    """get_samples_from_posterior (mppi.py:489-506): the reference's samples are loc + sigma * (the next normals of
+    the stream) and its states are the batch rollout of those unclamped actions."""
+    g, cfg = load("nav2d_T20_N256_posterior"), CASES["nav2d_T20_N256_posterior"]
+    k0 = int(g["posterior_after"])
+    samples, states = g["posterior_samples"], g["posterior_states"]
+    P = oracle_problem("nav2d", 1, cfg["T"])
+    for i in range(samples.shape[0]):
+        assert rel_err(P.rollout_single(g[f"x0_{k0}"], samples[i]), states[i]) < TOL
+    # stream position: ctor draw, solve 0, the posterior's [16, T, dc] normals, then solve 1
+    s = orc.TorchCpuStream(42)
+    n = cfg["N"] * cfg["T"] * 2
+    s.randn(n), s.randn(n)
+    z = s.randn(samples.size).reshape(samples.shape) * np.float32(0.5)
+    assert np.max(np.abs((g[f"action_seq_{k0}"][None] + z) - samples)) < 2e-6
+    assert np.max(np.abs(s.randn(n).reshape(cfg["N"], cfg["T"], 2) * np.float32(0.5) - g[f"eps_{k0 + 1}"])) < 2e-6
