@@ -3,21 +3,29 @@
 
 Workload (config.workload): racing kinematic-bicycle, horizon T=50, num_samples N=1,048,576 per GPU,
 lambda=1.0 (BASELINE configs[2] = C3; with --gpus G it is C4: G*N samples sharded over G ranks, weak
-scaling, one all_gather of 4+T*dc floats per solve).  A "step" is one MPPI solve = one pass of the hot
+scaling, ONE exchange of 4+T*dc floats per solve).  A "step" is one MPPI solve = one pass of the hot
 path: sample -> rollout+cost -> weights+reduce -> finalize, with every input resident in HBM.
 
-    python bench.py --gpus 1 --steps 200 --warmup 20
+    python bench.py                       # 1 GPU, 200 steps, 20 warm-up
+    python bench.py --gpus 8              # launches its own 8 ranks (one per GPU, RCCL); or, equivalently,
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \\
         --master-port 29500 bench.py --gpus 8 --steps 50 --warmup 10
+    MPPI_BENCH_ONE_DEVICE=1 MPPI_BENCH_BACKEND=gloo python bench.py --gpus 2   # dry run of the N>1 path on ONE GPU
 
 Prints ONE JSON line on rank 0.  `value` = sample-steps/s (N_total * T * solves/s), whole job.
 `roofline` is for the dominant kernel (rollout_cost_kernel), measured with HIP events on the launch
-stream inside the timed region; `cpu_baseline` is the oracle (C restatement of the reference
-algorithm, OpenMP over samples) timed on this host, rank 0, N=1 only.
+stream inside the timed region.  At N=1, rank 0 also reports, in the same line:
+  cpu_baseline        the oracle (C restatement of the reference algorithm, OpenMP over samples) on this host
+  cpu_baseline_torch  the reference's own op structure (per-timestep Python loops of batched torch ops, all cores)
+                      over the same plugins on this host (SURVEY 8d / BASELINE.md section 3)
+  closed_loop         >= 100 racing control ticks: reference window recomputed, solve, a[0] applied (example/racing.py:221-266)
+  other_configs       solve times of BASELINE configs C1 / C2 / C5
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,6 +35,22 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured copy
+SETUP_SOLVES = 200     # un-timed solves before the contract's warm-up: leave the idle power state (see main)
+
+
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher: re-run this script under torch.distributed.run, one rank per
+    GPU of this node, rendezvous on 127.0.0.1; the ranks' output (rank 0's JSON line) passes through."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -36,15 +60,25 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--samples", type=int, default=1 << 20, help="samples per GPU")
     ap.add_argument("--horizon", type=int, default=50)
+    ap.add_argument("--exchange", choices=("nccl", "p2p", "auto"), default="nccl",
+                    help="per-solve exchange of the shard summaries at N > 1: one RCCL all_gather (default), the "
+                         "library's peer-to-peer buffers, or auto (buffers when their self-test passes on every rank)")
     ap.add_argument("--math", type=int, default=1, help="1 = fast-path math (default), 0 = library math")
     ap.add_argument("--noise-regen", type=int, default=1,
                     help="1 = regenerate the Philox noise in registers (default), 0 = materialise the noise tiles")
     ap.add_argument("--mapping", type=int, default=0, help="0 = lane per trajectory (default), 1 = the literal "
                     "wavefront-per-trajectory rollout (comparison only)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip both CPU baselines")
+    ap.add_argument("--no-extras", action="store_true", help="skip closed_loop and other_configs")
+    ap.add_argument("--workload", choices=("c3", "c2", "c5"), default="c3",
+                    help="c3 (default) = the metric's workload; c2 / c5 = time another BASELINE config's solve loop "
+                         "(profiling aid: prints a short line, not the contract's)")
     ap.add_argument("--timing", type=int, default=2, help="HIP-event instrumentation inside the timed region: "
                     "1 = every stage, 2 = dominant kernel only, 0 = none (stage times from a second pass)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
 
     import numpy as np
     import torch
@@ -57,12 +91,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 or world > 1:
-        assert world == args.gpus, f"launch with torch.distributed.run --nproc-per-node {args.gpus}"
+    one_device = bool(os.environ.get("MPPI_BENCH_ONE_DEVICE"))
+    backend = "none"
+    if world > 1 or args.gpus > 1:
+        if world != args.gpus:
+            sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                     f"(python bench.py --gpus {args.gpus} does that itself)")
+        ndev = torch.cuda.device_count()
+        if ndev < world and not one_device:
+            sys.exit(f"bench.py: {world} ranks but {ndev} visible GPU(s).  For a dry run of the multi-rank path on one "
+                     "GPU set MPPI_BENCH_ONE_DEVICE=1 MPPI_BENCH_BACKEND=gloo (RCCL needs one device per rank)")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ["MPPI_EXCHANGE"] = args.exchange
         # MPPI_BENCH_BACKEND=gloo + MPPI_BENCH_ONE_DEVICE=1: dry run of the multi-rank path on a 1-GPU box
         backend = os.environ.get("MPPI_BENCH_BACKEND", "nccl")
-        dev = 0 if os.environ.get("MPPI_BENCH_ONE_DEVICE") else local_rank
+        dev = 0 if one_device else local_rank
         torch.cuda.set_device(dev)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
@@ -70,6 +113,9 @@ def main():
             dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
+
+    if args.workload != "c3":
+        return other_workload(args, torch, np)
 
     N_local, T = args.samples, args.horizon
     N_total = N_local * world
@@ -92,8 +138,9 @@ def main():
         torch.cuda.synchronize()
 
     # set-up, before the contract's W warm-up steps: bring the device out of its idle power state (the first
-    # ~20 ms of load run at lower clocks) so that short --warmup values do not time the clock ramp
-    for _ in range(200):
+    # ~20 ms of load run at lower clocks) so that short --warmup values do not time the clock ramp.  Reported as
+    # `setup_solves` in the JSON line; never inside the timed region.
+    for _ in range(SETUP_SOLVES):
         solver.forward(x0)
     sync()
     for _ in range(args.warmup):
@@ -107,15 +154,21 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     stages = solver.stage_times_ms()
+    t_exchange_ms = None
     if args.timing != 1:  # complete the per-stage picture with a separate instrumented pass
         solver.set_option("timing", 1)
-        for _ in range(min(args.steps, 50)):
+        n2 = min(args.steps, 50)
+        t1 = time.perf_counter()
+        for _ in range(n2):
             solver.forward(x0)
-        torch.cuda.synchronize()
+        sync()
+        wall2 = (time.perf_counter() - t1) / n2 * 1e3
         extra = solver.stage_times_ms()
         if args.timing == 2:
             extra["rollout_cost"] = stages["rollout_cost"]
         stages = extra
+        if world > 1:  # what is left of a solve's wall time after the device stages: the exchange + its stream hand-offs
+            t_exchange_ms = max(wall2 - sum(stages[k] for k in ("sample", "rollout_cost", "weights_reduce", "finalize")), 0.0)
     solver.set_option("timing", 0)
     if world > 1:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
@@ -137,52 +190,160 @@ def main():
         t_roll = stages["rollout_cost"] * 1e-3
         achieved = b_alg_rollout / t_roll / 1e9
         dev_solve_ms = sum(stages[k] for k in ("sample", "rollout_cost", "weights_reduce", "finalize"))
-        # PMC-derived constants of the dominant kernel for THIS configuration (profiles/pmc_constants.json)
-        traffic, valu = None, None
+        # PMC counters of the dominant kernel for THIS configuration, per launch: collected with rocprofv3 --pmc in
+        # separate passes over this same command and committed (profiles/pmc_constants.json names the CSV summaries
+        # they were generated from by scripts/pmc_constants.py); a bench run cannot collect counters on itself.
+        traffic, valu, traffic_src = None, None, None
         try:
             if (N_local, T, args.math) == (1 << 20, 50, 1):
                 pc = json.load(open(os.path.join(ROOT, "profiles", "pmc_constants.json")))
                 k = pc["rollout_regen" if args.noise_regen else "rollout_tiles"]
-                traffic = int((2 * k["fetch_kb"] + k["write_kb"]) * 1024)
+                traffic = int((2 * k["fetch_kb"] + k["write_kb"]) * 1024)  # FETCH_SIZE doubled: gfx950 wide-read correction
+                traffic_src = pc.get("source")
                 peak = 1024 * 2.4e9 / 2  # wave64 VALU instructions/s: 1024 SIMD32s, 2 cycles each, 2.4 GHz
                 valu = {"kernel": "rollout_cost_kernel<racing>", "valu_insts_per_launch": k["valu_insts"],
                         "achieved_Ginst_per_s": k["valu_insts"] / t_roll / 1e9, "peak_Ginst_per_s": peak / 1e9,
                         "frac": k["valu_insts"] / t_roll / peak,
                         "measured_peak_Ginst_per_s": pc.get("valu_issue_ubench", {}).get("mul_add_Ginst_per_s"),
                         "cycles_per_inst_per_simd_at_2p4GHz": 1024 * 2.4e9 * t_roll / k["valu_insts"],
-                        "note": "wave64 VALU instructions (SQ_INSTS_VALU, rocprofv3) / live kernel time; the kernel "
-                                "is VALU-issue bound, not HBM bound (profiles/r01_experiments.md)"}
+                        "note": "wave64 VALU instructions (SQ_INSTS_VALU, rocprofv3) / live kernel time"}
         except Exception:
             pass
         out = {
             "metric": "sample_steps_per_sec", "value": value, "unit": "sample-steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": "racing kinematic-bicycle MPPI solve (BASELINE configs[2]/[3])",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "setup_solves": SETUP_SOLVES,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "racing kinematic-bicycle MPPI solve (BASELINE configs[2]; configs[3] when n_gpus = 8)",
                        "num_samples_per_gpu": N_local, "num_samples_total": N_total, "horizon": T,
                        "lambda": 1.0, "noise": "device philox4x32-10 (" + ("regenerated in registers" if args.noise_regen else "materialised tiles") + ")", "math": "fast" if args.math else "library",
                        "mapping": "lane-per-trajectory" if not args.mapping else "wavefront-per-trajectory",
                        "sharding": f"num_samples x{world}" if world > 1 else "none",
-                       "exchange": ("peer-to-peer buffers" if solver._p2p else "all_gather") if world > 1 else "none"},
+                       "exchange": ("peer-to-peer buffers (xGMI stores, polled)" if solver._p2p else "all_gather of 4+T*dc floats")
+                       if world > 1 else "none",
+                       "exchange_requested": args.exchange if world > 1 else None,
+                       "backend": backend, "ranks_share_one_device": one_device and world > 1},
             "solves_per_sec": solves_per_s,
-            "roofline": {"bound": "hbm", "kernel": "rollout_cost_kernel<racing>", "achieved": achieved,
+            # the kernel is VALU-issue bound (valu_roofline), not HBM bound: `achieved`/`frac` price its ALGORITHMIC
+            # bytes (the noise it consumes is regenerated in registers, so `traffic` is ~1 % of them) against the
+            # HBM peak, as the metric asks; they cannot exceed ~0.4 at this instruction count
+            "roofline": {"bound": "valu", "kernel": "rollout_cost_kernel<racing>", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "algorithmic_bytes_per_launch": b_alg_rollout,
-                         "kernel_ms": stages["rollout_cost"]},
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": b_alg_rollout, "kernel_ms": stages["rollout_cost"]},
             "solve_roofline": {"algorithmic_bytes_per_solve": b_alg_solve, "device_ms_per_solve": dev_solve_ms,
                                "achieved_GBps": b_alg_solve / (dev_solve_ms * 1e-3) / 1e9,
                                "frac_of_8TBps": b_alg_solve / (dev_solve_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "stages_ms": {k: stages[k] for k in ("sample", "rollout_cost", "weights_reduce", "finalize")},
         }
+        if t_exchange_ms is not None:
+            out["stages_ms"]["exchange_and_handoffs"] = t_exchange_ms
         if valu is not None:
             out["valu_roofline"] = valu
+        if world == 1 and not args.no_extras:
+            out["closed_loop"] = closed_loop(torch, env, ctrl, T, N_total)
+            out["other_configs"] = other_configs(torch, np)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(np, T, ref.numpy(), x0.cpu().numpy())
+            del solver, ctrl
+            torch.cuda.empty_cache()
+            out["cpu_baseline_torch"] = cpu_baseline_torch(torch, np, T)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def closed_loop(torch, env, ctrl, T, N):
+    """The reference's racing control loop minus rendering (example/racing.py:221-266): every tick recomputes the
+    reference window on the host from the current state (calc_ref_trajectory: one device->host read of the state),
+    solves with the warm start of the previous tick, and applies a[0] through env.step (batch-1 torch dynamics)."""
+    state = env.reset()
+    ctrl.current_path_index = 0
+    ctrl.solver.reset()
+    ticks, warm = 100, 20
+    t_upd = t_step = 0.0
+    for tick in range(warm + ticks):
+        if tick == warm:
+            torch.cuda.synchronize()
+            t_upd = t_step = 0.0
+            t0 = time.perf_counter()
+        ta = time.perf_counter()
+        a, s = ctrl.update(state, env.racing_center_path)
+        tb = time.perf_counter()
+        state, _ = env.step(a[0, :])
+        tc = time.perf_counter()
+        t_upd += tb - ta
+        t_step += tc - tb
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"ticks": ticks, "warmup_ticks": warm, "ms_per_tick": dt / ticks * 1e3, "solves_per_sec": ticks / dt,
+            "sample_steps_per_sec": N * T * ticks / dt,
+            "host_ms_per_tick": {"controller.update (state read-back + reference window + solve enqueue)": t_upd / ticks * 1e3,
+                                 "env.step (batch-1 torch dynamics)": t_step / ticks * 1e3},
+            "final_speed_mps": float(state[3]),
+            "note": "open-loop `value` above times solves from a fixed state; here the state, the reference window and "
+                    "the warm start change every tick"}
+
+
+def _time_solver(torch, solver, x0, n=50, warm=10):
+    for _ in range(warm):
+        solver.forward(x0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        solver.forward(x0)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+
+def _other_solvers(torch, np, which=None):
+    """The other BASELINE configs: (key, label, N*T, B_alg per solve, solver factory, x0)."""
+    from envs import classic_control as cc
+    from envs.navigation_2d import Navigation2DEnv
+    from pi_mpc.mppi import MPPI
+
+    nav = Navigation2DEnv()
+    t = torch.tensor
+    rows = [
+        ("c1", "C1 pendulum T=50 N=1000 ESSPS", 1000 * 50, 3 * 4 * 1 * 1000 * 50 + 8 * 1000,
+         lambda: MPPI(50, 1000, 2, 1, cc.pendulum_dynamics, cc.pendulum_cost, t([-2.0]), t([2.0]), t([1.0]), "ESSPS"),
+         t([np.pi, 0.0], device="cuda", dtype=torch.float32)),
+        ("c2", "C2 nav2d T=50 N=65536 lambda=1", 65536 * 50, 3 * 4 * 2 * 65536 * 50 + 8 * 65536,
+         lambda: MPPI(50, 65536, 3, 2, nav.dynamics, nav.cost_function, nav.u_min, nav.u_max, t([0.5, 0.5]), 1.0),
+         nav.reset().clone()),
+        ("c2_essps", "C2 nav2d T=50 N=65536 ESSPS", 65536 * 50, 3 * 4 * 2 * 65536 * 50 + 8 * 65536,
+         lambda: MPPI(50, 65536, 3, 2, nav.dynamics, nav.cost_function, nav.u_min, nav.u_max, t([0.5, 0.5]), "ESSPS"),
+         nav.reset().clone()),
+        ("c5", "C5 cartpole T=64 N=262144 ESSPS + Savitzky-Golay", 262144 * 64, 3 * 4 * 1 * 262144 * 64 + 8 * 262144,
+         lambda: MPPI(64, 262144, 4, 1, cc.cartpole_dynamics, cc.cartpole_cost, t([-3.0]), t([3.0]), t([1.0]), "ESSPS",
+                      use_sg_filter=True),
+         t([0.01, 0.0, 0.02, 0.0], device="cuda")),
+    ]
+    return [r for r in rows if which is None or r[0] in which]
+
+
+def other_configs(torch, np):
+    """Solve times of the other BASELINE configs (open loop, 10 warm-up + 50 timed solves each)."""
+    out = {}
+    for key, label, work, b_alg, make, x0 in _other_solvers(torch, np):
+        s = make()
+        dt = _time_solver(torch, s, x0)
+        out[key] = {"config": label, "ms_per_solve": dt * 1e3, "solves_per_sec": 1 / dt,
+                    "sample_steps_per_sec": work / dt, "algorithmic_bytes_per_solve": b_alg,
+                    "frac_of_8TBps": b_alg / dt / 1e9 / HBM_PEAK_GBS, "lambda": s._last_lambda}
+        del s
+    return out
+
+
+def other_workload(args, torch, np):
+    """--workload c2|c5: the solve loop of another BASELINE config (ESSPS variants), for rocprofv3 runs."""
+    which = {"c2": ("c2_essps",), "c5": ("c5",)}[args.workload]
+    for key, label, work, b_alg, make, x0 in _other_solvers(torch, np, which):
+        s = make()
+        dt = _time_solver(torch, s, x0, n=args.steps, warm=args.warmup)
+        print(json.dumps({"workload": label, "ms_per_solve": dt * 1e3, "steps": args.steps,
+                          "algorithmic_bytes_per_solve": b_alg, "lambda": s._last_lambda}), flush=True)
 
 
 def cpu_baseline(np, T, ref, x0):
@@ -208,6 +369,48 @@ def cpu_baseline(np, T, ref, x0):
     return {"value": reps * n * T / dt, "unit": "sample-steps/s", "cores": orc.num_threads(), "kind": "port",
             "sample": f"{reps} full solves of racing N={n} T={T} in {dt:.1f} s (oracle C port, OpenMP over samples; "
                       "noise generation excluded)", "solves_per_sec": reps / dt}
+
+
+def cpu_baseline_torch(torch, np, T):
+    """The reference's own op structure on this host's cores: oracle/
+    torch_reference_loop.py — one [N,T,dc] torch.randn draw, two Python loops of T batched torch ops over the
+    racing plugins (strided [N,ds] views of S[N,T+1,ds]), the dead action-cost product, softmax, weighted sum, batch-1
+    rollout — at the metric's size (C3: N = 1,048,576, T = 50, ~4.3 GB resident).  1 warm-up, then 2-5 timed solves
+    (stops after ~12 s).  Pinned against the reference fixtures by tests/test_oracle_vs_golden.py."""
+    from envs.racing_controller import racing_controller
+    from envs.racing_env import RacingEnv
+    from oracle.torch_reference_loop import TorchReferenceLoop
+
+    n = 1 << 20
+    cpu = torch.device("cpu")
+    env = RacingEnv(device=cpu)
+    ctrl = racing_controller(env, device=cpu, horizon=T, num_samples=n, lambda_=1.0, mppi_cls=TorchReferenceLoop)
+    ctrl.set_cost_map(env._obstacle_map, env._lane_map)
+    state = env.reset()
+    ref, _ = ctrl.calc_ref_trajectory(state, env.racing_center_path, 0, T, DL=0.1, lookahead_distance=3,
+                                      reference_path_interval=0.85)
+    ctrl.set_reference(ref)
+    ctrl.solver.forward(state.clone())  # warm-up: page in ~4 GB, start the thread pool
+    times = []
+    t_all = time.perf_counter()
+    while len(times) < 2 or (len(times) < 5 and time.perf_counter() - t_all < 12.0):
+        t0 = time.perf_counter()
+        ctrl.solver.forward(state.clone())
+        times.append(time.perf_counter() - t0)
+    best, med = min(times), float(np.median(times))
+    cpu_model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": n * T / med, "unit": "sample-steps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{len(times)} solves of racing N={n} T={T} after 1 warm-up (torch-CPU restatement of the reference "
+                      f"loop, noise draw included): median {med:.2f} s, min {best:.2f} s per solve",
+            "solves_per_sec": 1 / med, "solves_per_sec_best": 1 / best, "nproc": os.cpu_count(), "cpu_model": cpu_model,
+            "torch_threads": torch.get_num_threads()}
 
 
 if __name__ == "__main__":

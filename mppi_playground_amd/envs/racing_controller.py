@@ -26,7 +26,10 @@ def _racing_cost_inputs(ctrl: "racing_controller") -> dict:
 
 class racing_controller:
     def __init__(self, env, debug=False, device=torch.device("cuda"), dtype=torch.float32, horizon: int = 25,
-                 num_samples: int = 4000, lambda_: float = 1.0, **mppi_kwargs) -> None:
+                 num_samples: int = 4000, lambda_: float = 1.0, mppi_cls=MPPI, **mppi_kwargs) -> None:
+        """`mppi_cls`: the solver class to construct (default: the MI355X MPPI).  Anything with the reference's
+        constructor / forward() contract works — the CPU baseline in bench.py passes its torch restatement of the
+        reference loop here, so that it runs this very controller's cost function."""
         self.debug = debug
         self.current_path_index = 0
         self.env = env
@@ -37,7 +40,7 @@ class racing_controller:
         self._reference_path_np: np.ndarray = None
         self.obstacle_map = None
         self.lane_map = None
-        self.solver = MPPI(horizon=horizon, num_samples=num_samples, dim_state=4, dim_control=2,
+        self.solver = mppi_cls(horizon=horizon, num_samples=num_samples, dim_state=4, dim_control=2,
                            dynamics=env.dynamics, cost_func=self.cost_function, u_min=env.u_min, u_max=env.u_max,
                            sigmas=torch.tensor([0.5, 0.1]), lambda_=lambda_, **mppi_kwargs)
 

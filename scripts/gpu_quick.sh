@@ -2,8 +2,8 @@
 # quick GPU visit: parity tests + bench variants (stage times only)
 set -u
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests -m gpu -q --maxfail=6 -p no:cacheprovider 2>&1 | tail -25 > gpurun_out/pytest_gpu.log; tail -6 gpurun_out/pytest_gpu.log
-for args in "" "--noise-regen 0" "--math 0"; do
+timeout 1200 python -m pytest tests -m gpu -q --maxfail=12 -rfs -p no:cacheprovider 2>&1 | tail -150 > gpurun_out/pytest_gpu.log; tail -40 gpurun_out/pytest_gpu.log
+for args in "" "--noise-regen 0"; do
   timeout 300 python bench.py --steps 100 --warmup 20 --no-cpu-baseline $args 2>/dev/null | python -c "
 import sys,json
 for l in sys.stdin:

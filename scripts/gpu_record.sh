@@ -1,23 +1,40 @@
 #!/bin/bash
-# GPU visit: full record for profiles/ — tests, bench (all modes), kernel trace, PMC passes.
+# GPU visit: full record for profiles/ — tests, smoke, bench (1 rank; 2- and 8-rank dry runs on this one GPU),
+# rocprofv3 kernel trace + separate PMC passes for C3 (regen / tiles) and for the dense-weight configs C2 / C5.
+# Usage: bash scripts/gpu_record.sh [tag]   (writes gpurun_out/prof_<tag>/, default tag r2)
 set -u
+TAG=${1:-r2}
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-rm -rf gpurun_out/prof_r8
-timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | tail -30 > gpurun_out/pytest_gpu.log; tail -3 gpurun_out/pytest_gpu.log
+P=$R/gpurun_out/prof_$TAG
+rm -rf $P
+timeout 1200 python -m pytest tests -m gpu -q -rfs -p no:cacheprovider 2>&1 | tail -60 > gpurun_out/pytest_gpu.log; tail -4 gpurun_out/pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; tail -1 gpurun_out/smoke.log
-timeout 600 python bench.py --steps 200 --warmup 20 > gpurun_out/bench.log 2>&1; tail -1 gpurun_out/bench.log
-timeout 300 python bench.py --steps 100 --warmup 20 --noise-regen 0 --no-cpu-baseline > gpurun_out/bench_tiles.log 2>&1; tail -1 gpurun_out/bench_tiles.log
-timeout 300 python bench.py --steps 100 --warmup 20 --math 0 --no-cpu-baseline > gpurun_out/bench_math0.log 2>&1
+timeout 900 python bench.py > gpurun_out/bench.log 2>&1; tail -c 600 gpurun_out/bench.log; echo
+timeout 300 python bench.py --steps 100 --warmup 20 --noise-regen 0 --no-cpu-baseline --no-extras > gpurun_out/bench_tiles.log 2>&1
+# the N > 1 path on this one GPU: ranks share the device, gloo instead of RCCL (RCCL needs one device per rank)
+for spec in "2 nccl" "2 p2p" "8 nccl" "8 p2p"; do
+  set -- $spec
+  MPPI_BENCH_ONE_DEVICE=1 MPPI_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus $1 --exchange $2 --steps 20 --warmup 5 > gpurun_out/bench_dry_g$1_$2.log 2>&1
+  echo "dry run --gpus $1 --exchange $2: rc=$? $(tail -1 gpurun_out/bench_dry_g$1_$2.log | cut -c1-160)"
+done
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_r8 -o kt -- python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline > $R/gpurun_out/rocprof_kt.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_r8 -o kt_tiles -- python $R/bench.py --steps 30 --warmup 5 --noise-regen 0 --no-cpu-baseline > $R/gpurun_out/rocprof_kt_tiles.log 2>&1
-for mode in regen tiles; do
-  if [ $mode = tiles ]; then extra="--noise-regen 0"; else extra=""; fi
+B="python $R/bench.py --no-cpu-baseline --no-extras"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $P -o kt -- $B --steps 30 --warmup 5 > $R/gpurun_out/rocprof_kt.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $P -o kt_tiles -- $B --steps 30 --warmup 5 --noise-regen 0 > /dev/null 2>&1
+for wl in c2 c5; do
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $P -o kt_$wl -- $B --workload $wl --steps 200 --warmup 20 > $R/gpurun_out/rocprof_kt_$wl.log 2>&1
+done
+for mode in regen tiles c2 c5; do
+  case $mode in
+    regen) extra="--steps 6 --warmup 2";;
+    tiles) extra="--steps 6 --warmup 2 --noise-regen 0";;
+    *) extra="--workload $mode --steps 40 --warmup 10";;
+  esac
   for pass in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU" "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE"; do
     tag=$(echo $pass | tr ' ' '_' | cut -c1-24)
-    timeout 300 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $R/gpurun_out/prof_r8 -o pmc_${mode}_$tag -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline $extra > /dev/null 2>&1
+    timeout 300 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $P -o pmc_${mode}_$tag -- $B $extra > /dev/null 2>&1
   done
 done
-cd $R; ls gpurun_out/prof_r8 | wc -l
+cd $R; ls $P | wc -l

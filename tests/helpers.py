@@ -147,3 +147,15 @@ def same_lbps_minimum(costs, lam, lam_ref, delta=0.01):
         return True
     f, f_ref = lbps_objective64(costs, lam, delta), lbps_objective64(costs, lam_ref, delta)
     return abs(lam - lam_ref) <= 2e-2 * lam_ref and f - f_ref <= 4 * float(np.finfo(np.float32).eps) * abs(f_ref)
+
+
+def mpo_lambda_tolerance(costs, lam_dual):
+    """How well an MPO temperature (src/pi_mpc/mppi.py:387-398) can be reproduced from costs that agree with the
+    reference's to fp32 rounding only.  The rule's gradient eps + LSE + E_w[c]/T cancels |LSE| ~ |c|/T against itself,
+    and the reference keeps LSE as an fp32 scalar: when a cost perturbation moves LSE across an fp32 rounding boundary
+    the gradient jumps by sigmoid(logT) * ulp32(LSE) * |LSE| (nav2d: 0.45 * 1.2e-4 * 1260 = 0.07 against |g| ~ 0.3) and
+    one Adam(lr = 0.2) step turns a gradient change dg into ~0.15-0.2 * dg of relative temperature change (measured:
+    one flipped ulp moves lambda by 0.4-0.6 %).  Allow two such ulps.  `lam_dual` = the lambda before the update.  On
+    IDENTICAL costs the rule is pinned to 3e-5 (tests/test_host_logic.py)."""
+    lse = abs(float(np.min(costs))) / float(np.log1p(lam_dual))  # the dual evaluates at T = softplus(log lambda)
+    return 1e-4 + 0.1 * 2.0 * float(np.spacing(np.float32(lse))) * lse

@@ -324,3 +324,25 @@ def test_library_searches_match_reference_fixtures():
         for k in range(3):
             assert abs(lams[k] - float(g[f"lambda_{k}"])) <= 3e-5 * float(g[f"lambda_{k}"])
             assert abs(lams[k] - m.step(g[f"costs_{k}"])) <= 2e-6 * lams[k]
+
+
+def test_bench_launches_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus N` without a launcher re-runs itself under torch.distributed.run with one rank per GPU
+    on 127.0.0.1 (the driver's N=1 command shape must work for N>1 too)."""
+    import importlib
+    import subprocess
+    import sys
+
+    bench = importlib.import_module("bench")
+    seen = {}
+    monkeypatch.setattr(subprocess, "call", lambda cmd, env=None: seen.update(cmd=cmd, env=env) or 0)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "50", "--warmup", "10"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "8", "--steps", "50", "--warmup", "10"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

@@ -113,3 +113,63 @@ def test_posterior_samples_roll_out_through_the_oracle():
     z = s.randn(samples.size).reshape(samples.shape) * np.float32(0.5)
     assert np.max(np.abs((g[f"action_seq_{k0}"][None] + z) - samples)) < 2e-6
     assert np.max(np.abs(s.randn(n).reshape(cfg["N"], cfg["T"], 2) * np.float32(0.5) - g[f"eps_{k0 + 1}"])) < 2e-6
+
+
+@pytest.mark.parametrize("name", ["pendulum_T15_N256_fixed", "pendulum_T15_N200_explore", "cartpole_T64_N1024_essps_sg",
+                                  "nav2d_T30_N256_fixed_explore", "racing_T25_N256_fixed", "racing_T25_N4096_dense"])
+def test_torch_cpu_restatement_of_the_reference_loop(name):
+    """oracle/torch_reference_loop.py (the `cpu_baseline_torch` leg of bench.py: the reference's op structure over the
+    product's torch plugins, on CPU) reproduces the reference run for run: same global seed -> the same noise bit for
+    bit, and the same temperatures, action and state sequences over the closed loop."""
+    import torch
+
+    from helpers import MODEL_CFG, SOLVER_KW
+    from oracle.torch_reference_loop import TorchReferenceLoop
+
+    cfg, g = CASES[name], load(name)
+    model, T, N = cfg["model"], cfg["T"], cfg["N"]
+    mc = MODEL_CFG[model]
+    kw = {k: cfg[k] for k in SOLVER_KW if k in cfg}
+    common = dict(horizon=T, num_samples=N, lambda_=cfg["lambda_"], seed=42, **kw)
+    cpu = torch.device("cpu")
+    ctrl = env = None
+    if model == "racing":
+        from envs.racing_controller import racing_controller
+        from envs.racing_env import RacingEnv
+
+        env = RacingEnv(device=cpu)
+        ctrl = racing_controller(env, device=cpu, mppi_cls=TorchReferenceLoop, **common)
+        ctrl.set_cost_map(env._obstacle_map, env._lane_map)
+        solver = ctrl.solver
+    elif model == "nav2d":
+        from envs.navigation_2d import Navigation2DEnv
+
+        env = Navigation2DEnv(device=cpu)
+        solver = TorchReferenceLoop(dim_state=3, dim_control=2, dynamics=env.dynamics, cost_func=env.cost_function,
+                                    u_min=env.u_min, u_max=env.u_max, sigmas=torch.tensor(mc["sigmas"]), **common)
+    else:
+        from envs import classic_control as cc
+
+        ds, dc = orc.MODEL_DIMS[orc.MODEL_IDS[model]]
+        solver = TorchReferenceLoop(dim_state=ds, dim_control=dc, dynamics=getattr(cc, f"{model}_dynamics"),
+                                    cost_func=getattr(cc, f"{model}_cost"), u_min=torch.tensor(mc["u_min"]),
+                                    u_max=torch.tensor(mc["u_max"]), sigmas=torch.tensor(mc["sigmas"]), **common)
+    assert np.array_equal(solver._action_noises.numpy(), g["ctor_eps"])
+    state = torch.from_numpy(g["x0_0"])
+    for k in range(int(g["K"])):
+        if ctrl is not None:
+            ref, ctrl.current_path_index = ctrl.calc_ref_trajectory(state, env.racing_center_path, ctrl.current_path_index,
+                                                                    T, DL=0.1, lookahead_distance=3,
+                                                                    reference_path_interval=0.85)
+            ctrl.set_reference(ref)
+        a, s = solver.forward(state.clone())
+        assert np.array_equal(solver._action_noises.numpy(), g[f"eps_{k}"])
+        assert rel_err(solver._costs.numpy(), g[f"costs_{k}"]) < 1e-6
+        assert abs(float(solver._lambda) - float(g[f"lambda_{k}"])) <= 1e-5 * float(g[f"lambda_{k}"])
+        assert rel_err(a.numpy(), g[f"action_seq_{k}"]) < 2e-5 * (k + 1)
+        assert rel_err(s.numpy(), g[f"state_seq_{k}"]) < 2e-5 * (k + 1)
+        if ctrl is not None:
+            u = torch.clamp(a[0], env.u_min, env.u_max)
+            state = env.dynamics(state.unsqueeze(0), u.unsqueeze(0)).squeeze(0)
+        else:
+            state = s[0, 1].clone()
