@@ -187,7 +187,8 @@ int mppi_set_costs(mppi_handle_t h, const float* src, int on_device, void* strea
  * writes the shard summary {min c, sum e, sum e^2, sum e*c, A[T*dc] = sum e_i*U_i} with
  * e_i = exp((-c_i)/lambda - max_j (-c_j)/lambda) over THIS shard.  summary_out_dev may be NULL
  * (the handle keeps its own copy). */
-int mppi_weights_reduce(mppi_handle_t h, float lambda, float* summary_out_dev, void* stream);
+int mppi_weights_reduce(mppi_handle_t h, float lambda /* > 0, or MPPI_LAMBDA_DEVICE */, float* summary_out_dev,
+                        void* stream);
 /* Combine `num_shards` summaries (device array [num_shards][MPPI_SUMMARY_HEAD + T*dc]; NULL = this
  * handle's own, num_shards = 1 — or, with option "exchange_p2p", the summaries of all ranks from the
  * peer-to-peer buffer), form action_seq = A / sum e (mppi.py:381-385), optionally store it
@@ -220,6 +221,13 @@ int mppi_softmax_stats_multi(mppi_handle_t h, const float* lambdas_host, int cou
  * handles; synchronises twice. */
 int mppi_essps_lambda(mppi_handle_t h, double target_ess, double lam_min, double lam_max, double* lambda_out_host,
                       void* stream);
+/* The same search with NO host synchronisation: both statistics passes and both scalar steps (end-point rules /
+ * refined grid, root interpolation) run as kernels on `stream`, and the temperature stays in device memory.  Pass
+ * MPPI_LAMBDA_DEVICE as the `lambda` of mppi_weights_reduce / mppi_finalize to use it; mppi_get_lambda reads it back
+ * (synchronises the stream).  Identical arithmetic to mppi_essps_lambda (both call csrc/host_search.hpp). */
+#define MPPI_LAMBDA_DEVICE (-1.0f)
+int mppi_essps_lambda_device(mppi_handle_t h, double target_ess, double lam_min, double lam_max, void* stream);
+int mppi_get_lambda(mppi_handle_t h, double* lambda_out_host, void* stream);
 /* LBPS (mppi.py:341-349,534-557): argmin over [lam_min, lam_max] of -(E_w[-c] - (max c - min c) * sqrt((1-delta)/delta)
  * / sqrt(ESS)), searched on the host with Brent's bounded minimiser (scipy minimize_scalar(method="bounded"): xatol
  * 1e-5, at most 500 evaluations); every probe is one mppi_softmax_stats round trip.  Unsharded handles; synchronises. */

@@ -19,6 +19,7 @@ MODEL_IDS = {"pendulum": 0, "cartpole": 1, "mountaincar": 2, "nav2d": 3, "racing
 MODEL_DIMS = {"pendulum": (2, 1), "cartpole": (4, 1), "mountaincar": (2, 1), "nav2d": (3, 2), "racing": (4, 2),
               "mjcartpole": (4, 1), "goalzone": (7, 2)}
 SUMMARY_HEAD = 4
+LAMBDA_DEVICE = -1.0  # MPPI_LAMBDA_DEVICE: "the temperature mppi_essps_lambda_device left on the device"
 
 # every symbol include/mppi_hip.h declares
 SYMBOLS = [
@@ -26,7 +27,7 @@ SYMBOLS = [
     "mppi_set_model_params", "mppi_upload_map", "mppi_build_obstacle_map", "mppi_build_lane_map",
     "mppi_download_map", "mppi_set_reference", "mppi_set_mean", "mppi_get_mean",
     "mppi_set_state", "mppi_bind_state", "mppi_sample", "mppi_inject_noise", "mppi_export_noise", "mppi_rollout_cost",
-    "mppi_get_costs", "mppi_set_costs", "mppi_weights_reduce", "mppi_finalize", "mppi_set_sg_filter", "mppi_get_sg_history", "mppi_softmax_stats", "mppi_softmax_stats_multi", "mppi_essps_lambda", "mppi_lbps_lambda", "mppi_mpo_reset", "mppi_mpo_step", "mppi_mpo_state", "mppi_weights", "mppi_sample_posterior",
+    "mppi_get_costs", "mppi_set_costs", "mppi_weights_reduce", "mppi_finalize", "mppi_set_sg_filter", "mppi_get_sg_history", "mppi_softmax_stats", "mppi_softmax_stats_multi", "mppi_essps_lambda", "mppi_essps_lambda_device", "mppi_get_lambda", "mppi_lbps_lambda", "mppi_mpo_reset", "mppi_mpo_step", "mppi_mpo_state", "mppi_weights", "mppi_sample_posterior",
     "mppi_p2p_alloc", "mppi_p2p_connect", "mppi_p2p_exchange", "mppi_p2p_error", "mppi_rollout_actions", "mppi_rollout_samples", "mppi_top_samples", "mppi_top_candidates", "mppi_rollout_candidates", "mppi_set_option", "mppi_get_timing",
 ]
 
@@ -79,6 +80,8 @@ def load():
     lib.mppi_rollout_candidates.argtypes = [vp, vp, i32, f32, vp, vp, vp]
     lib.mppi_essps_lambda.argtypes = [vp, C.c_double, C.c_double, C.c_double, vp, vp]
     lib.mppi_lbps_lambda.argtypes = [vp, C.c_double, C.c_double, C.c_double, vp, vp]
+    lib.mppi_essps_lambda_device.argtypes = [vp, C.c_double, C.c_double, C.c_double, vp]
+    lib.mppi_get_lambda.argtypes = [vp, vp, vp]
     lib.mppi_mpo_reset.argtypes = [vp, C.c_double, C.c_double, C.c_double]
     lib.mppi_mpo_step.argtypes = [vp, vp, vp]
     lib.mppi_mpo_state.argtypes = [vp, vp]

@@ -17,6 +17,12 @@
 #include <cmath>
 #include <cstdint>
 
+#if defined(__HIPCC__)
+#define MPPI_SEARCH_HD __host__ __device__ inline  // the ESSPS steps also run inside essps_select_kernel
+#else
+#define MPPI_SEARCH_HD inline
+#endif
+
 namespace mppi {
 namespace host {
 
@@ -123,45 +129,68 @@ bool lbps_lambda(S&& stats, double delta, double lam_min, double lam_max, double
 
 // ---------------------------------------------------------------------------------------------------------
 // ESSPS (mppi.py:351-370,559-566): the root of ESS(lambda) = target on [lam_min, lam_max] with the reference's
-// end-point rules, from `rounds` geometric grids of P temperatures (ess_grid(lams[P], ess_out[P]) -> bool is ONE
-// pass over the costs on the device) and an inverse cubic interpolation in (ESS, log lambda).  Same algorithm as
-// pi_mpc/_host.py::essps_lambda_grid (within ~1e-7 relative of scipy's brentq on the same statistics).
-template <int P, class G>
-bool essps_lambda(G&& ess_grid, double target_ess, double lam_min, double lam_max, double& lam_out) {
+// end-point rules, from two geometric grids of P temperatures (ONE pass over the costs on the device per grid) and an
+// inverse cubic interpolation in (ESS, log lambda).  Same algorithm as pi_mpc/_host.py::essps_lambda_grid (within
+// ~1e-7 relative of scipy's brentq on the same statistics).  The search is written as three steps so that the host
+// loop below (statistics read back per grid) and the device-resident chain in mppi_kernels.hpp (essps_select_kernel:
+// no read-back at all) run the very same arithmetic.
+template <int P>
+MPPI_SEARCH_HD void essps_make_grid(double lo, double hi, double* grid) {
+    const double llo = log(lo), lhi = log(hi);
+    for (int j = 0; j < P; ++j) grid[j] = exp(llo + (lhi - llo) * (double)j / (double)(P - 1));
+    grid[0] = lo; grid[P - 1] = hi;
+}
+// first bracketing step of a round: the grid interval [grid[i-1], grid[i]] that holds the root
+template <int P>
+MPPI_SEARCH_HD int essps_bracket(const double* ess, double target_ess) {
+    int i = P - 1;
+    for (int j = 0; j < P; ++j) if (ess[j] >= target_ess) { i = j; break; }
+    return i < 1 ? 1 : i;
+}
+// round 0 (mppi.py:361-364): true when an end-point rule decided (lam_out set), else [lo, hi] = the bracket
+template <int P>
+MPPI_SEARCH_HD bool essps_round0(const double* grid, const double* ess, double target_ess, double lam_min, double lam_max,
+                                 double& lo, double& hi, double& lam_out) {
+    if (target_ess <= ess[0]) { lam_out = lam_min; return true; }
+    if (target_ess >= ess[P - 1]) { lam_out = lam_max; return true; }
+    const int i = essps_bracket<P>(ess, target_ess);
+    lo = grid[i - 1]; hi = grid[i];
+    return false;
+}
+// round 1: bracket on the refined grid, then the Lagrange form of log(lambda) as a function of ESS at ESS = target
+// through the four grid points around the root (linear interpolation when ESS is not strictly increasing there)
+template <int P>
+MPPI_SEARCH_HD double essps_round1(const double* grid, const double* ess, double target_ess) {
     static_assert(P >= 4, "grid too small for the cubic");
-    double grid[P], ess[P];
-    double lo = lam_min, hi = lam_max;
-    int i = 1;
-    for (int rnd = 0; rnd < 2; ++rnd) {
-        const double llo = std::log(lo), lhi = std::log(hi);
-        for (int j = 0; j < P; ++j) grid[j] = std::exp(llo + (lhi - llo) * (double)j / (double)(P - 1));
-        grid[0] = lo; grid[P - 1] = hi;
-        if (!ess_grid(grid, ess)) return false;
-        if (rnd == 0) {  // mppi.py:361-364
-            if (target_ess <= ess[0]) { lam_out = lam_min; return true; }
-            if (target_ess >= ess[P - 1]) { lam_out = lam_max; return true; }
-        }
-        i = P - 1;
-        for (int j = 0; j < P; ++j) if (ess[j] >= target_ess) { i = j; break; }
-        if (i < 1) i = 1;
-        lo = grid[i - 1]; hi = grid[i];
-    }
-    const int j0 = std::min(std::max(i - 2, 0), P - 4);
+    const int i = essps_bracket<P>(ess, target_ess);
+    const double lo = grid[i - 1], hi = grid[i];
+    const int j0 = (i - 2 < 0 ? 0 : (i - 2 > P - 4 ? P - 4 : i - 2));
     bool increasing = true;
     for (int a = 0; a < 3; ++a) increasing = increasing && ess[j0 + a + 1] > ess[j0 + a];
-    if (increasing) {  // Lagrange form of log(lambda) as a function of ESS, at ESS = target
+    if (increasing) {
         double x = 0.0;
         for (int a = 0; a < 4; ++a) {
             double w = 1.0;
             for (int b = 0; b < 4; ++b)
                 if (b != a) w *= (target_ess - ess[j0 + b]) / (ess[j0 + a] - ess[j0 + b]);
-            x += w * std::log(grid[j0 + a]);
+            x += w * log(grid[j0 + a]);
         }
-        const double lam = std::exp(x);
-        if (lam >= lo && lam <= hi) { lam_out = lam; return true; }
+        const double lam = exp(x);
+        if (lam >= lo && lam <= hi) return lam;
     }
     const double e0 = ess[i - 1], e1 = ess[i];
-    lam_out = (e1 == e0) ? 0.5 * (lo + hi) : lo + (hi - lo) * (target_ess - e0) / (e1 - e0);
+    return (e1 == e0) ? 0.5 * (lo + hi) : lo + (hi - lo) * (target_ess - e0) / (e1 - e0);
+}
+// host loop: ess_grid(lams[P], ess_out[P]) -> bool evaluates ESS for P temperatures (one device pass + read-back)
+template <int P, class G>
+bool essps_lambda(G&& ess_grid, double target_ess, double lam_min, double lam_max, double& lam_out) {
+    double grid[P], ess[P], lo = lam_min, hi = lam_max;
+    essps_make_grid<P>(lo, hi, grid);
+    if (!ess_grid(grid, ess)) return false;
+    if (essps_round0<P>(grid, ess, target_ess, lam_min, lam_max, lo, hi, lam_out)) return true;
+    essps_make_grid<P>(lo, hi, grid);
+    if (!ess_grid(grid, ess)) return false;
+    lam_out = essps_round1<P>(grid, ess, target_ess);
     return true;
 }
 

@@ -74,7 +74,12 @@ struct MppiSolver {
     float* heads = nullptr;
     float* summary = nullptr;
     float* stats_part = nullptr;     // [STATS_BLOCKS][max(4, STATS_L*3)]
-    double* stats_host = nullptr;    // mapped pinned [8 + STATS_L*3]
+    double* stats_host = nullptr;    // mapped pinned [8 + STATS_L*3 + 1]: single-lambda stats, grid stats, device-searched lambda
+    float* lams_dev = nullptr;       // [3][STATS_L]: caller's grid, ESSPS round-0 grid (preset), ESSPS round-1 grid (device-written)
+    EsspsDev* essps_dev = nullptr;   // state of the device-resident ESSPS search
+    float* lambda_dev = nullptr;     // the temperature that search left on the device (MPPI_LAMBDA_DEVICE)
+    double essps_lo = 0.0, essps_hi = 0.0;  // [lam_min, lam_max] the preset round-0 grid was built for
+    bool lambda_dev_valid = false;
     uint8_t* map_cells[2] = {nullptr, nullptr};
     uint8_t* map_pad = nullptr;      // padded (and, for racing, summed) grid of the FAST lookup
     size_t map_bytes[2] = {0, 0}, map_pad_bytes = 0;
@@ -344,7 +349,10 @@ int mppi_create(const MppiConfig* cfg, mppi_handle_t* out) {
     HIP_TRY(h, hipMalloc(&h->heads, sizeof(float) * (size_t)max_blocks * 4));
     HIP_TRY(h, hipMalloc(&h->summary, sizeof(float) * (size_t)(MPPI_SUMMARY_HEAD + d.row)));
     HIP_TRY(h, hipMalloc(&h->stats_part, sizeof(float) * STATS_L * 3 * STATS_BLOCKS));
-    HIP_TRY(h, hipHostMalloc((void**)&h->stats_host, sizeof(double) * (8 + STATS_L * 3), hipHostMallocMapped));
+    HIP_TRY(h, hipHostMalloc((void**)&h->stats_host, sizeof(double) * (8 + STATS_L * 3 + 1), hipHostMallocMapped));
+    HIP_TRY(h, hipMalloc(&h->lams_dev, sizeof(float) * 3 * STATS_L));
+    HIP_TRY(h, hipMalloc(&h->essps_dev, sizeof(EsspsDev)));
+    HIP_TRY(h, hipMalloc(&h->lambda_dev, sizeof(float)));
     HIP_TRY(h, hipHostMalloc((void**)&h->live_hint, sizeof(int), hipHostMallocMapped));
     *h->live_hint = 0;
     HIP_TRY(h, hipHostGetDevicePointer((void**)&h->live_hint_dev, h->live_hint, 0));
@@ -391,7 +399,8 @@ int mppi_set_control_limits(mppi_handle_t h, const float* u_min, const float* u_
 int mppi_destroy(mppi_handle_t h) {
     if (!h) return MPPI_E_INVALID;
     (void)hipFree(h->noise); (void)hipFree(h->costs); (void)hipFree(h->min_key); (void)hipFree(h->x0);
-    (void)hipFree(h->x0_used); (void)hipFree(h->coltab);
+    (void)hipFree(h->x0_used); (void)hipFree(h->coltab); (void)hipFree(h->lams_dev); (void)hipFree(h->essps_dev);
+    (void)hipFree(h->lambda_dev);
     (void)hipFree(h->mean); (void)hipFree(h->mean_used); (void)hipFree(h->solve_stats); (void)hipFree(h->topk_hist);
     (void)hipFree(h->topk_sel); (void)hipFree(h->topk_cand); (void)hipFree(h->sg_coeffs); (void)hipFree(h->sg_history);
     (void)hipFree(h->ref); (void)hipFree(h->partials); (void)hipFree(h->heads);
@@ -720,8 +729,22 @@ int mppi_set_costs(mppi_handle_t h, const float* src, int on_device, void* strea
     return MPPI_OK;
 }
 
+// lambda argument of the reduce / finalize entry points -> (launch constant, device pointer or null)
+static int resolve_lambda(mppi_handle_t h, float lambda, const float** lam_dev) {
+    *lam_dev = nullptr;
+    if (lambda == MPPI_LAMBDA_DEVICE) {
+        if (!h->lambda_dev_valid) return fail(h, MPPI_E_STATE, "MPPI_LAMBDA_DEVICE: no temperature on the device (call mppi_essps_lambda_device first)");
+        *lam_dev = h->lambda_dev;
+        return MPPI_OK;
+    }
+    if (!(lambda > 0.0f)) return fail(h, MPPI_E_INVALID, "lambda must be > 0");
+    return MPPI_OK;
+}
+
 int mppi_weights_reduce(mppi_handle_t h, float lambda, float* summary_out_dev, void* stream) {
-    if (!h || !(lambda > 0.0f)) return fail(h, MPPI_E_INVALID, "lambda must be > 0");
+    if (!h) return MPPI_E_INVALID;
+    const float* lam_dev = nullptr;
+    if (int rc = resolve_lambda(h, lambda, &lam_dev)) return rc;
     hipStream_t s = (hipStream_t)stream;
     StageTimer tm(h, 2, s);
     // one wave per tile up to reduce_blocks blocks (dense weights need the parallelism; with sparse
@@ -735,7 +758,7 @@ int mppi_weights_reduce(mppi_handle_t h, float lambda, float* summary_out_dev, v
     const unsigned* mk = h->min_key + h->min_slot;
 #define CALL_REDUCE(GPWV, GENV, WIDEV)                                                                \
     hipLaunchKernelGGL((weights_reduce_kernel<GPWV, GENV, WIDEV>), grid, dim3(BLOCK), 0, s, h->noise, h->mean, h->costs, mk, \
-                       h->partials, h->heads, h->d, h->gen, lambda, (const float*)h->coltab)
+                       h->partials, h->heads, h->d, h->gen, lambda, lam_dev, (const float*)h->coltab)
     if (h->wide) { if (h->GPW == 8) CALL_REDUCE(8, false, true); else CALL_REDUCE(32, false, true); }
     else if (h->GPW == 8) { if (gen) CALL_REDUCE(8, true, false); else CALL_REDUCE(8, false, false); }
     else { if (gen) CALL_REDUCE(32, true, false); else CALL_REDUCE(32, false, false); }
@@ -765,7 +788,9 @@ int mppi_weights_reduce(mppi_handle_t h, float lambda, float* summary_out_dev, v
 
 int mppi_finalize(mppi_handle_t h, const float* summaries_dev, int num_shards, float lambda, int store_mean,
                   float* action_out, float* state_out, float* stats_out, void* stream) {
-    if (!h || !(lambda > 0.0f) || num_shards < 1) return fail(h, MPPI_E_INVALID, "bad finalize arguments");
+    if (!h || num_shards < 1) return fail(h, MPPI_E_INVALID, "bad finalize arguments");
+    const float* lam_dev = nullptr;
+    if (int rc = resolve_lambda(h, lambda, &lam_dev)) return rc;
     const bool generic = h->cfg.model == MPPI_MODEL_GENERIC;
     if (generic && state_out) return fail(h, MPPI_E_INVALID, "generic model: roll the action out with the host dynamics");
     if (!generic) { if (int rc = check_ready(h)) return rc; }
@@ -791,7 +816,7 @@ int mppi_finalize(mppi_handle_t h, const float* summaries_dev, int num_shards, f
 #define CALL_FINALIZE(MODEL, FASTV)                                                                   \
     hipLaunchKernelGGL((finalize_kernel<MODEL, FASTV>), dim3(1), dim3(FIN_BLOCK), shmem, s, summaries_dev, num_shards, \
                        h->partials, h->heads, mk, h->last_reduce_blocks, h->colsp, h->summary, h->live_hint_dev,  \
-                       lambda, h->d.row, h->d.T, h->x0_cur, store_mean ? h->mean : (float*)nullptr, action_out,  \
+                       lambda, lam_dev, h->d.row, h->d.T, h->x0_cur, store_mean ? h->mean : (float*)nullptr, action_out,  \
                        state_out, stats_out, h->solve_stats, sg, p2p, h->ctx)
     MPPI_DISPATCH(h, CALL_FINALIZE);
 #undef CALL_FINALIZE
@@ -844,27 +869,80 @@ int mppi_softmax_stats(mppi_handle_t h, float lambda, double* out5_host, void* s
     return MPPI_OK;
 }
 
+static int stats_blocks(mppi_handle_t h) {
+    return (int)std::max<int64_t>(1, std::min<int64_t>(STATS_BLOCKS, (h->d.N + STATS_THREADS - 1) / STATS_THREADS));
+}
+
 int mppi_softmax_stats_multi(mppi_handle_t h, const float* lambdas_host, int count, double* out_host, void* stream) {
     if (!h || !lambdas_host || !out_host || count < 1 || count > STATS_L)
         return fail(h, MPPI_E_INVALID, "bad softmax_stats_multi arguments (1..32 lambdas)");
-    LambdaGrid g{};
-    g.count = count;
+    float lam[STATS_L];
     for (int l = 0; l < STATS_L; ++l) {
-        g.lam[l] = l < count ? lambdas_host[l] : 1.0f;
-        if (!(g.lam[l] > 0.0f)) return fail(h, MPPI_E_INVALID, "lambda must be > 0");
-        g.inv_lam[l] = 1.0f / g.lam[l];
+        lam[l] = l < count ? lambdas_host[l] : 1.0f;
+        if (!(lam[l] > 0.0f)) return fail(h, MPPI_E_INVALID, "lambda must be > 0");
     }
     hipStream_t s = (hipStream_t)stream;
+    if (int rc = upload_small(h, h->lams_dev, lam, STATS_L, s)) return rc;
     const unsigned* mk = h->min_key + h->min_slot;
-    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(STATS_BLOCKS, (h->d.N + BLOCK - 1) / BLOCK));
-    hipLaunchKernelGGL(stats_multi_partial_kernel, dim3(blocks), dim3(BLOCK), 0, s, h->costs, h->d.N, mk, g, h->stats_part);
+    const int blocks = stats_blocks(h);
+    hipLaunchKernelGGL(stats_multi_kernel, dim3(blocks), dim3(STATS_THREADS), 0, s, h->costs, h->d.N, mk,
+                       (const float*)h->lams_dev, h->stats_part);
     HIP_TRY(h, hipGetLastError());
     double* dev_out = nullptr;
     HIP_TRY(h, hipHostGetDevicePointer((void**)&dev_out, h->stats_host, 0));
-    hipLaunchKernelGGL(stats_multi_combine_kernel, dim3(1), dim3(STATS_COMB_THREADS), 0, s, h->stats_part, blocks, dev_out + 8);
+    hipLaunchKernelGGL(stats_multi_combine_kernel, dim3(1), dim3(1024), 0, s, h->stats_part, blocks, dev_out + 8);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipStreamSynchronize(s));
     for (int j = 0; j < count * 3; ++j) out_host[j] = h->stats_host[8 + j];
+    return MPPI_OK;
+}
+
+// ESSPS with no host synchronisation (mppi.py:351-370): statistics pass over the preset round-0 grid -> select
+// (end-point rules / refined grid, on the device) -> statistics pass over that grid -> select (root) -> the
+// temperature stays in HBM, where mppi_weights_reduce / mppi_finalize read it when called with MPPI_LAMBDA_DEVICE;
+// mppi_get_lambda fetches it (synchronises).  Same arithmetic as mppi_essps_lambda: both run host_search.hpp.
+int mppi_essps_lambda_device(mppi_handle_t h, double target_ess, double lam_min, double lam_max, void* stream) {
+    if (!h || !(lam_min > 0.0) || !(lam_max > lam_min) || !(target_ess > 0.0))
+        return fail(h, MPPI_E_INVALID, "bad essps arguments");
+    hipStream_t s = (hipStream_t)stream;
+    if (h->essps_lo != lam_min || h->essps_hi != lam_max) {  // (re)build the round-0 grid: setup path, blocking
+        EsspsDev st{};
+        float lamf[STATS_L];
+        mppi::host::essps_make_grid<STATS_L>(lam_min, lam_max, st.grid0);
+        for (int j = 0; j < STATS_L; ++j) { lamf[j] = (float)st.grid0[j]; st.grid1[j] = st.grid0[j]; }
+        HIP_TRY(h, hipDeviceSynchronize());
+        HIP_TRY(h, hipMemcpy(h->lams_dev + STATS_L, lamf, sizeof(lamf), hipMemcpyHostToDevice));
+        // (round 1's grid is rewritten by every search; a valid one for the searches an end-point rule cuts short)
+        HIP_TRY(h, hipMemcpy(h->lams_dev + 2 * STATS_L, lamf, sizeof(lamf), hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(h->essps_dev, &st, sizeof(st), hipMemcpyHostToDevice));
+        h->essps_lo = lam_min; h->essps_hi = lam_max;
+    }
+    const unsigned* mk = h->min_key + h->min_slot;
+    const int blocks = stats_blocks(h);
+    double* host_lam = nullptr;
+    HIP_TRY(h, hipHostGetDevicePointer((void**)&host_lam, h->stats_host, 0));
+    host_lam += 8 + STATS_L * 3;
+    float* lams0 = h->lams_dev + STATS_L;
+    float* lams1 = h->lams_dev + 2 * STATS_L;
+    hipLaunchKernelGGL(stats_multi_kernel, dim3(blocks), dim3(STATS_THREADS), 0, s, h->costs, h->d.N, mk, (const float*)lams0,
+                       h->stats_part);
+    hipLaunchKernelGGL(essps_select_kernel<0>, dim3(1), dim3(1024), 0, s, (const float*)h->stats_part, blocks, target_ess,
+                       lam_min, lam_max, h->essps_dev, lams1, h->lambda_dev, host_lam);
+    hipLaunchKernelGGL(stats_multi_kernel, dim3(blocks), dim3(STATS_THREADS), 0, s, h->costs, h->d.N, mk, (const float*)lams1,
+                       h->stats_part);
+    hipLaunchKernelGGL(essps_select_kernel<1>, dim3(1), dim3(1024), 0, s, (const float*)h->stats_part, blocks, target_ess,
+                       lam_min, lam_max, h->essps_dev, lams1, h->lambda_dev, host_lam);
+    HIP_TRY(h, hipGetLastError());
+    h->lambda_dev_valid = true;
+    return MPPI_OK;
+}
+
+// The temperature of the last mppi_essps_lambda_device.  Synchronises the stream.
+int mppi_get_lambda(mppi_handle_t h, double* lambda_out_host, void* stream) {
+    if (!h || !lambda_out_host) return fail(h, MPPI_E_INVALID, "null");
+    if (!h->lambda_dev_valid) return fail(h, MPPI_E_STATE, "no temperature on the device");
+    HIP_TRY(h, hipStreamSynchronize((hipStream_t)stream));
+    *lambda_out_host = h->stats_host[8 + STATS_L * 3];
     return MPPI_OK;
 }
 

@@ -9,6 +9,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "host_search.hpp"
 #include "mppi_models.hpp"
 #include "philox.hpp"
 
@@ -393,8 +394,11 @@ __global__ __launch_bounds__(BLOCK) void weights_reduce_kernel(const float4* __r
                                                                const unsigned* __restrict__ min_key,
                                                                float* __restrict__ partials,
                                                                float* __restrict__ heads, Dims d, GenCtx gen,
-                                                               float lambda, const float* __restrict__ coltab) {
+                                                               float lambda_arg, const float* __restrict__ lambda_dev,
+                                                               const float* __restrict__ coltab) {
     static_assert(!(GEN && WIDE), "wide control rows are reduced from the materialised tiles");
+    // the temperature: a launch constant, or (ESSPS searched on the device) the value the search left in HBM
+    const float lambda = lambda_dev ? *lambda_dev : lambda_arg;
     constexpr int NACC = GPW * 4;
     constexpr int NW = BLOCK / WAVE;
     constexpr int CHG = NW * GPW;  // float4 groups per column chunk
@@ -748,7 +752,8 @@ __global__ __launch_bounds__(FIN_BLOCK) void finalize_kernel(const float* __rest
                                                              const float* __restrict__ heads,
                                                              const unsigned* __restrict__ min_key, int nblocks,
                                                              int colsp, float* __restrict__ summary_out,
-                                                             int* __restrict__ nlive_out, float lambda, int row, int T,
+                                                             int* __restrict__ nlive_out, float lambda_arg,
+                                                             const float* __restrict__ lambda_dev, int row, int T,
                                                              const float* __restrict__ x0,
                                                              float* __restrict__ mean_store,
                                                              float* __restrict__ action_out,
@@ -757,6 +762,7 @@ __global__ __launch_bounds__(FIN_BLOCK) void finalize_kernel(const float* __rest
                                                              float* __restrict__ stats_keep, SgFilter sg,
                                                              P2pCtx p2p, ModelCtx ctx) {
     constexpr int DC = ModelT<MODEL, FAST>::DC;
+    const float lambda = lambda_dev ? *lambda_dev : lambda_arg;
     // [row] action, [max(1, W) * (4 + row)] own / collected summaries, then (SG filter) [(2T-1+2*(w/2))*dc]
     extern __shared__ __attribute__((aligned(16))) float s_fin[];
     const int stride = MPPI_SUMMARY_HEAD + row;
@@ -786,7 +792,10 @@ __global__ __launch_bounds__(FIN_BLOCK) void finalize_kernel(const float* __rest
         const int ncols = row + 3;  // the last 3 "columns" are the heads
         // [NG][ncols] group sums, behind the filter staging (the host sizes the dynamic LDS for it)
         float* s_fold = s_yp + (sg.window ? (2 * T - 1 + 2 * (sg.window / 2)) * (row / T) : 0);
-        for (int p = threadIdx.x; p < NG * ncols; p += FIN_BLOCK) {
+        // row groups g >= nlive hold no row: their sums are +0 and adding them changes nothing, so only the first
+        // min(NG, nlive) groups are formed and summed (one pass of row + 3 threads when one or two blocks were live)
+        const int ng = min(NG, nlive);
+        for (int p = threadIdx.x; p < ng * ncols; p += FIN_BLOCK) {
             const int g = p / ncols, col = p - g * ncols;  // consecutive lanes: consecutive columns of one row
             const bool is_head = col >= row;
             const float* base = is_head ? heads + (col - row) : partials + col;
@@ -806,7 +815,7 @@ __global__ __launch_bounds__(FIN_BLOCK) void finalize_kernel(const float* __rest
         __syncthreads();
         for (int col = threadIdx.x; col < ncols; col += FIN_BLOCK) {
             float v = 0.f;
-            for (int q = 0; q < NG; ++q) v += s_fold[q * ncols + col];
+            for (int q = 0; q < ng; ++q) v += s_fold[q * ncols + col];
             const int dst = col < row ? MPPI_SUMMARY_HEAD + col : 1 + (col - row);
             s_sum[dst] = v;
             if (summary_out) summary_out[dst] = v;
@@ -962,54 +971,62 @@ __global__ __launch_bounds__(WAVE) void stats_combine_kernel(const float* __rest
 
 // The same statistics for up to STATS_L temperatures in one pass over the costs (a grid of lambdas
 // for the bracketing search of ESSPS): part [blocks][STATS_L][3] = {sum e, sum e^2, sum e*c}.
+//
+// Mapping: a block of 1024 threads stages 1024 costs in LDS per round; thread (l = tid & 31, chunk = tid >> 5) then
+// walks the 32 costs of its chunk for ITS temperature l (LDS broadcast reads: the 32 lanes of a half-wave share the
+// address).  Every lane therefore owns one temperature and the cross-lane work at the end is one shuffle (the two
+// half-waves) plus a 16-way sum through LDS — instead of 96 full wave reductions per thread when every lane carried
+// all 32 temperatures (12.6 us -> launch-bound at N = 65 536, profiles/r02_visitA_c2_c5_dense_path.md).
+// `lams` is a DEVICE array [STATS_L] (entries past the caller's count hold 1): the temperatures of the second ESSPS
+// grid are produced on the device (essps_select_kernel) and never visit the host.
 constexpr int STATS_L = 32;
-struct LambdaGrid {
-    float lam[STATS_L];
-    float inv_lam[STATS_L];
-    int32_t count;
-};
-__global__ __launch_bounds__(BLOCK) void stats_multi_partial_kernel(const float* __restrict__ costs, int64_t N,
-                                                                   const unsigned* __restrict__ min_key,
-                                                                   LambdaGrid g, float* __restrict__ part) {
-    __shared__ float s_p[BLOCK / WAVE][STATS_L][3];
+constexpr int STATS_THREADS = 1024;
+__global__ __launch_bounds__(STATS_THREADS) void stats_multi_kernel(const float* __restrict__ costs, int64_t N,
+                                                                    const unsigned* __restrict__ min_key,
+                                                                    const float* __restrict__ lams,
+                                                                    float* __restrict__ part) {
+    constexpr int NWV = STATS_THREADS / WAVE;
+    __shared__ float s_c[STATS_THREADS];
+    __shared__ float s_p[NWV][STATS_L][3];
     const float cmin = key_to_float(*min_key);
-    float se[STATS_L], se2[STATS_L], sec[STATS_L];
-#pragma unroll
-    for (int l = 0; l < STATS_L; ++l) se[l] = se2[l] = sec[l] = 0.0f;
-    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < N; i += (int64_t)gridDim.x * BLOCK) {
-        const float c = costs[i];
-        const float dc0 = cmin - c;  // <= 0, exact for costs within a factor 2 of the minimum
-#pragma unroll
-        for (int l = 0; l < STATS_L; ++l) {
-            if (l < g.count) {
-                // exp(-(c - cmin)/lambda) with the reciprocal of lambda: this kernel only brackets the
-                // temperature (the weights themselves use the reference's (-c)/lambda - max form)
-                const float e = expf(dc0 * g.inv_lam[l]);
-                se[l] += e;
-                se2[l] = fmaf(e, e, se2[l]);
-                sec[l] = fmaf(e, c, sec[l]);
-            }
+    const int l = threadIdx.x & (STATS_L - 1), chunk = threadIdx.x >> 5;
+    const float inv_lam = 1.0f / lams[l];
+    float se = 0.0f, se2 = 0.0f, sec = 0.0f;
+    for (int64_t base = (int64_t)blockIdx.x * STATS_THREADS; base < N; base += (int64_t)gridDim.x * STATS_THREADS) {
+        __syncthreads();
+        const int64_t i = base + threadIdx.x;
+        // padding: a huge finite cost -> e = exp(-inf) = 0 and 0 * c = 0
+        s_c[threadIdx.x] = i < N ? costs[i] : 3.0e38f;
+        __syncthreads();
+        const float* cc = s_c + chunk * 32;
+#pragma unroll 8
+        for (int j = 0; j < 32; ++j) {
+            const float c = cc[j];
+            // exp(-(c - cmin)/lambda) with the reciprocal of lambda: this kernel only brackets the temperature (the
+            // weights themselves use the reference's (-c)/lambda - max form); cmin - c is exact within a factor 2
+            const float e = expf((cmin - c) * inv_lam);
+            se += e;
+            se2 = fmaf(e, e, se2);
+            sec = fmaf(e, c, sec);
         }
     }
+    se += __shfl_xor(se, 32); se2 += __shfl_xor(se2, 32); sec += __shfl_xor(sec, 32);  // the wave's two chunks
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-#pragma unroll
-    for (int l = 0; l < STATS_L; ++l) {
-        const float a = wave_sum(se[l]), b = wave_sum(se2[l]), c3 = wave_sum(sec[l]);
-        if (lane == 0) { s_p[wid][l][0] = a; s_p[wid][l][1] = b; s_p[wid][l][2] = c3; }
-    }
+    if (lane < STATS_L) { s_p[wid][lane][0] = se; s_p[wid][lane][1] = se2; s_p[wid][lane][2] = sec; }
     __syncthreads();
-    for (int j = threadIdx.x; j < STATS_L * 3; j += BLOCK) {
+    if (threadIdx.x < STATS_L * 3) {
         float v = 0.0f;
 #pragma unroll
-        for (int w = 0; w < BLOCK / WAVE; ++w) v += (&s_p[w][0][0])[j];
-        part[(int64_t)blockIdx.x * STATS_L * 3 + j] = v;
+        for (int w = 0; w < NWV; ++w) v += (&s_p[w][0][0])[threadIdx.x];
+        part[(int64_t)blockIdx.x * STATS_L * 3 + threadIdx.x] = v;
     }
 }
-constexpr int STATS_COMB_THREADS = 960;  // 96 columns x 10 row groups
-__global__ __launch_bounds__(1024) void stats_multi_combine_kernel(const float* __restrict__ part, int nblocks,
-                                                                   double* __restrict__ out /*[STATS_L][3] mapped*/) {
+// Block-wide (960 of 1024 threads = 96 columns x 10 row groups): column sums of part[nblocks][96] in double, fixed
+// order -> s_out[96] (LDS or global).  Ends with a barrier.
+constexpr int STATS_COMB_THREADS = 960;
+__device__ __forceinline__ void stats_combine_columns(const float* __restrict__ part, int nblocks, double* s_acc /*[10][96]*/,
+                                                      double* out /*[96]*/) {
     constexpr int COLS = STATS_L * 3, GROUPS = STATS_COMB_THREADS / COLS;
-    __shared__ double s_acc[GROUPS][COLS];
     const int j = threadIdx.x % COLS, g = threadIdx.x / COLS;
     if (g < GROUPS) {
         double v0 = 0.0, v1 = 0.0;
@@ -1019,14 +1036,66 @@ __global__ __launch_bounds__(1024) void stats_multi_combine_kernel(const float* 
             v1 += part[(int64_t)(b + GROUPS) * COLS + j];
         }
         if (b < nblocks) v0 += part[(int64_t)b * COLS + j];
-        s_acc[g][j] = v0 + v1;
+        s_acc[g * COLS + j] = v0 + v1;
     }
     __syncthreads();
     if (threadIdx.x < COLS) {
         double v = 0.0;
 #pragma unroll
-        for (int q = 0; q < GROUPS; ++q) v += s_acc[q][threadIdx.x];
+        for (int q = 0; q < GROUPS; ++q) v += s_acc[q * COLS + threadIdx.x];
         out[threadIdx.x] = v;
+    }
+    __syncthreads();
+}
+__global__ __launch_bounds__(1024) void stats_multi_combine_kernel(const float* __restrict__ part, int nblocks,
+                                                                   double* __restrict__ out /*[STATS_L][3] mapped*/) {
+    __shared__ double s_acc[(STATS_COMB_THREADS / (STATS_L * 3)) * STATS_L * 3];
+    stats_combine_columns(part, nblocks, s_acc, out);
+}
+
+// ESSPS without leaving the device (mppi.py:351-370): after each 32-temperature statistics pass one block combines
+// the partial sums and runs the scalar step of the search (host_search.hpp: the same functions the host loop of
+// mppi_essps_lambda calls) — round 0 applies the end-point rules or writes the refined grid for the second pass,
+// round 1 interpolates the root.  The temperature ends up in `lambda_out` (device, fp32: what weights_reduce_kernel
+// and finalize_kernel read) and in mapped host memory (double) for whoever asks later; the host never waits.
+struct EsspsDev {
+    double grid0[STATS_L];  // round-0 temperatures: geometric over [lam_min, lam_max], written once by the host
+    double grid1[STATS_L];  // round-1 temperatures: the refined grid round 0 wrote (`lams` holds their fp32 casts)
+    double lo, hi;          // bracket after round 0
+    double lam;             // result
+    int32_t done, pad;      // an end-point rule of round 0 already decided
+};
+template <int ROUND>
+__global__ __launch_bounds__(1024) void essps_select_kernel(const float* __restrict__ part, int nblocks, double target_ess,
+                                                            double lam_min, double lam_max, EsspsDev* __restrict__ st,
+                                                            float* __restrict__ lams, float* __restrict__ lambda_out,
+                                                            double* __restrict__ lambda_host) {
+    __shared__ double s_acc[(STATS_COMB_THREADS / (STATS_L * 3)) * STATS_L * 3];
+    __shared__ double s_sum[STATS_L * 3];
+    stats_combine_columns(part, nblocks, s_acc, s_sum);
+    if (threadIdx.x != 0) return;
+    if (ROUND == 1 && st->done) return;
+    double ess[STATS_L];
+    for (int j = 0; j < STATS_L; ++j) ess[j] = s_sum[3 * j] * s_sum[3 * j] / s_sum[3 * j + 1];
+    double lam = 0.0;
+    bool have = false;
+    if (ROUND == 0) {
+        double lo = lam_min, hi = lam_max;
+        have = mppi::host::essps_round0<STATS_L>(st->grid0, ess, target_ess, lam_min, lam_max, lo, hi, lam);
+        st->done = have ? 1 : 0;
+        st->lo = lo; st->hi = hi;
+        if (!have) {
+            mppi::host::essps_make_grid<STATS_L>(lo, hi, st->grid1);
+            for (int j = 0; j < STATS_L; ++j) lams[j] = (float)st->grid1[j];
+        }
+    } else {
+        lam = mppi::host::essps_round1<STATS_L>(st->grid1, ess, target_ess);
+        have = true;
+    }
+    if (have) {
+        st->lam = lam;
+        *lambda_out = (float)lam;
+        *lambda_host = lam;
     }
 }
 

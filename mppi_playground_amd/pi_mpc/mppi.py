@@ -62,7 +62,7 @@ class MPPI(nn.Module):
         shard_samples: bool = False,
         process_group=None,
         auto_lambda_stats: str = "device",
-        essps_search: str = "grid",
+        essps_search: str = "device",
         sg_filter: str = "device",
     ) -> None:
         """Arguments up to `seed` are the reference's (src/pi_mpc/mppi.py:24-47).
@@ -74,10 +74,13 @@ class MPPI(nn.Module):
             auto_lambda_stats: "device" (default) evaluates the softmax sums of the ESSPS/LBPS/MPO searches
                 on the GPU (mppi_softmax_stats; the root-finders stay on the host), "host" copies
                 costs[N] to the CPU and evaluates them in numpy like the reference does.
-            essps_search: with device statistics, "grid" (default) brackets the ESSPS root with two
+            essps_search: with device statistics, "device" (default) and "grid" bracket the ESSPS root with two
                 32-temperature geometric grids (one pass over the costs each) and an inverse cubic
-                interpolation, "brentq" probes one lambda at a time like the reference's scipy call; both
-                return the same root (to ~1e-7 relative).
+                interpolation — "device" runs the scalar steps of that search as kernels too, so the solve never
+                waits for the host (the temperature stays in HBM; reading `_lambda` fetches it), "grid" reads the
+                statistics back after each pass; "brentq" probes one lambda at a time like the reference's scipy
+                call.  All return the same root (to ~1e-7 relative).  Sharded solvers combine the shards'
+                statistics on the host ("device" behaves like "grid" there).
             sg_filter: "device" (default) runs the Savitzky-Golay step inside the finalize kernel
                 (bit-identical to the host statement), "host" keeps the reference's numpy-style round trip.
             shard_samples: treat `num_samples` as the GLOBAL sample count and let this rank own the
@@ -125,8 +128,8 @@ class MPPI(nn.Module):
         if auto_lambda_stats not in ("device", "host"):
             raise ValueError("auto_lambda_stats must be 'device' or 'host'")
         self._auto_lambda_stats = auto_lambda_stats
-        if essps_search not in ("grid", "brentq"):
-            raise ValueError("essps_search must be 'grid' or 'brentq'")
+        if essps_search not in ("device", "grid", "brentq"):
+            raise ValueError("essps_search must be 'device', 'grid' or 'brentq'")
         self._essps_search = essps_search
         assert sg_filter in ("device", "host")
         self._sg_on_device = sg_filter == "device"
@@ -166,7 +169,9 @@ class MPPI(nn.Module):
                 raise ValueError(f"dim_control must be in 1..{_capi.MAX_DIM_CONTROL_GENERIC}")
 
         # ---- auto lambda (src/pi_mpc/mppi.py:183-210)
-        self._lambda: float | str = lambda_
+        self._lambda_pending = False  # the temperature of the last solve still lives on the device only
+        self._lambda_value = self._last_lambda_value = None
+        self._lambda = lambda_
         self._lbps_delta = lbps_delta
         self._essps_target_ess = essps_target_ess if essps_target_ess is not None else num_samples / 10
         self._lambda_min = lambda_min
@@ -246,6 +251,37 @@ class MPPI(nn.Module):
         self._state_seq_batch_buf = None
         self._perturbed_action_seqs_buf = None
         self._x0_tensor = None
+
+    # ------------------------------------------------------------------ temperature (lazily fetched)
+    def _fetch_lambda(self) -> None:
+        """The ESSPS search of the last solve ran on the device without a read-back: fetch its result now."""
+        out = C.c_double(0.0)
+        self._h.call("mppi_get_lambda", C.byref(out), self._stream())
+        self._lambda_value = self._last_lambda_value = out.value
+        self._lambda_pending = False
+
+    @property
+    def _lambda(self):
+        """`_lambda` of the reference (mppi.py:183,349,370,398): the current temperature."""
+        if self._lambda_pending:
+            self._fetch_lambda()
+        return self._lambda_value
+
+    @_lambda.setter
+    def _lambda(self, value) -> None:
+        self._lambda_value = value
+        self._lambda_pending = False
+
+    @property
+    def _last_lambda(self):
+        """The temperature the weights of the last solve used."""
+        if self._lambda_pending:
+            self._fetch_lambda()
+        return self._last_lambda_value
+
+    @_last_lambda.setter
+    def _last_lambda(self, value) -> None:
+        self._last_lambda_value = value
 
     # ------------------------------------------------------------------ helpers
     def _stream(self):
@@ -471,20 +507,28 @@ class MPPI(nn.Module):
             self._lambda = (_host.lbps_lambda_stats(self._softmax_stats, self._lbps_delta, self._lambda_min,
                                                     self._lambda_max) if on_dev else
                             _host.lbps_lambda(costs_host, self._lbps_delta, self._lambda_min, self._lambda_max))
+        elif self._auto_lambda == "ESSPS" and on_dev and self._essps_search == "device" and self._world == 1:
+            # the whole search as kernels on this stream: nothing is read back, the temperature stays in HBM
+            h.call("mppi_essps_lambda_device", float(self._essps_target_ess), float(self._lambda_min),
+                   float(self._lambda_max), st)
+            self._lambda_pending = True
         elif self._auto_lambda == "ESSPS" and on_dev and self._essps_search == "grid" and self._world == 1:
-            lam_out = C.c_double(0.0)  # the whole search inside the library (same algorithm as essps_lambda_grid)
+            lam_out = C.c_double(0.0)  # the search as a host loop inside the library (same algorithm, one read-back per grid)
             h.call("mppi_essps_lambda", float(self._essps_target_ess), float(self._lambda_min),
                    float(self._lambda_max), C.byref(lam_out), st)
             self._lambda = lam_out.value
         elif self._auto_lambda == "ESSPS":
             self._lambda = ((_host.essps_lambda_grid(self._ess_grid, self._essps_target_ess, self._lambda_min,
-                                                     self._lambda_max) if self._essps_search == "grid" else
+                                                     self._lambda_max) if self._essps_search != "brentq" else
                              _host.essps_lambda_stats(self._softmax_stats, self._essps_target_ess, self._lambda_min,
                                                       self._lambda_max)) if on_dev else
                             _host.essps_lambda(costs_host, self._essps_target_ess, self._lambda_min,
                                                self._lambda_max))
-        lam = float(self._lambda)
-        self._last_lambda = lam
+        if self._lambda_pending:
+            lam = _capi.LAMBDA_DEVICE  # weights_reduce / finalize read the temperature from device memory
+        else:
+            lam = float(self._lambda)
+            self._last_lambda = lam
 
         # Steps 5-6: weights + weighted mean (src/pi_mpc/mppi.py:376-385)
         sharded = self._world > 1

@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""A/B timings of the dense-weight configs (C2 nav2d, C5 cartpole, C1 pendulum) on one box: ESSPS search variant x
+reduction grid.  Usage (GPU box): python scripts/gpu_dense_ab.py"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+import numpy as np
+import torch
+
+import mppi_playground_amd  # noqa: F401
+from envs import classic_control as cc
+from envs.navigation_2d import Navigation2DEnv
+from pi_mpc.mppi import MPPI
+
+
+def timeit(s, x0, n=200, warm=30):
+    for _ in range(warm):
+        s.forward(x0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        s.forward(x0)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e6
+
+
+nav = Navigation2DEnv()
+t = torch.tensor
+cases = {
+    "C1 pendulum N=1000": lambda **k: (MPPI(50, 1000, 2, 1, cc.pendulum_dynamics, cc.pendulum_cost, t([-2.0]), t([2.0]), t([1.0]), "ESSPS", **k),
+                                        t([np.pi, 0.0], dtype=torch.float32).cuda()),
+    "C2 nav2d N=65536": lambda **k: (MPPI(50, 65536, 3, 2, nav.dynamics, nav.cost_function, nav.u_min, nav.u_max, t([0.5, 0.5]), "ESSPS", **k),
+                                      nav.reset().clone()),
+    "C5 cartpole N=262144 +SG": lambda **k: (MPPI(64, 262144, 4, 1, cc.cartpole_dynamics, cc.cartpole_cost, t([-3.0]), t([3.0]), t([1.0]), "ESSPS",
+                                                   use_sg_filter=True, **k), t([0.01, 0.0, 0.02, 0.0]).cuda()),
+}
+for name, make in cases.items():
+    row = []
+    for search in ("device", "grid"):
+        for rb in (512, 1024, 2048):
+            s, x0 = make(essps_search=search)
+            s.set_option("reduce_blocks", rb)
+            row.append(f"{search}/rb{rb}: {timeit(s, x0):7.1f} us")
+            lam = s._last_lambda
+            del s
+    print(f"{name:28s} lambda {lam:.6f} | " + " | ".join(row), flush=True)

@@ -710,12 +710,30 @@ def test_device_softmax_stats_drive_the_same_temperature(lam_mode):
         outs.append((solver._last_lambda, a.cpu().numpy(), a2.cpu().numpy(), solver))
     tol = {"ESSPS": 1e-4, "LBPS": 5e-3, "MPO": 1e-3}[lam_mode]
     assert abs(outs[0][0] - outs[1][0]) <= tol * outs[1][0]
-    if lam_mode == "ESSPS":  # grid bracketing (default) and one-lambda-at-a-time brentq find the same root
+    if lam_mode == "ESSPS":  # grid bracketing and one-lambda-at-a-time brentq find the same root
         sb, _ = make_solver("nav2d", T, N, lambda_="ESSPS", essps_search="brentq")
         sb.forward(torch.tensor([-9.0, -9.0, 0.785]))
         sg, _ = make_solver("nav2d", T, N, lambda_="ESSPS", essps_search="grid")
         sg.forward(torch.tensor([-9.0, -9.0, 0.785]))
         assert abs(sb._last_lambda - sg._last_lambda) <= 1e-6 * sb._last_lambda
+        # the default: the same search with its scalar steps on the device too (no read-back during the solve) — same
+        # arithmetic (csrc/host_search.hpp on both sides), so the same temperature and the same action
+        sd, _ = make_solver("nav2d", T, N, lambda_="ESSPS", essps_search="device")
+        ad, _ = sd.forward(torch.tensor([-9.0, -9.0, 0.785]))
+        assert sd._lambda_pending and outs[0][3]._essps_search == "device"
+        assert abs(sd._last_lambda - sg._last_lambda) <= 1e-12 * sg._last_lambda and not sd._lambda_pending
+        assert rel_err(ad.cpu().numpy(), outs[0][1]) == 0.0
+        # end-point rules decided on the device (mppi.py:361-364): racing costs never reach ESS = N/10 below lambda_max
+        sr, cr = make_solver("racing", 25, 4096, lambda_="ESSPS")
+        env = _envs["racing"]
+        ref, _ = cr.calc_ref_trajectory(env.reset(), env.racing_center_path, 0, 25, DL=0.1, lookahead_distance=3,
+                                        reference_path_interval=0.85)
+        cr.set_reference(ref)
+        sr.forward(env.reset().clone())
+        assert sr._last_lambda == 10.0
+        st, _ = make_solver("pendulum", 15, 256, lambda_="ESSPS", essps_target_ess=1.0)
+        st.forward(torch.tensor([3.0, 0.0]))
+        assert st._last_lambda == 0.01
         # the library's own search (mppi_essps_lambda, what forward() used) == the host statement of it
         from pi_mpc import _host
         lam_py = _host.essps_lambda_grid(sg._ess_grid, sg._essps_target_ess, sg._lambda_min, sg._lambda_max)
