@@ -763,6 +763,11 @@ __global__ __launch_bounds__(FIN_BLOCK) void finalize_kernel(const float* __rest
                                                              P2pCtx p2p, ModelCtx ctx) {
     constexpr int DC = ModelT<MODEL, FAST>::DC;
     const float lambda = lambda_dev ? *lambda_dev : lambda_arg;
+    // issued before the first barrier so that their latency hides behind the fold: the shard minimum and the start
+    // state of the batch-1 rollout (both would otherwise be dependent loads at the end of the chain)
+    const unsigned min_key_now = *min_key;
+    __shared__ float s_x0[MPPI_MAX_DIM_STATE];
+    if (threadIdx.x < ModelT<MODEL, FAST>::DS) s_x0[threadIdx.x] = x0[threadIdx.x];
     // [row] action, [max(1, W) * (4 + row)] own / collected summaries, then (SG filter) [(2T-1+2*(w/2))*dc]
     extern __shared__ __attribute__((aligned(16))) float s_fin[];
     const int stride = MPPI_SUMMARY_HEAD + row;
@@ -821,7 +826,7 @@ __global__ __launch_bounds__(FIN_BLOCK) void finalize_kernel(const float* __rest
             if (summary_out) summary_out[dst] = v;
         }
         if (threadIdx.x == 0) {
-            s_sum[0] = key_to_float(*min_key);
+            s_sum[0] = key_to_float(min_key_now);
             if (summary_out) summary_out[0] = s_sum[0];
             if (nlive_out) *nlive_out = nlive;
         }
@@ -907,13 +912,13 @@ __global__ __launch_bounds__(FIN_BLOCK) void finalize_kernel(const float* __rest
         if (T <= 63) {  // the serial part of the batch-1 rollout shrinks to the heading/speed recurrences
             if (threadIdx.x >= WAVE) return;
             bool bad = false;
-            ModelT<MODEL, FAST>::rollout_wave(ctx, x0, s_act, T, state_out, bad);
+            ModelT<MODEL, FAST>::rollout_wave(ctx, s_x0, s_act, T, state_out, bad);
             if (__ballot(bad) != 0ull && threadIdx.x == 0)  // left a fast-path validity range: library math
-                (void)rollout_states<MODEL, false>(x0, T, ctx, state_out, getu);
+                (void)rollout_states<MODEL, false>(s_x0, T, ctx, state_out, getu);
             return;
         }
     }
-    if (threadIdx.x == 0) rollout_states_checked<MODEL, FAST>(x0, T, ctx, state_out, getu);
+    if (threadIdx.x == 0) rollout_states_checked<MODEL, FAST>(s_x0, T, ctx, state_out, getu);
 }
 
 // Softmax statistics of the cost vector for one temperature — the device half of the auto-lambda
