@@ -149,6 +149,7 @@ def test_forward_parity(name, math):
     P = oracle_problem(model, N, T, cfg.get("exploration", 0.0))
     from pi_mpc import _host
 
+    flipped = []
     for k in range(int(g["K"])):
         x0, mean, eps = g[f"x0_{k}"], g[f"mean_in_{k}"], g[f"eps_{k}"]
         if ctrl is not None:
@@ -204,8 +205,12 @@ def test_forward_parity(name, math):
             a, s = (t.cpu().numpy() for t in twin.forward(torch.from_numpy(x0)))
             assert np.array_equal(twin._costs.cpu().numpy(), c_gpu)
         if nflip:  # an occupancy cell flipped under <=1.5-ulp sin/cos differences: the two runs saw different maps
-            pytest.skip(f"{name} solve {k}: {nflip} boundary sample(s) flipped a map cell; end-to-end check not applicable")
-        check_end_to_end(a, s, c_gpu, lam_ref, g, k, cfg, P)
+            flipped.append((k, nflip))
+        else:
+            check_end_to_end(a, s, c_gpu, lam_ref, g, k, cfg, P)
+    if flipped:  # every other check of every solve ran; the omitted one is reported, not passed over
+        pytest.skip(f"{name}: boundary sample(s) flipped a map cell in solve(s) {flipped}; the end-to-end comparison "
+                    "with the reference fixture was not applicable there (all other checks passed)")
 
 
 @pytest.mark.parametrize("name", ["pendulum_T15_N256_fixed", "pendulum_T15_N200_explore", "cartpole_T10_N100_fixed",
