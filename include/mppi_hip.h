@@ -197,6 +197,13 @@ int mppi_weights_reduce(mppi_handle_t h, float lambda /* > 0, or MPPI_LAMBDA_DEV
  * sum e*c} (global); any output may be NULL. */
 int mppi_finalize(mppi_handle_t h, const float* summaries_dev, int num_shards, float lambda, int store_mean,
                   float* action_out_dev, float* state_seq_out_dev, float* stats_out_dev, void* stream);
+/* MPPI.forward() of a native model in one call (mppi.py:223-460) = mppi_bind_state (x0_dev != NULL; NULL keeps the state
+ * already set) + mppi_sample(solve_idx) + mppi_rollout_cost + [lambda == MPPI_LAMBDA_DEVICE: mppi_essps_lambda_device(
+ * essps_target_ess, lam_min, lam_max)] + mppi_weights_reduce(lambda) + mppi_finalize(own summary, store_mean = 1).  Same
+ * kernels and results as the individual calls; one host -> library transition per solve instead of five. */
+int mppi_solve(mppi_handle_t h, const float* x0_dev, uint32_t solve_idx, float lambda, double essps_target_ess,
+               double lam_min, double lam_max, float* action_out_dev, float* state_seq_out_dev, float* stats_out_dev,
+               void* stream);
 /* Step 7 inside mppi_finalize (mppi.py:423-443,598-620): Savitzky-Golay smoothing of [history(T-1); a(T)] per control
  * dimension (symmetric-flip padding, valid cross-correlation, keep the last T), applied whenever mppi_finalize is
  * called with store_mean != 0; the smoothed sequence is what is returned, stored as the warm start and rolled out,

@@ -27,7 +27,7 @@ SYMBOLS = [
     "mppi_set_model_params", "mppi_upload_map", "mppi_build_obstacle_map", "mppi_build_lane_map",
     "mppi_download_map", "mppi_set_reference", "mppi_set_mean", "mppi_get_mean",
     "mppi_set_state", "mppi_bind_state", "mppi_sample", "mppi_inject_noise", "mppi_export_noise", "mppi_rollout_cost",
-    "mppi_get_costs", "mppi_set_costs", "mppi_weights_reduce", "mppi_finalize", "mppi_set_sg_filter", "mppi_get_sg_history", "mppi_softmax_stats", "mppi_softmax_stats_multi", "mppi_essps_lambda", "mppi_essps_lambda_device", "mppi_get_lambda", "mppi_lbps_lambda", "mppi_mpo_reset", "mppi_mpo_step", "mppi_mpo_state", "mppi_weights", "mppi_sample_posterior",
+    "mppi_get_costs", "mppi_set_costs", "mppi_weights_reduce", "mppi_finalize", "mppi_solve", "mppi_set_sg_filter", "mppi_get_sg_history", "mppi_softmax_stats", "mppi_softmax_stats_multi", "mppi_essps_lambda", "mppi_essps_lambda_device", "mppi_get_lambda", "mppi_lbps_lambda", "mppi_mpo_reset", "mppi_mpo_step", "mppi_mpo_state", "mppi_weights", "mppi_sample_posterior",
     "mppi_p2p_alloc", "mppi_p2p_connect", "mppi_p2p_exchange", "mppi_p2p_error", "mppi_rollout_actions", "mppi_rollout_samples", "mppi_top_samples", "mppi_top_candidates", "mppi_rollout_candidates", "mppi_set_option", "mppi_get_timing",
 ]
 
@@ -100,6 +100,7 @@ def load():
     lib.mppi_set_costs.argtypes = [vp, vp, i32, vp]
     lib.mppi_weights_reduce.argtypes = [vp, f32, vp, vp]
     lib.mppi_finalize.argtypes = [vp, vp, i32, f32, i32, vp, vp, vp, vp]
+    lib.mppi_solve.argtypes = [vp, vp, u32, f32, C.c_double, C.c_double, C.c_double, vp, vp, vp, vp]
     lib.mppi_softmax_stats.argtypes = [vp, f32, vp, vp]
     lib.mppi_softmax_stats_multi.argtypes = [vp, vp, i32, vp, vp]
     lib.mppi_weights.argtypes = [vp, f32, f32, f32, vp, vp]

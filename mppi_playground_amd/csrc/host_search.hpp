@@ -134,11 +134,17 @@ bool lbps_lambda(S&& stats, double delta, double lam_min, double lam_max, double
 // ~1e-7 relative of scipy's brentq on the same statistics).  The search is written as three steps so that the host
 // loop below (statistics read back per grid) and the device-resident chain in mppi_kernels.hpp (essps_select_kernel:
 // no read-back at all) run the very same arithmetic.
+// point j of the geometric grid over [lo, hi] (end points exact); the device evaluates one point per lane
+template <int P>
+MPPI_SEARCH_HD double essps_grid_point(double lo, double hi, int j) {
+    if (j == 0) return lo;
+    if (j == P - 1) return hi;
+    const double llo = log(lo), lhi = log(hi);
+    return exp(llo + (lhi - llo) * (double)j / (double)(P - 1));
+}
 template <int P>
 MPPI_SEARCH_HD void essps_make_grid(double lo, double hi, double* grid) {
-    const double llo = log(lo), lhi = log(hi);
-    for (int j = 0; j < P; ++j) grid[j] = exp(llo + (lhi - llo) * (double)j / (double)(P - 1));
-    grid[0] = lo; grid[P - 1] = hi;
+    for (int j = 0; j < P; ++j) grid[j] = essps_grid_point<P>(lo, hi, j);
 }
 // first bracketing step of a round: the grid interval [grid[i-1], grid[i]] that holds the root
 template <int P>

@@ -824,6 +824,24 @@ int mppi_finalize(mppi_handle_t h, const float* summaries_dev, int num_shards, f
     return MPPI_OK;
 }
 
+// MPPI.forward() for a native model in ONE call (mppi.py:223-460): bind the state, fix the noise identity, rollout +
+// costs, the temperature (fixed, or the ESSPS search resident on the device), weights + reduction, finalize with the
+// warm start stored.  Exactly the sequence of the individual entry points (same kernels, same results); it exists
+// because small problems are bound by the host's enqueue rate (~26 us per solve through five Python -> C calls).
+int mppi_solve(mppi_handle_t h, const float* x0_dev, uint32_t solve_idx, float lambda, double essps_target_ess,
+               double lam_min, double lam_max, float* action_out_dev, float* state_seq_out_dev, float* stats_out_dev,
+               void* stream) {
+    if (!h) return MPPI_E_INVALID;
+    if (x0_dev) { if (int rc = mppi_bind_state(h, x0_dev)) return rc; }
+    if (int rc = mppi_sample(h, solve_idx, stream)) return rc;
+    if (int rc = mppi_rollout_cost(h, stream)) return rc;
+    if (lambda == MPPI_LAMBDA_DEVICE) {
+        if (int rc = mppi_essps_lambda_device(h, essps_target_ess, lam_min, lam_max, stream)) return rc;
+    }
+    if (int rc = mppi_weights_reduce(h, lambda, nullptr, stream)) return rc;
+    return mppi_finalize(h, nullptr, 1, lambda, 1, action_out_dev, state_seq_out_dev, stats_out_dev, stream);
+}
+
 // Savitzky-Golay smoothing of the solution inside mppi_finalize (step 7, mppi.py:423-443): taps = first row of
 // pinv(vander) computed by the caller (mppi.py:568-596), history = `_actions_history_for_sg`.
 int mppi_set_sg_filter(mppi_handle_t h, const float* coeffs_host, int window, const float* history_host) {
@@ -886,7 +904,7 @@ int mppi_softmax_stats_multi(mppi_handle_t h, const float* lambdas_host, int cou
     const unsigned* mk = h->min_key + h->min_slot;
     const int blocks = stats_blocks(h);
     hipLaunchKernelGGL(stats_multi_kernel, dim3(blocks), dim3(STATS_THREADS), 0, s, h->costs, h->d.N, mk,
-                       (const float*)h->lams_dev, h->stats_part);
+                       (const float*)h->lams_dev, h->stats_part, (const int32_t*)nullptr);
     HIP_TRY(h, hipGetLastError());
     double* dev_out = nullptr;
     HIP_TRY(h, hipHostGetDevicePointer((void**)&dev_out, h->stats_host, 0));
@@ -925,11 +943,11 @@ int mppi_essps_lambda_device(mppi_handle_t h, double target_ess, double lam_min,
     float* lams0 = h->lams_dev + STATS_L;
     float* lams1 = h->lams_dev + 2 * STATS_L;
     hipLaunchKernelGGL(stats_multi_kernel, dim3(blocks), dim3(STATS_THREADS), 0, s, h->costs, h->d.N, mk, (const float*)lams0,
-                       h->stats_part);
+                       h->stats_part, (const int32_t*)nullptr);
     hipLaunchKernelGGL(essps_select_kernel<0>, dim3(1), dim3(1024), 0, s, (const float*)h->stats_part, blocks, target_ess,
                        lam_min, lam_max, h->essps_dev, lams1, h->lambda_dev, host_lam);
     hipLaunchKernelGGL(stats_multi_kernel, dim3(blocks), dim3(STATS_THREADS), 0, s, h->costs, h->d.N, mk, (const float*)lams1,
-                       h->stats_part);
+                       h->stats_part, (const int32_t*)&h->essps_dev->done);
     hipLaunchKernelGGL(essps_select_kernel<1>, dim3(1), dim3(1024), 0, s, (const float*)h->stats_part, blocks, target_ess,
                        lam_min, lam_max, h->essps_dev, lams1, h->lambda_dev, host_lam);
     HIP_TRY(h, hipGetLastError());

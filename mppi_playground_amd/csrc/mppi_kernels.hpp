@@ -989,8 +989,10 @@ constexpr int STATS_THREADS = 1024;
 __global__ __launch_bounds__(STATS_THREADS) void stats_multi_kernel(const float* __restrict__ costs, int64_t N,
                                                                     const unsigned* __restrict__ min_key,
                                                                     const float* __restrict__ lams,
-                                                                    float* __restrict__ part) {
+                                                                    float* __restrict__ part,
+                                                                    const int32_t* __restrict__ skip /* nullable */) {
     constexpr int NWV = STATS_THREADS / WAVE;
+    if (skip && *skip) return;  // second pass of a search that an end-point rule already decided
     __shared__ float s_c[STATS_THREADS];
     __shared__ float s_p[NWV][STATS_L][3];
     const float cmin = key_to_float(*min_key);
@@ -1034,14 +1036,17 @@ __device__ __forceinline__ void stats_combine_columns(const float* __restrict__ 
     constexpr int COLS = STATS_L * 3, GROUPS = STATS_COMB_THREADS / COLS;
     const int j = threadIdx.x % COLS, g = threadIdx.x / COLS;
     if (g < GROUPS) {
-        double v0 = 0.0, v1 = 0.0;
-        int b = g;
-        for (; b + GROUPS < nblocks; b += 2 * GROUPS) {  // two independent loads in flight
-            v0 += part[(int64_t)b * COLS + j];
-            v1 += part[(int64_t)(b + GROUPS) * COLS + j];
+        double v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = 0.0;
+        for (int b = g; b < nblocks; b += 8 * GROUPS) {  // eight independent loads in flight per thread
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int bb = b + q * GROUPS;
+                if (bb < nblocks) v[q] += (double)part[(int64_t)bb * COLS + j];
+            }
         }
-        if (b < nblocks) v0 += part[(int64_t)b * COLS + j];
-        s_acc[g * COLS + j] = v0 + v1;
+        s_acc[g * COLS + j] = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
     }
     __syncthreads();
     if (threadIdx.x < COLS) {
@@ -1077,27 +1082,33 @@ __global__ __launch_bounds__(1024) void essps_select_kernel(const float* __restr
                                                             double* __restrict__ lambda_host) {
     __shared__ double s_acc[(STATS_COMB_THREADS / (STATS_L * 3)) * STATS_L * 3];
     __shared__ double s_sum[STATS_L * 3];
+    __shared__ double s_ess[STATS_L];
+    __shared__ double s_bracket[2];
+    __shared__ int s_have;
     stats_combine_columns(part, nblocks, s_acc, s_sum);
-    if (threadIdx.x != 0) return;
+    if (threadIdx.x >= WAVE) return;  // the scalar step: one wave, lane j owns temperature j where that helps
     if (ROUND == 1 && st->done) return;
-    double ess[STATS_L];
-    for (int j = 0; j < STATS_L; ++j) ess[j] = s_sum[3 * j] * s_sum[3 * j] / s_sum[3 * j + 1];
-    double lam = 0.0;
-    bool have = false;
+    const int j = threadIdx.x;
+    if (j < STATS_L) s_ess[j] = s_sum[3 * j] * s_sum[3 * j] / s_sum[3 * j + 1];  // 32 double divisions, one per lane
+    __builtin_amdgcn_wave_barrier();
     if (ROUND == 0) {
-        double lo = lam_min, hi = lam_max;
-        have = mppi::host::essps_round0<STATS_L>(st->grid0, ess, target_ess, lam_min, lam_max, lo, hi, lam);
-        st->done = have ? 1 : 0;
-        st->lo = lo; st->hi = hi;
-        if (!have) {
-            mppi::host::essps_make_grid<STATS_L>(lo, hi, st->grid1);
-            for (int j = 0; j < STATS_L; ++j) lams[j] = (float)st->grid1[j];
+        if (j == 0) {
+            double lo = lam_min, hi = lam_max, lam = 0.0;
+            const bool have = mppi::host::essps_round0<STATS_L>(st->grid0, s_ess, target_ess, lam_min, lam_max, lo, hi, lam);
+            st->done = have ? 1 : 0;
+            st->lo = lo; st->hi = hi;
+            s_bracket[0] = lo; s_bracket[1] = hi;
+            s_have = have ? 1 : 0;
+            if (have) { st->lam = lam; *lambda_out = (float)lam; *lambda_host = lam; }
         }
-    } else {
-        lam = mppi::host::essps_round1<STATS_L>(st->grid1, ess, target_ess);
-        have = true;
-    }
-    if (have) {
+        __builtin_amdgcn_wave_barrier();
+        if (!s_have && j < STATS_L) {  // the refined grid, one point (two logs + one exp in double) per lane
+            const double gj = mppi::host::essps_grid_point<STATS_L>(s_bracket[0], s_bracket[1], j);
+            st->grid1[j] = gj;
+            lams[j] = (float)gj;
+        }
+    } else if (j == 0) {
+        const double lam = mppi::host::essps_round1<STATS_L>(st->grid1, s_ess, target_ess);
         st->lam = lam;
         *lambda_out = (float)lam;
         *lambda_host = lam;

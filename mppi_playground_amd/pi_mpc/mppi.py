@@ -245,6 +245,11 @@ class MPPI(nn.Module):
         if self._world > 1:
             self._setup_exchange()
         self._previous_action_seq = torch.zeros(T, dcn, device=self._device, dtype=dtype)
+        # forward() in one library call (mppi_solve) when nothing needs the host between the steps
+        self._one_call = (self._model is not None and noise_source == "philox" and self._world == 1
+                          and not (use_sg_filter and not self._sg_on_device)
+                          and (self._auto_lambda is None
+                               or (self._auto_lambda == "ESSPS" and auto_lambda_stats == "device" and essps_search == "device")))
         self._last_lambda = None
         self._injected = None
         self._mean_of_last_solve = self._previous_action_seq
@@ -462,6 +467,8 @@ class MPPI(nn.Module):
         """Solve one MPPI step (src/pi_mpc/mppi.py:223-460)."""
         assert state.shape == (self._dim_state,)
         h, st = self._h, self._stream()
+        if self._one_call and self._injected is None:
+            return self._forward_one_call(state, h, st)
         if torch.is_tensor(state) and state.is_cuda:
             # zero-copy: this solve's kernels read the caller's tensor (kept alive until the next solve); the rollout
             # kernel snapshots it, so later re-rolls (get_top_samples, _state_seq_batch) do not depend on it
@@ -572,6 +579,34 @@ class MPPI(nn.Module):
             self._actions_history_for_sg = np.concatenate([self._actions_history_for_sg[1:], first[None, :]])
         if not native:  # Step 8 with the user's dynamics (src/pi_mpc/mppi.py:448-449,508-524)
             self._state_out = self._states_prediction(self._x0_tensor, self._action_out.repeat(1, 1, 1))
+        self._previous_action_seq = self._action_out
+        return self._action_out, self._state_out
+
+    def _forward_one_call(self, state, h, st):
+        """forward() through mppi_solve: the same kernel sequence as the step-by-step path below in one library call
+        (native model, device noise, fixed lambda or the device-resident ESSPS search, one GPU): small problems are
+        bound by how fast the host can enqueue a solve."""
+        if torch.is_tensor(state) and state.is_cuda:
+            self._x0_keep = state.detach().to(self._device, self._dtype).contiguous()
+            x0p = _ptr(self._x0_keep)
+        else:
+            x0h = np.ascontiguousarray(state.detach().cpu().numpy() if torch.is_tensor(state) else state,
+                                       dtype=np.float32)
+            h.call("mppi_set_state", x0h.ctypes.data_as(C.c_void_p), 0, st)
+            x0p = None
+        self._refresh_model_inputs()
+        self._mean_of_last_solve = self._previous_action_seq
+        if self._auto_lambda is None:
+            lam = float(self._lambda)
+            self._last_lambda = lam
+        else:  # ESSPS, searched on the device
+            lam = _capi.LAMBDA_DEVICE
+            self._lambda_pending = True
+        self._action_out = torch.empty(self._horizon, self._dim_control, device=self._device, dtype=self._dtype)
+        self._state_out = torch.empty(1, self._horizon + 1, self._dim_state, device=self._device, dtype=self._dtype)
+        h.call("mppi_solve", x0p, self._solve_idx, lam, float(self._essps_target_ess), float(self._lambda_min),
+               float(self._lambda_max), _ptr(self._action_out), _ptr(self._state_out), _ptr(self._stats), st)
+        self._solve_idx += 1
         self._previous_action_seq = self._action_out
         return self._action_out, self._state_out
 

@@ -40,10 +40,10 @@ cases = {
 for name, make in cases.items():
     row = []
     for search in ("device", "grid"):
-        for rb in (512, 1024, 2048):
+        for fold in (0, 1):  # who folds the partial rows: by the live-row hint (summarize when dense) / always finalize
             s, x0 = make(essps_search=search)
-            s.set_option("reduce_blocks", rb)
-            row.append(f"{search}/rb{rb}: {timeit(s, x0):7.1f} us")
+            s.set_option("fold_path", fold)
+            row.append(f"{search}/fold{fold}: {timeit(s, x0):7.1f} us")
             lam = s._last_lambda
             del s
     print(f"{name:28s} lambda {lam:.6f} | " + " | ".join(row), flush=True)
