@@ -92,7 +92,7 @@ class MPPI(nn.Module):
 
         `device`: the hot path exists on MI355X only.  The reference falls back to the CPU silently when CUDA is
         unavailable or another device is asked for (src/pi_mpc/mppi.py:102-105); this class raises instead — a
-        CPU device is refused, a "cuda" device (with or without an index) selects that GPU.
+        CPU device is refused; "cuda" / "cuda:i" must name the process's current device (one process per GPU).
         """
         super().__init__()
         assert u_min.shape == (dim_control,)
@@ -108,7 +108,11 @@ class MPPI(nn.Module):
             raise _capi.MppiError("no GPU visible: this MPPI runs its hot path on MI355X only "
                                   "(no CPU fallback)")
         _capi.load()  # fail loudly if the extension is missing
-        self._device = torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
+        if dev.index is not None and dev.index != torch.cuda.current_device():
+            # one process drives one GPU: the library launches on the calling thread's current device
+            raise ValueError(f"device={dev} is not the current device (cuda:{torch.cuda.current_device()}): select it "
+                             "with torch.cuda.set_device() before constructing the solver")
+        self._device = torch.device("cuda", torch.cuda.current_device())
         self._dtype = dtype
 
         self._horizon = horizon
