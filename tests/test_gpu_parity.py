@@ -1352,3 +1352,34 @@ def test_top_samples_with_tied_costs():
         want = np.sort(ref_w)[::-1][:k]
         assert rel_err(w.cpu().numpy(), want) < TOL and torch.isfinite(out).all()
         assert torch.equal(out[:, 0, :], x0.cuda().expand(k, 2))
+
+
+def test_reference_side_binding_is_self_sufficient():
+    """example/reference_binding.py — the ctypes stub INTEGRATION.md shows a maintainer of the reference, using only
+    libmppi_hip.so through include/mppi_hip.h — drives the same solves as this build's MPPI class: bit-identical
+    action / state sequences over a closed loop, step-by-step calls and the one-call entry point, fixed lambda and ESSPS."""
+    _need_gpu()
+    import importlib.util
+    import os
+
+    from helpers import ROOT
+    from mppi_playground_amd import _capi
+
+    spec = importlib.util.spec_from_file_location("reference_binding", os.path.join(ROOT, "example", "reference_binding.py"))
+    rb = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rb)
+    for model, T, N, x0 in (("pendulum", 15, 1000, [3.0, 0.1]), ("cartpole", 20, 4096, [0.01, 0.0, 0.02, 0.0])):
+        mc = MODEL_CFG[model]
+        for essps in (False, True):
+            ours, _ = make_solver(model, T, N, lambda_="ESSPS" if essps else 0.7)
+            hips = [rb.HipForward(_capi.LIB_PATH, model, T, N, mc["u_min"], mc["u_max"], mc["sigmas"], seed=42) for _ in range(2)]
+            states = [torch.tensor(x0, device="cuda") for _ in range(3)]
+            for tick in range(4):
+                a0, s0 = ours.forward(states[0])
+                outs = [hips[i].forward(states[1 + i], lam=0.7, essps_target=N / 10 if essps else None, one_call=bool(i))
+                        for i in range(2)]
+                for a, s in outs:
+                    assert torch.equal(a, a0) and torch.equal(s, s0), (model, essps, tick)
+                states = [s0[0, 1].clone()] + [s[0, 1].clone() for _, s in outs]
+            for hp in hips:
+                hp.close()
