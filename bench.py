@@ -63,6 +63,10 @@ def main():
     ap.add_argument("--exchange", choices=("nccl", "p2p", "auto"), default="nccl",
                     help="per-solve exchange of the shard summaries at N > 1: one RCCL all_gather (default), the "
                          "library's peer-to-peer buffers, or auto (buffers when their self-test passes on every rank)")
+    ap.add_argument("--both-exchanges", action="store_true",
+                    help="N > 1: after the timed run, also time a short run with the OTHER transport (nccl <-> p2p) and "
+                         "report it as `exchange_alt` in the same line (off by default: the contract's line never depends "
+                         "on the less-tested path)")
     ap.add_argument("--math", type=int, default=1, help="1 = fast-path math (default), 0 = library math")
     ap.add_argument("--noise-regen", type=int, default=1,
                     help="1 = regenerate the Philox noise in registers (default), 0 = materialise the noise tiles")
@@ -174,6 +178,9 @@ def main():
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    alt = None
+    if world > 1 and args.both_exchanges:
+        alt = time_other_exchange(args, torch, dist, env, T, N_total, ref, x0, "p2p" if not solver._p2p else "nccl")
     assert torch.isfinite(a).all() and torch.isfinite(s).all()
 
     ms_per_step = dt / args.steps * 1e3
@@ -238,6 +245,8 @@ def main():
         }
         if t_exchange_ms is not None:
             out["stages_ms"]["exchange_and_handoffs"] = t_exchange_ms
+        if alt is not None:
+            out["exchange_alt"] = alt
         if valu is not None:
             out["valu_roofline"] = valu
         if world == 1 and not args.no_extras:
@@ -252,6 +261,45 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def time_other_exchange(args, torch, dist, env, T, N_total, ref, x0, mode):
+    """A second sharded solver on the other transport, min(steps, 50) solves after 20 warm-up: {exchange, ms_per_step}
+    or {exchange, error}.  Every rank takes the same branch (the transport's self-test is collective)."""
+    from envs.racing_controller import racing_controller
+    from mppi_playground_amd import _capi
+
+    os.environ["MPPI_EXCHANGE"] = mode
+    try:
+        ctrl = racing_controller(env, horizon=T, num_samples=N_total, lambda_=1.0, shard_samples=True)
+    except _capi.MppiError as e:
+        return {"exchange": mode, "error": str(e)}
+    finally:
+        os.environ["MPPI_EXCHANGE"] = args.exchange
+    ctrl.set_cost_map(env._obstacle_map, env._lane_map)
+    ctrl.set_reference(ref)
+    s = ctrl.solver
+    s.set_option("math", args.math)
+    s.set_option("noise_regen", args.noise_regen)
+    n = min(args.steps, 50)
+    try:
+        for _ in range(20):
+            s.forward(x0)
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            a, _ = s.forward(x0)
+        dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        ok = bool(torch.isfinite(a).all())
+    except _capi.MppiError as e:
+        return {"exchange": mode, "error": str(e)}
+    t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return {"exchange": "peer-to-peer buffers" if s._p2p else "all_gather", "steps": n,
+            "ms_per_step": float(t.item()) / n * 1e3, "finite": ok}
 
 
 def closed_loop(torch, env, ctrl, T, N):

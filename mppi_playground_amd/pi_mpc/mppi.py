@@ -552,7 +552,9 @@ class MPPI(nn.Module):
         else:
             h.call("mppi_weights_reduce", lam, _ptr(self._summary) if sharded else None, st)
             if sharded:  # the only exchange of the solve: 4+T*dc floats per rank over RCCL/xGMI
-                summaries, nsh = all_gather_summaries(self._summary, self._pg), self._world
+                if self._gathered is None:
+                    self._gathered = torch.empty(self._world, self._summary.numel(), device=self._device, dtype=self._dtype)
+                summaries, nsh = all_gather_summaries(self._summary, self._pg, out=self._gathered), self._world
 
         # Steps 6-8: normalise, warm start, batch-1 rollout (src/pi_mpc/mppi.py:381-385,448-452)
         use_sg = self._use_sg_filter and not self._sg_on_device  # host round trip only for sg_filter="host"

@@ -45,11 +45,13 @@ def combine_summaries(summaries: np.ndarray, lam: float):
     return (A / se).astype(np.float32), stats
 
 
-def all_gather_summaries(summary: torch.Tensor, group=None) -> torch.Tensor:
-    """One collective per solve: [len] on every rank -> [W, len] on every rank (RCCL on GPU, gloo on CPU)."""
+def all_gather_summaries(summary: torch.Tensor, group=None, out: torch.Tensor = None) -> torch.Tensor:
+    """One collective per solve: [len] on every rank -> [W, len] on every rank (RCCL on GPU, gloo on CPU).
+    `out`: a reusable [W, len] buffer (the solver keeps one, so the per-solve path allocates nothing)."""
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
-    flat = torch.empty(world * summary.numel(), device=summary.device, dtype=summary.dtype)
-    dist.all_gather_into_tensor(flat, summary.contiguous().view(-1), group=group)
-    return flat.view(world, summary.numel())
+    if out is None:
+        out = torch.empty(world, summary.numel(), device=summary.device, dtype=summary.dtype)
+    dist.all_gather_into_tensor(out.view(-1), summary.contiguous().view(-1), group=group)
+    return out
