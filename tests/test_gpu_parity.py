@@ -1383,3 +1383,65 @@ def test_reference_side_binding_is_self_sufficient():
                 states = [s0[0, 1].clone()] + [s[0, 1].clone() for _, s in outs]
             for hp in hips:
                 hp.close()
+
+
+def test_c4_eight_shards_at_full_size_on_one_device():
+    """BASELINE configs[3] (racing, N = 8 388 608 over 8 GPUs) minus the transport: eight shard handles of 2^20 samples
+    each (sample_offset = r * 2^20, global exploration threshold) run one after the other on THIS device, their
+    summaries combined by mppi_finalize(num_shards = 8), against one unsharded handle of 2^23 samples.  The noise is
+    a function of the global index, so each shard's costs must equal its slice of the full run bit for bit; the
+    combined action / state sequence differs from the unsharded one by the rounding of the combine only."""
+    _need_gpu()
+    from mppi_playground_amd import _capi
+
+    W, NL, T = 8, 1 << 20, 50
+    N = W * NL
+    full, ctrl = make_solver("racing", T, N, lambda_=5000.0, exploration=0.1)  # lambda: thousands of samples carry weight
+    env = _envs["racing"]
+    x0 = env.reset().clone()
+    ref, _ = ctrl.calc_ref_trajectory(x0, env.racing_center_path, 0, T, DL=0.1, lookahead_distance=3,
+                                      reference_path_interval=0.85)
+    ctrl.set_reference(ref)
+    mean = (np.random.default_rng(4).standard_normal((T, 2)) * np.array([0.3, 0.05])).astype(np.float32)
+    full.set_warm_start(mean)
+    a_full, s_full = full.forward(x0)
+    c_full = full._costs
+    st_full = full.last_stats()
+    assert st_full["ess"] > 100  # a dense softmax: every shard contributes
+    sums, shard0 = [], None
+    for r in range(W):
+        sol, c2 = make_solver("racing", T, NL, lambda_=5000.0)
+        cfg = _capi.MppiConfig()
+        cfg.model, cfg.horizon, cfg.dim_state, cfg.dim_control = 4, T, 4, 2
+        cfg.num_samples, cfg.sample_offset, cfg.inherit_count = NL, r * NL, int(N * 0.9)
+        for k in range(2):
+            cfg.u_min[k], cfg.u_max[k], cfg.sigmas[k] = (MODEL_CFG["racing"][q][k] for q in ("u_min", "u_max", "sigmas"))
+        cfg.seed, cfg.device = 42, 0
+        sol._h.close()
+        sol._h = _capi.Handle(cfg)
+        sol._uploaded, sol._params_set, sol._ref_uploaded = {}, None, None
+        c2.set_reference(ref)
+        sol._h.call("mppi_set_state", C.c_void_p(x0.data_ptr()), 1, sol._stream())
+        sol._refresh_model_inputs()
+        md = torch.from_numpy(mean).cuda()
+        sol._h.call("mppi_set_mean", C.c_void_p(md.data_ptr()), 1, sol._stream())
+        sol._h.call("mppi_sample", 1, sol._stream())
+        sol._h.call("mppi_rollout_cost", sol._stream())
+        assert torch.equal(sol._costs, c_full[r * NL:(r + 1) * NL]), f"shard {r}: costs differ from the unsharded slice"
+        sums.append(_summary(sol, 5000.0))
+        torch.cuda.synchronize()
+        if r == 0:
+            shard0 = sol  # (kept: its handle runs the combine)
+        else:
+            sol._h.close()
+    allsum = torch.stack(sums).contiguous()
+    a = torch.zeros(T, 2, device="cuda")
+    s = torch.zeros(1, T + 1, 4, device="cuda")
+    stats = torch.zeros(4, device="cuda")
+    shard0._h.call("mppi_finalize", C.c_void_p(allsum.data_ptr()), W, 5000.0, 0, C.c_void_p(a.data_ptr()),
+                   C.c_void_p(s.data_ptr()), C.c_void_p(stats.data_ptr()), shard0._stream())
+    assert rel_err(a.cpu().numpy(), a_full.cpu().numpy()) < 4e-6
+    assert rel_err(s.cpu().numpy(), s_full.cpu().numpy()) < 4e-6
+    st = stats.cpu().numpy()
+    assert st[0] == st_full["cmin"] and abs(st[1] - st_full["sum_e"]) <= 2e-5 * st_full["sum_e"]
+    assert abs(st[1] * st[1] / st[2] - st_full["ess"]) <= 1e-4 * st_full["ess"]
