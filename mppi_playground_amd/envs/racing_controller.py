@@ -80,24 +80,37 @@ class racing_controller:
 
     def calc_ref_trajectory(self, state, path, cind: int, horizon: int, DL=0.1, lookahead_distance=1.0,
                             reference_path_interval=0.5):
-        """Reference window [horizon+1, 4] = (x, y, yaw, v_target) ahead of the nearest path point.
-        Nearest-point search is one vectorised fp32 hypot + argmin (first minimum, like the reference's
-        Python min over indices)."""
-        p = path.detach().cpu().numpy().astype(np.float32) if torch.is_tensor(path) else np.asarray(path, np.float32)
+        """Reference window [horizon+1, 4] = (x, y, yaw, v_target) ahead of the nearest path point
+        (example/racing.py:161-218).  Nearest-point search is one vectorised fp32 hypot + argmin (first minimum, like
+        the reference's Python min over indices); the window rows are one gather.  What does not change between ticks
+        is kept: the host copy of the centre line (the reference re-reads it element by element from the device every
+        tick), the row offsets, V_MAX."""
+        cache = self.__dict__.setdefault("_ref_cache", {})
+        if torch.is_tensor(path):
+            hit = cache.get("path")
+            if hit is None or hit[0] is not path or hit[1] != path._version:
+                hit = cache["path"] = (path, path._version, path.detach().cpu().numpy().astype(np.float32))
+            p = hit[2]
+        else:
+            p = np.asarray(path, np.float32)
         s = state.detach().cpu().numpy().astype(np.float32) if torch.is_tensor(state) else np.asarray(state, np.float32)
         ncourse = len(p)
         ind = int(np.argmin(np.hypot(p[:, 0] - s[0], p[:, 1] - s[1])))
         ind = max(cind, ind)
+        # index offsets of the window rows: travel = lookahead + (i+1) intervals accumulated one by one in float64,
+        # dind = int(round(travel / DL)) (round half to even) — a function of the arguments only
+        key = (horizon, float(DL), float(lookahead_distance), float(reference_path_interval))
+        dind = cache.get(key)
+        if dind is None:
+            travel = np.cumsum(np.concatenate([[float(lookahead_distance)],
+                                               np.full(horizon + 1, float(reference_path_interval))]))[1:]
+            dind = cache[key] = np.rint(travel / DL).astype(np.int64)
+        if "v_max" not in cache:
+            cache["v_max"] = float(self.env.V_MAX)  # (a device scalar: read back once)
+        idx = ind + dind
+        inside = idx < ncourse
         xref = np.zeros((horizon + 1, s.shape[0]), np.float32)
-        travel = lookahead_distance
-        v_max = float(self.env.V_MAX)
-        for i in range(horizon + 1):
-            travel += reference_path_interval
-            dind = int(round(travel / DL))
-            if ind + dind < ncourse:
-                xref[i, :3] = p[ind + dind]
-                xref[i, 3] = v_max
-            else:
-                xref[i, :3] = p[-1]
-                xref[:, 3] = 0.0  # past the end of the course: stop
+        xref[:, :3] = p[np.where(inside, idx, ncourse - 1)]
+        if inside.all():  # past the end of the course the reference zeroes the whole target-velocity column: stop
+            xref[:, 3] = cache["v_max"]
         return torch.from_numpy(xref), ind
