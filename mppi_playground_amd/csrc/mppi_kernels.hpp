@@ -1028,30 +1028,36 @@ __global__ __launch_bounds__(STATS_THREADS) void stats_multi_kernel(const float*
         part[(int64_t)blockIdx.x * STATS_L * 3 + threadIdx.x] = v;
     }
 }
-// Block-wide (960 of 1024 threads = 96 columns x 10 row groups): column sums of part[nblocks][96] in double, fixed
-// order -> s_out[96] (LDS or global).  Ends with a barrier.
+// Block-wide (960 of 1024 threads = 24 column quads x 40 row groups): column sums of part[nblocks][96] in double, fixed
+// order -> out[96] (LDS or global).  The partial rows were written by other XCDs a moment ago, so every load is a
+// trip to memory: one float4 per (row, quad) and up to eight rows per thread in flight make it ONE round of latency
+// for up to 320 rows (a thread per (row group, column) with two loads in flight needed 13).  Ends with a barrier.
 constexpr int STATS_COMB_THREADS = 960;
-__device__ __forceinline__ void stats_combine_columns(const float* __restrict__ part, int nblocks, double* s_acc /*[10][96]*/,
-                                                      double* out /*[96]*/) {
-    constexpr int COLS = STATS_L * 3, GROUPS = STATS_COMB_THREADS / COLS;
-    const int j = threadIdx.x % COLS, g = threadIdx.x / COLS;
+constexpr int STATS_COMB_GROUPS = 40;
+__device__ __forceinline__ void stats_combine_columns(const float* __restrict__ part, int nblocks,
+                                                      double* s_acc /*[STATS_COMB_GROUPS][96]*/, double* out /*[96]*/) {
+    constexpr int COLS = STATS_L * 3, QUADS = COLS / 4, GROUPS = STATS_COMB_GROUPS;
+    static_assert(QUADS * GROUPS == STATS_COMB_THREADS, "thread layout");
+    const int quad = threadIdx.x % QUADS, g = threadIdx.x / QUADS;
     if (g < GROUPS) {
-        double v[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = 0.0;
-        for (int b = g; b < nblocks; b += 8 * GROUPS) {  // eight independent loads in flight per thread
+        double v[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int b0 = g; b0 < nblocks; b0 += 8 * GROUPS) {
+            float4 r[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                const int bb = b + q * GROUPS;
-                if (bb < nblocks) v[q] += (double)part[(int64_t)bb * COLS + j];
+                const int bb = b0 + q * GROUPS;
+                r[q] = bb < nblocks ? *reinterpret_cast<const float4*>(part + (int64_t)bb * COLS + 4 * quad)
+                                    : make_float4(0.f, 0.f, 0.f, 0.f);
             }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { v[0] += r[q].x; v[1] += r[q].y; v[2] += r[q].z; v[3] += r[q].w; }
         }
-        s_acc[g * COLS + j] = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+#pragma unroll
+        for (int c = 0; c < 4; ++c) s_acc[g * COLS + 4 * quad + c] = v[c];
     }
     __syncthreads();
     if (threadIdx.x < COLS) {
         double v = 0.0;
-#pragma unroll
         for (int q = 0; q < GROUPS; ++q) v += s_acc[q * COLS + threadIdx.x];
         out[threadIdx.x] = v;
     }
@@ -1059,7 +1065,7 @@ __device__ __forceinline__ void stats_combine_columns(const float* __restrict__ 
 }
 __global__ __launch_bounds__(1024) void stats_multi_combine_kernel(const float* __restrict__ part, int nblocks,
                                                                    double* __restrict__ out /*[STATS_L][3] mapped*/) {
-    __shared__ double s_acc[(STATS_COMB_THREADS / (STATS_L * 3)) * STATS_L * 3];
+    __shared__ double s_acc[STATS_COMB_GROUPS * STATS_L * 3];
     stats_combine_columns(part, nblocks, s_acc, out);
 }
 
@@ -1080,7 +1086,7 @@ __global__ __launch_bounds__(1024) void essps_select_kernel(const float* __restr
                                                             double lam_min, double lam_max, EsspsDev* __restrict__ st,
                                                             float* __restrict__ lams, float* __restrict__ lambda_out,
                                                             double* __restrict__ lambda_host) {
-    __shared__ double s_acc[(STATS_COMB_THREADS / (STATS_L * 3)) * STATS_L * 3];
+    __shared__ double s_acc[STATS_COMB_GROUPS * STATS_L * 3];
     __shared__ double s_sum[STATS_L * 3];
     __shared__ double s_ess[STATS_L];
     __shared__ double s_bracket[2];
