@@ -64,6 +64,7 @@ class MPPI(nn.Module):
         auto_lambda_stats: str = "device",
         essps_search: str = "device",
         sg_filter: str = "device",
+        graph_callables: bool = False,
     ) -> None:
         """Arguments up to `seed` are the reference's (src/pi_mpc/mppi.py:24-47).
 
@@ -83,6 +84,13 @@ class MPPI(nn.Module):
                 statistics on the host ("device" behaves like "grid" there).
             sg_filter: "device" (default) runs the Savitzky-Golay step inside the finalize kernel
                 (bit-identical to the host statement), "host" keeps the reference's numpy-style round trip.
+            graph_callables: opaque (untagged) callables only.  The reference's two T-step Python loops over the user's
+                `dynamics` / `cost_func` are ~2*T*(10..40) tiny kernels bound by launch latency; with True they are
+                captured ONCE into a hipGraph (torch.cuda.CUDAGraph on static [N,T,*] buffers, after one eager solve as
+                warm-up) and replayed every solve.  Requires capturable callables: no host synchronisation, no
+                data-dependent shapes (boolean-mask assignment is not capturable), and an `info` dict used as the
+                reference documents it (tensor views + the integer `t`).  If the capture fails the solver says so once
+                and stays on the eager loops.
             shard_samples: treat `num_samples` as the GLOBAL sample count and let this rank own the
                 contiguous block rank*N/W .. (rank+1)*N/W of it (torch.distributed must be
                 initialised); the 4+T*dc-float shard summaries are exchanged once per solve with one RCCL
@@ -132,6 +140,10 @@ class MPPI(nn.Module):
         if auto_lambda_stats not in ("device", "host"):
             raise ValueError("auto_lambda_stats must be 'device' or 'host'")
         self._auto_lambda_stats = auto_lambda_stats
+        self._graph_callables = bool(graph_callables)
+        self._graph = None           # captured loops (generic path)
+        self._graph_b1 = None        # captured batch-1 rollout of the solution (generic path)
+        self._graph_state = "off" if not graph_callables else "warmup"  # warmup -> capture -> replay | failed
         if essps_search not in ("device", "grid", "brentq"):
             raise ValueError("essps_search must be 'device', 'grid' or 'brentq'")
         self._essps_search = essps_search
@@ -584,7 +596,10 @@ class MPPI(nn.Module):
             first = a[0]
             self._actions_history_for_sg = np.concatenate([self._actions_history_for_sg[1:], first[None, :]])
         if not native:  # Step 8 with the user's dynamics (src/pi_mpc/mppi.py:448-449,508-524)
-            self._state_out = self._states_prediction(self._x0_tensor, self._action_out.repeat(1, 1, 1))
+            if self._graph_state == "replay":
+                self._state_out = self._states_prediction_graphed()
+            else:
+                self._state_out = self._states_prediction(self._x0_tensor, self._action_out.repeat(1, 1, 1))
         self._previous_action_seq = self._action_out
         return self._action_out, self._state_out
 
@@ -620,21 +635,36 @@ class MPPI(nn.Module):
     def _generic_rollout_costs(self, state, info: Dict) -> None:
         """Steps 2-3 of forward() with the user's torch callables on GPU tensors, same call sequence and
         `info` protocol as the reference (src/pi_mpc/mppi.py:280-336); the summed costs go back to the
-        library with mppi_set_costs."""
+        library with mppi_set_costs.  With graph_callables the two loops are one hipGraph replay."""
         N, T = self._local_samples, self._horizon
         x0 = torch.as_tensor(np.asarray(state) if not torch.is_tensor(state) else state)
         x0 = x0.to(self._device, self._dtype)
-        self._x0_tensor = x0
+        if self._x0_tensor is None:
+            self._x0_tensor = torch.empty(self._dim_state, device=self._device, dtype=self._dtype)
+        self._x0_tensor.copy_(x0)  # static buffers: the same storage every solve (what a captured graph replays on)
         # clamp(mean + eps) in the reference layout [N,T,dc]; the handle's warm start still holds the
         # mean of this solve (it is replaced by mppi_finalize)
-        U = torch.empty(N, T, self._dim_control, device=self._device, dtype=self._dtype)
+        if self._perturbed_action_seqs_buf is None:
+            self._perturbed_action_seqs_buf = torch.empty(N, T, self._dim_control, device=self._device, dtype=self._dtype)
+            self._state_seq_batch_buf = torch.zeros(N, T + 1, self._dim_state, device=self._device, dtype=self._dtype)
+            self._generic_costs_keep = torch.empty(N, device=self._device, dtype=self._dtype)
+        U = self._perturbed_action_seqs_buf
         self._h.call("mppi_export_noise", None, _ptr(U), self._stream())
-        self._perturbed_action_seqs_buf = U
-        S = self._state_seq_batch_buf
-        if S is None or S.shape[0] != N:
-            S = self._state_seq_batch_buf = torch.zeros(N, T + 1, self._dim_state, device=self._device,
-                                                        dtype=self._dtype)
-        S[:, 0, :] = x0.repeat(N, 1)
+        if self._graph_state == "replay":
+            self._graph.replay()
+        elif self._graph_state == "capture":
+            self._capture_callables(info)
+        else:
+            self._callable_loops(info)
+            if self._graph_state == "warmup":
+                self._graph_state = "capture"  # the next solve captures (this one warmed the allocator / kernels up)
+        self._h.call("mppi_set_costs", _ptr(self._generic_costs_keep), 1, self._stream())
+
+    def _callable_loops(self, info: Dict) -> None:
+        """src/pi_mpc/mppi.py:280-336 on the static buffers: S <- rollout of U from x0, total costs -> _generic_costs_keep."""
+        N, T = self._local_samples, self._horizon
+        U, S = self._perturbed_action_seqs_buf, self._state_seq_batch_buf
+        S[:, 0, :] = self._x0_tensor.repeat(N, 1)
         for t in range(T):
             S[:, t + 1, :] = self._dynamics(S[:, t, :], U[:, t, :])
         costs = torch.zeros(N, T, device=self._device, dtype=self._dtype)
@@ -649,9 +679,42 @@ class MPPI(nn.Module):
         info["prev_state"] = S[:, -2, :]
         zero_action = torch.zeros(N, self._dim_control, device=self._device, dtype=self._dtype)
         terminal = self._cost_func(S[:, -1, :], zero_action, info)
-        total = (torch.sum(costs, dim=1) + terminal).contiguous()
-        self._h.call("mppi_set_costs", _ptr(total), 1, self._stream())
-        self._generic_costs_keep = total
+        self._generic_costs_keep.copy_(torch.sum(costs, dim=1) + terminal)
+
+    def _states_prediction_graphed(self) -> torch.Tensor:
+        """Step 8 (the batch-1 rollout of the solution through the user's dynamics, T launch-bound calls) as a second
+        captured graph on static buffers; returns a fresh tensor like the eager path."""
+        if self._graph_b1 is None:
+            self._b1_actions = torch.empty(1, self._horizon, self._dim_control, device=self._device, dtype=self._dtype)
+            self._b1_actions.copy_(self._action_out)
+            self._states_prediction(self._x0_tensor, self._b1_actions)  # warm-up at batch 1
+            torch.cuda.synchronize(self._device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._b1_states = self._states_prediction(self._x0_tensor, self._b1_actions)
+            self._graph_b1 = g
+        self._b1_actions.copy_(self._action_out)
+        self._graph_b1.replay()
+        return self._b1_states.clone()
+
+    def _capture_callables(self, info: Dict) -> None:
+        """Capture _callable_loops into a hipGraph and run it once; on failure fall back to the eager loops for good."""
+        import warnings
+
+        try:
+            torch.cuda.synchronize(self._device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._callable_loops(info)
+            self._graph = g
+            self._graph_state = "replay"
+            g.replay()
+        except Exception as e:  # not capturable (host sync, data-dependent shapes, ...): stay eager
+            self._graph, self._graph_state = None, "failed"
+            torch.cuda.synchronize(self._device)
+            warnings.warn(f"graph_callables: the dynamics / cost_func loops could not be captured ({type(e).__name__}: "
+                          f"{str(e).splitlines()[0] if str(e) else ''}); staying on the eager loops")
+            self._callable_loops(info)
 
     def _states_prediction(self, state: torch.Tensor, action_seqs: torch.Tensor) -> torch.Tensor:
         """src/pi_mpc/mppi.py:508-524 with the user's dynamics."""

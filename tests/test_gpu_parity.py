@@ -1445,3 +1445,55 @@ def test_c4_eight_shards_at_full_size_on_one_device():
     st = stats.cpu().numpy()
     assert st[0] == st_full["cmin"] and abs(st[1] - st_full["sum_e"]) <= 2e-5 * st_full["sum_e"]
     assert abs(st[1] * st[1] / st[2] - st_full["ess"]) <= 1e-4 * st_full["ess"]
+
+
+def test_generic_path_hipgraph_capture_of_the_callables():
+    """graph_callables=True: the reference's two T-step Python loops over opaque callables, captured once into a
+    hipGraph (after one eager warm-up solve) and replayed — bit-identical to the eager loops over a closed loop
+    (pendulum, mountain car with its in-place mutation, cart-pole with its masked assignments) and faster; a callable
+    that is not capturable (it synchronises with the host) falls back to the eager loops with a warning, same results."""
+    _need_gpu()
+    import time
+    import warnings
+
+    from envs import classic_control as cc
+    from pi_mpc.mppi import MPPI
+
+    def host_sync_cost(s, u, info):  # .item() cannot be captured
+        return cc.pendulum_cost(s, u, info) * (1.0 + 0.0 * float(s[0, 0].item()))
+
+    for model, T, N, x0, cost_fn in (("pendulum", 30, 8192, [3.0, 0.1], None), ("mountaincar", 40, 4096, [-0.5, 0.0], None),
+                                     ("cartpole", 20, 2048, [0.01, 0.0, 0.02, 0.0], None),
+                                     ("pendulum", 10, 512, [3.0, 0.1], host_sync_cost)):
+        mc = MODEL_CFG[model]
+        ds, dc = orc.MODEL_DIMS[orc.MODEL_IDS[model]]
+        make = lambda **kw: MPPI(horizon=T, num_samples=N, dim_state=ds, dim_control=dc,  # noqa: E731
+                                 dynamics=_untagged(getattr(cc, f"{model}_dynamics")),
+                                 cost_func=cost_fn or _untagged(getattr(cc, f"{model}_cost")), u_min=torch.tensor(mc["u_min"]),
+                                 u_max=torch.tensor(mc["u_max"]), sigmas=torch.tensor(mc["sigmas"]), lambda_=0.5, **kw)
+        eager, graph = make(), make(graph_callables=True)
+        assert eager._model is None and graph._model is None
+        xe = xg = torch.tensor(x0)
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            for tick in range(6):
+                ae, se = eager.forward(xe)
+                ag, sg = graph.forward(xg)
+                assert torch.equal(ae, ag) and torch.equal(se, sg), (model, tick)
+                assert torch.equal(eager._costs, graph._costs)
+                xe, xg = se[0, 1].clone(), sg[0, 1].clone()
+        warned = [w for w in caught if "graph_callables" in str(w.message)]
+        if cost_fn is None:
+            assert graph._graph_state == "replay" and not warned
+            times = []
+            for sol, x in ((eager, xe), (graph, xg)):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(20):
+                    sol.forward(x)
+                torch.cuda.synchronize()
+                times.append((time.perf_counter() - t0) / 20 * 1e3)
+            print(f"generic {model} N={N} T={T}: eager loops {times[0]:.2f} ms/solve, hipGraph replay {times[1]:.2f} ms/solve")
+            assert times[1] < times[0]
+        else:
+            assert graph._graph_state == "failed" and warned
