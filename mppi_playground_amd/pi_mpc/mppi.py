@@ -164,6 +164,10 @@ class MPPI(nn.Module):
             self._world = dist.get_world_size(process_group)
             self._rank = dist.get_rank(process_group)
         self._sample_offset, self._local_samples = shard_range(num_samples, self._world, self._rank)
+        # measurement / test hook: run the per-solve exchange (summary -> all_gather -> combine) even with ONE rank, so
+        # that the real RCCL-backed path can be exercised and its fixed cost measured on a single GPU
+        import os as _os
+        self._force_exchange = bool(shard_samples and self._world == 1 and _os.environ.get("MPPI_FORCE_EXCHANGE") == "1")
 
         # ---- plugin recognition
         dyn, cst = resolve(dynamics), resolve(cost_func)
@@ -263,6 +267,7 @@ class MPPI(nn.Module):
         self._previous_action_seq = torch.zeros(T, dcn, device=self._device, dtype=dtype)
         # forward() in one library call (mppi_solve) when nothing needs the host between the steps
         self._one_call = (self._model is not None and noise_source == "philox" and self._world == 1
+                          and not self._force_exchange
                           and not (use_sg_filter and not self._sg_on_device)
                           and (self._auto_lambda is None
                                or (self._auto_lambda == "ESSPS" and auto_lambda_stats == "device" and essps_search == "device")))
@@ -554,7 +559,7 @@ class MPPI(nn.Module):
             self._last_lambda = lam
 
         # Steps 5-6: weights + weighted mean (src/pi_mpc/mppi.py:376-385)
-        sharded = self._world > 1
+        sharded = self._world > 1 or self._force_exchange
         summaries, nsh = None, 1
         if self._p2p:  # the shard summaries travel through the peer-to-peer buffers: no collective launch
             if h.lib.mppi_p2p_error(h.h):

@@ -1497,3 +1497,25 @@ def test_generic_path_hipgraph_capture_of_the_callables():
             assert times[1] < times[0]
         else:
             assert graph._graph_state == "failed" and warned
+
+
+def test_rccl_backed_exchange_path_with_one_rank():
+    """The default multi-GPU exchange on the REAL backend: a one-rank `nccl` (= RCCL) process group — RCCL cannot put two
+    ranks on one device, which is why the two-rank tests above use gloo — with MPPI_FORCE_EXCHANGE=1, so that every solve
+    takes the N-GPU code path: summary written by summarize_kernel -> all_gather_into_tensor on ProcessGroupNCCL's
+    stream -> mppi_finalize on the gathered buffer.  scripts/nccl_single_rank.py checks the result against the
+    unsharded solve and prints the fixed cost of the path (~12 us per solve)."""
+    _need_gpu()
+    import os
+    import subprocess
+    import sys
+
+    from helpers import ROOT
+
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "nccl_single_rank.py")], env=env, capture_output=True,
+                       text=True, timeout=300)
+    lines = [ln for ln in r.stdout.splitlines() if "forced exchange" in ln or "RCCL all_gather path" in ln]
+    print("\n".join(lines))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert len(lines) == 3
