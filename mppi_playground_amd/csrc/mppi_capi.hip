@@ -826,8 +826,8 @@ int mppi_finalize(mppi_handle_t h, const float* summaries_dev, int num_shards, f
 
 // MPPI.forward() for a native model in ONE call (mppi.py:223-460): bind the state, fix the noise identity, rollout +
 // costs, the temperature (fixed, or the ESSPS search resident on the device), weights + reduction, finalize with the
-// warm start stored.  Exactly the sequence of the individual entry points (same kernels, same results); it exists
-// because small problems are bound by the host's enqueue rate (~26 us per solve through five Python -> C calls).
+// warm start stored.  Exactly the sequence of the individual entry points (same kernels, same results): one
+// host -> library transition per solve for callers that need nothing in between.
 int mppi_solve(mppi_handle_t h, const float* x0_dev, uint32_t solve_idx, float lambda, double essps_target_ess,
                double lam_min, double lam_max, float* action_out_dev, float* state_seq_out_dev, float* stats_out_dev,
                void* stream) {

@@ -610,8 +610,7 @@ class MPPI(nn.Module):
 
     def _forward_one_call(self, state, h, st):
         """forward() through mppi_solve: the same kernel sequence as the step-by-step path below in one library call
-        (native model, device noise, fixed lambda or the device-resident ESSPS search, one GPU): small problems are
-        bound by how fast the host can enqueue a solve."""
+        (native model, device noise, fixed lambda or the device-resident ESSPS search, one GPU)."""
         if torch.is_tensor(state) and state.is_cuda:
             self._x0_keep = state.detach().to(self._device, self._dtype).contiguous()
             x0p = _ptr(self._x0_keep)
