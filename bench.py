@@ -423,8 +423,12 @@ def cpu_baseline_torch(torch, np, T):
     """The reference's own op structure on this host's cores: oracle/
     torch_reference_loop.py — one [N,T,dc] torch.randn draw, two Python loops of T batched torch ops over the
     racing plugins (strided [N,ds] views of S[N,T+1,ds]), the dead action-cost product, softmax, weighted sum, batch-1
-    rollout — at the metric's size (C3: N = 1,048,576, T = 50, ~4.3 GB resident).  1 warm-up, then 2-5 timed solves
-    (stops after ~12 s).  Pinned against the reference fixtures by tests/test_oracle_vs_golden.py."""
+    rollout — at the metric's size (C3: N = 1,048,576, T = 50, ~4.3 GB resident).  Pinned against the reference
+    fixtures by tests/test_oracle_vs_golden.py.
+
+    These strided batch ops do not scale with cores (128 intra-op threads are ~7x SLOWER than 16 on a 2 x 64-core
+    host), so `value` is the BEST of a short scan over thread counts (1 warm-up + 2 timed solves each) — the baseline
+    is not handicapped by its default — and the all-cores figure the survey asked for is reported next to it."""
     from envs.racing_controller import racing_controller
     from envs.racing_env import RacingEnv
     from oracle.torch_reference_loop import TorchReferenceLoop
@@ -438,14 +442,24 @@ def cpu_baseline_torch(torch, np, T):
     ref, _ = ctrl.calc_ref_trajectory(state, env.racing_center_path, 0, T, DL=0.1, lookahead_distance=3,
                                       reference_path_interval=0.85)
     ctrl.set_reference(ref)
-    ctrl.solver.forward(state.clone())  # warm-up: page in ~4 GB, start the thread pool
-    times = []
-    t_all = time.perf_counter()
-    while len(times) < 2 or (len(times) < 5 and time.perf_counter() - t_all < 12.0):
-        t0 = time.perf_counter()
-        ctrl.solver.forward(state.clone())
-        times.append(time.perf_counter() - t0)
-    best, med = min(times), float(np.median(times))
+    default_threads = torch.get_num_threads()
+
+    def timed(threads, reps):
+        torch.set_num_threads(threads)
+        ctrl.solver.forward(state.clone())  # warm-up (first call also pages in ~4 GB)
+        out = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            ctrl.solver.forward(state.clone())
+            out.append(time.perf_counter() - t0)
+        return out
+
+    scan = {}
+    for threads in sorted({min(16, default_threads), min(8, default_threads), min(32, default_threads)}):
+        scan[threads] = float(np.median(timed(threads, 2)))
+    best = min(scan, key=scan.get)
+    all_cores = timed(default_threads, 1)[0] if default_threads not in scan else scan[default_threads]
+    torch.set_num_threads(default_threads)
     cpu_model = "unknown"
     try:
         for line in open("/proc/cpuinfo"):
@@ -454,11 +468,12 @@ def cpu_baseline_torch(torch, np, T):
                 break
     except OSError:
         pass
-    return {"value": n * T / med, "unit": "sample-steps/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{len(times)} solves of racing N={n} T={T} after 1 warm-up (torch-CPU restatement of the reference "
-                      f"loop, noise draw included): median {med:.2f} s, min {best:.2f} s per solve",
-            "solves_per_sec": 1 / med, "solves_per_sec_best": 1 / best, "nproc": os.cpu_count(), "cpu_model": cpu_model,
-            "torch_threads": torch.get_num_threads()}
+    return {"value": n * T / scan[best], "unit": "sample-steps/s", "cores": best, "kind": "port",
+            "sample": f"racing N={n} T={T}, torch-CPU restatement of the reference loop (noise draw included): median of 2 "
+                      f"solves after 1 warm-up per thread count; best = {best} threads, {scan[best]:.2f} s per solve",
+            "solves_per_sec": 1 / scan[best], "s_per_solve_by_threads": {str(k): v for k, v in scan.items()},
+            "all_cores": {"torch_threads": default_threads, "s_per_solve": all_cores, "solves_per_sec": 1 / all_cores},
+            "nproc": os.cpu_count(), "cpu_model": cpu_model}
 
 
 if __name__ == "__main__":
