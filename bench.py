@@ -16,8 +16,8 @@ Prints ONE JSON line on rank 0.  `value` = sample-steps/s (N_total * T * solves/
 `roofline` is for the dominant kernel (rollout_cost_kernel), measured with HIP events on the launch
 stream inside the timed region.  At N=1, rank 0 also reports, in the same line:
   cpu_baseline        the oracle (C restatement of the reference algorithm, OpenMP over samples) on this host
-  cpu_baseline_torch  the reference's own op structure (per-timestep Python loops of batched torch ops, all cores)
-                      over the same plugins on this host (SURVEY 8d / BASELINE.md section 3)
+  cpu_baseline_torch  the reference's own op structure (per-timestep Python loops of batched torch ops) over the same
+                      plugins on this host: best of a thread-count scan + the all-cores figure (SURVEY 8d / BASELINE.md 3)
   closed_loop         >= 100 racing control ticks: reference window recomputed, solve, a[0] applied (example/racing.py:221-266)
   other_configs       solve times of BASELINE configs C1 / C2 / C5
 """
