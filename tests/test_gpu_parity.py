@@ -1519,3 +1519,48 @@ def test_rccl_backed_exchange_path_with_one_rank():
     print("\n".join(lines))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert len(lines) == 3
+
+
+def test_essps_device_search_equals_the_host_loop_on_random_costs():
+    """mppi_essps_lambda_device (both statistics passes AND both scalar steps as kernels, the default of forward()) against
+    mppi_essps_lambda (the same steps in a host loop over read-back statistics) and against scipy's brentq on a float64
+    evaluation of ESS(lambda), over cost vectors of very different shapes: Gaussian, heavy-tailed, two clusters, a huge
+    common offset, all equal (ESS = N at every temperature: lambda_min), one far outlier (ESS stays near 1: lambda_max)."""
+    _need_gpu()
+    from scipy.optimize import brentq
+
+    rng = np.random.default_rng(11)
+    solver, _ = make_solver("pendulum", 10, 300_000, lambda_=1.0)
+    solver.forward(torch.tensor([1.0, 0.0]))  # (a handle with costs[N] allocated and a noise identity)
+    h, st = solver._h, solver._stream()
+    N = 300_000
+    shapes = {
+        "gauss": lambda: rng.standard_normal(N) * 3.0 + 50.0,
+        "gauss_small_spread": lambda: rng.standard_normal(N) * 0.02 + 7.0,
+        "exponential": lambda: rng.exponential(5.0, N),
+        "lognormal": lambda: np.exp(rng.standard_normal(N) * 1.5),
+        "two_clusters": lambda: np.where(rng.random(N) < 0.05, rng.standard_normal(N) * 0.5, 40.0 + rng.standard_normal(N)),
+        "offset_1e6": lambda: 1.0e6 + rng.standard_normal(N) * 4.0,
+        "all_equal": lambda: np.full(N, 3.25),
+        "one_outlier": lambda: np.concatenate([[-1.0e4], 100.0 + rng.standard_normal(N - 1)]),
+    }
+    for name, draw in shapes.items():
+        c = draw().astype(np.float32)
+        cd = torch.from_numpy(c).cuda()
+        h.call("mppi_set_costs", cd.data_ptr(), 1, st)
+        for target in (N / 10, 50.0, N * 0.9):
+            lam_host = C.c_double(0.0)
+            h.call("mppi_essps_lambda", float(target), 0.01, 10.0, C.byref(lam_host), st)
+            h.call("mppi_essps_lambda_device", float(target), 0.01, 10.0, st)
+            lam_dev = C.c_double(0.0)
+            h.call("mppi_get_lambda", C.byref(lam_dev), st)
+            assert abs(lam_dev.value - lam_host.value) <= 1e-12 * lam_host.value, (name, target, lam_dev.value, lam_host.value)
+            c64 = c.astype(np.float64)
+            ess = lambda lam: (lambda e: e.sum() ** 2 / (e * e).sum())(np.exp(-(c64 - c64.min()) / lam))  # noqa: E731
+            if target <= ess(0.01):
+                want = 0.01
+            elif target >= ess(10.0):
+                want = 10.0
+            else:
+                want = brentq(lambda lam: ess(lam) - target, 0.01, 10.0, xtol=1e-12)
+            assert abs(lam_dev.value - want) <= 2e-4 * want, (name, target, lam_dev.value, want)
