@@ -648,10 +648,13 @@ class MPPI(nn.Module):
         self._x0_tensor.copy_(x0)  # static buffers: the same storage every solve (what a captured graph replays on)
         # clamp(mean + eps) in the reference layout [N,T,dc]; the handle's warm start still holds the
         # mean of this solve (it is replaced by mppi_finalize)
-        if self._perturbed_action_seqs_buf is None:
-            self._perturbed_action_seqs_buf = torch.empty(N, T, self._dim_control, device=self._device, dtype=self._dtype)
+        if self._state_seq_batch_buf is None:  # (the reference allocates `_state_seq_batch` once, too: mppi.py:168-174)
             self._state_seq_batch_buf = torch.zeros(N, T + 1, self._dim_state, device=self._device, dtype=self._dtype)
             self._generic_costs_keep = torch.empty(N, device=self._device, dtype=self._dtype)
+        if self._perturbed_action_seqs_buf is None or not self._graph_callables:
+            # a new `_perturbed_action_seqs` tensor every solve like the reference (mppi.py:266-275); a captured graph
+            # needs the same storage every solve instead
+            self._perturbed_action_seqs_buf = torch.empty(N, T, self._dim_control, device=self._device, dtype=self._dtype)
         U = self._perturbed_action_seqs_buf
         self._h.call("mppi_export_noise", None, _ptr(U), self._stream())
         if self._graph_state == "replay":
