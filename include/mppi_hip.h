@@ -99,6 +99,10 @@ typedef struct MppiConfig {
 
 /* Library / build information ("gfx950", version). */
 const char* mppi_version(void);
+/* Integer version of THIS header's function signatures; bindings compare it with the constant they were written
+ * against and refuse a stale library (a changed argument list would otherwise be called with shifted arguments). */
+#define MPPI_ABI_VERSION 3
+int mppi_abi_version(void);
 /* Number of visible HIP devices (0 => the product cannot run; callers must fail loudly). */
 int mppi_device_count(void);
 const char* mppi_last_error(mppi_handle_t h);
@@ -146,6 +150,33 @@ int mppi_download_map(mppi_handle_t h, int slot, uint8_t* cells_host, int* nx, i
 /* racing_controller.reference_path = calc_ref_trajectory(...) (example/racing.py:73-81):
  * ref [rows][4] = (x, y, yaw, v_target), rows >= T (the cost reads rows 0..T-1). */
 int mppi_set_reference(mppi_handle_t h, const float* ref_host, int rows, void* stream);
+
+/* The racing control tick without the host (example/racing.py:73-81,161-218,221-266).
+ *   mppi_set_center_path  `env.racing_center_path` [n][3] = (x, y, yaw) and the constants of
+ *                         calc_ref_trajectory(horizon, DL, lookahead_distance, reference_path_interval): dind_host [rows]
+ *                         = int(round(travel_i / DL)) for the rows = T+1 window rows (:201-205; float64 arithmetic of
+ *                         the caller), v_target = env.V_MAX (:209).  Resets nothing else; synchronises (set-up path).
+ *   mppi_ref_window       calc_ref_trajectory(state, path, cind, ...) as one kernel on `stream`: nearest centre-line
+ *                         point (first minimum of the fp32 hypot, :189-196), ind = max(cind, ind) (:198) with the index
+ *                         kept in device memory, window rows gathered straight into the model's reference table — the
+ *                         same values mppi_set_reference would have uploaded, bit for bit.  state_dev [>= 2] device
+ *                         pointer, or NULL for the state bound to the handle.  No host synchronisation.
+ *   mppi_set/get_path_index  `racing_controller.current_path_index` (both synchronise the stream).
+ *   mppi_get_reference    the current window as `reference_path` [rows][4] (device or host copy; host copies synchronise). */
+int mppi_set_center_path(mppi_handle_t h, const float* path_host, int n, const int32_t* dind_host, int rows,
+                         float v_target);
+int mppi_ref_window(mppi_handle_t h, const float* state_dev, void* stream);
+int mppi_set_path_index(mppi_handle_t h, int32_t cind, void* stream);
+int mppi_get_path_index(mppi_handle_t h, int32_t* cind_out_host, void* stream);
+int mppi_get_reference(mppi_handle_t h, float* ref_out, int rows, int on_device, void* stream);
+/* `env.step(u)` of the shipped environments (src/envs/racing_env.py:142-163, src/envs/navigation_2d.py step) as one
+ * launch, no handle needed: next = dynamics(state, clamp(u, u_min, u_max)) for native model `model` with the library
+ * math in the reference's operation order; params_host = the model's MPPI_*P_* vector (cost weights may be omitted);
+ * u_min_host / u_max_host [dim_control] or NULL (no pre-clamp); state_dev and next_state_dev may alias.  With
+ * reached_out_dev != NULL also the goal test: *reached = norm(next[:2] - goal_xy_host) < goal_threshold (one byte). */
+int mppi_model_step(int model, const float* params_host, int n_params, const float* u_min_host, const float* u_max_host,
+                    const float* state_dev, const float* action_dev, float* next_state_dev, const float* goal_xy_host,
+                    float goal_threshold, uint8_t* reached_out_dev, void* stream);
 
 /* `_previous_action_seq` (mppi.py:157,255,452).  on_device != 0: pointer is a device pointer. */
 int mppi_set_mean(mppi_handle_t h, const float* mean, int on_device, void* stream);

@@ -22,13 +22,17 @@ SUMMARY_HEAD = 4
 LAMBDA_DEVICE = -1.0  # MPPI_LAMBDA_DEVICE: "the temperature mppi_essps_lambda_device left on the device"
 
 # every symbol include/mppi_hip.h declares
+ABI_VERSION = 3  # MPPI_ABI_VERSION of the header this binding was written against
+
 SYMBOLS = [
-    "mppi_version", "mppi_device_count", "mppi_last_error", "mppi_create", "mppi_destroy", "mppi_set_control_limits",
+    "mppi_version", "mppi_abi_version", "mppi_device_count", "mppi_last_error", "mppi_create", "mppi_destroy", "mppi_set_control_limits",
     "mppi_set_model_params", "mppi_upload_map", "mppi_build_obstacle_map", "mppi_build_lane_map",
     "mppi_download_map", "mppi_set_reference", "mppi_set_mean", "mppi_get_mean",
     "mppi_set_state", "mppi_bind_state", "mppi_sample", "mppi_inject_noise", "mppi_export_noise", "mppi_rollout_cost",
     "mppi_get_costs", "mppi_set_costs", "mppi_weights_reduce", "mppi_finalize", "mppi_solve", "mppi_set_sg_filter", "mppi_get_sg_history", "mppi_softmax_stats", "mppi_softmax_stats_multi", "mppi_essps_lambda", "mppi_essps_lambda_device", "mppi_get_lambda", "mppi_lbps_lambda", "mppi_mpo_reset", "mppi_mpo_step", "mppi_mpo_state", "mppi_weights", "mppi_sample_posterior",
     "mppi_p2p_alloc", "mppi_p2p_connect", "mppi_p2p_exchange", "mppi_p2p_error", "mppi_rollout_actions", "mppi_rollout_samples", "mppi_top_samples", "mppi_top_candidates", "mppi_rollout_candidates", "mppi_set_option", "mppi_get_timing",
+    "mppi_set_center_path", "mppi_ref_window", "mppi_set_path_index", "mppi_get_path_index", "mppi_get_reference",
+    "mppi_model_step",
 ]
 
 
@@ -59,6 +63,13 @@ def load():
             "(hipcc --offload-arch=gfx950). There is no CPU fallback for the MPPI hot path.")
     lib = C.CDLL(LIB_PATH)
     vp, i32, i64, u32, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_uint32, C.c_float
+    try:
+        got = int(lib.mppi_abi_version())
+    except AttributeError:
+        got = None
+    if got != ABI_VERSION:
+        raise MppiError(f"{LIB_PATH} exports ABI version {got}, this binding needs {ABI_VERSION}: rebuild the extension "
+                        "(python -m mppi_playground_amd._build)")
     lib.mppi_version.restype = C.c_char_p
     lib.mppi_last_error.restype = C.c_char_p
     lib.mppi_last_error.argtypes = [vp]
@@ -106,6 +117,12 @@ def load():
     lib.mppi_weights.argtypes = [vp, f32, f32, f32, vp, vp]
     lib.mppi_rollout_actions.argtypes = [vp, vp, i32, vp, vp, vp]
     lib.mppi_rollout_samples.argtypes = [vp, vp, i32, vp, vp]
+    lib.mppi_set_center_path.argtypes = [vp, vp, i32, vp, i32, f32]
+    lib.mppi_ref_window.argtypes = [vp, vp, vp]
+    lib.mppi_set_path_index.argtypes = [vp, C.c_int32, vp]
+    lib.mppi_get_path_index.argtypes = [vp, vp, vp]
+    lib.mppi_get_reference.argtypes = [vp, vp, i32, i32, vp]
+    lib.mppi_model_step.argtypes = [i32, vp, i32, vp, vp, vp, vp, vp, vp, f32, vp, vp]
     lib.mppi_set_option.argtypes = [vp, C.c_char_p, i64]
     lib.mppi_get_timing.argtypes = [vp, vp]
     for name in SYMBOLS:

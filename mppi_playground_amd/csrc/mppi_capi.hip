@@ -70,6 +70,12 @@ struct MppiSolver {
     int sg_window = 0;
     float* ref = nullptr;
     int ref_cap = 0;
+    // device-resident reference window (mppi_set_center_path / mppi_ref_window)
+    float* center8 = nullptr;        // [n][8] centre line with sin/cos of the yaw
+    int32_t* win_dind = nullptr;     // [rows] index offsets of the window rows
+    int32_t* path_index = nullptr;   // `current_path_index`, kept on the device
+    int center_n = 0, win_rows = 0;
+    float win_v = 0.0f;
     float* partials = nullptr;
     float* heads = nullptr;
     float* summary = nullptr;
@@ -273,7 +279,8 @@ P2pCtx p2p_ctx(mppi_handle_t h) {
 
 extern "C" {
 
-const char* mppi_version(void) { return "mppi_hip 0.1.0 (gfx950, wave64, lane-per-trajectory)"; }
+const char* mppi_version(void) { return "mppi_hip 0.3.0 (gfx950, wave64, lane-per-trajectory)"; }
+int mppi_abi_version(void) { return MPPI_ABI_VERSION; }
 
 int mppi_device_count(void) {
     int n = 0;
@@ -404,6 +411,7 @@ int mppi_destroy(mppi_handle_t h) {
     (void)hipFree(h->mean); (void)hipFree(h->mean_used); (void)hipFree(h->solve_stats); (void)hipFree(h->topk_hist);
     (void)hipFree(h->topk_sel); (void)hipFree(h->topk_cand); (void)hipFree(h->sg_coeffs); (void)hipFree(h->sg_history);
     (void)hipFree(h->ref); (void)hipFree(h->partials); (void)hipFree(h->heads);
+    (void)hipFree(h->center8); (void)hipFree(h->win_dind); (void)hipFree(h->path_index);
     (void)hipFree(h->summary); (void)hipFree(h->map_cells[0]); (void)hipFree(h->map_cells[1]);
     (void)hipFree(h->map_pad); (void)hipFree(h->stats_part); (void)hipFree(h->noise_std);
     if (h->stats_host) (void)hipHostFree(h->stats_host);
@@ -551,15 +559,12 @@ static int upload_small(mppi_handle_t h, float* dst_dev, const float* src_host, 
     return MPPI_OK;
 }
 
+static int reserve_ref(mppi_handle_t h, int rows);
+
 int mppi_set_reference(mppi_handle_t h, const float* ref, int rows, void* stream) {
     if (!h || !ref || rows < 1) return fail(h, MPPI_E_INVALID, "bad reference");
     hipStream_t s = (hipStream_t)stream;
-    if (rows > h->ref_cap) {
-        if (h->ref) { HIP_TRY(h, hipDeviceSynchronize()); (void)hipFree(h->ref); }
-        h->ref = nullptr;
-        HIP_TRY(h, hipMalloc(&h->ref, sizeof(float) * 8 * (size_t)rows));
-        h->ref_cap = rows;
-    }
+    if (int rc = reserve_ref(h, rows)) return rc;
     float* st = nullptr; hipEvent_t ev = nullptr;
     if (int rc = stage_slot(h, (size_t)rows * 8, &st, &ev)) return rc;
     for (int i = 0; i < rows; ++i) {
@@ -573,6 +578,119 @@ int mppi_set_reference(mppi_handle_t h, const float* ref, int rows, void* stream
     h->ctx.ref = h->ref;
     h->ctx.ref_rows = rows;
     return MPPI_OK;
+}
+
+// make sure h->ref holds `rows` rows (blocking reallocation: set-up path)
+static int reserve_ref(mppi_handle_t h, int rows) {
+    if (rows <= h->ref_cap) return MPPI_OK;
+    if (h->ref) { HIP_TRY(h, hipDeviceSynchronize()); (void)hipFree(h->ref); }
+    h->ref = nullptr; h->ref_cap = 0;
+    HIP_TRY(h, hipMalloc(&h->ref, sizeof(float) * 8 * (size_t)rows));
+    h->ref_cap = rows;
+    return MPPI_OK;
+}
+
+int mppi_set_center_path(mppi_handle_t h, const float* path_host, int n, const int32_t* dind_host, int rows,
+                         float v_target) {
+    if (!h || !path_host || !dind_host || n < 1 || rows < 1) return fail(h, MPPI_E_INVALID, "bad centre path");
+    if (h->cfg.model != MPPI_MODEL_RACING) return fail(h, MPPI_E_INVALID, "the reference window belongs to the racing model");
+    if (rows < h->d.T) return fail(h, MPPI_E_INVALID, "window shorter than the horizon");
+    for (int i = 0; i < rows; ++i)
+        if (dind_host[i] < 0 || (i && dind_host[i] < dind_host[i - 1])) return fail(h, MPPI_E_INVALID, "window offsets must be >= 0 and non-decreasing");
+    std::vector<float> tab((size_t)n * 8, 0.0f);
+    for (int i = 0; i < n; ++i) {
+        float* o = tab.data() + (size_t)i * 8;
+        o[0] = path_host[3 * i]; o[1] = path_host[3 * i + 1]; o[2] = path_host[3 * i + 2];
+        o[4] = sinf(o[2]); o[5] = cosf(o[2]);  // the calls mppi_set_reference makes per window row
+    }
+    HIP_TRY(h, hipDeviceSynchronize());
+    (void)hipFree(h->center8); (void)hipFree(h->win_dind);
+    h->center8 = nullptr; h->win_dind = nullptr; h->center_n = 0;
+    HIP_TRY(h, hipMalloc(&h->center8, sizeof(float) * tab.size()));
+    HIP_TRY(h, hipMemcpy(h->center8, tab.data(), sizeof(float) * tab.size(), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMalloc(&h->win_dind, sizeof(int32_t) * (size_t)rows));
+    HIP_TRY(h, hipMemcpy(h->win_dind, dind_host, sizeof(int32_t) * (size_t)rows, hipMemcpyHostToDevice));
+    if (!h->path_index) {
+        HIP_TRY(h, hipMalloc(&h->path_index, sizeof(int32_t)));
+        HIP_TRY(h, hipMemset(h->path_index, 0, sizeof(int32_t)));
+    }
+    if (int rc = reserve_ref(h, rows)) return rc;
+    h->center_n = n; h->win_rows = rows; h->win_v = v_target;
+    return MPPI_OK;
+}
+
+int mppi_ref_window(mppi_handle_t h, const float* state_dev, void* stream) {
+    if (!h) return MPPI_E_INVALID;
+    if (!h->center_n) return fail(h, MPPI_E_STATE, "mppi_ref_window before mppi_set_center_path");
+    const RefWindowCtx w{h->center8, h->win_dind, h->path_index, h->center_n, h->win_rows, h->win_v};
+    hipLaunchKernelGGL(ref_window_kernel, dim3(1), dim3(REFWIN_BLOCK), 0, (hipStream_t)stream, w,
+                       state_dev ? state_dev : h->x0_cur, h->ref);
+    HIP_TRY(h, hipGetLastError());
+    h->ctx.ref = h->ref;
+    h->ctx.ref_rows = h->win_rows;
+    return MPPI_OK;
+}
+
+int mppi_set_path_index(mppi_handle_t h, int32_t cind, void* stream) {
+    if (!h || cind < 0) return fail(h, MPPI_E_INVALID, "bad path index");
+    if (!h->path_index) return fail(h, MPPI_E_STATE, "mppi_set_path_index before mppi_set_center_path");
+    HIP_TRY(h, hipStreamSynchronize((hipStream_t)stream));
+    HIP_TRY(h, hipMemcpy(h->path_index, &cind, sizeof(int32_t), hipMemcpyHostToDevice));
+    return MPPI_OK;
+}
+
+int mppi_get_path_index(mppi_handle_t h, int32_t* cind_out_host, void* stream) {
+    if (!h || !cind_out_host) return fail(h, MPPI_E_INVALID, "null");
+    if (!h->path_index) return fail(h, MPPI_E_STATE, "mppi_get_path_index before mppi_set_center_path");
+    HIP_TRY(h, hipStreamSynchronize((hipStream_t)stream));
+    HIP_TRY(h, hipMemcpy(cind_out_host, h->path_index, sizeof(int32_t), hipMemcpyDeviceToHost));
+    return MPPI_OK;
+}
+
+int mppi_get_reference(mppi_handle_t h, float* ref_out, int rows, int on_device, void* stream) {
+    if (!h || !ref_out || rows < 1) return fail(h, MPPI_E_INVALID, "bad get_reference arguments");
+    if (!h->ctx.ref || rows > h->ctx.ref_rows) return fail(h, MPPI_E_STATE, "no reference window of that many rows");
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(h, hipMemcpy2DAsync(ref_out, 4 * sizeof(float), h->ref, 8 * sizeof(float), 4 * sizeof(float), (size_t)rows,
+                                on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
+    if (!on_device) HIP_TRY(h, hipStreamSynchronize(s));
+    return MPPI_OK;
+}
+
+int mppi_model_step(int model, const float* params_host, int n_params, const float* u_min_host, const float* u_max_host,
+                    const float* state_dev, const float* action_dev, float* next_state_dev, const float* goal_xy_host,
+                    float goal_threshold, uint8_t* reached_out_dev, void* stream) {
+    ModelDims md{};
+    if (!model_dims(model, md) || n_params < 0 || n_params > MPPI_MAX_PARAMS || (n_params && !params_host) ||
+        !state_dev || !action_dev || !next_state_dev || (reached_out_dev && !goal_xy_host) || md.dc > MPPI_MAX_DIM_CONTROL)
+        return MPPI_E_INVALID;
+    const int need = model == MPPI_MODEL_RACING ? MPPI_RP_COUNT : model == MPPI_MODEL_NAV2D ? MPPI_NP_COUNT
+                     : model == MPPI_MODEL_GOALZONE ? MPPI_GP_COUNT : 0;
+    if (n_params < need) return MPPI_E_INVALID;  // (the cost weights at the tail are not read by the dynamics)
+    ModelCtx ctx;
+    std::memset(&ctx, 0, sizeof(ctx));
+    for (int i = 0; i < n_params; ++i) ctx.P[i] = params_host[i];
+    StepBounds ub;
+    for (int k = 0; k < MPPI_MAX_DIM_CONTROL; ++k) {
+        ub.lo[k] = (u_min_host && k < md.dc) ? u_min_host[k] : -INFINITY;
+        ub.hi[k] = (u_max_host && k < md.dc) ? u_max_host[k] : INFINITY;
+    }
+    const float gx = goal_xy_host ? goal_xy_host[0] : 0.0f, gy = goal_xy_host ? goal_xy_host[1] : 0.0f;
+    hipStream_t s = (hipStream_t)stream;
+#define CALL_STEP(MODEL)                                                                              \
+    hipLaunchKernelGGL((model_step_kernel<MODEL>), dim3(1), dim3(WAVE), 0, s, ctx, state_dev, action_dev, ub,  \
+                       next_state_dev, gx, gy, goal_threshold, reached_out_dev)
+    switch (model) {
+    case MPPI_MODEL_PENDULUM: CALL_STEP(MPPI_MODEL_PENDULUM); break;
+    case MPPI_MODEL_CARTPOLE: CALL_STEP(MPPI_MODEL_CARTPOLE); break;
+    case MPPI_MODEL_MOUNTAINCAR: CALL_STEP(MPPI_MODEL_MOUNTAINCAR); break;
+    case MPPI_MODEL_NAV2D: CALL_STEP(MPPI_MODEL_NAV2D); break;
+    case MPPI_MODEL_RACING: CALL_STEP(MPPI_MODEL_RACING); break;
+    case MPPI_MODEL_MJCARTPOLE: CALL_STEP(MPPI_MODEL_MJCARTPOLE); break;
+    case MPPI_MODEL_GOALZONE: CALL_STEP(MPPI_MODEL_GOALZONE); break;
+    }
+#undef CALL_STEP
+    return hipGetLastError() == hipSuccess ? MPPI_OK : MPPI_E_HIP;
 }
 
 // device <-> device / device -> host copies of small vectors

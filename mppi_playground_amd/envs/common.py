@@ -5,3 +5,33 @@ import torch
 def angle_normalize(x: torch.Tensor) -> torch.Tensor:
     """Wrap to [-pi, pi): ((x + pi) mod 2 pi) - pi with Python-style modulo."""
     return torch.remainder(x + torch.pi, 2 * torch.pi) - torch.pi
+
+
+class NativeStep:
+    """env.step() as ONE launch of the library's model functor (mppi_model_step: next = dynamics(state, clamp(u)) with
+    the library math in the reference's operation order, plus the goal test) instead of ~20 batch-1 torch kernels.
+    Holds the constants of the call (read back from the env's device tensors once).  Raises when the extension is
+    missing: there is no silent torch fallback for a GPU env constructed with native_step=True."""
+
+    def __init__(self, model: str, params, u_min, u_max, goal_xy, goal_threshold: float, dim_state: int, device, dtype):
+        import ctypes as C
+
+        from mppi_playground_amd import _capi
+
+        f = lambda v: (C.c_float * len(v))(*[float(x) for x in v])  # noqa: E731
+        self._capi, self._lib = _capi, _capi.load()
+        self._model = _capi.MODEL_IDS[model]
+        self._params, self._lo, self._hi, self._goal = f(params), f(u_min), f(u_max), f(goal_xy)
+        self._thr, self._ds, self._device, self._dtype = float(goal_threshold), dim_state, device, dtype
+
+    def __call__(self, state: torch.Tensor, u: torch.Tensor):
+        assert u.dtype == torch.float32 and state.dtype == torch.float32 and state.is_contiguous()
+        u = u if u.is_contiguous() else u.contiguous()
+        nxt = torch.empty(self._ds, device=self._device, dtype=self._dtype)
+        reached = torch.empty((), device=self._device, dtype=torch.bool)
+        rc = self._lib.mppi_model_step(self._model, self._params, len(self._params), self._lo, self._hi, state.data_ptr(),
+                                       u.data_ptr(), nxt.data_ptr(), self._goal, self._thr, reached.data_ptr(),
+                                       torch.cuda.current_stream(self._device).cuda_stream)
+        if rc != 0:
+            raise self._capi.MppiError(f"mppi_model_step failed ({rc})")
+        return nxt, reached

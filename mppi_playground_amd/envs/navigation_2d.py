@@ -10,7 +10,7 @@ from typing import Tuple
 
 import torch
 
-from envs.common import angle_normalize
+from envs.common import NativeStep, angle_normalize
 from envs.obstacle_map_2d import ObstacleMap, _device, generate_random_obstacles
 from pi_mpc.native import native_model
 
@@ -25,8 +25,10 @@ def _nav_inputs(env: "Navigation2DEnv") -> dict:
 
 
 class Navigation2DEnv:
-    def __init__(self, device=torch.device("cuda"), dtype=torch.float32, seed: int = 42) -> None:
+    def __init__(self, device=torch.device("cuda"), dtype=torch.float32, seed: int = 42, native_step: bool = True) -> None:
+        """`native_step`: on a GPU, step() is one launch of the library's nav2d functor (envs.common.NativeStep)."""
         self._device, self._dtype = _device(device), dtype
+        self._native_step, self._step_fn = bool(native_step), None
         self._obstacle_map = ObstacleMap(map_size=(20, 20), cell_size=0.1, device=self._device, dtype=dtype)
         self._seed = seed
         generate_random_obstacles(self._obstacle_map, random_x_range=(-7.5, 7.5), random_y_range=(-7.5, 7.5),
@@ -52,6 +54,12 @@ class Navigation2DEnv:
         return self._robot_state
 
     def step(self, u: torch.Tensor) -> Tuple[torch.Tensor, bool]:
+        if self._native_step and self._device.type == "cuda" and torch.is_tensor(u) and u.is_cuda:
+            if self._step_fn is None:
+                self._step_fn = NativeStep("nav2d", _nav_inputs(self)["params"], self.u_min, self.u_max, self._goal_pos,
+                                           0.5, 3, self._device, self._dtype)
+            self._robot_state, reached = self._step_fn(self._robot_state, u)
+            return self._robot_state, reached
         u = torch.clamp(u, self.u_min, self.u_max)
         self._robot_state = self.dynamics(self._robot_state.unsqueeze(0), u.unsqueeze(0)).squeeze(0)
         reached = torch.norm(self._robot_state[:2] - self._goal_pos) < 0.5

@@ -12,7 +12,7 @@ from typing import Tuple
 import numpy as np
 import torch
 
-from envs.common import angle_normalize
+from envs.common import NativeStep, angle_normalize
 from envs.lane_map_2d import LaneMap
 from envs.obstacle_map_2d import ObstacleMap, _device, generate_random_obstacles
 from pi_mpc.native import native_model
@@ -25,8 +25,13 @@ def _racing_dyn_inputs(env: "RacingEnv") -> dict:
 
 
 class RacingEnv:
-    def __init__(self, device=torch.device("cuda"), dtype=torch.float32, seed: int = 42) -> None:
+    def __init__(self, device=torch.device("cuda"), dtype=torch.float32, seed: int = 42, native_step: bool = True) -> None:
+        """`native_step`: on a GPU, step() runs the plant's batch-1 dynamics call and the goal test as ONE launch of
+        the library's racing functor (mppi_model_step, library math in the reference's operation order) instead of
+        ~20 batch-1 torch kernels; False keeps the torch ops of `dynamics` (the two agree to fp32 rounding)."""
         self._device, self._dtype = _device(device), dtype
+        self._native_step = bool(native_step)
+        self._step_args = None
         self.u_min = torch.tensor([-2.0, -0.25], device=self._device, dtype=dtype)  # [accel, steer]
         self.u_max = torch.tensor([2.0, 0.25], device=self._device, dtype=dtype)
         self.L = torch.tensor(1, device=self._device, dtype=dtype)
@@ -63,9 +68,19 @@ class RacingEnv:
         return self._robot_state
 
     def step(self, u: torch.Tensor) -> Tuple[torch.Tensor, bool]:
+        """src/envs/racing_env.py:142-163: clamp the control, advance the plant one step, test the goal."""
+        if self._native_step and self._device.type == "cuda" and torch.is_tensor(u) and u.is_cuda:
+            return self._step_native(u)
         u = torch.clamp(u, self.u_min, self.u_max)
         self._robot_state = self.dynamics(self._robot_state.unsqueeze(0), u.unsqueeze(0)).squeeze(0)
         reached = torch.norm(self._robot_state[:2] - self._goal_pos) < 1.0
+        return self._robot_state, reached
+
+    def _step_native(self, u: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        if self._step_args is None:
+            self._step_args = NativeStep("racing", self.model_params([0.0] * 6), self.u_min, self.u_max, self._goal_pos,
+                                         1.0, 4, self._device, self._dtype)
+        self._robot_state, reached = self._step_args(self._robot_state, u)
         return self._robot_state, reached
 
     def model_params(self, weights) -> list:

@@ -430,6 +430,44 @@ class MPPI(nn.Module):
         if mode == "p2p":
             raise _capi.MppiError("MPPI_EXCHANGE=p2p: the peer-to-peer exchange is not usable here: " + (why or "self-test mismatch"))
 
+    # ------------------------------------------------------------------ device-resident racing tick
+    def set_center_path(self, path_xyyaw: np.ndarray, dind: np.ndarray, v_target: float) -> None:
+        """Hand the racing centre line [n,3] and the window row offsets of calc_ref_trajectory (example/racing.py:
+        161-218: dind[i] = int(round(travel_i / DL))) to the library, so that `update_reference_window` can rebuild
+        `reference_path` on the device every tick.  Set-up path (synchronises)."""
+        p = np.ascontiguousarray(path_xyyaw, dtype=np.float32)
+        d = np.ascontiguousarray(dind, dtype=np.int32)
+        assert p.ndim == 2 and p.shape[1] == 3 and d.ndim == 1
+        self._h.call("mppi_set_center_path", p.ctypes.data_as(C.c_void_p), p.shape[0], d.ctypes.data_as(C.c_void_p),
+                     d.shape[0], float(v_target))
+        self._ref_uploaded = None
+
+    def update_reference_window(self, state: torch.Tensor) -> None:
+        """calc_ref_trajectory(state, path, current_path_index, ...) (example/racing.py:73-81,161-218) as one kernel
+        on the current stream: the window goes straight into the cost's reference table and the path index stays on
+        the device — no read-back of the state, no host work."""
+        assert state.is_cuda and state.dtype == torch.float32 and state.shape == (self._dim_state,)
+        self._window_state_keep = state  # alive until the enqueued kernel ran
+        self._h.call("mppi_ref_window", _ptr(state), self._stream())
+        self._ref_uploaded = None  # a later host-side reference must be uploaded again
+
+    def reference_window(self) -> torch.Tensor:
+        """The window the next solve's cost reads, as `reference_path` [T+1, 4] (x, y, yaw, v_target) on the device."""
+        out = torch.empty(self._horizon + 1, 4, device=self._device, dtype=self._dtype)
+        self._h.call("mppi_get_reference", _ptr(out), self._horizon + 1, 1, self._stream())
+        return out
+
+    @property
+    def path_index(self) -> int:
+        """`racing_controller.current_path_index` as kept on the device (reading synchronises)."""
+        out = C.c_int32(0)
+        self._h.call("mppi_get_path_index", C.byref(out), self._stream())
+        return int(out.value)
+
+    @path_index.setter
+    def path_index(self, value: int) -> None:
+        self._h.call("mppi_set_path_index", int(value), self._stream())
+
     def inject_noise(self, eps: torch.Tensor) -> None:
         """Parity hook: use `eps` [N_local,T,dc] (already scaled by sigma) for the next solve instead of
         drawing it."""

@@ -1564,3 +1564,112 @@ def test_essps_device_search_equals_the_host_loop_on_random_costs():
             else:
                 want = brentq(lambda lam: ess(lam) - target, 0.01, 10.0, xtol=1e-12)
             assert abs(lam_dev.value - want) <= 2e-4 * want, (name, target, lam_dev.value, want)
+
+
+# ------------------------------------------------------------------------------ device-resident racing tick
+def _device_window(solver, ctrl, env, T, state, cind):
+    """calc_ref_trajectory through the library: (reference_path [T+1,4], path index)."""
+    solver.path_index = int(cind)
+    solver.update_reference_window(torch.as_tensor(np.asarray(state, np.float32)).cuda())
+    return solver.reference_window().cpu().numpy(), solver.path_index
+
+
+def test_device_reference_window_matches_fixtures_and_host():
+    """mppi_ref_window == racing_controller.calc_ref_trajectory (example/racing.py:161-218), bit for bit: the
+    reference's own (state, cind) -> (window, index) pairs, random vehicle positions (nearest-point search: first
+    minimum of the fp32 hypot), the monotone index guard, and the end of the course (last point repeated, whole speed
+    column zeroed)."""
+    env_np = None
+    for name in ("racing_T50_N512_fixed", "racing_T25_N256_fixed"):
+        g, T = load(name), CASES[name]["T"]
+        solver, ctrl = make_solver("racing", T, 256)
+        env = _envs["racing"]
+        env_np = env.racing_center_path.cpu().numpy()
+        solver.set_center_path(env_np, ctrl._window_offsets(T, 0.1, 3, 0.85), ctrl._v_max())
+        for k in range(3):
+            ref, ind = _device_window(solver, ctrl, env, T, g[f"x0_{k}"], int(g[f"cind_in_{k}"]))
+            assert np.array_equal(ref, g[f"ref_path_{k}"]) and ind == int(g[f"cind_out_{k}"])
+    rng = np.random.default_rng(11)
+    n = len(env_np)
+    for trial in range(60):
+        j = int(rng.integers(0, n))
+        s = np.zeros(4, np.float32)
+        s[:2] = env_np[j, :2] + rng.standard_normal(2).astype(np.float32) * (0.05 if trial % 3 else 6.0)
+        cind = int(rng.integers(0, n)) if trial % 4 == 0 else 0
+        ref_h, ind_h = ctrl.calc_ref_trajectory(torch.from_numpy(s), env.racing_center_path, cind, T, DL=0.1,
+                                                lookahead_distance=3, reference_path_interval=0.85)
+        ref_d, ind_d = _device_window(solver, ctrl, env, T, s, cind)
+        assert ind_d == ind_h and np.array_equal(ref_d, ref_h.numpy()), (trial, ind_d, ind_h)
+    # exact ties: a state ON a centre-line point and the midpoint of two neighbours
+    for s2 in (env_np[100, :2], 0.5 * (env_np[200, :2] + env_np[201, :2])):
+        s = np.array([s2[0], s2[1], 0, 0], np.float32)
+        ref_h, ind_h = ctrl.calc_ref_trajectory(torch.from_numpy(s), env.racing_center_path, 0, T, DL=0.1,
+                                                lookahead_distance=3, reference_path_interval=0.85)
+        ref_d, ind_d = _device_window(solver, ctrl, env, T, s, 0)
+        assert ind_d == ind_h and np.array_equal(ref_d, ref_h.numpy())
+    # past the end of the course
+    s = np.concatenate([env_np[n - 5, :3], [0.0]]).astype(np.float32)
+    ref_h, ind_h = ctrl.calc_ref_trajectory(torch.from_numpy(s), env.racing_center_path, n - 5, T, DL=0.1,
+                                            lookahead_distance=3, reference_path_interval=0.85)
+    ref_d, ind_d = _device_window(solver, ctrl, env, T, s, n - 5)
+    assert ind_d == ind_h and np.array_equal(ref_d, ref_h.numpy()) and float(np.abs(ref_d[:, 3]).max()) == 0.0
+
+
+def test_device_tick_equals_host_tick_in_a_closed_loop():
+    """The racing control loop (example/racing.py:221-266) with the tick resident on the device — reference window by
+    mppi_ref_window from the state in HBM, solve, plant step by mppi_model_step — against the host statement of the
+    same loop fed the same states: windows, path indices, costs and actions bit-identical every tick; the native plant
+    step within 1e-6 of the env's torch dynamics (src/envs/racing_env.py:142-163)."""
+    from envs.racing_controller import racing_controller
+    from envs.racing_env import RacingEnv
+
+    T, N, ticks = 50, 4096, 40
+    env = RacingEnv()
+    env_t = RacingEnv(native_step=False)
+    ctrls = []
+    for device_tick in (True, False):
+        c = racing_controller(env, horizon=T, num_samples=N, lambda_=1.0)
+        c.set_cost_map(env._obstacle_map, env._lane_map)
+        c.device_tick = device_tick
+        ctrls.append(c)
+    cd, ch = ctrls
+    state = env.reset().clone()
+    for k in range(ticks):
+        a_d, s_d = cd.update(state, env.racing_center_path)
+        a_h, s_h = ch.update(state, env.racing_center_path)
+        assert cd._window_on_device and not ch._window_on_device
+        assert np.array_equal(cd.reference_path.cpu().numpy(), ch.reference_path.numpy()), k
+        assert cd.current_path_index == ch.current_path_index
+        assert torch.equal(cd.solver._costs, ch.solver._costs), k
+        assert torch.equal(a_d, a_h) and torch.equal(s_d, s_h), k
+        env._robot_state = state.clone()
+        nxt, reached = env.step(a_d[0, :])          # one native launch
+        env_t._robot_state = state.clone()
+        nxt_t, reached_t = env_t.step(a_d[0, :])    # the torch ops of the plugin
+        assert rel_err(nxt.cpu().numpy(), nxt_t.cpu().numpy()) <= 1e-6
+        assert bool(reached) == bool(reached_t)
+        # the solver's own prediction of that step (batch-1 rollout, fast math) agrees to the parity tolerance
+        assert rel_err(s_d[0, 1].cpu().numpy(), nxt.cpu().numpy()) <= 1e-5
+        state = nxt
+    assert cd.current_path_index > 0 and float(state[3]) > 1.0  # the vehicle actually moved along the course
+    # switching a controller between the two ticks hands the path index over
+    ind = cd.current_path_index
+    cd.device_tick = False
+    cd.update(state, env.racing_center_path)
+    assert not cd._window_on_device and cd.current_path_index >= ind
+    cd.device_tick = True
+    cd.update(state, env.racing_center_path)
+    assert cd._window_on_device and cd.current_path_index >= ind
+
+
+def test_native_env_step_matches_torch_dynamics_nav2d():
+    from envs.navigation_2d import Navigation2DEnv
+
+    e1, e2 = Navigation2DEnv(), Navigation2DEnv(native_step=False)
+    rng = np.random.default_rng(5)
+    for _ in range(25):
+        u = torch.tensor(rng.uniform([-0.5, -1.5], [2.5, 1.5]).astype(np.float32)).cuda()
+        s1, r1 = e1.step(u)
+        s2, r2 = e2.step(u)
+        assert rel_err(s1.cpu().numpy(), s2.cpu().numpy()) <= 1e-6 and bool(r1) == bool(r2)
+        e2._robot_state = s1.clone()
