@@ -67,7 +67,8 @@ def main():
                     help="N > 1: after the timed run, also time a short run with the OTHER transport (nccl <-> p2p) and "
                          "report it as `exchange_alt` in the same line (off by default: the contract's line never depends "
                          "on the less-tested path)")
-    ap.add_argument("--math", type=int, default=1, help="1 = fast-path math (default), 0 = library math")
+    ap.add_argument("--math", type=int, default=2, help="2 = fast-path math with hardware sin/cos of the wrapped heading "
+                    "(default), 1 = fast-path math with polynomial sin/cos, 0 = library math")
     ap.add_argument("--noise-regen", type=int, default=1,
                     help="1 = regenerate the Philox noise in registers (default), 0 = materialise the noise tiles")
     ap.add_argument("--mapping", type=int, default=0, help="0 = lane per trajectory (default), 1 = the literal "
@@ -202,7 +203,7 @@ def main():
         # they were generated from by scripts/pmc_constants.py); a bench run cannot collect counters on itself.
         traffic, valu, traffic_src = None, None, None
         try:
-            if (N_local, T, args.math) == (1 << 20, 50, 1):
+            if (N_local, T, args.math) == (1 << 20, 50, 2):
                 pc = json.load(open(os.path.join(ROOT, "profiles", "pmc_constants.json")))
                 k = pc["rollout_regen" if args.noise_regen else "rollout_tiles"]
                 traffic = int((2 * k["fetch_kb"] + k["write_kb"]) * 1024)  # FETCH_SIZE doubled: gfx950 wide-read correction
@@ -223,7 +224,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "racing kinematic-bicycle MPPI solve (BASELINE configs[2]; configs[3] when n_gpus = 8)",
                        "num_samples_per_gpu": N_local, "num_samples_total": N_total, "horizon": T,
-                       "lambda": 1.0, "noise": "device philox4x32-10 (" + ("regenerated in registers" if args.noise_regen else "materialised tiles") + ")", "math": "fast" if args.math else "library",
+                       "lambda": 1.0, "noise": "device philox4x32-10 (" + ("regenerated in registers" if args.noise_regen else "materialised tiles") + ")", "math": {0: "library", 1: "fast (polynomial sin/cos)", 2: "fast (hardware sin/cos of the wrapped heading)"}[args.math],
                        "mapping": "lane-per-trajectory" if not args.mapping else "wavefront-per-trajectory",
                        "sharding": f"num_samples x{world}" if world > 1 else "none",
                        "exchange": ("peer-to-peer buffers (xGMI stores, polled)" if solver._p2p else "all_gather of 4+T*dc floats")
@@ -303,9 +304,10 @@ def time_other_exchange(args, torch, dist, env, T, N_total, ref, x0, mode):
 
 
 def closed_loop(torch, env, ctrl, T, N):
-    """The reference's racing control loop minus rendering (example/racing.py:221-266): every tick recomputes the
-    reference window on the host from the current state (calc_ref_trajectory: one device->host read of the state),
-    solves with the warm start of the previous tick, and applies a[0] through env.step (batch-1 torch dynamics)."""
+    """The reference's racing control loop minus rendering (example/racing.py:221-266), resident on the device: every tick
+    rebuilds the reference window from the state in HBM (mppi_ref_window: nearest centre-line point, monotone path index
+    kept on the device), solves with the warm start of the previous tick, and applies a[0] through env.step (one launch
+    of the library's racing functor, mppi_model_step).  No host synchronisation per tick."""
     state = env.reset()
     ctrl.current_path_index = 0
     ctrl.solver.reset()
@@ -327,8 +329,10 @@ def closed_loop(torch, env, ctrl, T, N):
     dt = time.perf_counter() - t0
     return {"ticks": ticks, "warmup_ticks": warm, "ms_per_tick": dt / ticks * 1e3, "solves_per_sec": ticks / dt,
             "sample_steps_per_sec": N * T * ticks / dt,
-            "host_ms_per_tick": {"controller.update (state read-back + reference window + solve enqueue)": t_upd / ticks * 1e3,
-                                 "env.step (batch-1 torch dynamics)": t_step / ticks * 1e3},
+            "device_resident_tick": bool(ctrl._window_on_device and env._native_step),
+            "host_enqueue_ms_per_tick": {"controller.update (reference-window kernel + solve)": t_upd / ticks * 1e3,
+                                         "env.step (one native launch)": t_step / ticks * 1e3},
+            "path_index_after": int(ctrl.current_path_index),
             "final_speed_mps": float(state[3]),
             "note": "open-loop `value` above times solves from a fixed state; here the state, the reference window and "
                     "the warm start change every tick"}

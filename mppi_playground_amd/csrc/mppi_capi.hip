@@ -92,7 +92,7 @@ struct MppiSolver {
     bool params_set = false;
     ModelCtx ctx{};
     // options
-    int math_fast = 1;
+    int math_fast = 2;
     int reduce_blocks = 512;
     int timing = 0;
     std::vector<hipEvent_t> ev_pool[4];  // per stage: start0, stop0, start1, stop1, ...
@@ -158,20 +158,24 @@ struct StageTimer {
     }
 };
 
-bool use_fast(mppi_handle_t h);
-// dispatch on (model, math variant)
+int math_level(mppi_handle_t h);
+// dispatch on (model, math level); level 2 exists for the models with wrapped-heading trigonometry only
+#define MPPI_DISPATCH_HW(MODEL_, CALL)                                                                \
+        case MODEL_: if (ml_ == 2) { CALL(MODEL_, 2); } else if (ml_ == 1) { CALL(MODEL_, 1); } else { CALL(MODEL_, 0); } break;
+#define MPPI_DISPATCH_NOHW(MODEL_, CALL)                                                              \
+        case MODEL_: if (ml_) { CALL(MODEL_, 1); } else { CALL(MODEL_, 0); } break;
 #define MPPI_DISPATCH(h, CALL)                                                                        \
     do {                                                                                              \
-        const bool fast_ = use_fast(h);                                                               \
+        const int ml_ = math_level(h);                                                                \
         switch ((h)->cfg.model) {                                                                     \
         case MPPI_MODEL_GENERIC: /* only reached by mppi_finalize without a state output */          \
-        case MPPI_MODEL_PENDULUM: if (fast_) { CALL(MPPI_MODEL_PENDULUM, true); } else { CALL(MPPI_MODEL_PENDULUM, false); } break; \
-        case MPPI_MODEL_CARTPOLE: if (fast_) { CALL(MPPI_MODEL_CARTPOLE, true); } else { CALL(MPPI_MODEL_CARTPOLE, false); } break; \
-        case MPPI_MODEL_MOUNTAINCAR: if (fast_) { CALL(MPPI_MODEL_MOUNTAINCAR, true); } else { CALL(MPPI_MODEL_MOUNTAINCAR, false); } break; \
-        case MPPI_MODEL_NAV2D: if (fast_) { CALL(MPPI_MODEL_NAV2D, true); } else { CALL(MPPI_MODEL_NAV2D, false); } break; \
-        case MPPI_MODEL_RACING: if (fast_) { CALL(MPPI_MODEL_RACING, true); } else { CALL(MPPI_MODEL_RACING, false); } break; \
-        case MPPI_MODEL_MJCARTPOLE: if (fast_) { CALL(MPPI_MODEL_MJCARTPOLE, true); } else { CALL(MPPI_MODEL_MJCARTPOLE, false); } break; \
-        case MPPI_MODEL_GOALZONE: if (fast_) { CALL(MPPI_MODEL_GOALZONE, true); } else { CALL(MPPI_MODEL_GOALZONE, false); } break; \
+        MPPI_DISPATCH_NOHW(MPPI_MODEL_PENDULUM, CALL)                                                 \
+        MPPI_DISPATCH_NOHW(MPPI_MODEL_CARTPOLE, CALL)                                                 \
+        MPPI_DISPATCH_NOHW(MPPI_MODEL_MOUNTAINCAR, CALL)                                              \
+        MPPI_DISPATCH_HW(MPPI_MODEL_NAV2D, CALL)                                                      \
+        MPPI_DISPATCH_HW(MPPI_MODEL_RACING, CALL)                                                     \
+        MPPI_DISPATCH_NOHW(MPPI_MODEL_MJCARTPOLE, CALL)                                               \
+        MPPI_DISPATCH_HW(MPPI_MODEL_GOALZONE, CALL)                                                   \
         }                                                                                             \
     } while (0)
 
@@ -186,6 +190,9 @@ bool use_fast(mppi_handle_t h) {
         return h->ctx.wrap_safe != 0 && h->ctx.u_in_bounds != 0 && h->ctx.maps[0].inv_cell != 0.0f && h->ctx.pad != nullptr && h->ctx.tan_small != 0 && h->ctx.inv_L != 0.0f;
     return true;
 }
+
+// 0 = library math; 1 = polynomial fast paths; 2 = 1 + hardware sin/cos of the wrapped headings (option "math")
+int math_level(mppi_handle_t h) { return use_fast(h) ? (h->math_fast >= 2 ? 2 : 1) : 0; }
 
 int check_ready(mppi_handle_t h) {
     const int m = h->cfg.model;
@@ -809,7 +816,7 @@ int mppi_rollout_cost(mppi_handle_t h, void* stream) {
 #define CALL_ROLLOUT(MODEL, FASTV)                                                                    \
     do {                                                                                              \
         const size_t shmem = sizeof(float) * ((size_t)8 * h->d.R + (size_t)h->d.T * ModelT<MODEL, FASTV>::KROW); \
-        constexpr bool UCV = FASTV;  /* the FAST kernels exist in the u_in_bounds form only (see use_fast) */ \
+        constexpr bool UCV = FASTV != 0;  /* the FAST kernels exist in the u_in_bounds form only (see use_fast) */ \
         if (gen)                                                                                      \
             hipLaunchKernelGGL((rollout_cost_kernel<MODEL, FASTV, true, UCV>), dim3(grid), dim3(BLOCK), shmem, s, \
                                h->noise, h->mean, h->x0_cur, h->costs, mk, mk_next, h->mean_used, h->x0_used, h->d, h->gen, h->ctx); \
@@ -1342,7 +1349,7 @@ int mppi_p2p_error(mppi_handle_t h) { return (h && h->p2p_error) ? *(volatile in
 int mppi_set_option(mppi_handle_t h, const char* key, int64_t value) {
     if (!h || !key) return MPPI_E_INVALID;
     const std::string k(key);
-    if (k == "math") { h->math_fast = value ? 1 : 0; return MPPI_OK; }
+    if (k == "math") { h->math_fast = value < 0 ? 0 : value > 2 ? 2 : (int)value; return MPPI_OK; }
     if (k == "reduce_blocks") { h->reduce_blocks = (int)std::max<int64_t>(1, std::min<int64_t>(value, 2048)); return MPPI_OK; }
     if (k == "timing") { h->timing = (int)value; return MPPI_OK; }
     if (k == "mapping") { h->mapping = value ? 1 : 0; return MPPI_OK; }

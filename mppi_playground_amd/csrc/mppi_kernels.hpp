@@ -71,6 +71,21 @@ __device__ __forceinline__ float wave_sum(float v) {
 // WIDE (generic handles whose dim_control is not 1, 2 or 4): the control index of a flat column depends on the
 // group, so sigma / bounds come from the per-column table `coltab` = {sigma[4R], lo[4R], hi[4R]} (built on the host,
 // zeros past the row) instead of the launch constants in Dims.
+// The two halves of gen_noise4 (the integer hash and the Box-Muller transform of its output), separately callable so
+// that the rollout loop can run them one group apart (software pipeline: see trajectory_cost).
+__device__ __forceinline__ u32x4 noise_bits(uint64_t gi, int r, const GenCtx& g) {
+    return philox4x32_10((uint32_t)gi, (uint32_t)(gi >> 32), (uint32_t)r, g.solve_idx, g.seed_lo, g.seed_hi);
+}
+template <bool WIDE = false>
+__device__ __forceinline__ float4 noise_from_bits(const u32x4& x, int r, const Dims& d,
+                                                  const float* __restrict__ sig_cols = nullptr) {
+    float z[4];
+    box_muller(x.x, x.y, z[0], z[1]);
+    box_muller(x.z, x.w, z[2], z[3]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) z[j] *= WIDE ? sig_cols[4 * r + j] : d.sigma[ctrl_index(j, d.dc)];
+    return make_float4(z[0], z[1], z[2], z[3]);
+}
 template <bool WIDE = false>
 __device__ __forceinline__ float4 gen_noise4(uint64_t gi, int r, const GenCtx& g, const Dims& d,
                                              const float* __restrict__ sig_cols = nullptr) {
@@ -137,7 +152,7 @@ __device__ __forceinline__ float4 noise_group(const float4* __restrict__ np, int
 // which scalar (SMEM) loads — out of order, lgkmcnt(0) only — do not allow.
 // UC: the solver's clamp range lies inside the model's own action clamp (compile-time so that the
 // second clamp disappears).
-template <int MODEL, bool FAST, bool GEN, bool UC>
+template <int MODEL, int FAST, bool GEN, bool UC>
 __device__ __forceinline__ float trajectory_cost(const float4* __restrict__ np, uint64_t gi, const GenCtx& gen,
                                                  const float4* mean4, const float* ktab,
                                                  const float* __restrict__ x0, const Dims& d, const ModelCtx& ctx,
@@ -148,7 +163,10 @@ __device__ __forceinline__ float trajectory_cost(const float4* __restrict__ np, 
     float s[DS], pu[DC], pl[DC];
 #pragma unroll
     for (int j = 0; j < DS; ++j) s[j] = x0[j];
-    if (FAST) M::check_state(ctx, s, bad);
+    if (FAST) {
+        M::check_state(ctx, s, bad);
+        M::enter(s);  // kinematic models: wrap the heading once; every later heading is a fixed point of that wrap
+    }
     // clamp bounds live in VGPRs: v_med3_f32 takes one SGPR operand only, and the compiler would
     // otherwise re-materialise the second bound with a v_mov in every step
     float lo[DC], hi[DC];
@@ -174,7 +192,7 @@ __device__ __forceinline__ float trajectory_cost(const float4* __restrict__ np, 
 #pragma unroll
         for (int k = 0; k < DC; ++k) u[k] = clampf(mv[k] + ev[k], lo[k], hi[k]);
         float sn[DS], ss[DS];
-        M::step(ctx, s, u, sn, ss, bad, UC);
+        M::step(ctx, s, u, sn, ss, bad, UC, FAST != 0);
         acc += M::cost(ctx, kcur, ss, u, pu, bad);
 #pragma unroll
         for (int k = 0; k < DC; ++k) { pl[k] = pu[k]; pu[k] = u[k]; }
@@ -195,14 +213,6 @@ __device__ __forceinline__ float trajectory_cost(const float4* __restrict__ np, 
             for (int g = 0; g < SPG; ++g) one_step(ev + g * DC, mv + g * DC);
             e = en;
             m4 = m4n;
-#if defined(MPPI_SCHED_TRANS)
-            // experiment: spread the transcendentals of the noise chain over the iteration (one per MPPI_SCHED_TRANS VALU)
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, MPPI_SCHED_TRANS, 0);
-            }
-#endif
         }
     } else {
         // Tiles: loads return in order (one vmcnt), so the first map gather consumed after a noise load also
@@ -241,7 +251,7 @@ __device__ __forceinline__ float trajectory_cost(const float4* __restrict__ np, 
 #ifndef MPPI_ROLLOUT_ATTR
 #define MPPI_ROLLOUT_ATTR  // e.g. __attribute__((amdgpu_waves_per_eu(8))) for occupancy experiments
 #endif
-template <int MODEL, bool FAST, bool GEN, bool UC>
+template <int MODEL, int FAST, bool GEN, bool UC>
 __global__ __launch_bounds__(BLOCK) MPPI_ROLLOUT_ATTR void rollout_cost_kernel(const float4* __restrict__ noise,
                                                              const float* __restrict__ mean,
                                                              const float* __restrict__ x0,
@@ -286,7 +296,7 @@ __global__ __launch_bounds__(BLOCK) MPPI_ROLLOUT_ATTR void rollout_cost_kernel(c
         if (FAST) {
             if (bad) {  // a fast path left its validity range: redo this lane with the library math
                 bool ignore = false;
-                total = trajectory_cost<MODEL, false, GEN, false>(np, gi, gen, mp, s_ktab, x0, d, ctx, ignore);
+                total = trajectory_cost<MODEL, 0, GEN, false>(np, gi, gen, mp, s_ktab, x0, d, ctx, ignore);
             }
         }
         if (i < d.N) costs[i] = total;
@@ -312,7 +322,7 @@ __global__ __launch_bounds__(BLOCK) MPPI_ROLLOUT_ATTR void rollout_cost_kernel(c
 // cost) and a wavefront shuffle reduction sums them.  Same model functors, same results up to the
 // summation order of the T+1 stage costs.  Measured 20x slower than the lane-per-trajectory mapping
 //  because the recurrence runs on 1/64 of the machine.
-template <int MODEL, bool FAST>
+template <int MODEL, int FAST>
 __global__ __launch_bounds__(BLOCK) void rollout_cost_wave_kernel(const float* __restrict__ eps_std,
                                                                   const float* __restrict__ mean,
                                                                   const float* __restrict__ x0,
@@ -675,7 +685,7 @@ __global__ __launch_bounds__(SUM_BLOCK) void summarize_kernel(const float* __res
 
 // One trajectory rolled out from explicit actions (reference layout row) or from noise, writing the
 // states the reference would leave in its state buffer.  GETU(t, u) fills the action of step t.
-template <int MODEL, bool FAST, class GETU>
+template <int MODEL, int FAST, class GETU>
 __device__ __forceinline__ bool rollout_states(const float* __restrict__ x0, int T, const ModelCtx& ctx,
                                                float* __restrict__ out, GETU getu) {
     using M = ModelT<MODEL, FAST>;
@@ -696,12 +706,12 @@ __device__ __forceinline__ bool rollout_states(const float* __restrict__ x0, int
     for (int j = 0; j < DS; ++j) out[T * DS + j] = s[j];
     return bad;
 }
-template <int MODEL, bool FAST, class GETU>
+template <int MODEL, int FAST, class GETU>
 __device__ __forceinline__ void rollout_states_checked(const float* __restrict__ x0, int T, const ModelCtx& ctx,
                                                        float* __restrict__ out, GETU getu) {
     const bool bad = rollout_states<MODEL, FAST>(x0, T, ctx, out, getu);
     if (FAST) {
-        if (bad) (void)rollout_states<MODEL, false>(x0, T, ctx, out, getu);
+        if (bad) (void)rollout_states<MODEL, 0>(x0, T, ctx, out, getu);
     }
 }
 
@@ -754,7 +764,7 @@ __global__ __launch_bounds__(BLOCK) void p2p_collect_kernel(P2pCtx x, int len, f
 // the host's hint for the next solve).  A timed-out peer-to-peer poll voids the outputs (NaN) instead of
 // returning a partial combine.
 constexpr int FIN_BLOCK = 1024;
-template <int MODEL, bool FAST>
+template <int MODEL, int FAST>
 __global__ __launch_bounds__(FIN_BLOCK) void finalize_kernel(const float* __restrict__ summaries, int num_shards,
                                                              const float* __restrict__ partials,
                                                              const float* __restrict__ heads,
@@ -922,7 +932,7 @@ __global__ __launch_bounds__(FIN_BLOCK) void finalize_kernel(const float* __rest
             bool bad = false;
             ModelT<MODEL, FAST>::rollout_wave(ctx, s_x0, s_act, T, state_out, bad);
             if (__ballot(bad) != 0ull && threadIdx.x == 0)  // left a fast-path validity range: library math
-                (void)rollout_states<MODEL, false>(s_x0, T, ctx, state_out, getu);
+                (void)rollout_states<MODEL, 0>(s_x0, T, ctx, state_out, getu);
             return;
         }
     }
@@ -1137,7 +1147,7 @@ __global__ __launch_bounds__(BLOCK) void weights_kernel(const float* __restrict_
 }
 
 // `_states_prediction` (mppi.py:508-524) for k action sequences in the reference layout.
-template <int MODEL, bool FAST>
+template <int MODEL, int FAST>
 __global__ __launch_bounds__(WAVE) void rollout_actions_kernel(const float* __restrict__ actions, int k, int T,
                                                                const float* __restrict__ x0,
                                                                float* __restrict__ states, ModelCtx ctx) {
@@ -1153,7 +1163,7 @@ __global__ __launch_bounds__(WAVE) void rollout_actions_kernel(const float* __re
 }
 
 // `_state_seq_batch[idx]` (mppi.py:481) re-rolled from the resident noise.
-template <int MODEL, bool FAST>
+template <int MODEL, int FAST>
 __global__ __launch_bounds__(WAVE) void rollout_samples_kernel(const float4* __restrict__ noise,
                                                                const float* __restrict__ mean,
                                                                const int64_t* __restrict__ idx, int k,
@@ -1291,7 +1301,7 @@ __global__ __launch_bounds__(BLOCK) void topk_collect_kernel(const float* __rest
     }
 }
 
-template <int MODEL, bool FAST>
+template <int MODEL, int FAST>
 __global__ __launch_bounds__(TOPK_MAX) void topk_rollout_kernel(const unsigned long long* __restrict__ cand, int k,
                                                                 const float4* __restrict__ noise, bool gen_noise,
                                                                 const float* __restrict__ mean,

@@ -90,24 +90,45 @@ MPPI_HD float clampf(float x, float lo, float hi) {
 #pragma clang fp contract(off)
 #endif
 #define MPPI_MODEL_NS strict
+#define MPPI_MODEL_HWTRIG false
 #include "mppi_models.inc"
 #undef MPPI_MODEL_NS
+#undef MPPI_MODEL_HWTRIG
+//   mppi::fused_hw — as mppi::fused, with sin/cos of the WRAPPED HEADINGS of the kinematic models (racing, nav2d,
+//                  goal zone: the `CHECK = false` call sites of sincos_f, argument in [-pi, pi)) evaluated by the
+//                  hardware v_sin_f32 / v_cos_f32 (argument in revolutions): measured max abs error 2.7e-7 against
+//                  7.8e-8 of the polynomials (scripts/ubench/hw_sincos_acc.hip) — below half an ulp of any position
+//                  beyond 4 m — for 3 instead of 24 instructions per step.  Device only.
 #if defined(__clang__)
 #pragma clang fp contract(fast)
 #endif
 #define MPPI_MODEL_NS fused
+#define MPPI_MODEL_HWTRIG false
 #include "mppi_models.inc"
 #undef MPPI_MODEL_NS
+#undef MPPI_MODEL_HWTRIG
+#if defined(__HIPCC__)
+#define MPPI_MODEL_NS fused_hw
+#define MPPI_MODEL_HWTRIG true
+#include "mppi_models.inc"
+#undef MPPI_MODEL_NS
+#undef MPPI_MODEL_HWTRIG
+#endif
 #if defined(__clang__)
 #pragma clang fp contract(off)
 #endif
 
 namespace mppi {
-// FAST selects both the math variant and the contraction variant
-template <int MODEL, bool FAST>
+// The math level selects the functor: 0 = library math, unfused (the reference's operation order);
+// 1 = range-checked fast paths, fused; 2 = level 1 + hardware sin/cos for the wrapped headings.
+template <int MODEL, int MATH>
 struct ModelSel { using type = strict::Model<MODEL, false>; };
 template <int MODEL>
-struct ModelSel<MODEL, true> { using type = fused::Model<MODEL, true>; };
-template <int MODEL, bool FAST>
-using ModelT = typename ModelSel<MODEL, FAST>::type;
+struct ModelSel<MODEL, 1> { using type = fused::Model<MODEL, true>; };
+#if defined(__HIPCC__)
+template <int MODEL>
+struct ModelSel<MODEL, 2> { using type = fused_hw::Model<MODEL, true>; };
+#endif
+template <int MODEL, int MATH>
+using ModelT = typename ModelSel<MODEL, MATH>::type;
 }  // namespace mppi

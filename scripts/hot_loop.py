@@ -6,7 +6,7 @@ import collections
 import re
 import sys
 
-KERNEL = "_ZN4mppi19rollout_cost_kernelILi4ELb1ELb1ELb1EEE"
+KERNEL = "_ZN4mppi19rollout_cost_kernelILi4ELi2ELb1ELb1EEE"
 TRANS = r"v_(log|sqrt|sin|cos|rcp|rsq|exp)_"
 
 

@@ -133,7 +133,7 @@ LAMBDA_TOL = {"ESSPS": 1e-4, "MPO": 1e-4}  # LBPS: same_lbps_minimum()
 
 
 # ------------------------------------------------------------------------------ whole solve vs oracle / golden
-@pytest.mark.parametrize("math", [1, 0])
+@pytest.mark.parametrize("math", [2, 1, 0])  # 2 = default (hardware sin/cos of the wrapped headings), 1 = polynomials, 0 = library
 @pytest.mark.parametrize("name", list(CASES))
 def test_forward_parity(name, math):
     cfg, g = CASES[name], load(name)
@@ -1284,7 +1284,7 @@ def test_randomised_model_parameters_against_oracle(seed):
     eps = (rng.standard_normal((N, T, 2)) * scale).astype(np.float32)
     P = orc.Problem(model, N, T, u_min, u_max, params=params, maps=maps, ref_path=ref)
     r = P.rollout_cost(x0, mean, eps, want_margin=True)
-    for math in (1, 0):
+    for math in (2, 1, 0):
         c, a, s = _capi_rollout(model, T, N, params, maps, u_min, u_max, x0, mean, eps, ref, math)
         check_costs(c, r, max_flips=3 + N // 50)
         w, _ = orc.softmax_weights(c, 3.0)

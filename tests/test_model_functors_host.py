@@ -127,3 +127,23 @@ def test_markstein_division_is_correctly_rounded(cell):
     L.emul_div_cell(_p(x), _p(y0), x.size, cell, 0)
     L.emul_div_cell(_p(x), _p(y1), x.size, cell, 1)
     assert np.array_equal(y0, y1)
+
+
+def test_entry_wrap_is_the_identity_on_wrapped_headings():
+    """rewrap_f(t) == t for every t = fl(r - pi), r a float in [0, 2 pi] — what lets the fast kinematic steps skip their
+    entry wrap after the first one (mppi_models.inc: rewrap_f, Model::enter).  All 1 086 918 620 floats of the range were
+    checked once (same loop, step 1); here every 61st of them plus both ends and the neighbourhoods of 0, pi/2, pi."""
+    PI, TWO = F32(3.14159274), F32(6.28318548)
+    hi = int(np.array([TWO], F32).view(np.uint32)[0])
+    bits = np.concatenate([np.arange(0, hi + 1, 61, dtype=np.uint32), np.arange(0, 4096, dtype=np.uint32),
+                           np.arange(hi - 4096, hi + 1, dtype=np.uint32)] +
+                          [np.arange(int(np.array([v], F32).view(np.uint32)[0]) - 2048,
+                                     int(np.array([v], F32).view(np.uint32)[0]) + 2048, dtype=np.uint32)
+                           for v in (PI / 2, PI, 1.5 * PI, 1e-3, 1.0)])
+    r = bits.view(F32)
+    t1 = r - PI
+    assert np.array_equal((t1 + PI) - PI, t1)
+    x = np.ascontiguousarray(t1[::997])  # the product's own function (host build of the functors) agrees
+    fast, lib = np.empty_like(x), np.empty_like(x)
+    emul.lib().emul_loop_wraps(_p(x), _p(fast), _p(lib), len(x), 0)
+    assert np.array_equal(fast, x)
