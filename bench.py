@@ -60,13 +60,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--samples", type=int, default=1 << 20, help="samples per GPU")
     ap.add_argument("--horizon", type=int, default=50)
-    ap.add_argument("--exchange", choices=("nccl", "p2p", "auto"), default="nccl",
-                    help="per-solve exchange of the shard summaries at N > 1: one RCCL all_gather (default), the "
-                         "library's peer-to-peer buffers, or auto (buffers when their self-test passes on every rank)")
-    ap.add_argument("--both-exchanges", action="store_true",
-                    help="N > 1: after the timed run, also time a short run with the OTHER transport (nccl <-> p2p) and "
-                         "report it as `exchange_alt` in the same line (off by default: the contract's line never depends "
-                         "on the less-tested path)")
+    ap.add_argument("--exchange", choices=("nccl", "rccl", "p2p", "auto"), default="nccl",
+                    help="per-solve exchange of the shard summaries at N > 1 for the timed run: one RCCL all_gather through "
+                         "torch.distributed (default), the library's own RCCL communicator on the solve's stream (rccl), the "
+                         "library's peer-to-peer buffers (p2p), or auto (rccl when its self-test passes on every rank)")
+    ap.add_argument("--no-alt-exchanges", action="store_true",
+                    help="N > 1: skip the short runs of the OTHER transports after the timed run (reported as "
+                         "`exchange_alt`; they run behind a wall-clock guard, so a transport that hangs cannot lose the "
+                         "timed result)")
+    ap.add_argument("--alt-budget-s", type=float, default=90.0, help="wall-clock guard of the alternative-transport runs")
     ap.add_argument("--math", type=int, default=2, help="2 = fast-path math with hardware sin/cos of the wrapped heading "
                     "(default), 1 = fast-path math with polynomial sin/cos, 0 = library math")
     ap.add_argument("--noise-regen", type=int, default=1,
@@ -179,15 +181,20 @@ def main():
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    alt = None
-    if world > 1 and args.both_exchanges:
-        alt = time_other_exchange(args, torch, dist, env, T, N_total, ref, x0, "p2p" if not solver._p2p else "nccl")
     assert torch.isfinite(a).all() and torch.isfinite(s).all()
+    used = "p2p" if solver._p2p else "rccl" if solver._comm else "nccl"
+    alt_state = {"alt": None, "printed": False}
 
     ms_per_step = dt / args.steps * 1e3
     solves_per_s = args.steps / dt
     value = N_total * T * solves_per_s
 
+    def emit(out):
+        if not alt_state["printed"]:
+            alt_state["printed"] = True
+            print(json.dumps(out), flush=True)
+
+    out = None
     if rank == 0:
         dc = 2
         # algorithmic bytes: per sample-step 4*dc B noise written by the sampler, read by the
@@ -227,8 +234,9 @@ def main():
                        "lambda": 1.0, "noise": "device philox4x32-10 (" + ("regenerated in registers" if args.noise_regen else "materialised tiles") + ")", "math": {0: "library", 1: "fast (polynomial sin/cos)", 2: "fast (hardware sin/cos of the wrapped heading)"}[args.math],
                        "mapping": "lane-per-trajectory" if not args.mapping else "wavefront-per-trajectory",
                        "sharding": f"num_samples x{world}" if world > 1 else "none",
-                       "exchange": ("peer-to-peer buffers (xGMI stores, polled)" if solver._p2p else "all_gather of 4+T*dc floats")
-                       if world > 1 else "none",
+                       "exchange": {"p2p": "peer-to-peer buffers (xGMI stores, polled)",
+                                    "rccl": "ncclAllGather of 4+T*dc floats issued by the library on the solve's stream",
+                                    "nccl": "torch.distributed all_gather of 4+T*dc floats"}[used] if world > 1 else "none",
                        "exchange_requested": args.exchange if world > 1 else None,
                        "backend": backend, "ranks_share_one_device": one_device and world > 1},
             "solves_per_sec": solves_per_s,
@@ -246,8 +254,7 @@ def main():
         }
         if t_exchange_ms is not None:
             out["stages_ms"]["exchange_and_handoffs"] = t_exchange_ms
-        if alt is not None:
-            out["exchange_alt"] = alt
+            out["exchange_us"] = t_exchange_ms * 1e3  # per solve: wall time minus the device stages (instrumented pass)
         if valu is not None:
             out["valu_roofline"] = valu
         if world == 1 and not args.no_extras:
@@ -258,23 +265,50 @@ def main():
             del solver, ctrl
             torch.cuda.empty_cache()
             out["cpu_baseline_torch"] = cpu_baseline_torch(torch, np, T)
-        print(json.dumps(out), flush=True)
+    if world > 1 and not args.no_alt_exchanges:
+        # The other transports, each a short run, behind a wall-clock guard: if one of them hangs (they have never
+        # crossed a device boundary before the first multi-GPU run), every rank's watchdog ends the process after rank 0
+        # printed the timed result with what was collected so far.
+        import threading
+
+        def watchdog():
+            if rank == 0:
+                out["exchange_alt"] = (alt_state["alt"] or []) + [{"error": f"alternative transports exceeded {args.alt_budget_s:.0f} s"}]
+                emit(out)
+            os._exit(0)
+
+        timer = threading.Timer(args.alt_budget_s, watchdog)
+        timer.daemon = True
+        timer.start()
+        alts = []
+        alt_state["alt"] = alts
+        for mode in [m for m in ("nccl", "rccl", "p2p") if m != used]:
+            r = time_other_exchange(args, torch, dist, env, T, N_total, ref, x0, mode)
+            if "ms_per_step" in r:
+                r["us_vs_timed_run"] = (r["ms_per_step"] - dt / args.steps * 1e3) * 1e3
+            alts.append(r)
+        timer.cancel()
+        if rank == 0:
+            out["exchange_alt"] = alts
+    if rank == 0:
+        emit(out)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
 def time_other_exchange(args, torch, dist, env, T, N_total, ref, x0, mode):
-    """A second sharded solver on the other transport, min(steps, 50) solves after 20 warm-up: {exchange, ms_per_step}
-    or {exchange, error}.  Every rank takes the same branch (the transport's self-test is collective)."""
+    """A second sharded solver on another transport, min(steps, 50) solves after 20 warm-up: {exchange, ms_per_step,
+    } or {exchange, error}; the caller adds `us_vs_timed_run`, the difference to the timed run's solve.  Every rank takes
+    the same branch (the transports' self-tests are collective)."""
     from envs.racing_controller import racing_controller
     from mppi_playground_amd import _capi
 
     os.environ["MPPI_EXCHANGE"] = mode
     try:
         ctrl = racing_controller(env, horizon=T, num_samples=N_total, lambda_=1.0, shard_samples=True)
-    except _capi.MppiError as e:
-        return {"exchange": mode, "error": str(e)}
+    except (_capi.MppiError, RuntimeError) as e:
+        return {"exchange": mode, "error": str(e)[:300]}
     finally:
         os.environ["MPPI_EXCHANGE"] = args.exchange
     ctrl.set_cost_map(env._obstacle_map, env._lane_map)
@@ -299,8 +333,8 @@ def time_other_exchange(args, torch, dist, env, T, N_total, ref, x0, mode):
         return {"exchange": mode, "error": str(e)}
     t = torch.tensor([dt], device="cuda", dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return {"exchange": "peer-to-peer buffers" if s._p2p else "all_gather", "steps": n,
-            "ms_per_step": float(t.item()) / n * 1e3, "finite": ok}
+    ms = float(t.item()) / n * 1e3
+    return {"exchange": "p2p" if s._p2p else "rccl" if s._comm else "nccl", "steps": n, "ms_per_step": ms, "finite": ok}
 
 
 def closed_loop(torch, env, ctrl, T, N):

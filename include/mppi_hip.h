@@ -101,7 +101,7 @@ typedef struct MppiConfig {
 const char* mppi_version(void);
 /* Integer version of THIS header's function signatures; bindings compare it with the constant they were written
  * against and refuse a stale library (a changed argument list would otherwise be called with shifted arguments). */
-#define MPPI_ABI_VERSION 3
+#define MPPI_ABI_VERSION 4
 int mppi_abi_version(void);
 /* Number of visible HIP devices (0 => the product cannot run; callers must fail loudly). */
 int mppi_device_count(void);
@@ -312,6 +312,23 @@ int mppi_top_samples(mppi_handle_t h, int k, float lambda, float* states_out_dev
 int mppi_top_candidates(mppi_handle_t h, int k, uint64_t* cand_out_dev, void* stream);
 int mppi_rollout_candidates(mppi_handle_t h, const uint64_t* cand_dev, int k, float lambda, float* states_out_dev,
                             float* weights_out_dev, void* stream);
+
+/* In-library collective for sharded solves (variant A: one all_gather of the 4+T*dc-float shard summaries; the
+ * reference has no counterpart, src/pi_mpc/mppi.py:102-105 is single-device).  One process per GPU; RCCL is dlopen()ed
+ * (librccl.so.1) on first use, so unsharded callers do not need it.
+ *   mppi_comm_unique_id  ncclGetUniqueId on ONE rank: id_out128 [128 bytes]; hand it to every rank by any host channel
+ *   mppi_comm_init       ncclCommInitRank(world, rank, id) for this handle's device — collective over the job's ranks
+ *   mppi_comm_exchange   one stand-alone all_gather (self-test): data_dev [4+T*dc] -> gathered_out_dev [world][4+T*dc];
+ *                        synchronises
+ *   option "exchange_comm" = 1: mppi_weights_reduce (summary_out_dev = NULL) ends with ncclAllGather on ITS OWN stream —
+ *                        no process-group stream, no events — and mppi_finalize called with summaries_dev = NULL combines
+ *                        all `world` shards; a sharded solve is then the same single call as an unsharded one
+ *                        (mppi_solve).  Every rank must issue the same sequence of solves.
+ *   mppi_comm_destroy    ncclCommDestroy (also done by mppi_destroy). */
+int mppi_comm_unique_id(void* id_out128);
+int mppi_comm_init(mppi_handle_t h, int world, int rank, const void* id128);
+int mppi_comm_exchange(mppi_handle_t h, const float* data_dev, float* gathered_out_dev, void* stream);
+int mppi_comm_destroy(mppi_handle_t h);
 
 /* Peer-to-peer exchange of the shard summaries (one process per GPU, same node): instead of an all_gather between
  * mppi_weights_reduce and mppi_finalize, every rank stores its 4+T*dc summary straight into all peers' exchange

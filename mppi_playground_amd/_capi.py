@@ -22,7 +22,7 @@ SUMMARY_HEAD = 4
 LAMBDA_DEVICE = -1.0  # MPPI_LAMBDA_DEVICE: "the temperature mppi_essps_lambda_device left on the device"
 
 # every symbol include/mppi_hip.h declares
-ABI_VERSION = 3  # MPPI_ABI_VERSION of the header this binding was written against
+ABI_VERSION = 4  # MPPI_ABI_VERSION of the header this binding was written against
 
 SYMBOLS = [
     "mppi_version", "mppi_abi_version", "mppi_device_count", "mppi_last_error", "mppi_create", "mppi_destroy", "mppi_set_control_limits",
@@ -32,7 +32,7 @@ SYMBOLS = [
     "mppi_get_costs", "mppi_set_costs", "mppi_weights_reduce", "mppi_finalize", "mppi_solve", "mppi_set_sg_filter", "mppi_get_sg_history", "mppi_softmax_stats", "mppi_softmax_stats_multi", "mppi_essps_lambda", "mppi_essps_lambda_device", "mppi_get_lambda", "mppi_lbps_lambda", "mppi_mpo_reset", "mppi_mpo_step", "mppi_mpo_state", "mppi_weights", "mppi_sample_posterior",
     "mppi_p2p_alloc", "mppi_p2p_connect", "mppi_p2p_exchange", "mppi_p2p_error", "mppi_rollout_actions", "mppi_rollout_samples", "mppi_top_samples", "mppi_top_candidates", "mppi_rollout_candidates", "mppi_set_option", "mppi_get_timing",
     "mppi_set_center_path", "mppi_ref_window", "mppi_set_path_index", "mppi_get_path_index", "mppi_get_reference",
-    "mppi_model_step",
+    "mppi_model_step", "mppi_comm_unique_id", "mppi_comm_init", "mppi_comm_exchange", "mppi_comm_destroy",
 ]
 
 
@@ -123,6 +123,10 @@ def load():
     lib.mppi_get_path_index.argtypes = [vp, vp, vp]
     lib.mppi_get_reference.argtypes = [vp, vp, i32, i32, vp]
     lib.mppi_model_step.argtypes = [i32, vp, i32, vp, vp, vp, vp, vp, vp, f32, vp, vp]
+    lib.mppi_comm_unique_id.argtypes = [vp]
+    lib.mppi_comm_init.argtypes = [vp, i32, i32, vp]
+    lib.mppi_comm_exchange.argtypes = [vp, vp, vp, vp]
+    lib.mppi_comm_destroy.argtypes = [vp]
     lib.mppi_set_option.argtypes = [vp, C.c_char_p, i64]
     lib.mppi_get_timing.argtypes = [vp, vp]
     for name in SYMBOLS:

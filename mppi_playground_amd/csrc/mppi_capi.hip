@@ -2,6 +2,8 @@
 // Host-side state only: buffers, model context, launch geometry.  No torch, no exceptions across
 // the boundary.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and prototypes only: the library is dlopen()ed when a communicator is asked for
 
 #include <cmath>
 #include <cstdio>
@@ -65,6 +67,12 @@ struct MppiSolver {
     int p2p_world = 0, p2p_rank = 0, p2p_lenp = 0;
     unsigned p2p_seq = 0;
     bool p2p_connected = false, p2p_enabled = false;
+    // in-library collective (mppi_comm_*): one ncclAllGather of the shard summaries on the solve's own stream
+    ncclComm_t comm = nullptr;
+    int comm_world = 0, comm_rank = 0;
+    float* comm_send = nullptr;      // [4 + T*dc] this shard's summary (written by summarize_kernel)
+    float* comm_recv = nullptr;      // [world][4 + T*dc]
+    bool comm_enabled = false;
     float* sg_coeffs = nullptr;      // Savitzky-Golay taps (device), window sg_window (0 = filter off)
     float* sg_history = nullptr;     // [T-1][dc] `_actions_history_for_sg` (mppi.py:160-166,441-443)
     int sg_window = 0;
@@ -278,6 +286,39 @@ bool fold_fits(mppi_handle_t h) {
     return finalize_lds_floats(h, 1, 255 /* widest filter */, true) * sizeof(float) <= 64 * 1024;
 }
 
+// RCCL through dlopen: the library stays loadable (and every unsharded path usable) on a host without RCCL.  In a
+// process that already holds a librccl.so.1 (PyTorch bundles one) the loader hands back that copy.
+struct RcclApi {
+    decltype(&ncclGetUniqueId) get_unique_id = nullptr;
+    decltype(&ncclCommInitRank) comm_init_rank = nullptr;
+    decltype(&ncclCommDestroy) comm_destroy = nullptr;
+    decltype(&ncclAllGather) all_gather = nullptr;
+    decltype(&ncclGetErrorString) error_string = nullptr;
+    bool ok = false;
+};
+const RcclApi& rccl() {
+    static const RcclApi api = [] {
+        RcclApi a;
+        void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) return a;
+        a.get_unique_id = reinterpret_cast<decltype(a.get_unique_id)>(dlsym(lib, "ncclGetUniqueId"));
+        a.comm_init_rank = reinterpret_cast<decltype(a.comm_init_rank)>(dlsym(lib, "ncclCommInitRank"));
+        a.comm_destroy = reinterpret_cast<decltype(a.comm_destroy)>(dlsym(lib, "ncclCommDestroy"));
+        a.all_gather = reinterpret_cast<decltype(a.all_gather)>(dlsym(lib, "ncclAllGather"));
+        a.error_string = reinterpret_cast<decltype(a.error_string)>(dlsym(lib, "ncclGetErrorString"));
+        a.ok = a.get_unique_id && a.comm_init_rank && a.comm_destroy && a.all_gather && a.error_string;
+        return a;
+    }();
+    return api;
+}
+#define RCCL_TRY(h, expr)                                                                             \
+    do {                                                                                              \
+        ncclResult_t _r = (expr);                                                                     \
+        if (_r != ncclSuccess)                                                                        \
+            return fail(h, MPPI_E_HIP, std::string(#expr) + ": " + rccl().error_string(_r));          \
+    } while (0)
+
 P2pCtx p2p_ctx(mppi_handle_t h) {
     return P2pCtx{h->p2p_peers_dev, h->p2p_local, h->p2p_error_dev, h->p2p_world, h->p2p_rank, h->p2p_lenp, h->p2p_seq};
 }
@@ -423,6 +464,8 @@ int mppi_destroy(mppi_handle_t h) {
     (void)hipFree(h->map_pad); (void)hipFree(h->stats_part); (void)hipFree(h->noise_std);
     if (h->stats_host) (void)hipHostFree(h->stats_host);
     if (h->live_hint) (void)hipHostFree(h->live_hint);
+    if (h->comm) (void)rccl().comm_destroy(h->comm);
+    (void)hipFree(h->comm_send); (void)hipFree(h->comm_recv);
     for (void* pm : h->p2p_opened) (void)hipIpcCloseMemHandle(pm);
     (void)hipFree(h->p2p_local); (void)hipFree(h->p2p_peers_dev);
     if (h->p2p_error) (void)hipHostFree(h->p2p_error);
@@ -901,13 +944,17 @@ int mppi_weights_reduce(mppi_handle_t h, float lambda, float* summary_out_dev, v
         p2p = p2p_ctx(h);
     }
     const bool many_rows = h->fold_mode == 0 ? *(volatile int*)h->live_hint > FOLD_IN_FINALIZE_MAX_ROWS : h->fold_mode == 2;
-    if (summary_out_dev || h->p2p_enabled || !fold_fits(h) || many_rows) {
+    const bool comm = h->comm_enabled && !h->p2p_enabled;
+    if (comm && summary_out_dev) return fail(h, MPPI_E_INVALID, "exchange_comm: the library gathers the summaries itself (pass NULL)");
+    if (summary_out_dev || h->p2p_enabled || comm || !fold_fits(h) || many_rows) {
         const unsigned sgrid = (unsigned)((h->colsp + SUM_COLS - 1) / SUM_COLS + 1);
         hipLaunchKernelGGL(summarize_kernel, dim3(sgrid), dim3(SUM_BLOCK), 0, s, h->partials, h->heads, mk, (int)blocks,
-                           h->colsp, h->d.row, h->summary, summary_out_dev, h->live_hint_dev, p2p);
+                           h->colsp, h->d.row, h->summary, comm ? h->comm_send : summary_out_dev, h->live_hint_dev, p2p);
         HIP_TRY(h, hipGetLastError());
         h->summary_valid = true;
     }
+    if (comm)  // the solve's only exchange: 4 + T*dc floats per rank, on the solve's own stream
+        RCCL_TRY(h, rccl().all_gather(h->comm_send, h->comm_recv, (size_t)(MPPI_SUMMARY_HEAD + h->d.row), ncclFloat, h->comm, s));
     return MPPI_OK;
 }
 
@@ -927,6 +974,9 @@ int mppi_finalize(mppi_handle_t h, const float* summaries_dev, int num_shards, f
         if (h->p2p_enabled) {
             p2p = p2p_ctx(h);  // all shards' summaries of this solve, through the exchange buffer
             num_shards = h->p2p_world;
+        } else if (h->comm_enabled) {
+            summaries_dev = h->comm_recv;  // gathered by mppi_weights_reduce
+            num_shards = h->comm_world;
         } else {
             if (h->summary_valid) summaries_dev = h->summary;  // else the kernel folds the partial rows itself
             num_shards = 1;
@@ -1278,6 +1328,46 @@ int mppi_rollout_candidates(mppi_handle_t h, const uint64_t* cand_dev, int k, fl
                         false, (hipStream_t)stream);
 }
 
+// ---- in-library collective: RCCL all_gather of the shard summaries on the solve's stream (SURVEY 8e variant A)
+int mppi_comm_unique_id(void* id_out128) {
+    if (!id_out128) return MPPI_E_INVALID;
+    if (!rccl().ok) return MPPI_E_STATE;
+    static_assert(sizeof(ncclUniqueId) == 128, "unique id size");
+    return rccl().get_unique_id(reinterpret_cast<ncclUniqueId*>(id_out128)) == ncclSuccess ? MPPI_OK : MPPI_E_HIP;
+}
+
+int mppi_comm_init(mppi_handle_t h, int world, int rank, const void* id128) {
+    if (!h || !id128 || world < 1 || rank < 0 || rank >= world) return fail(h, MPPI_E_INVALID, "bad comm arguments");
+    if (h->comm) return fail(h, MPPI_E_STATE, "communicator already initialised");
+    if (!rccl().ok) return fail(h, MPPI_E_STATE, "librccl.so.1 not found (or incomplete): no in-library collective");
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof(id));
+    const size_t len = (size_t)(MPPI_SUMMARY_HEAD + h->d.row);
+    HIP_TRY(h, hipMalloc(&h->comm_send, sizeof(float) * len));
+    HIP_TRY(h, hipMalloc(&h->comm_recv, sizeof(float) * len * (size_t)world));
+    RCCL_TRY(h, rccl().comm_init_rank(&h->comm, world, id, rank));  // collective: every rank of the job calls it
+    h->comm_world = world; h->comm_rank = rank;
+    return MPPI_OK;
+}
+
+int mppi_comm_destroy(mppi_handle_t h) {
+    if (!h) return MPPI_E_INVALID;
+    h->comm_enabled = false;
+    if (h->comm) { HIP_TRY(h, hipDeviceSynchronize()); (void)rccl().comm_destroy(h->comm); h->comm = nullptr; }
+    return MPPI_OK;
+}
+
+// One stand-alone all_gather of data_dev [4 + T*dc] (self-test; every rank calls it the same number of times):
+// gathered_out_dev [world][4 + T*dc].  Synchronises.
+int mppi_comm_exchange(mppi_handle_t h, const float* data_dev, float* gathered_out_dev, void* stream) {
+    if (!h || !data_dev || !gathered_out_dev) return fail(h, MPPI_E_INVALID, "bad comm arguments");
+    if (!h->comm) return fail(h, MPPI_E_STATE, "comm: not initialised");
+    hipStream_t s = (hipStream_t)stream;
+    RCCL_TRY(h, rccl().all_gather(data_dev, gathered_out_dev, (size_t)(MPPI_SUMMARY_HEAD + h->d.row), ncclFloat, h->comm, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    return MPPI_OK;
+}
+
 // ---- peer-to-peer exchange of the shard summaries (sharded solves; see P2pCtx in mppi_kernels.hpp)
 int mppi_p2p_alloc(mppi_handle_t h, int world, int rank, void* ipc_handle_out64) {
     if (!h || !ipc_handle_out64 || world < 2 || world > 64 || rank < 0 || rank >= world)
@@ -1357,6 +1447,11 @@ int mppi_set_option(mppi_handle_t h, const char* key, int64_t value) {
     if (k == "exchange_p2p") {  // sharded solves: summaries travel through the peer-to-peer buffer, no collective
         if (value && !h->p2p_connected) return fail(h, MPPI_E_STATE, "exchange_p2p: call mppi_p2p_alloc / mppi_p2p_connect first");
         h->p2p_enabled = value != 0;
+        return MPPI_OK;
+    }
+    if (k == "exchange_comm") {  // sharded solves: mppi_weights_reduce all_gathers the summaries itself (RCCL, same stream)
+        if (value && !h->comm) return fail(h, MPPI_E_STATE, "exchange_comm: call mppi_comm_init first");
+        h->comm_enabled = value != 0;
         return MPPI_OK;
     }
     if (k == "noise_regen") { h->noise_regen = value ? 1 : 0; h->tiles_valid = h->tiles_valid && h->injected; return MPPI_OK; }

@@ -65,6 +65,7 @@ class MPPI(nn.Module):
         essps_search: str = "device",
         sg_filter: str = "device",
         graph_callables: bool = False,
+        _force_exchange: bool = False,
     ) -> None:
         """Arguments up to `seed` are the reference's (src/pi_mpc/mppi.py:24-47).
 
@@ -164,10 +165,10 @@ class MPPI(nn.Module):
             self._world = dist.get_world_size(process_group)
             self._rank = dist.get_rank(process_group)
         self._sample_offset, self._local_samples = shard_range(num_samples, self._world, self._rank)
-        # measurement / test hook: run the per-solve exchange (summary -> all_gather -> combine) even with ONE rank, so
-        # that the real RCCL-backed path can be exercised and its fixed cost measured on a single GPU
-        import os as _os
-        self._force_exchange = bool(shard_samples and self._world == 1 and _os.environ.get("MPPI_FORCE_EXCHANGE") == "1")
+        # measurement / test hook (private keyword, not an ambient switch): run the per-solve exchange (summary ->
+        # all_gather -> combine) even with ONE rank, so that the real RCCL-backed paths can be exercised and their fixed
+        # cost measured on a single GPU
+        self._force_exchange = bool(_force_exchange and shard_samples and self._world == 1)
 
         # ---- plugin recognition
         dyn, cst = resolve(dynamics), resolve(cost_func)
@@ -261,13 +262,15 @@ class MPPI(nn.Module):
         self._stats = torch.zeros(4, device=self._device, dtype=dtype)
         self._summary = torch.zeros(_capi.SUMMARY_HEAD + T * dcn, device=self._device, dtype=dtype)
         self._gathered = None
-        self._p2p = False
-        if self._world > 1:
+        self._p2p = self._comm = False
+        if self._world > 1 or self._force_exchange:
             self._setup_exchange()
         self._previous_action_seq = torch.zeros(T, dcn, device=self._device, dtype=dtype)
         # forward() in one library call (mppi_solve) when nothing needs the host between the steps
-        self._one_call = (self._model is not None and noise_source == "philox" and self._world == 1
-                          and not self._force_exchange
+        in_library_exchange = self._p2p or self._comm  # the sharded solve needs nothing from the host either
+        self._one_call = (self._model is not None and noise_source == "philox"
+                          and ((self._world == 1 and not self._force_exchange) or in_library_exchange)
+                          and not (self._world > 1 and lambda_ in ("MPO", "LBPS", "ESSPS"))
                           and not (use_sg_filter and not self._sg_on_device)
                           and (self._auto_lambda is None
                                or (self._auto_lambda == "ESSPS" and auto_lambda_stats == "device" and essps_search == "device")))
@@ -372,29 +375,71 @@ class MPPI(nn.Module):
         return out
 
     def _setup_exchange(self) -> None:
-        """Pick the per-solve exchange of a sharded solver.  MPPI_EXCHANGE = "nccl" (default): one RCCL all_gather
-        per solve (torch.distributed);  "auto": try the library's peer-to-peer buffer exchange (mppi_p2p_*: no
-        collective launch on the critical path), verify it with a few pattern exchanges, and use it only if
-        EVERY rank succeeded — otherwise all ranks fall back to the all_gather together;  "p2p": as auto, but raise
-        instead of falling back.  The all_gather is the default because the buffer exchange has only been measured
-        between processes sharing one device."""
+        """Pick the per-solve exchange of a sharded solver (environment variable MPPI_EXCHANGE):
+          "nccl" (default)  one all_gather per solve through torch.distributed (RCCL on ProcessGroupNCCL's stream);
+          "rccl"            the library's own communicator (mppi_comm_*): ncclAllGather issued by mppi_weights_reduce on
+                            the solve's stream — no process-group stream, no events, the sharded solve is ONE library
+                            call like the unsharded one;
+          "p2p"             the library's peer-to-peer buffers (mppi_p2p_*: xGMI stores + polling, no collective launch);
+          "auto"            "rccl" when it passes its start-up self-test on every rank, else "nccl".
+        "rccl" / "p2p" raise when their set-up or self-test fails; every decision is agreed on by all ranks (all_reduce),
+        so the ranks always take the same path."""
         import os
 
         import torch.distributed as dist
 
         mode = os.environ.get("MPPI_EXCHANGE", "nccl").lower()
-        if mode not in ("nccl", "p2p", "auto"):
-            raise ValueError("MPPI_EXCHANGE must be nccl, p2p or auto")
+        if mode not in ("nccl", "rccl", "p2p", "auto"):
+            raise ValueError("MPPI_EXCHANGE must be nccl, rccl, p2p or auto")
         if mode == "nccl":
             return
         W, r, length = self._world, self._rank, int(self._summary.numel())
 
         def all_ok(ok: bool) -> bool:  # agreement point: every rank takes the same branch afterwards
+            if W == 1:
+                return ok
             t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self._device)
             dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self._pg)
             return bool(int(t.item()))
 
+        def pattern_ok(entry: str) -> bool:  # rank w sends 1000*w + j + round; everybody must see everybody's
+            base = torch.arange(length, device=self._device, dtype=torch.float32)
+            got = torch.empty(W, length, device=self._device, dtype=torch.float32)
+            ok = True
+            for rnd in range(3):
+                self._h.call(entry, _ptr(base + (1000.0 * r + rnd)), _ptr(got), self._stream())
+                want = base[None, :] + (1000.0 * torch.arange(W, device=self._device)[:, None] + rnd)
+                ok = ok and bool(torch.equal(got, want))
+            return ok
+
         why = ""
+        if mode in ("rccl", "auto"):
+            ident = torch.zeros(128, dtype=torch.uint8, device=self._device)
+            ok = True
+            if r == 0:
+                buf = (C.c_ubyte * 128)()
+                ok = self._h.lib.mppi_comm_unique_id(buf) == 0
+                ident = torch.tensor(list(bytes(buf)), dtype=torch.uint8, device=self._device)
+                why = "" if ok else "librccl.so.1 is not loadable"
+            if all_ok(ok):
+                if W > 1:
+                    dist.broadcast(ident, src=dist.get_global_rank(self._pg, 0) if self._pg is not None else 0,
+                                   group=self._pg)
+                blob = (C.c_ubyte * 128)(*ident.cpu().tolist())
+                try:
+                    self._h.call("mppi_comm_init", W, r, blob)
+                    ok = pattern_ok("mppi_comm_exchange")
+                except _capi.MppiError as e:
+                    ok, why = False, str(e)
+                if all_ok(ok):
+                    self._h.call("mppi_set_option", b"exchange_comm", 1)
+                    self._comm = True
+                    return
+            if mode == "rccl":
+                raise _capi.MppiError("MPPI_EXCHANGE=rccl: the in-library collective is not usable here: "
+                                      + (why or "self-test mismatch"))
+            return  # auto: fall back to the torch.distributed all_gather, on every rank
+
         handle = (C.c_ubyte * 64)()
         ok = True
         try:
@@ -414,21 +459,15 @@ class MPPI(nn.Module):
             except _capi.MppiError as e:
                 ok, why = False, str(e)
             if all_ok(ok):
-                try:  # pattern exchanges: rank w sends 1000*w + j + round
-                    base = torch.arange(length, device=self._device, dtype=torch.float32)
-                    got = torch.empty(W, length, device=self._device, dtype=torch.float32)
-                    for rnd in range(3):
-                        self._h.call("mppi_p2p_exchange", _ptr(base + (1000.0 * r + rnd)), _ptr(got), self._stream())
-                        want = base[None, :] + (1000.0 * torch.arange(W, device=self._device)[:, None] + rnd)
-                        ok = ok and bool(torch.equal(got, want))
+                try:
+                    ok = pattern_ok("mppi_p2p_exchange")
                 except _capi.MppiError as e:
                     ok, why = False, str(e)
                 if all_ok(ok):
                     self._h.call("mppi_set_option", b"exchange_p2p", 1)
                     self._p2p = True
                     return
-        if mode == "p2p":
-            raise _capi.MppiError("MPPI_EXCHANGE=p2p: the peer-to-peer exchange is not usable here: " + (why or "self-test mismatch"))
+        raise _capi.MppiError("MPPI_EXCHANGE=p2p: the peer-to-peer exchange is not usable here: " + (why or "self-test mismatch"))
 
     # ------------------------------------------------------------------ device-resident racing tick
     def set_center_path(self, path_xyyaw: np.ndarray, dind: np.ndarray, v_target: float) -> None:
@@ -599,8 +638,8 @@ class MPPI(nn.Module):
         # Steps 5-6: weights + weighted mean (src/pi_mpc/mppi.py:376-385)
         sharded = self._world > 1 or self._force_exchange
         summaries, nsh = None, 1
-        if self._p2p:  # the shard summaries travel through the peer-to-peer buffers: no collective launch
-            if h.lib.mppi_p2p_error(h.h):
+        if self._p2p or self._comm:  # the library exchanges the shard summaries itself (buffers / its own all_gather)
+            if self._p2p and h.lib.mppi_p2p_error(h.h):
                 raise _capi.MppiError("peer-to-peer exchange timed out on an earlier solve (a rank is missing or stalled)")
             h.call("mppi_weights_reduce", lam, None, st)
             nsh = self._world
@@ -827,10 +866,14 @@ class MPPI(nn.Module):
         if self._world > 1:
             import torch.distributed as dist
 
-            t = torch.from_numpy(c).to(self._device)
-            out = torch.empty(self._num_samples, device=self._device, dtype=torch.float32)
-            dist.all_gather_into_tensor(out, t, group=self._pg)
-            c = out.cpu().numpy()
+            counts = [shard_range(self._num_samples, self._world, r)[1] for r in range(self._world)]
+            width = max(counts)  # shards may differ by one sample: gather equal-sized rows, then drop the padding
+            row = np.full(width, np.nan, np.float32)
+            row[:len(c)] = c
+            out = torch.empty(self._world * width, device=self._device, dtype=torch.float32)
+            dist.all_gather_into_tensor(out, torch.from_numpy(row).to(self._device), group=self._pg)
+            rows = out.cpu().numpy().reshape(self._world, width)
+            c = np.concatenate([rows[r, :counts[r]] for r in range(self._world)])
         return c
 
     # ------------------------------------------------------------------ lazily materialised state

@@ -15,10 +15,13 @@ import torch
 
 
 def shard_range(num_samples: int, world: int, rank: int):
-    if num_samples % world != 0:
-        raise ValueError("num_samples must be divisible by the world size")
-    n = num_samples // world
-    return rank * n, n
+    """(offset, count) of rank's contiguous block.  Any num_samples works, like in the reference (src/pi_mpc/mppi.py:
+    96-98 puts no constraint on it): the first num_samples % world ranks own one sample more; a rank may own none only
+    if num_samples < world, which is refused."""
+    if num_samples < world:
+        raise ValueError("num_samples must be at least the world size")
+    q, rem = divmod(num_samples, world)
+    return rank * q + min(rank, rem), q + (1 if rank < rem else 0)
 
 
 def local_summary(costs: np.ndarray, actions: np.ndarray, lam: float) -> np.ndarray:

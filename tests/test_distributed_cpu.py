@@ -73,5 +73,11 @@ def test_shard_range():
     from pi_mpc.sharding import shard_range
 
     assert shard_range(8388608, 8, 3) == (3 * 1048576, 1048576)
+    # any num_samples (the reference accepts any, src/pi_mpc/mppi.py:96-98): contiguous blocks that differ by at most one
+    for n, w in ((10, 4), (1000, 7), (5, 5), (1 << 20, 3)):
+        blocks = [shard_range(n, w, r) for r in range(w)]
+        assert blocks[0][0] == 0 and sum(c for _, c in blocks) == n
+        assert all(blocks[r + 1][0] == blocks[r][0] + blocks[r][1] for r in range(w - 1))
+        assert max(c for _, c in blocks) - min(c for _, c in blocks) <= 1
     with pytest.raises(ValueError):
-        shard_range(10, 4, 0)
+        shard_range(3, 4, 0)

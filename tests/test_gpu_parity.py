@@ -1500,11 +1500,12 @@ def test_generic_path_hipgraph_capture_of_the_callables():
 
 
 def test_rccl_backed_exchange_path_with_one_rank():
-    """The default multi-GPU exchange on the REAL backend: a one-rank `nccl` (= RCCL) process group — RCCL cannot put two
-    ranks on one device, which is why the two-rank tests above use gloo — with MPPI_FORCE_EXCHANGE=1, so that every solve
-    takes the N-GPU code path: summary written by summarize_kernel -> all_gather_into_tensor on ProcessGroupNCCL's
-    stream -> mppi_finalize on the gathered buffer.  scripts/nccl_single_rank.py checks the result against the
-    unsharded solve and prints the fixed cost of the path (~12 us per solve)."""
+    """The multi-GPU exchanges on the REAL backend: a one-rank `nccl` (= RCCL) process group — RCCL cannot put two ranks
+    on one device, which is why the two-rank tests above use gloo — with the solver's `_force_exchange` hook, so that
+    every solve takes the N-GPU code path: summary written by summarize_kernel -> all_gather (torch.distributed on
+    ProcessGroupNCCL's stream, or the library's own ncclAllGather on the solve's stream) -> mppi_finalize on the gathered
+    buffer.  scripts/nccl_single_rank.py checks the results against the unsharded solve and prints the fixed cost of each
+    path per solve."""
     _need_gpu()
     import os
     import subprocess
@@ -1518,7 +1519,7 @@ def test_rccl_backed_exchange_path_with_one_rank():
     lines = [ln for ln in r.stdout.splitlines() if "forced exchange" in ln or "RCCL all_gather path" in ln]
     print("\n".join(lines))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert len(lines) == 3
+    assert len(lines) == 5
 
 
 def test_essps_device_search_equals_the_host_loop_on_random_costs():
@@ -1673,3 +1674,59 @@ def test_native_env_step_matches_torch_dynamics_nav2d():
         s2, r2 = e2.step(u)
         assert rel_err(s1.cpu().numpy(), s2.cpu().numpy()) <= 1e-6 and bool(r1) == bool(r2)
         e2._robot_state = s1.clone()
+
+
+# ------------------------------------------------------------------------------ uneven shards
+def _uneven_worker(rank, world, port, q):
+    import os
+
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ["MPPI_EXCHANGE"] = "nccl"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import mppi_playground_amd  # noqa: F401
+
+        out = [rank]
+        xn = torch.tensor([-9.0, -9.0, 0.785])
+        for stats in ("device", "host"):
+            nav, _ = make_solver("nav2d", 30, 1001, lambda_="ESSPS", exploration=0.25, shard_samples=True,
+                                 auto_lambda_stats=stats)
+            assert nav._local_samples == (334 if rank < 2 else 333) and nav._sample_offset == (0, 334, 668)[rank]
+            nav.forward(xn)
+            a, s = nav.forward(xn)
+            out += [a.cpu().numpy(), s.cpu().numpy(), nav._last_lambda]
+        q.put(tuple(out))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_uneven_shards_match_the_unsharded_solver():
+    """num_samples that the world size does not divide (the reference accepts any num_samples, mppi.py:96-98): three
+    ranks own 334 + 334 + 333 of 1001 nav2d samples; ESSPS from device statistics and from gathered host costs."""
+    _need_gpu()
+    import socket
+
+    import torch.multiprocessing as mp
+
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_uneven_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(3)], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    nav, _ = make_solver("nav2d", 30, 1001, lambda_="ESSPS", exploration=0.25)
+    xn = torch.tensor([-9.0, -9.0, 0.785])
+    nav.forward(xn)
+    a, s = nav.forward(xn)
+    for r in res:
+        for base in (1, 4):
+            assert abs(r[base + 2] - nav._last_lambda) <= 1e-4 * nav._last_lambda
+            assert rel_err(r[base], a.cpu().numpy()) < 5e-5 and rel_err(r[base + 1], s.cpu().numpy()) < 5e-5
+        assert np.array_equal(r[1], res[0][1])  # the ranks agree exactly
