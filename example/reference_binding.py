@@ -35,7 +35,8 @@ class HipForward:
         lib.mppi_essps_lambda.argtypes = [vp, C.c_double, C.c_double, C.c_double, vp, vp]
         lib.mppi_weights_reduce.argtypes = [vp, C.c_float, vp, vp]
         lib.mppi_finalize.argtypes = [vp, vp, C.c_int, C.c_float, C.c_int, vp, vp, vp, vp]
-        lib.mppi_solve.argtypes = [vp, vp, C.c_uint32, C.c_float, C.c_double, C.c_double, C.c_double, vp, vp, vp, vp]
+        lib.mppi_set_auto_lambda.argtypes = [vp, C.c_int, C.c_double, C.c_double, C.c_double]
+        lib.mppi_solve.argtypes = [vp, vp, C.c_uint32, C.c_float, vp, vp, vp, vp]
         model_id, ds, dc = MODELS[model]
         f4 = lambda v: (C.c_float * 4)(*(list(v) + [0.0] * (4 - len(v))))  # noqa: E731
         cfg = MppiConfig(model_id, horizon, ds, dc, num_samples, 0, int(num_samples * (1 - exploration)),
@@ -58,9 +59,12 @@ class HipForward:
         x = torch.empty(1, self.T + 1, self.ds, device="cuda")
         self._keep = state  # the bound tensor stays alive until the enqueued kernels ran
         if one_call:
-            lam_arg = MPPI_LAMBDA_DEVICE if essps_target is not None else lam
-            self._check(lib.mppi_solve(h, C.c_void_p(state.data_ptr()), self.solve_idx, lam_arg, essps_target or 0.0,
-                                       lam_min, lam_max, C.c_void_p(a.data_ptr()), C.c_void_p(x.data_ptr()), None, s))
+            lam_arg = lam
+            if essps_target is not None:  # lambda_ = "ESSPS": the rule runs on the device inside mppi_solve (MPPI_AUTO_ESSPS = 1)
+                self._check(lib.mppi_set_auto_lambda(h, 1, essps_target, lam_min, lam_max))
+                lam_arg = MPPI_LAMBDA_DEVICE
+            self._check(lib.mppi_solve(h, C.c_void_p(state.data_ptr()), self.solve_idx, lam_arg, C.c_void_p(a.data_ptr()),
+                                       C.c_void_p(x.data_ptr()), None, s))
         else:
             self._check(lib.mppi_bind_state(h, C.c_void_p(state.data_ptr())))
             self._check(lib.mppi_sample(h, self.solve_idx, s))

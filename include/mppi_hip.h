@@ -101,7 +101,7 @@ typedef struct MppiConfig {
 const char* mppi_version(void);
 /* Integer version of THIS header's function signatures; bindings compare it with the constant they were written
  * against and refuse a stale library (a changed argument list would otherwise be called with shifted arguments). */
-#define MPPI_ABI_VERSION 4
+#define MPPI_ABI_VERSION 5
 int mppi_abi_version(void);
 /* Number of visible HIP devices (0 => the product cannot run; callers must fail loudly). */
 int mppi_device_count(void);
@@ -228,13 +228,19 @@ int mppi_weights_reduce(mppi_handle_t h, float lambda /* > 0, or MPPI_LAMBDA_DEV
  * sum e*c} (global); any output may be NULL. */
 int mppi_finalize(mppi_handle_t h, const float* summaries_dev, int num_shards, float lambda, int store_mean,
                   float* action_out_dev, float* state_seq_out_dev, float* stats_out_dev, void* stream);
+/* `lambda_` = "ESSPS" | "LBPS" | "MPO" (mppi.py:183-210): the rule mppi_solve runs ON THE DEVICE when it is called with
+ * lambda = MPPI_LAMBDA_DEVICE.  param = essps_target_ess (ESSPS), lbps_delta (LBPS), unused (MPO: see mppi_mpo_reset);
+ * [lam_min, lam_max] = `lambda_min`, `lambda_max` (ESSPS, LBPS). */
+enum { MPPI_AUTO_NONE = 0, MPPI_AUTO_ESSPS = 1, MPPI_AUTO_LBPS = 2, MPPI_AUTO_MPO = 3 };
+int mppi_set_auto_lambda(mppi_handle_t h, int rule, double param, double lam_min, double lam_max);
 /* MPPI.forward() of a native model in one call (mppi.py:223-460) = mppi_bind_state (x0_dev != NULL; NULL keeps the state
- * already set) + mppi_sample(solve_idx) + mppi_rollout_cost + [lambda == MPPI_LAMBDA_DEVICE: mppi_essps_lambda_device(
- * essps_target_ess, lam_min, lam_max)] + mppi_weights_reduce(lambda) + mppi_finalize(own summary, store_mean = 1).  Same
- * kernels and results as the individual calls; one host -> library transition per solve instead of five. */
-int mppi_solve(mppi_handle_t h, const float* x0_dev, uint32_t solve_idx, float lambda, double essps_target_ess,
-               double lam_min, double lam_max, float* action_out_dev, float* state_seq_out_dev, float* stats_out_dev,
-               void* stream);
+ * already set) + mppi_sample(solve_idx) + mppi_rollout_cost + [lambda == MPPI_LAMBDA_DEVICE: the configured rule —
+ * mppi_essps_lambda_device / mppi_lbps_lambda_device before the weights, mppi_mpo_step_device after mppi_finalize] +
+ * mppi_weights_reduce(lambda) + mppi_finalize(own summary — or all shards' with option "exchange_comm" /
+ * "exchange_p2p" — store_mean = 1).  Same kernels and results as the individual calls; one host -> library transition
+ * per solve and no host synchronisation for any temperature rule. */
+int mppi_solve(mppi_handle_t h, const float* x0_dev, uint32_t solve_idx, float lambda, float* action_out_dev,
+               float* state_seq_out_dev, float* stats_out_dev, void* stream);
 /* Step 7 inside mppi_finalize (mppi.py:423-443,598-620): Savitzky-Golay smoothing of [history(T-1); a(T)] per control
  * dimension (symmetric-flip padding, valid cross-correlation, keep the last T), applied whenever mppi_finalize is
  * called with store_mean != 0; the smoothed sequence is what is returned, stored as the warm start and rolled out,
@@ -265,7 +271,15 @@ int mppi_essps_lambda(mppi_handle_t h, double target_ess, double lam_min, double
  * (synchronises the stream).  Identical arithmetic to mppi_essps_lambda (both call csrc/host_search.hpp). */
 #define MPPI_LAMBDA_DEVICE (-1.0f)
 int mppi_essps_lambda_device(mppi_handle_t h, double target_ess, double lam_min, double lam_max, void* stream);
-int mppi_get_lambda(mppi_handle_t h, double* lambda_out_host, void* stream);
+/* The temperature a device-resident rule left in HBM, and (lambda_used_out_host != NULL) the one the last solve's weights
+ * used — the same value for ESSPS / LBPS, the previous one for MPO (mppi.py:387-398 updates it AFTER the weights).
+ * Synchronises `stream` (pass the stream the solve was enqueued on). */
+int mppi_get_lambda(mppi_handle_t h, double* lambda_out_host, double* lambda_used_out_host, void* stream);
+/* LBPS (mppi.py:341-349,534-557) with NO host synchronisation: the reference's ~25 dependent Brent probes become three
+ * 32-temperature grids (one pass over the costs each; the grid minimum is bracketed by the next, finer grid) and a
+ * parabola through the last three points in log(lambda) — within 1e-3 relative of the Brent minimiser wherever the
+ * objective is not flat to fp32 rounding.  The temperature stays in HBM (MPPI_LAMBDA_DEVICE). */
+int mppi_lbps_lambda_device(mppi_handle_t h, double delta, double lam_min, double lam_max, void* stream);
 /* LBPS (mppi.py:341-349,534-557): argmin over [lam_min, lam_max] of -(E_w[-c] - (max c - min c) * sqrt((1-delta)/delta)
  * / sqrt(ESS)), searched on the host with Brent's bounded minimiser (scipy minimize_scalar(method="bounded"): xatol
  * 1e-5, at most 500 evaluations); every probe is one mppi_softmax_stats round trip.  Unsharded handles; synchronises. */
@@ -277,6 +291,9 @@ int mppi_lbps_lambda(mppi_handle_t h, double delta, double lam_min, double lam_m
  *   mppi_mpo_state  out4_host = {log T, first moment, second moment, step count}. */
 int mppi_mpo_reset(mppi_handle_t h, double lambda0, double epsilon, double lr);
 int mppi_mpo_step(mppi_handle_t h, double* lambda_out_host, void* stream);
+/* mppi_mpo_step without the read-back (no host synchronisation): the dual, its moments and the resulting temperature
+ * stay in device memory; the NEXT solve's weights read it through MPPI_LAMBDA_DEVICE.  Call it after mppi_finalize. */
+int mppi_mpo_step_device(mppi_handle_t h, void* stream);
 int mppi_mpo_state(mppi_handle_t h, double* out4_host);
 
 /* `_weights` (mppi.py:376) for this shard given the GLOBAL {min c, sum e}: w_out_dev[N]. */

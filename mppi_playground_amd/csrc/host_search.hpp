@@ -28,7 +28,7 @@ namespace host {
 
 struct SoftmaxStats {  // of softmax(-c/lambda) over all samples, e_i = exp(-(c_i - cmin)/lambda)
     double cmin, cmax, se, se2, sec;
-    double ess() const { return se * se / se2; }
+    MPPI_SEARCH_HD double ess() const { return se * se / se2; }
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -107,9 +107,9 @@ bool fminbound(F&& f, double x1, double x2, double xatol, int maxiter, double& x
 }
 
 // LBPS objective (mppi.py:534-557): -(E_w[-c] - range * sqrt((1-delta)/delta) / sqrt(ESS)).
-inline double lbps_objective(const SoftmaxStats& st, double delta) {
+MPPI_SEARCH_HD double lbps_objective(const SoftmaxStats& st, double delta) {
     const double expected_return = -st.sec / st.se;
-    const double penalty = (st.cmax - st.cmin) * std::sqrt((1.0 - delta) / delta) / std::sqrt(st.ess());
+    const double penalty = (st.cmax - st.cmin) * sqrt((1.0 - delta) / delta) / sqrt(st.se * st.se / st.se2);
     return -(expected_return - penalty);
 }
 
@@ -201,6 +201,41 @@ bool essps_lambda(G&& ess_grid, double target_ess, double lam_min, double lam_ma
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// LBPS, device-resident variant.  The same minimisation as a grid search (device-resident variant: one pass over the costs per grid of P temperatures
+// instead of one per probe).  One step: obj[j] = objective at grid[j] (geometric grid).  Not the last round: [lo, hi] =
+// the two grid intervals around the first grid minimum (the next round's geometric grid spans them).  Last round:
+// lam = the vertex of the parabola through the three points around the minimum in (log lambda, objective), kept
+// inside them; the grid point itself when the minimum sits at an end of the grid or the three points are not convex.
+template <int P>
+MPPI_SEARCH_HD void lbps_grid_step(const double* grid, const double* obj, bool last, double& lo, double& hi, double& lam) {
+    int i = 0;
+    for (int j = 1; j < P; ++j) if (obj[j] < obj[i]) i = j;
+    const int a = i > 0 ? i - 1 : 0, b = i < P - 1 ? i + 1 : P - 1;
+    lo = grid[a]; hi = grid[b];
+    lam = grid[i];
+    if (last && a < i && i < b) {
+        const double x0 = log(grid[a]), x1 = log(grid[i]), x2 = log(grid[b]);
+        const double d01 = (obj[i] - obj[a]) / (x1 - x0), d12 = (obj[b] - obj[i]) / (x2 - x1);
+        const double curv = (d12 - d01) / (x2 - x0);
+        if (curv > 0.0) {
+            const double xv = 0.5 * (x0 + x1) - 0.5 * d01 / curv;
+            if (xv > x0 && xv < x2) lam = exp(xv);
+        }
+    }
+}
+// host loop over the grid rounds: obj_grid(lams[P], obj_out[P]) -> bool (one device pass + read-back per round)
+template <int P, int ROUNDS, class G>
+bool lbps_lambda_grid(G&& obj_grid, double lam_min, double lam_max, double& lam_out) {
+    double grid[P], obj[P], lo = lam_min, hi = lam_max;
+    for (int r = 0; r < ROUNDS; ++r) {
+        essps_make_grid<P>(lo, hi, grid);
+        if (!obj_grid(grid, obj)) return false;
+        lbps_grid_step<P>(grid, obj, r == ROUNDS - 1, lo, hi, lam_out);
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // MPO temperature (mppi.py:191-200,387-398): one Adam(lr) step per solve on
 //   loss(logT) = T * (epsilon + logsumexp(-c / T)),  T = softplus(logT),  then lambda = exp(logT)   (B-Q12)
 // with the gradient written out: dL/dT = epsilon + LSE + E_w[c] / T, dT/dlogT = sigmoid(logT).  The two large terms
@@ -213,7 +248,7 @@ struct MpoState {
     float log_temperature = 0.0f, m = 0.0f, v = 0.0f;
     int32_t t = 0;
     double epsilon = 0.1, lr = 0.2;
-    float temperature() const { return (float)std::log1p(std::exp((double)log_temperature)); }  // softplus(logT), fp32
+    MPPI_SEARCH_HD float temperature() const { return (float)log1p(exp((double)log_temperature)); }  // softplus(logT), fp32
 };
 inline void mpo_reset(MpoState& s, double lam0, double epsilon, double lr) {
     s = MpoState{};
@@ -221,22 +256,22 @@ inline void mpo_reset(MpoState& s, double lam0, double epsilon, double lr) {
     s.epsilon = epsilon; s.lr = lr;
 }
 // `st` = the softmax statistics at lambda = s.temperature().  Returns the new lambda = exp(logT).
-inline double mpo_step(MpoState& s, const SoftmaxStats& st) {
+MPPI_SEARCH_HD double mpo_step(MpoState& s, const SoftmaxStats& st) {
     const double b1 = 0.9, b2 = 0.999, adam_eps = 1e-8;
     const double lt = (double)s.log_temperature;
     const float T = s.temperature();
     const float xmax32 = (-(float)st.cmin) / T;
-    const float lse32 = xmax32 + (float)std::log((double)(float)st.se);
-    const double scale = std::exp((double)xmax32 - (double)lse32);
+    const float lse32 = xmax32 + (float)log((double)(float)st.se);
+    const double scale = exp((double)xmax32 - (double)lse32);
     const float dL_dT = ((float)s.epsilon + lse32) + (float)(scale * st.sec / (double)T);
-    const float g = (float)((double)dL_dT * (1.0 / (1.0 + std::exp(-lt))));
+    const float g = (float)((double)dL_dT * (1.0 / (1.0 + exp(-lt))));
     s.t += 1;
     s.m = (float)(b1 * (double)s.m + (1.0 - b1) * (double)g);
     s.v = (float)(b2 * (double)s.v + (1.0 - b2) * (double)g * (double)g);
-    const double bc1 = 1.0 - std::pow(b1, (double)s.t), bc2 = 1.0 - std::pow(b2, (double)s.t);
-    const double denom = std::sqrt((double)s.v) / std::sqrt(bc2) + adam_eps;
+    const double bc1 = 1.0 - pow(b1, (double)s.t), bc2 = 1.0 - pow(b2, (double)s.t);
+    const double denom = sqrt((double)s.v) / sqrt(bc2) + adam_eps;
     s.log_temperature = (float)(lt - (s.lr / bc1) * (double)s.m / denom);
-    return (double)std::exp(s.log_temperature);  // np.exp of the fp32 scalar: fp32 result
+    return (double)exp(s.log_temperature);  // np.exp of the fp32 scalar: fp32 result
 }
 
 }  // namespace host

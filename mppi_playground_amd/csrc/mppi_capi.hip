@@ -37,7 +37,14 @@ struct MppiSolver {
     // generic handles whose dim_control is not 1, 2 or 4: per-column {sigma, lo, hi}[4R] table (see gen_noise4)
     float* coltab = nullptr;
     bool wide = false, limits_set = true;
-    mppi::host::MpoState mpo{};    // MPO temperature dual (mppi_mpo_*)
+    mppi::host::MpoState* mpo_dev = nullptr;  // MPO temperature dual + Adam moments, resident on the device (mppi_mpo_*)
+    float* mpo_temp_dev = nullptr;            // softplus(log T): the temperature of the dual's next statistics pass
+    LbpsDev* lbps_dev = nullptr;              // grids of the device-resident LBPS search
+    float* stats_max = nullptr;               // [STATS_BLOCKS] per-block maximum cost (LBPS: the cost range)
+    double lbps_lo = 0.0, lbps_hi = 0.0;      // [lam_min, lam_max] the preset round-0 grid was built for
+    // the temperature rule mppi_solve applies when called with MPPI_LAMBDA_DEVICE (mppi_set_auto_lambda)
+    int auto_rule = 0;
+    double auto_param = 0.0, auto_lo = 0.0, auto_hi = 0.0;
     // pinned staging ring for small host -> device uploads without a stream synchronisation
     static constexpr int RING = 8;
     float* stage[RING] = {};
@@ -325,6 +332,8 @@ P2pCtx p2p_ctx(mppi_handle_t h) {
 
 }  // namespace
 
+static int mpo_upload(mppi_handle_t h, double lambda0, double epsilon, double lr, bool lambda_too);
+
 extern "C" {
 
 const char* mppi_version(void) { return "mppi_hip 0.3.0 (gfx950, wave64, lane-per-trajectory)"; }
@@ -404,7 +413,11 @@ int mppi_create(const MppiConfig* cfg, mppi_handle_t* out) {
     HIP_TRY(h, hipMalloc(&h->heads, sizeof(float) * (size_t)max_blocks * 4));
     HIP_TRY(h, hipMalloc(&h->summary, sizeof(float) * (size_t)(MPPI_SUMMARY_HEAD + d.row)));
     HIP_TRY(h, hipMalloc(&h->stats_part, sizeof(float) * STATS_L * 3 * STATS_BLOCKS));
-    HIP_TRY(h, hipHostMalloc((void**)&h->stats_host, sizeof(double) * (8 + STATS_L * 3 + 1), hipHostMallocMapped));
+    HIP_TRY(h, hipHostMalloc((void**)&h->stats_host, sizeof(double) * (8 + STATS_L * 3 + 2), hipHostMallocMapped));
+    HIP_TRY(h, hipMalloc(&h->mpo_dev, sizeof(mppi::host::MpoState)));
+    HIP_TRY(h, hipMalloc(&h->mpo_temp_dev, sizeof(float)));
+    HIP_TRY(h, hipMalloc(&h->lbps_dev, sizeof(LbpsDev)));
+    HIP_TRY(h, hipMalloc(&h->stats_max, sizeof(float) * STATS_BLOCKS));
     HIP_TRY(h, hipMalloc(&h->lams_dev, sizeof(float) * 3 * STATS_L));
     HIP_TRY(h, hipMalloc(&h->essps_dev, sizeof(EsspsDev)));
     HIP_TRY(h, hipMalloc(&h->lambda_dev, sizeof(float)));
@@ -412,13 +425,13 @@ int mppi_create(const MppiConfig* cfg, mppi_handle_t* out) {
     *h->live_hint = 0;
     HIP_TRY(h, hipHostGetDevicePointer((void**)&h->live_hint_dev, h->live_hint, 0));
     std::memset(&h->ctx, 0, sizeof(h->ctx));
-    mppi::host::mpo_reset(h->mpo, 1.0, 0.1, 0.2);  // mppi.py:191-200
     if (h->wide) {
         HIP_TRY(h, hipMalloc(&h->coltab, sizeof(float) * 12 * (size_t)d.R));
         h->limits_set = false;
         if (md.dc <= MPPI_MAX_DIM_CONTROL)  // the config arrays hold all of it (dim_control = 3)
             if (int rc = mppi_set_control_limits(h, cfg->u_min, cfg->u_max, cfg->sigmas, md.dc)) return rc;
     }
+    if (int rc = mpo_upload(h, 1.0, 0.1, 0.2, false)) return rc;  // mppi.py:191-200
     HIP_TRY(h, hipDeviceSynchronize());
     return MPPI_OK;
 }
@@ -455,7 +468,8 @@ int mppi_destroy(mppi_handle_t h) {
     if (!h) return MPPI_E_INVALID;
     (void)hipFree(h->noise); (void)hipFree(h->costs); (void)hipFree(h->min_key); (void)hipFree(h->x0);
     (void)hipFree(h->x0_used); (void)hipFree(h->coltab); (void)hipFree(h->lams_dev); (void)hipFree(h->essps_dev);
-    (void)hipFree(h->lambda_dev);
+    (void)hipFree(h->lambda_dev); (void)hipFree(h->mpo_dev); (void)hipFree(h->mpo_temp_dev); (void)hipFree(h->lbps_dev);
+    (void)hipFree(h->stats_max);
     (void)hipFree(h->mean); (void)hipFree(h->mean_used); (void)hipFree(h->solve_stats); (void)hipFree(h->topk_hist);
     (void)hipFree(h->topk_sel); (void)hipFree(h->topk_cand); (void)hipFree(h->sg_coeffs); (void)hipFree(h->sg_history);
     (void)hipFree(h->ref); (void)hipFree(h->partials); (void)hipFree(h->heads);
@@ -901,7 +915,7 @@ int mppi_set_costs(mppi_handle_t h, const float* src, int on_device, void* strea
 static int resolve_lambda(mppi_handle_t h, float lambda, const float** lam_dev) {
     *lam_dev = nullptr;
     if (lambda == MPPI_LAMBDA_DEVICE) {
-        if (!h->lambda_dev_valid) return fail(h, MPPI_E_STATE, "MPPI_LAMBDA_DEVICE: no temperature on the device (call mppi_essps_lambda_device first)");
+        if (!h->lambda_dev_valid) return fail(h, MPPI_E_STATE, "MPPI_LAMBDA_DEVICE: no temperature on the device (run a device-resident rule or mppi_mpo_reset first)");
         *lam_dev = h->lambda_dev;
         return MPPI_OK;
     }
@@ -999,22 +1013,38 @@ int mppi_finalize(mppi_handle_t h, const float* summaries_dev, int num_shards, f
     return MPPI_OK;
 }
 
+// The temperature rule mppi_solve applies when it is called with lambda = MPPI_LAMBDA_DEVICE (mppi.py:183-210).
+int mppi_set_auto_lambda(mppi_handle_t h, int rule, double param, double lam_min, double lam_max) {
+    if (!h || rule < MPPI_AUTO_NONE || rule > MPPI_AUTO_MPO) return fail(h, MPPI_E_INVALID, "bad temperature rule");
+    if ((rule == MPPI_AUTO_ESSPS || rule == MPPI_AUTO_LBPS) && (!(lam_min > 0.0) || !(lam_max > lam_min) || !(param > 0.0)))
+        return fail(h, MPPI_E_INVALID, "bad temperature rule arguments");
+    h->auto_rule = rule; h->auto_param = param; h->auto_lo = lam_min; h->auto_hi = lam_max;
+    return MPPI_OK;
+}
+
 // MPPI.forward() for a native model in ONE call (mppi.py:223-460): bind the state, fix the noise identity, rollout +
-// costs, the temperature (fixed, or the ESSPS search resident on the device), weights + reduction, finalize with the
+// costs, the temperature (fixed, or the configured rule resident on the device), weights + reduction, finalize with the
 // warm start stored.  Exactly the sequence of the individual entry points (same kernels, same results): one
 // host -> library transition per solve for callers that need nothing in between.
-int mppi_solve(mppi_handle_t h, const float* x0_dev, uint32_t solve_idx, float lambda, double essps_target_ess,
-               double lam_min, double lam_max, float* action_out_dev, float* state_seq_out_dev, float* stats_out_dev,
-               void* stream) {
+int mppi_solve(mppi_handle_t h, const float* x0_dev, uint32_t solve_idx, float lambda, float* action_out_dev,
+               float* state_seq_out_dev, float* stats_out_dev, void* stream) {
     if (!h) return MPPI_E_INVALID;
+    const bool dev = lambda == MPPI_LAMBDA_DEVICE;
+    if (dev && h->auto_rule == MPPI_AUTO_NONE)
+        return fail(h, MPPI_E_STATE, "MPPI_LAMBDA_DEVICE: no temperature rule configured (mppi_set_auto_lambda)");
     if (x0_dev) { if (int rc = mppi_bind_state(h, x0_dev)) return rc; }
     if (int rc = mppi_sample(h, solve_idx, stream)) return rc;
     if (int rc = mppi_rollout_cost(h, stream)) return rc;
-    if (lambda == MPPI_LAMBDA_DEVICE) {
-        if (int rc = mppi_essps_lambda_device(h, essps_target_ess, lam_min, lam_max, stream)) return rc;
+    if (dev && h->auto_rule == MPPI_AUTO_ESSPS) {
+        if (int rc = mppi_essps_lambda_device(h, h->auto_param, h->auto_lo, h->auto_hi, stream)) return rc;
+    } else if (dev && h->auto_rule == MPPI_AUTO_LBPS) {
+        if (int rc = mppi_lbps_lambda_device(h, h->auto_param, h->auto_lo, h->auto_hi, stream)) return rc;
     }
     if (int rc = mppi_weights_reduce(h, lambda, nullptr, stream)) return rc;
-    return mppi_finalize(h, nullptr, 1, lambda, 1, action_out_dev, state_seq_out_dev, stats_out_dev, stream);
+    if (int rc = mppi_finalize(h, nullptr, 1, lambda, 1, action_out_dev, state_seq_out_dev, stats_out_dev, stream)) return rc;
+    // MPO: the dual steps after every solve, whatever temperature this solve's weights were given (mppi.py:387-398)
+    if (h->auto_rule == MPPI_AUTO_MPO) return mppi_mpo_step_device(h, stream);
+    return MPPI_OK;
 }
 
 // Savitzky-Golay smoothing of the solution inside mppi_finalize (step 7, mppi.py:423-443): taps = first row of
@@ -1051,7 +1081,8 @@ int mppi_softmax_stats(mppi_handle_t h, float lambda, double* out5_host, void* s
     hipStream_t s = (hipStream_t)stream;
     const unsigned* mk = h->min_key + h->min_slot;
     const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(STATS_BLOCKS, (h->d.N + BLOCK - 1) / BLOCK));
-    hipLaunchKernelGGL(stats_partial_kernel, dim3(blocks), dim3(BLOCK), 0, s, h->costs, h->d.N, mk, lambda, h->stats_part);
+    hipLaunchKernelGGL(stats_partial_kernel, dim3(blocks), dim3(BLOCK), 0, s, h->costs, h->d.N, mk, lambda,
+                       (const float*)nullptr, h->stats_part);
     HIP_TRY(h, hipGetLastError());
     double* dev_out = nullptr;
     HIP_TRY(h, hipHostGetDevicePointer((void**)&dev_out, h->stats_host, 0));
@@ -1079,7 +1110,7 @@ int mppi_softmax_stats_multi(mppi_handle_t h, const float* lambdas_host, int cou
     const unsigned* mk = h->min_key + h->min_slot;
     const int blocks = stats_blocks(h);
     hipLaunchKernelGGL(stats_multi_kernel, dim3(blocks), dim3(STATS_THREADS), 0, s, h->costs, h->d.N, mk,
-                       (const float*)h->lams_dev, h->stats_part, (const int32_t*)nullptr);
+                       (const float*)h->lams_dev, h->stats_part, (const int32_t*)nullptr, (float*)nullptr);
     HIP_TRY(h, hipGetLastError());
     double* dev_out = nullptr;
     HIP_TRY(h, hipHostGetDevicePointer((void**)&dev_out, h->stats_host, 0));
@@ -1118,11 +1149,11 @@ int mppi_essps_lambda_device(mppi_handle_t h, double target_ess, double lam_min,
     float* lams0 = h->lams_dev + STATS_L;
     float* lams1 = h->lams_dev + 2 * STATS_L;
     hipLaunchKernelGGL(stats_multi_kernel, dim3(blocks), dim3(STATS_THREADS), 0, s, h->costs, h->d.N, mk, (const float*)lams0,
-                       h->stats_part, (const int32_t*)nullptr);
+                       h->stats_part, (const int32_t*)nullptr, (float*)nullptr);
     hipLaunchKernelGGL(essps_select_kernel<0>, dim3(1), dim3(1024), 0, s, (const float*)h->stats_part, blocks, target_ess,
                        lam_min, lam_max, h->essps_dev, lams1, h->lambda_dev, host_lam);
     hipLaunchKernelGGL(stats_multi_kernel, dim3(blocks), dim3(STATS_THREADS), 0, s, h->costs, h->d.N, mk, (const float*)lams1,
-                       h->stats_part, (const int32_t*)&h->essps_dev->done);
+                       h->stats_part, (const int32_t*)&h->essps_dev->done, (float*)nullptr);
     hipLaunchKernelGGL(essps_select_kernel<1>, dim3(1), dim3(1024), 0, s, (const float*)h->stats_part, blocks, target_ess,
                        lam_min, lam_max, h->essps_dev, lams1, h->lambda_dev, host_lam);
     HIP_TRY(h, hipGetLastError());
@@ -1130,12 +1161,61 @@ int mppi_essps_lambda_device(mppi_handle_t h, double target_ess, double lam_min,
     return MPPI_OK;
 }
 
-// The temperature of the last mppi_essps_lambda_device.  Synchronises the stream.
-int mppi_get_lambda(mppi_handle_t h, double* lambda_out_host, void* stream) {
+// The temperature a device-resident rule left behind (and, optionally, the one the last solve's weights used: the same
+// for ESSPS / LBPS, the previous one for MPO).  Synchronises the stream.
+int mppi_get_lambda(mppi_handle_t h, double* lambda_out_host, double* lambda_used_out_host, void* stream) {
     if (!h || !lambda_out_host) return fail(h, MPPI_E_INVALID, "null");
     if (!h->lambda_dev_valid) return fail(h, MPPI_E_STATE, "no temperature on the device");
     HIP_TRY(h, hipStreamSynchronize((hipStream_t)stream));
     *lambda_out_host = h->stats_host[8 + STATS_L * 3];
+    if (lambda_used_out_host) *lambda_used_out_host = h->stats_host[8 + STATS_L * 3 + 1];
+    return MPPI_OK;
+}
+
+// LBPS with no host synchronisation (mppi.py:341-349): LBPS_ROUNDS x (32-temperature statistics pass -> one-block
+// grid step), the temperature stays in HBM (MPPI_LAMBDA_DEVICE).  See lbps_select_kernel.
+int mppi_lbps_lambda_device(mppi_handle_t h, double delta, double lam_min, double lam_max, void* stream) {
+    if (!h || !(lam_min > 0.0) || !(lam_max > lam_min) || !(delta > 0.0) || !(delta < 1.0))
+        return fail(h, MPPI_E_INVALID, "bad lbps arguments");
+    hipStream_t s = (hipStream_t)stream;
+    float* lams0 = h->lams_dev;              // (the caller's-grid slot doubles as LBPS's preset round-0 grid)
+    float* lams1 = h->lams_dev + 2 * STATS_L;
+    if (h->lbps_lo != lam_min || h->lbps_hi != lam_max) {  // (re)build the round-0 grid: set-up path, blocking
+        LbpsDev st{};
+        float lamf[STATS_L];
+        mppi::host::essps_make_grid<STATS_L>(lam_min, lam_max, st.grid0);
+        for (int j = 0; j < STATS_L; ++j) { lamf[j] = (float)st.grid0[j]; st.grid[j] = st.grid0[j]; }
+        HIP_TRY(h, hipDeviceSynchronize());
+        HIP_TRY(h, hipMemcpy(h->lbps_dev, &st, sizeof(st), hipMemcpyHostToDevice));
+        h->lbps_lo = lam_min; h->lbps_hi = lam_max;
+    }
+    {   // the caller's-grid slot may have been overwritten by mppi_softmax_stats_multi: refresh it from the search state
+        float lamf[STATS_L];
+        double g0[STATS_L];
+        mppi::host::essps_make_grid<STATS_L>(lam_min, lam_max, g0);
+        for (int j = 0; j < STATS_L; ++j) lamf[j] = (float)g0[j];
+        if (int rc = upload_small(h, lams0, lamf, STATS_L, s)) return rc;
+    }
+    const unsigned* mk = h->min_key + h->min_slot;
+    const int blocks = stats_blocks(h);
+    double* host_lam = nullptr;
+    HIP_TRY(h, hipHostGetDevicePointer((void**)&host_lam, h->stats_host, 0));
+    host_lam += 8 + STATS_L * 3;
+    for (int r = 0; r < LBPS_ROUNDS; ++r) {
+        hipLaunchKernelGGL(stats_multi_kernel, dim3(blocks), dim3(STATS_THREADS), 0, s, h->costs, h->d.N, mk,
+                           (const float*)(r == 0 ? lams0 : lams1), h->stats_part, (const int32_t*)nullptr, h->stats_max);
+        if (r == 0)
+            hipLaunchKernelGGL((lbps_select_kernel<false, true>), dim3(1), dim3(1024), 0, s, (const float*)h->stats_part,
+                               (const float*)h->stats_max, blocks, mk, delta, h->lbps_dev, lams1, h->lambda_dev, host_lam);
+        else if (r < LBPS_ROUNDS - 1)
+            hipLaunchKernelGGL((lbps_select_kernel<false, false>), dim3(1), dim3(1024), 0, s, (const float*)h->stats_part,
+                               (const float*)h->stats_max, blocks, mk, delta, h->lbps_dev, lams1, h->lambda_dev, host_lam);
+        else
+            hipLaunchKernelGGL((lbps_select_kernel<true, false>), dim3(1), dim3(1024), 0, s, (const float*)h->stats_part,
+                               (const float*)h->stats_max, blocks, mk, delta, h->lbps_dev, lams1, h->lambda_dev, host_lam);
+    }
+    HIP_TRY(h, hipGetLastError());
+    h->lambda_dev_valid = true;
     return MPPI_OK;
 }
 
@@ -1184,25 +1264,56 @@ int mppi_lbps_lambda(mppi_handle_t h, double delta, double lam_min, double lam_m
     return ok ? MPPI_OK : rc;
 }
 
-// MPO temperature (mppi.py:191-200,387-398): the dual variable log T and its Adam moments live in the handle.
+// MPO temperature (mppi.py:191-200,387-398): the dual variable log T and its Adam moments live in DEVICE memory.
 int mppi_mpo_reset(mppi_handle_t h, double lambda0, double epsilon, double lr) {
     if (!h || !(lambda0 > 0.0) || !(lr > 0.0)) return fail(h, MPPI_E_INVALID, "bad mpo arguments");
-    mppi::host::mpo_reset(h->mpo, lambda0, epsilon, lr);
+    return mpo_upload(h, lambda0, epsilon, lr, true);
+}
+static int mpo_upload(mppi_handle_t h, double lambda0, double epsilon, double lr, bool lambda_too) {
+    mppi::host::MpoState st;
+    mppi::host::mpo_reset(st, lambda0, epsilon, lr);
+    const float lam0 = (float)lambda0, temp0 = st.temperature();
+    HIP_TRY(h, hipDeviceSynchronize());
+    HIP_TRY(h, hipMemcpy(h->mpo_dev, &st, sizeof(st), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->mpo_temp_dev, &temp0, sizeof(float), hipMemcpyHostToDevice));
+    if (!lambda_too) return MPPI_OK;  // (mppi_create: the dual exists, but no temperature has been asked for yet)
+    HIP_TRY(h, hipMemcpy(h->lambda_dev, &lam0, sizeof(float), hipMemcpyHostToDevice));  // the first solve's temperature
+    h->stats_host[8 + STATS_L * 3] = h->stats_host[8 + STATS_L * 3 + 1] = lambda0;
+    h->lambda_dev_valid = true;
     return MPPI_OK;
 }
-// One Adam step of the dual on the last solve's costs (statistics at softplus(logT): one mppi_softmax_stats round
-// trip), lambda_out = exp(logT) = the temperature of the NEXT solve.  Unsharded handles; synchronises.
+// One Adam step of the dual on the last solve's costs with NO host synchronisation: statistics at softplus(logT) (read
+// from device memory) + a one-thread step; lambda = exp(logT) — the temperature of the NEXT solve — replaces the one in
+// HBM that this solve's weights used (MPPI_LAMBDA_DEVICE).  Call it after mppi_finalize.
+int mppi_mpo_step_device(mppi_handle_t h, void* stream) {
+    if (!h) return MPPI_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned* mk = h->min_key + h->min_slot;
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(STATS_BLOCKS, (h->d.N + BLOCK - 1) / BLOCK));
+    double* host_lam = nullptr;
+    HIP_TRY(h, hipHostGetDevicePointer((void**)&host_lam, h->stats_host, 0));
+    host_lam += 8 + STATS_L * 3;
+    hipLaunchKernelGGL(stats_partial_kernel, dim3(blocks), dim3(BLOCK), 0, s, h->costs, h->d.N, mk, 1.0f,
+                       (const float*)h->mpo_temp_dev, h->stats_part);
+    hipLaunchKernelGGL(mpo_step_kernel, dim3(1), dim3(WAVE), 0, s, (const float*)h->stats_part, blocks, mk, h->mpo_dev,
+                       h->lambda_dev, h->mpo_temp_dev, host_lam);
+    HIP_TRY(h, hipGetLastError());
+    h->lambda_dev_valid = true;
+    return MPPI_OK;
+}
+// The same step, returning lambda_out = exp(logT) = the temperature of the NEXT solve.  Unsharded handles; synchronises.
 int mppi_mpo_step(mppi_handle_t h, double* lambda_out, void* stream) {
     if (!h || !lambda_out) return fail(h, MPPI_E_INVALID, "null");
-    double o[5];
-    if (int rc = mppi_softmax_stats(h, (float)h->mpo.temperature(), o, stream)) return rc;
-    *lambda_out = mppi::host::mpo_step(h->mpo, mppi::host::SoftmaxStats{o[0], o[1], o[2], o[3], o[4]});
-    return MPPI_OK;
+    if (int rc = mppi_mpo_step_device(h, stream)) return rc;
+    return mppi_get_lambda(h, lambda_out, nullptr, stream);
 }
-// {log T, first moment, second moment, step count} of the dual (inspection / tests).
+// {log T, first moment, second moment, step count} of the dual (inspection / tests).  Synchronises the device.
 int mppi_mpo_state(mppi_handle_t h, double* out4_host) {
     if (!h || !out4_host) return fail(h, MPPI_E_INVALID, "null");
-    out4_host[0] = h->mpo.log_temperature; out4_host[1] = h->mpo.m; out4_host[2] = h->mpo.v; out4_host[3] = h->mpo.t;
+    mppi::host::MpoState st;
+    HIP_TRY(h, hipDeviceSynchronize());
+    HIP_TRY(h, hipMemcpy(&st, h->mpo_dev, sizeof(st), hipMemcpyDeviceToHost));
+    out4_host[0] = st.log_temperature; out4_host[1] = st.m; out4_host[2] = st.v; out4_host[3] = st.t;
     return MPPI_OK;
 }
 

@@ -946,9 +946,11 @@ __global__ __launch_bounds__(FIN_BLOCK) void finalize_kernel(const float* __rest
 // (per-block partials, then a fixed-order combine written to mapped host memory): deterministic.
 constexpr int STATS_BLOCKS = 256;
 __global__ __launch_bounds__(BLOCK) void stats_partial_kernel(const float* __restrict__ costs, int64_t N,
-                                                             const unsigned* __restrict__ min_key, float lambda,
+                                                             const unsigned* __restrict__ min_key, float lambda_arg,
+                                                             const float* __restrict__ lambda_dev /* nullable */,
                                                              float* __restrict__ part /*[STATS_BLOCKS][4]*/) {
     __shared__ float s_p[BLOCK / WAVE][4];
+    const float lambda = lambda_dev ? *lambda_dev : lambda_arg;
     const float cmin = key_to_float(*min_key);
     const float xmax = (-cmin) / lambda;
     float se = 0.f, se2 = 0.f, sec = 0.f, cmax = -INFINITY;
@@ -1008,11 +1010,14 @@ __global__ __launch_bounds__(STATS_THREADS) void stats_multi_kernel(const float*
                                                                     const unsigned* __restrict__ min_key,
                                                                     const float* __restrict__ lams,
                                                                     float* __restrict__ part,
-                                                                    const int32_t* __restrict__ skip /* nullable */) {
+                                                                    const int32_t* __restrict__ skip /* nullable */,
+                                                                    float* __restrict__ part_max /* nullable: [blocks] max c */) {
     constexpr int NWV = STATS_THREADS / WAVE;
     if (skip && *skip) return;  // second pass of a search that an end-point rule already decided
     __shared__ float s_c[STATS_THREADS];
     __shared__ float s_p[NWV][STATS_L][3];
+    __shared__ float s_mx[NWV];
+    float cmaxv = -INFINITY;
     const float cmin = key_to_float(*min_key);
     const int l = threadIdx.x & (STATS_L - 1), chunk = threadIdx.x >> 5;
     const float inv_lam = 1.0f / lams[l];
@@ -1021,7 +1026,9 @@ __global__ __launch_bounds__(STATS_THREADS) void stats_multi_kernel(const float*
         __syncthreads();
         const int64_t i = base + threadIdx.x;
         // padding: a huge finite cost -> e = exp(-inf) = 0 and 0 * c = 0
-        s_c[threadIdx.x] = i < N ? costs[i] : 3.0e38f;
+        const float cv = i < N ? costs[i] : 3.0e38f;
+        if (i < N) cmaxv = fmaxf(cmaxv, cv);
+        s_c[threadIdx.x] = cv;
         __syncthreads();
         const float* cc = s_c + chunk * 32;
 #pragma unroll 8
@@ -1038,7 +1045,18 @@ __global__ __launch_bounds__(STATS_THREADS) void stats_multi_kernel(const float*
     se += __shfl_xor(se, 32); se2 += __shfl_xor(se2, 32); sec += __shfl_xor(sec, 32);  // the wave's two chunks
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     if (lane < STATS_L) { s_p[wid][lane][0] = se; s_p[wid][lane][1] = se2; s_p[wid][lane][2] = sec; }
+    if (part_max) {  // (uniform) the LBPS objective needs the cost range
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) cmaxv = fmaxf(cmaxv, __shfl_xor(cmaxv, m));
+        if (lane == 0) s_mx[wid] = cmaxv;
+    }
     __syncthreads();
+    if (part_max && threadIdx.x == 0) {
+        float v = s_mx[0];
+#pragma unroll
+        for (int w = 1; w < NWV; ++w) v = fmaxf(v, s_mx[w]);
+        part_max[blockIdx.x] = v;
+    }
     if (threadIdx.x < STATS_L * 3) {
         float v = 0.0f;
 #pragma unroll
@@ -1123,7 +1141,7 @@ __global__ __launch_bounds__(1024) void essps_select_kernel(const float* __restr
             st->lo = lo; st->hi = hi;
             s_bracket[0] = lo; s_bracket[1] = hi;
             s_have = have ? 1 : 0;
-            if (have) { st->lam = lam; *lambda_out = (float)lam; *lambda_host = lam; }
+            if (have) { st->lam = lam; *lambda_out = (float)lam; lambda_host[0] = lam; lambda_host[1] = lam; }
         }
         __builtin_amdgcn_wave_barrier();
         if (!s_have && j < STATS_L) {  // the refined grid, one point (two logs + one exp in double) per lane
@@ -1135,7 +1153,96 @@ __global__ __launch_bounds__(1024) void essps_select_kernel(const float* __restr
         const double lam = mppi::host::essps_round1<STATS_L>(st->grid1, s_ess, target_ess);
         st->lam = lam;
         *lambda_out = (float)lam;
-        *lambda_host = lam;
+        lambda_host[0] = lam; lambda_host[1] = lam;
+    }
+}
+
+// LBPS without leaving the device (mppi.py:341-349,534-557).  The reference minimises the lower-bound objective with
+// scipy's bounded Brent search, ~25 dependent probes; here every round evaluates the objective on a 32-temperature
+// geometric grid in ONE pass over the costs (stats_multi_kernel), one block picks the grid minimum and writes the next
+// grid over the two intervals around it; after LBPS_ROUNDS grids (spacing 25 % -> 1.4 % -> 0.09 % of lambda over
+// [0.01, 10]) the last round fits a parabola in log(lambda) through the three points around the minimum
+// (host_search.hpp: lbps_grid_step — the same code the CPU tests run against scipy).  The temperature stays in
+// `lambda_out` (device) + mapped host memory; the host never waits.
+constexpr int LBPS_ROUNDS = 3;
+struct LbpsDev {
+    double grid0[STATS_L];  // round-0 temperatures: geometric over [lam_min, lam_max], written once by the host
+    double grid[STATS_L];   // temperatures of the round in flight (`lams` holds their fp32 casts)
+};
+template <bool LAST, bool FIRST>
+__global__ __launch_bounds__(1024) void lbps_select_kernel(const float* __restrict__ part,
+                                                           const float* __restrict__ part_max, int nblocks,
+                                                           const unsigned* __restrict__ min_key, double delta,
+                                                           LbpsDev* __restrict__ st, float* __restrict__ lams,
+                                                           float* __restrict__ lambda_out,
+                                                           double* __restrict__ lambda_host /*[2]: next, used*/) {
+    __shared__ double s_acc[STATS_COMB_GROUPS * STATS_L * 3];
+    __shared__ double s_sum[STATS_L * 3];
+    __shared__ double s_obj[STATS_L], s_grid[STATS_L];
+    __shared__ double s_bracket[2];
+    __shared__ float s_cmax;
+    stats_combine_columns(part, nblocks, s_acc, s_sum);
+    if (threadIdx.x >= WAVE) return;
+    const int j = threadIdx.x;
+    {   // the cost range: per-block maxima -> one wave
+        float m = -INFINITY;
+        for (int b = j; b < nblocks; b += WAVE) m = fmaxf(m, part_max[b]);
+#pragma unroll
+        for (int q = 32; q >= 1; q >>= 1) m = fmaxf(m, __shfl_xor(m, q));
+        if (j == 0) s_cmax = m;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (j < STATS_L) {
+        const double g = FIRST ? st->grid0[j] : st->grid[j];
+        s_grid[j] = g;
+        const mppi::host::SoftmaxStats ss{(double)key_to_float(*min_key), (double)s_cmax, s_sum[3 * j], s_sum[3 * j + 1],
+                                          s_sum[3 * j + 2]};
+        s_obj[j] = mppi::host::lbps_objective(ss, delta);
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (j == 0) {
+        double lo, hi, lam;
+        mppi::host::lbps_grid_step<STATS_L>(s_grid, s_obj, LAST, lo, hi, lam);
+        s_bracket[0] = lo; s_bracket[1] = hi;
+        if (LAST) { *lambda_out = (float)lam; lambda_host[0] = lam; lambda_host[1] = lam; }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (!LAST && j < STATS_L) {
+        const double gj = mppi::host::essps_grid_point<STATS_L>(s_bracket[0], s_bracket[1], j);
+        st->grid[j] = gj;
+        lams[j] = (float)gj;
+    }
+}
+
+// MPO without leaving the device (mppi.py:191-200,387-398): the dual variable and its Adam moments live in device
+// memory; after the solve's weights one statistics pass at T = softplus(log T) (stats_partial_kernel reading T from
+// `temp_dev`) and this one-thread step (host_search.hpp: mpo_step — the arithmetic the CPU tests pin to the reference)
+// leave lambda = exp(log T) for the NEXT solve in `lambda_out`.
+__global__ __launch_bounds__(WAVE) void mpo_step_kernel(const float* __restrict__ part, int nblocks,
+                                                        const unsigned* __restrict__ min_key,
+                                                        mppi::host::MpoState* __restrict__ st,
+                                                        float* __restrict__ lambda_out, float* __restrict__ temp_dev,
+                                                        double* __restrict__ lambda_host /*[2]: next, used*/) {
+    double se = 0.0, se2 = 0.0, sec = 0.0;
+    float cmax = -INFINITY;
+    for (int b = threadIdx.x; b < nblocks; b += WAVE) {
+        se += part[b * 4]; se2 += part[b * 4 + 1]; sec += part[b * 4 + 2];
+        cmax = fmaxf(cmax, part[b * 4 + 3]);
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        se += __shfl_xor(se, m); se2 += __shfl_xor(se2, m); sec += __shfl_xor(sec, m);
+        cmax = fmaxf(cmax, __shfl_xor(cmax, m));
+    }
+    if (threadIdx.x == 0) {
+        mppi::host::MpoState s = *st;
+        const double used = (double)*lambda_out;
+        const mppi::host::SoftmaxStats ss{(double)key_to_float(*min_key), (double)cmax, se, se2, sec};
+        const double lam = mppi::host::mpo_step(s, ss);
+        *st = s;
+        *lambda_out = (float)lam;
+        *temp_dev = s.temperature();
+        lambda_host[0] = lam; lambda_host[1] = used;
     }
 }
 

@@ -63,6 +63,7 @@ class MPPI(nn.Module):
         process_group=None,
         auto_lambda_stats: str = "device",
         essps_search: str = "device",
+        lbps_search: str = "device",
         sg_filter: str = "device",
         graph_callables: bool = False,
         _force_exchange: bool = False,
@@ -83,6 +84,10 @@ class MPPI(nn.Module):
                 statistics back after each pass; "brentq" probes one lambda at a time like the reference's scipy
                 call.  All return the same root (to ~1e-7 relative).  Sharded solvers combine the shards'
                 statistics on the host ("device" behaves like "grid" there).
+            lbps_search: with device statistics on one GPU, "device" (default) replaces the reference's ~25 dependent Brent
+                probes by three 32-temperature grids + a parabola, all as kernels (no host wait; within 1e-3 relative of
+                the Brent minimiser), "brent" runs scipy's bounded Brent inside the library, one read-back per probe.
+                The MPO dual always steps on the device when the statistics are the device's own.
             sg_filter: "device" (default) runs the Savitzky-Golay step inside the finalize kernel
                 (bit-identical to the host statement), "host" keeps the reference's numpy-style round trip.
             graph_callables: opaque (untagged) callables only.  The reference's two T-step Python loops over the user's
@@ -148,6 +153,9 @@ class MPPI(nn.Module):
         if essps_search not in ("device", "grid", "brentq"):
             raise ValueError("essps_search must be 'device', 'grid' or 'brentq'")
         self._essps_search = essps_search
+        if lbps_search not in ("device", "brent"):
+            raise ValueError("lbps_search must be 'device' or 'brent'")
+        self._lbps_search = lbps_search
         assert sg_filter in ("device", "host")
         self._sg_on_device = sg_filter == "device"
         if noise_source not in ("philox", "torch_cpu"):
@@ -191,7 +199,11 @@ class MPPI(nn.Module):
 
         # ---- auto lambda (src/pi_mpc/mppi.py:183-210)
         self._lambda_pending = False  # the temperature of the last solve still lives on the device only
+        self._lambda_stream = None    # ... and this is the stream that solve was enqueued on
+        self._lambda_override = None  # MPO on the device: a temperature assigned to `_lambda` by the caller
+        self._used_known = True       # `_last_lambda_value` already holds the last solve's temperature
         self._lambda_value = self._last_lambda_value = None
+        self._h = None
         self._lambda = lambda_
         self._lbps_delta = lbps_delta
         self._essps_target_ess = essps_target_ess if essps_target_ess is not None else num_samples / 10
@@ -237,8 +249,21 @@ class MPPI(nn.Module):
         # the LBPS search and the MPO step run inside the library (no interpreter work per probe) whenever the
         # statistics come from this device alone; sharded solvers combine the shards' statistics in Python
         self._search_in_library = auto_lambda_stats == "device" and self._world == 1
-        if self._auto_lambda == "MPO":
-            self._h.call("mppi_mpo_reset", 1.0, 0.1, 0.2)  # mppi.py:191-200
+        # which rule runs as kernels with the temperature resident in HBM (no host wait): mppi_set_auto_lambda
+        self._rule_on_device = None
+        if self._search_in_library:
+            if self._auto_lambda == "ESSPS" and essps_search == "device":
+                self._rule_on_device = "ESSPS"
+                self._h.call("mppi_set_auto_lambda", _capi.AUTO_RULES["ESSPS"], float(self._essps_target_ess),
+                             float(lambda_min), float(lambda_max))
+            elif self._auto_lambda == "LBPS" and lbps_search == "device":
+                self._rule_on_device = "LBPS"
+                self._h.call("mppi_set_auto_lambda", _capi.AUTO_RULES["LBPS"], float(lbps_delta), float(lambda_min),
+                             float(lambda_max))
+            elif self._auto_lambda == "MPO":
+                self._rule_on_device = "MPO"
+                self._h.call("mppi_mpo_reset", 1.0, 0.1, 0.2)  # mppi.py:191-200
+                self._h.call("mppi_set_auto_lambda", _capi.AUTO_RULES["MPO"], 0.0, 0.0, 0.0)
         if self._sg_on_device:  # step 7 runs inside mppi_finalize (taps computed above, history zero)
             self._h.call("mppi_set_sg_filter", self._coeffs.ctypes.data_as(C.c_void_p), int(len(self._coeffs)), None)
         self._uploaded = {}  # slot -> (id(cells), version)
@@ -272,8 +297,7 @@ class MPPI(nn.Module):
                           and ((self._world == 1 and not self._force_exchange) or in_library_exchange)
                           and not (self._world > 1 and lambda_ in ("MPO", "LBPS", "ESSPS"))
                           and not (use_sg_filter and not self._sg_on_device)
-                          and (self._auto_lambda is None
-                               or (self._auto_lambda == "ESSPS" and auto_lambda_stats == "device" and essps_search == "device")))
+                          and (self._auto_lambda is None or self._rule_on_device is not None))
         self._last_lambda = None
         self._injected = None
         self._mean_of_last_solve = self._previous_action_seq
@@ -283,10 +307,13 @@ class MPPI(nn.Module):
 
     # ------------------------------------------------------------------ temperature (lazily fetched)
     def _fetch_lambda(self) -> None:
-        """The ESSPS search of the last solve ran on the device without a read-back: fetch its result now."""
-        out = C.c_double(0.0)
-        self._h.call("mppi_get_lambda", C.byref(out), self._stream())
-        self._lambda_value = self._last_lambda_value = out.value
+        """The temperature rule of the last solve ran on the device without a read-back: fetch its result now (waits for
+        the stream that solve was enqueued on)."""
+        nxt, used = C.c_double(0.0), C.c_double(0.0)
+        self._h.call("mppi_get_lambda", C.byref(nxt), C.byref(used), self._lambda_stream)
+        self._lambda_value = nxt.value
+        if not self._used_known:  # (an explicitly given temperature is already on record)
+            self._last_lambda_value = used.value
         self._lambda_pending = False
 
     @property
@@ -298,8 +325,11 @@ class MPPI(nn.Module):
 
     @_lambda.setter
     def _lambda(self, value) -> None:
+        if self._lambda_pending:  # settle what the last solve left on the device first (its `_last_lambda`)
+            self._fetch_lambda()
         self._lambda_value = value
-        self._lambda_pending = False
+        if getattr(self, "_rule_on_device", None) == "MPO":  # the next solve's weights use the caller's value
+            self._lambda_override = float(value)
 
     @property
     def _last_lambda(self):
@@ -603,7 +633,12 @@ class MPPI(nn.Module):
         on_dev = self._auto_lambda_stats == "device"
         if self._auto_lambda is not None and not on_dev:
             costs_host = self._gather_costs_host()
-        if self._auto_lambda == "LBPS" and self._search_in_library:
+        if self._rule_on_device == "LBPS":  # three grid rounds as kernels: nothing is read back
+            h.call("mppi_lbps_lambda_device", float(self._lbps_delta), float(self._lambda_min), float(self._lambda_max), st)
+            self._lambda_pending, self._lambda_stream = True, st
+        elif self._rule_on_device == "MPO":  # this solve uses the temperature the dual left in HBM (or the caller's)
+            self._lambda_pending, self._lambda_stream = self._lambda_override is None, st
+        elif self._auto_lambda == "LBPS" and self._search_in_library:
             lam_out = C.c_double(0.0)  # bounded Brent inside the library (same algorithm as scipy's, host C++)
             h.call("mppi_lbps_lambda", float(self._lbps_delta), float(self._lambda_min), float(self._lambda_max),
                    C.byref(lam_out), st)
@@ -616,7 +651,7 @@ class MPPI(nn.Module):
             # the whole search as kernels on this stream: nothing is read back, the temperature stays in HBM
             h.call("mppi_essps_lambda_device", float(self._essps_target_ess), float(self._lambda_min),
                    float(self._lambda_max), st)
-            self._lambda_pending = True
+            self._lambda_pending, self._lambda_stream = True, st
         elif self._auto_lambda == "ESSPS" and on_dev and self._essps_search == "grid" and self._world == 1:
             lam_out = C.c_double(0.0)  # the search as a host loop inside the library (same algorithm, one read-back per grid)
             h.call("mppi_essps_lambda", float(self._essps_target_ess), float(self._lambda_min),
@@ -631,9 +666,11 @@ class MPPI(nn.Module):
                                                self._lambda_max))
         if self._lambda_pending:
             lam = _capi.LAMBDA_DEVICE  # weights_reduce / finalize read the temperature from device memory
+            self._used_known = False
         else:
-            lam = float(self._lambda)
+            lam = float(self._lambda_override if self._lambda_override is not None else self._lambda)
             self._last_lambda = lam
+            self._used_known = True
 
         # Steps 5-6: weights + weighted mean (src/pi_mpc/mppi.py:376-385)
         sharded = self._world > 1 or self._force_exchange
@@ -660,10 +697,9 @@ class MPPI(nn.Module):
                _ptr(self._state_out) if (native and not use_sg) else None, _ptr(self._stats), st)
 
         if self._auto_lambda == "MPO":  # after the weights, affects the next solve (mppi.py:387-398)
-            if self._search_in_library:
-                lam_out = C.c_double(0.0)
-                h.call("mppi_mpo_step", C.byref(lam_out), st)
-                self._lambda = lam_out.value
+            if self._rule_on_device == "MPO":
+                h.call("mppi_mpo_step_device", st)  # dual, moments and the next temperature stay in HBM
+                self._lambda_pending, self._lambda_stream = True, st
             else:
                 self._lambda = (self._mpo.step_from_stats(self._softmax_stats(self._mpo.temperature())) if on_dev
                                 else self._mpo.step(costs_host))
@@ -682,6 +718,7 @@ class MPPI(nn.Module):
                 self._state_out = self._states_prediction_graphed()
             else:
                 self._state_out = self._states_prediction(self._x0_tensor, self._action_out.repeat(1, 1, 1))
+        self._lambda_override = None
         self._previous_action_seq = self._action_out
         return self._action_out, self._state_out
 
@@ -699,15 +736,18 @@ class MPPI(nn.Module):
         self._refresh_model_inputs()
         self._mean_of_last_solve = self._previous_action_seq
         if self._auto_lambda is None:
-            lam = float(self._lambda)
-            self._last_lambda = lam
-        else:  # ESSPS, searched on the device
+            lam = float(self._lambda_value)
+            self._last_lambda_value, self._used_known = lam, True
+        elif self._lambda_override is not None:  # MPO with a temperature assigned by the caller (the dual still steps)
+            lam = self._last_lambda_value = self._lambda_override
+            self._lambda_pending, self._lambda_stream, self._used_known = True, st, True
+            self._lambda_override = None
+        else:  # the configured rule runs on the device; the temperature is fetched when somebody asks for it
             lam = _capi.LAMBDA_DEVICE
-            self._lambda_pending = True
+            self._lambda_pending, self._lambda_stream, self._used_known = True, st, False
         self._action_out = torch.empty(self._horizon, self._dim_control, device=self._device, dtype=self._dtype)
         self._state_out = torch.empty(1, self._horizon + 1, self._dim_state, device=self._device, dtype=self._dtype)
-        h.call("mppi_solve", x0p, self._solve_idx, lam, float(self._essps_target_ess), float(self._lambda_min),
-               float(self._lambda_max), _ptr(self._action_out), _ptr(self._state_out), _ptr(self._stats), st)
+        h.call("mppi_solve", x0p, self._solve_idx, lam, _ptr(self._action_out), _ptr(self._state_out), _ptr(self._stats), st)
         self._solve_idx += 1
         self._previous_action_seq = self._action_out
         return self._action_out, self._state_out

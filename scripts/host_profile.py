@@ -27,7 +27,7 @@ h, st = s._h, s._stream()
 a = torch.empty(50, 1, device="cuda"); so = torch.empty(1, 51, 2, device="cuda")
 t0 = time.perf_counter()
 for i in range(2000):
-    h.lib.mppi_solve(h.h, C.c_void_p(x0.data_ptr()), 5 + i, 1.0, 0.0, 0.01, 10.0, C.c_void_p(a.data_ptr()), C.c_void_p(so.data_ptr()), None, st)
+    h.lib.mppi_solve(h.h, C.c_void_p(x0.data_ptr()), 5 + i, 1.0, C.c_void_p(a.data_ptr()), C.c_void_p(so.data_ptr()), None, st)
 t1 = time.perf_counter()
 torch.cuda.synchronize()
 print(f"bare mppi_solve: {1e6 * (t1 - t0) / 2000:.1f} us per call (enqueue), {1e6 * (time.perf_counter() - t0) / 2000:.1f} us wall")

@@ -65,6 +65,7 @@ def search_lib():
         _search = C.CDLL(_SEARCH_SO)
         d, vp, i = C.c_double, C.c_void_p, C.c_int
         _search.search_lbps.argtypes = [vp, i, d, d, d, vp, vp]
+        _search.search_lbps_grid.argtypes = [vp, i, d, d, d, vp]
         _search.search_fminbound_poly.argtypes = [d, d, d, d, d, vp, vp]
         _search.search_essps.argtypes = [vp, i, d, d, d, vp]
         _search.search_mpo.argtypes = [vp, i, i, d, d, d, vp]
@@ -76,6 +77,13 @@ def lbps(costs, delta, lo, hi):
     out, nf = C.c_double(0), C.c_int(0)
     assert search_lib().search_lbps(_p(c), len(c), delta, lo, hi, C.byref(out), C.byref(nf)) == 0
     return out.value, nf.value
+
+
+def lbps_grid(costs, delta, lo, hi):
+    c = np.ascontiguousarray(costs, np.float32)
+    out = C.c_double(0)
+    assert search_lib().search_lbps_grid(_p(c), len(c), delta, lo, hi, C.byref(out)) == 0
+    return out.value
 
 
 def fminbound_poly(a, b, c, lo, hi):

@@ -30,6 +30,27 @@ int search_lbps(const float* costs, int n, double delta, double lo, double hi, d
                        *lam_out, nfev) ? 0 : -1;
 }
 
+// the device-resident variant of the LBPS search (lbps_select_kernel): `rounds` geometric grids of 32 temperatures + the
+// final parabola, with the statistics the device pass produces (e = exp((cmin - c) * (1 / lam)) in fp32, sums in double)
+int search_lbps_grid(const float* costs, int n, double delta, double lo, double hi, double* lam_out) {
+    float cmin = INFINITY, cmax = -INFINITY;
+    for (int i = 0; i < n; ++i) { cmin = std::fmin(cmin, costs[i]); cmax = std::fmax(cmax, costs[i]); }
+    return lbps_lambda_grid<32, 3>(
+               [&](const double* grid, double* obj) {
+                   for (int j = 0; j < 32; ++j) {
+                       const float inv_lam = 1.0f / (float)grid[j];
+                       double se = 0, se2 = 0, sec = 0;
+                       for (int i = 0; i < n; ++i) {
+                           const double e = (double)std::exp((cmin - costs[i]) * inv_lam);
+                           se += e; se2 += e * e; sec += e * (double)costs[i];
+                       }
+                       obj[j] = lbps_objective(SoftmaxStats{cmin, cmax, se, se2, sec}, delta);
+                   }
+                   return true;
+               },
+               lo, hi, *lam_out) ? 0 : -1;
+}
+
 // generic check of the minimiser on f(x) = (x - a)^2 * (1 + b * sin(c * x)) over [lo, hi]
 int search_fminbound_poly(double a, double b, double c, double lo, double hi, double* xmin, int* nfev) {
     return fminbound([&](double x, double& out) { out = (x - a) * (x - a) * (1.0 + b * std::sin(c * x)) + 0.1 * x; return true; },

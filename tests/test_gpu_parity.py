@@ -753,6 +753,44 @@ def test_device_softmax_stats_drive_the_same_temperature(lam_mode):
         ess = sg._ess_grid([sg._last_lambda])[0]
         assert abs(ess - N / 10) <= 1e-4 * N / 10
     assert rel_err(outs[0][1], outs[1][1]) < 20 * tol
+    x0 = torch.tensor([-9.0, -9.0, 0.785])
+    if lam_mode == "LBPS":
+        # the default runs the search as kernels (three 32-temperature grids + a parabola, no host wait); scipy's
+        # Brent inside the library (one read-back per probe) lands on the same minimum
+        assert outs[0][3]._rule_on_device == "LBPS" and outs[0][3]._one_call
+        sb, _ = make_solver("nav2d", T, N, lambda_="LBPS", lbps_search="brent")
+        ab, _ = sb.forward(x0)
+        assert sb._rule_on_device is None
+        c = sb._costs.cpu().numpy()
+        sd, _ = make_solver("nav2d", T, N, lambda_="LBPS")
+        ad, _ = sd.forward(x0)
+        assert sd._lambda_pending
+        assert same_lbps_minimum(c, sd._last_lambda, sb._last_lambda) and not sd._lambda_pending
+        assert sd._lambda == sd._last_lambda
+    if lam_mode == "MPO":
+        # the dual and its Adam moments live on the device; the step-by-step entry points (what an injected-noise solve
+        # takes) and the one-call path agree bit for bit, and `_lambda` / `_last_lambda` follow the reference's
+        # bookkeeping: the weights of solve k use the temperature the dual had BEFORE its k-th step (mppi.py:387-398)
+        sa, _ = make_solver("nav2d", T, N, lambda_="MPO")
+        sb, _ = make_solver("nav2d", T, N, lambda_="MPO")
+        sb._one_call = False
+        lams = []
+        for k in range(4):
+            a1, _ = sa.forward(x0)
+            a2, _ = sb.forward(x0)
+            assert torch.equal(a1, a2)
+            assert sa._last_lambda == sb._last_lambda == (1.0 if k == 0 else lams[-1]) and sa._lambda == sb._lambda
+            lams.append(sa._lambda)
+        assert len(set(lams)) == 4
+        st4 = (C.c_double * 4)()
+        sa._h.call("mppi_mpo_state", st4)
+        assert int(st4[3]) == 4 and abs(np.exp(np.float32(st4[0])) - lams[-1]) <= 1e-6 * lams[-1]
+        # a temperature assigned by the caller is used by the next solve's weights; the dual steps on regardless
+        sa._lambda = 2.5
+        sa.forward(x0)
+        assert sa._last_lambda == 2.5 and sa._lambda != 2.5
+        sa._h.call("mppi_mpo_state", st4)
+        assert int(st4[3]) == 5
     solver = outs[0][3]
     c = solver._costs.cpu().numpy().astype(np.float64)
     st = solver._softmax_stats(3.0)
@@ -1554,7 +1592,7 @@ def test_essps_device_search_equals_the_host_loop_on_random_costs():
             h.call("mppi_essps_lambda", float(target), 0.01, 10.0, C.byref(lam_host), st)
             h.call("mppi_essps_lambda_device", float(target), 0.01, 10.0, st)
             lam_dev = C.c_double(0.0)
-            h.call("mppi_get_lambda", C.byref(lam_dev), st)
+            h.call("mppi_get_lambda", C.byref(lam_dev), None, st)
             assert abs(lam_dev.value - lam_host.value) <= 1e-12 * lam_host.value, (name, target, lam_dev.value, lam_host.value)
             c64 = c.astype(np.float64)
             ess = lambda lam: (lambda e: e.sum() ** 2 / (e * e).sum())(np.exp(-(c64 - c64.min()) / lam))  # noqa: E731

@@ -308,6 +308,10 @@ def test_library_searches_match_reference_fixtures():
             assert same_lbps_minimum(c, lam, float(g[f"lambda_{k}"]))
             assert same_lbps_minimum(c, lam, _host.lbps_lambda_stats(_np_stats(c), 0.01, 0.01, 10.0))
             assert 5 <= nfev <= 60
+            # the device-resident variant (three 32-temperature grids + a parabola, lbps_select_kernel) lands on the
+            # reference's minimum too
+            lam_grid = emul.lbps_grid(c, 0.01, 0.01, 10.0)
+            assert same_lbps_minimum(c, lam_grid, float(g[f"lambda_{k}"])), (name, k, lam_grid, float(g[f"lambda_{k}"]))
     for name in ("pendulum_T50_N1000_essps", "nav2d_T50_N512_essps", "cartpole_T64_N1024_essps_sg",
                  "nav2d_T30_N4096_essps", "racing_T25_N1024_essps"):
         g, cfg = load(name), CASES[name]
@@ -346,3 +350,28 @@ def test_bench_launches_its_own_ranks(monkeypatch):
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     assert cmd[-6:] == ["--gpus", "8", "--steps", "50", "--warmup", "10"] and cmd[-7].endswith("bench.py")
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_lbps_grid_search_finds_the_brent_minimum_on_random_costs():
+    """The grid variant of the LBPS search against scipy's bounded Brent minimiser (the reference's call) on a float64
+    evaluation of the objective, over cost vectors of different shapes; where Brent stops in a local minimum the grid may
+    only be better."""
+    import emul
+    from scipy.optimize import minimize_scalar
+
+    from helpers import lbps_objective64
+
+    rng = np.random.default_rng(9)
+    N = 2000
+    shapes = [lambda: rng.standard_normal(N) * 3 + 20, lambda: rng.standard_exponential(N) * 5,
+              lambda: np.concatenate([rng.standard_normal(N // 2), 8 + rng.standard_normal(N - N // 2)]),
+              lambda: 1e4 + rng.standard_normal(N) * 30, lambda: rng.standard_normal(N) * 0.05,
+              lambda: np.abs(rng.standard_cauchy(N)) * 2]
+    for i, draw in enumerate(shapes):
+        c = draw().astype(np.float32)
+        res = minimize_scalar(lambda lam: lbps_objective64(c, lam), bounds=(0.01, 10.0), method="bounded")
+        lam = emul.lbps_grid(c, 0.01, 0.01, 10.0)
+        f, f_ref = lbps_objective64(c, lam), lbps_objective64(c, res.x)
+        assert f <= f_ref + 1e-6 * abs(f_ref), (i, lam, res.x, f, f_ref)
+        if abs(lam - res.x) > 2e-3 * res.x:  # a different temperature only where the objective is no worse
+            assert f <= f_ref + 1e-7 * abs(f_ref), (i, lam, res.x)
