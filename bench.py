@@ -402,6 +402,12 @@ def _other_solvers(torch, np, which=None):
         ("c2_essps", "C2 nav2d T=50 N=65536 ESSPS", 65536 * 50, 3 * 4 * 2 * 65536 * 50 + 8 * 65536,
          lambda: MPPI(50, 65536, 3, 2, nav.dynamics, nav.cost_function, nav.u_min, nav.u_max, t([0.5, 0.5]), "ESSPS"),
          nav.reset().clone()),
+        ("c2_lbps", "C2 nav2d T=50 N=65536 LBPS (device-resident grid search)", 65536 * 50, 3 * 4 * 2 * 65536 * 50 + 8 * 65536,
+         lambda: MPPI(50, 65536, 3, 2, nav.dynamics, nav.cost_function, nav.u_min, nav.u_max, t([0.5, 0.5]), "LBPS"),
+         nav.reset().clone()),
+        ("c2_mpo", "C2 nav2d T=50 N=65536 MPO (dual on the device)", 65536 * 50, 3 * 4 * 2 * 65536 * 50 + 8 * 65536,
+         lambda: MPPI(50, 65536, 3, 2, nav.dynamics, nav.cost_function, nav.u_min, nav.u_max, t([0.5, 0.5]), "MPO"),
+         nav.reset().clone()),
         ("c5", "C5 cartpole T=64 N=262144 ESSPS + Savitzky-Golay", 262144 * 64, 3 * 4 * 1 * 262144 * 64 + 8 * 262144,
          lambda: MPPI(64, 262144, 4, 1, cc.cartpole_dynamics, cc.cartpole_cost, t([-3.0]), t([3.0]), t([1.0]), "ESSPS",
                       use_sg_filter=True),

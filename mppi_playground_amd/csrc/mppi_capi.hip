@@ -174,7 +174,8 @@ struct StageTimer {
 };
 
 int math_level(mppi_handle_t h);
-// dispatch on (model, math level); level 2 exists for the models with wrapped-heading trigonometry only
+// dispatch on (model, math level); level 2 exists for the models whose trigonometric arguments are bounded by the model
+// itself (wrapped headings, clamped pole angle / position): all but the pendulum, whose angle is free
 #define MPPI_DISPATCH_HW(MODEL_, CALL)                                                                \
         case MODEL_: if (ml_ == 2) { CALL(MODEL_, 2); } else if (ml_ == 1) { CALL(MODEL_, 1); } else { CALL(MODEL_, 0); } break;
 #define MPPI_DISPATCH_NOHW(MODEL_, CALL)                                                              \
@@ -185,11 +186,11 @@ int math_level(mppi_handle_t h);
         switch ((h)->cfg.model) {                                                                     \
         case MPPI_MODEL_GENERIC: /* only reached by mppi_finalize without a state output */          \
         MPPI_DISPATCH_NOHW(MPPI_MODEL_PENDULUM, CALL)                                                 \
-        MPPI_DISPATCH_NOHW(MPPI_MODEL_CARTPOLE, CALL)                                                 \
-        MPPI_DISPATCH_NOHW(MPPI_MODEL_MOUNTAINCAR, CALL)                                              \
+        MPPI_DISPATCH_HW(MPPI_MODEL_CARTPOLE, CALL)                                                   \
+        MPPI_DISPATCH_HW(MPPI_MODEL_MOUNTAINCAR, CALL)                                                \
         MPPI_DISPATCH_HW(MPPI_MODEL_NAV2D, CALL)                                                      \
         MPPI_DISPATCH_HW(MPPI_MODEL_RACING, CALL)                                                     \
-        MPPI_DISPATCH_NOHW(MPPI_MODEL_MJCARTPOLE, CALL)                                               \
+        MPPI_DISPATCH_HW(MPPI_MODEL_MJCARTPOLE, CALL)                                                 \
         MPPI_DISPATCH_HW(MPPI_MODEL_GOALZONE, CALL)                                                   \
         }                                                                                             \
     } while (0)

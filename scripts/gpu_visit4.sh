@@ -1,0 +1,11 @@
+#!/bin/bash
+set -u
+mkdir -p gpurun_out
+timeout 1500 python -m pytest tests -m gpu -q -x -rfs -p no:cacheprovider 2>&1 | tail -60 > gpurun_out/pytest_gpu.log; tail -12 gpurun_out/pytest_gpu.log
+timeout 900 python bench.py --no-cpu-baseline --steps 100 > gpurun_out/bench.log 2>&1; python -c "
+import json
+d=json.loads([l for l in open('gpurun_out/bench.log') if l.startswith('{')][-1])
+print('ms/step', d['ms_per_step'], 'stages', d['stages_ms'])
+print('closed', d['closed_loop']['ms_per_tick'])
+print({k:(round(v['ms_per_solve']*1e3,1), v['lambda']) for k,v in d['other_configs'].items()})
+" || tail -20 gpurun_out/bench.log

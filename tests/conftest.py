@@ -13,3 +13,12 @@ import mppi_playground_amd  # noqa: E402,F401  (puts pi_mpc/ and envs/ on sys.pa
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(autouse=True)
+def _name_the_running_test(request):
+    """tests/parity_report.py attributes what the checks measure to the test that is running."""
+    import parity_report
+
+    parity_report.current_test = request.node.name
+    yield

@@ -20,6 +20,7 @@ import numpy as np
 import pytest
 import torch
 
+import parity_report
 from helpers import (CASES, MODEL_CFG, SOLVER_KW, load, mpo_lambda_tolerance, oracle_problem, orc, rel_err,
                      same_lbps_minimum, sg_coeffs)
 
@@ -92,10 +93,21 @@ def check_costs(c_gpu, r, max_flips=None):
     diff = np.abs(c_gpu - r["costs"])
     clear = r["margin"] > 1e-3
     if clear.any():  # (a start pinned exactly onto a cell boundary by the position clamp leaves no clear sample)
+        parity_report.record("cost_rel_err_clear_samples", np.max(diff[clear]) / scale, TOL, n=int(len(c_gpu)))
         assert np.max(diff[clear]) <= TOL * scale, f"clear-sample cost error {np.max(diff[clear]) / scale:.2e}"
     nflip = int((diff > TOL * scale).sum())
+    parity_report.record("map_cell_flips", nflip, max_flips, n=int(len(c_gpu)),
+                         flips_on_clear_samples=int(((diff > TOL * scale) & clear).sum()))
     assert nflip <= max_flips, f"{nflip} samples differ beyond tolerance (all must be boundary samples)"
     return nflip
+
+
+def check_rel(quantity, got, want, tol):
+    """rel_err(got, want) < tol, with the measured value kept for the parity report."""
+    err = rel_err(got, want)
+    parity_report.record(quantity, err, tol)
+    assert err < tol, f"{quantity}: {err:.2e} >= {tol:.2e}"
+    return err
 
 
 def check_end_to_end(a, s, c_gpu, lam, g, k, cfg, P, extra=0.0):
@@ -118,14 +130,13 @@ def check_end_to_end(a, s, c_gpu, lam, g, k, cfg, P, extra=0.0):
                         np.float32(mc["u_max"])).astype(np.float32)
             if cfg.get("use_sg_filter"):
                 U = _host.sg_filter_sequence(g[f"sg_hist_in_{k}"], U, sg_coeffs(cfg))
+            parity_report.record("argmin_action_vs_reference_sample", np.abs(a - U).max() / max(np.abs(U).max(), 1e-30), 1e-6 + extra)
             assert np.abs(a - U).max() <= (1e-6 + extra) * max(np.abs(U).max(), 1e-30), "action != U[argmin]"
     dx = (c_gpu.astype(np.float64) - c_ref.astype(np.float64)) / lam
     dw = w_ref * (-dx + float((w_ref * dx).sum()))
     tol = TOL + 2.0 * float(np.abs(dw).sum()) + extra
-    err_a = rel_err(a, a_ref)
-    assert err_a < tol, f"action_seq vs reference: {err_a:.2e} > {tol:.2e}"
-    err_s = rel_err(s, s_ref)
-    assert err_s < tol, f"state_seq vs reference: {err_s:.2e} > {tol:.2e}"
+    err_a = check_rel("action_seq_vs_reference_fixture", a, a_ref, tol)
+    err_s = check_rel("state_seq_vs_reference_fixture", s, s_ref, tol)
     return max(err_a, err_s)
 
 
@@ -179,8 +190,11 @@ def test_forward_parity(name, math):
             # (the dual's Adam state is this solver's own: it has seen the reference's cost vectors up to fp32 rounding,
             # which is all the rule's cancelling gradient needs to move: mpo_lambda_tolerance)
             tol_mpo = (k + 1) * mpo_lambda_tolerance(c_gpu, lam)
+            parity_report.record("lambda_rel_err_MPO", abs(lam_next - lam_next_ref) / lam_next_ref, tol_mpo)
             assert abs(lam_next - lam_next_ref) <= tol_mpo * lam_next_ref, (k, lam_next, lam_next_ref, tol_mpo)
         else:
+            if cfg["lambda_"] in LAMBDA_TOL:
+                parity_report.record("lambda_rel_err_" + cfg["lambda_"], abs(lam - lam_ref) / lam_ref, LAMBDA_TOL[cfg["lambda_"]])
             assert abs(lam - lam_ref) <= LAMBDA_TOL.get(cfg["lambda_"], 0.0) * lam_ref + 1e-12
 
         # (3) weights/reduction/finalize against the oracle fed with the GPU's own costs
@@ -188,12 +202,13 @@ def test_forward_parity(name, math):
         a_or = P.weighted_actions(w, mean, eps)
         if cfg.get("use_sg_filter"):
             a_or = _host.sg_filter_sequence(g[f"sg_hist_in_{k}"], a_or, sg_coeffs(cfg))
-        assert rel_err(a, a_or) < TOL
+        check_rel("action_seq_vs_oracle_given_costs", a, a_or, TOL)
         stats = solver.last_stats()
         assert abs(stats["cmin"] - st["cmin"]) <= 1e-6 * abs(st["cmin"]) + 1e-12
+        parity_report.record("ess_rel_err", abs(stats["ess"] - st["ess"]) / st["ess"], 1e-4)
         assert abs(stats["ess"] - st["ess"]) <= 1e-4 * st["ess"]
-        assert rel_err(solver._weights.cpu().numpy(), w) < TOL
-        assert rel_err(s[0], P.rollout_single(x0, a)) < TOL
+        check_rel("weights_vs_oracle", solver._weights.cpu().numpy(), w, TOL)
+        check_rel("state_seq_vs_oracle_rollout", s[0], P.rollout_single(x0, a), TOL)
 
         # (4) end to end against the reference fixture, at the reference's temperature
         if auto:
@@ -645,9 +660,21 @@ def test_racing_full_size_against_oracle():
     nflip = check_costs(c_gpu, r)
     print("full-size racing: boundary flips", nflip, "of", N)
     w, st = orc.softmax_weights(c_gpu, 1.0)
-    assert rel_err(a1.cpu().numpy(), P.weighted_actions(w, mean, eps)) < TOL
+    check_rel("action_seq_vs_oracle_given_costs", a1.cpu().numpy(), P.weighted_actions(w, mean, eps), TOL)
     assert abs(stats["ess"] - st["ess"]) <= 1e-4 * st["ess"]
-    assert rel_err(s1.cpu().numpy()[0], P.rollout_single(x0.cpu().numpy(), a1.cpu().numpy())) < TOL
+    check_rel("state_seq_vs_oracle_rollout", s1.cpu().numpy()[0], P.rollout_single(x0.cpu().numpy(), a1.cpu().numpy()), TOL)
+    # the same costs under a DENSE softmax (lambda = 500: thousands of samples carry weight): the weighted reduction over
+    # all 2^20 samples against the oracle's float64 sums
+    dense, cd = make_solver("racing", T, N, lambda_=500.0)
+    cd.set_reference(ref)
+    ad, sd = dense.forward(x0)
+    assert torch.equal(dense._costs, solver._costs)  # same seed and solve index: the same noise, the same costs
+    wd, std = orc.softmax_weights(c_gpu, 500.0)
+    assert std["ess"] > 100
+    check_rel("action_seq_vs_oracle_given_costs", ad.cpu().numpy(), P.weighted_actions(wd, mean, eps), TOL)
+    parity_report.record("ess_rel_err", abs(dense.last_stats()["ess"] - std["ess"]) / std["ess"], 1e-4)
+    assert abs(dense.last_stats()["ess"] - std["ess"]) <= 1e-4 * std["ess"]
+    check_rel("state_seq_vs_oracle_rollout", sd.cpu().numpy()[0], P.rollout_single(x0.cpu().numpy(), ad.cpu().numpy()), TOL)
     # size-independent properties: weights sum to one, bounds respected, determinism
     assert abs(float(solver._weights.double().sum()) - 1.0) < 1e-5
     lo, hi = np.array(MODEL_CFG["racing"]["u_min"]), np.array(MODEL_CFG["racing"]["u_max"])
@@ -704,8 +731,8 @@ def test_baseline_configs_against_oracle(model, T, N, lam):
     a_or = P.weighted_actions(w, mean, eps)
     if kw:
         a_or = _host.sg_filter_sequence(np.zeros((T - 1, P.dc), np.float32), a_or, _host.savitzky_golay_coeffs(5, 3))
-    assert rel_err(a.cpu().numpy(), a_or) < TOL
-    assert rel_err(s.cpu().numpy()[0], P.rollout_single(x0, a.cpu().numpy())) < TOL
+    check_rel("action_seq_vs_oracle_given_costs", a.cpu().numpy(), a_or, TOL)
+    check_rel("state_seq_vs_oracle_rollout", s.cpu().numpy()[0], P.rollout_single(x0, a.cpu().numpy()), TOL)
 
 
 @pytest.mark.parametrize("lam_mode", ["ESSPS", "LBPS", "MPO"])
@@ -1423,7 +1450,8 @@ def test_reference_side_binding_is_self_sufficient():
                 hp.close()
 
 
-def test_c4_eight_shards_at_full_size_on_one_device():
+@pytest.mark.parametrize("lam", [5000.0, 1.0])
+def test_c4_eight_shards_at_full_size_on_one_device(lam):
     """BASELINE configs[3] (racing, N = 8 388 608 over 8 GPUs) minus the transport: eight shard handles of 2^20 samples
     each (sample_offset = r * 2^20, global exploration threshold) run one after the other on THIS device, their
     summaries combined by mppi_finalize(num_shards = 8), against one unsharded handle of 2^23 samples.  The noise is
@@ -1434,7 +1462,8 @@ def test_c4_eight_shards_at_full_size_on_one_device():
 
     W, NL, T = 8, 1 << 20, 50
     N = W * NL
-    full, ctrl = make_solver("racing", T, N, lambda_=5000.0, exploration=0.1)  # lambda: thousands of samples carry weight
+    # lambda = 5000: thousands of samples carry weight (every shard contributes); lambda = 1 (BASELINE configs[3]): arg-min
+    full, ctrl = make_solver("racing", T, N, lambda_=lam, exploration=0.1)
     env = _envs["racing"]
     x0 = env.reset().clone()
     ref, _ = ctrl.calc_ref_trajectory(x0, env.racing_center_path, 0, T, DL=0.1, lookahead_distance=3,
@@ -1445,10 +1474,10 @@ def test_c4_eight_shards_at_full_size_on_one_device():
     a_full, s_full = full.forward(x0)
     c_full = full._costs
     st_full = full.last_stats()
-    assert st_full["ess"] > 100  # a dense softmax: every shard contributes
+    assert st_full["ess"] > 100 or lam == 1.0  # a dense softmax: every shard contributes
     sums, shard0 = [], None
     for r in range(W):
-        sol, c2 = make_solver("racing", T, NL, lambda_=5000.0)
+        sol, c2 = make_solver("racing", T, NL, lambda_=lam)
         cfg = _capi.MppiConfig()
         cfg.model, cfg.horizon, cfg.dim_state, cfg.dim_control = 4, T, 4, 2
         cfg.num_samples, cfg.sample_offset, cfg.inherit_count = NL, r * NL, int(N * 0.9)
@@ -1466,7 +1495,7 @@ def test_c4_eight_shards_at_full_size_on_one_device():
         sol._h.call("mppi_sample", 1, sol._stream())
         sol._h.call("mppi_rollout_cost", sol._stream())
         assert torch.equal(sol._costs, c_full[r * NL:(r + 1) * NL]), f"shard {r}: costs differ from the unsharded slice"
-        sums.append(_summary(sol, 5000.0))
+        sums.append(_summary(sol, lam))
         torch.cuda.synchronize()
         if r == 0:
             shard0 = sol  # (kept: its handle runs the combine)
@@ -1476,10 +1505,10 @@ def test_c4_eight_shards_at_full_size_on_one_device():
     a = torch.zeros(T, 2, device="cuda")
     s = torch.zeros(1, T + 1, 4, device="cuda")
     stats = torch.zeros(4, device="cuda")
-    shard0._h.call("mppi_finalize", C.c_void_p(allsum.data_ptr()), W, 5000.0, 0, C.c_void_p(a.data_ptr()),
+    shard0._h.call("mppi_finalize", C.c_void_p(allsum.data_ptr()), W, lam, 0, C.c_void_p(a.data_ptr()),
                    C.c_void_p(s.data_ptr()), C.c_void_p(stats.data_ptr()), shard0._stream())
-    assert rel_err(a.cpu().numpy(), a_full.cpu().numpy()) < 4e-6
-    assert rel_err(s.cpu().numpy(), s_full.cpu().numpy()) < 4e-6
+    check_rel("sharded_action_seq_vs_unsharded", a.cpu().numpy(), a_full.cpu().numpy(), 4e-6)
+    check_rel("sharded_state_seq_vs_unsharded", s.cpu().numpy(), s_full.cpu().numpy(), 4e-6)
     st = stats.cpu().numpy()
     assert st[0] == st_full["cmin"] and abs(st[1] - st_full["sum_e"]) <= 2e-5 * st_full["sum_e"]
     assert abs(st[1] * st[1] / st[2] - st_full["ess"]) <= 1e-4 * st_full["ess"]
