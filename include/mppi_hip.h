@@ -313,8 +313,9 @@ int mppi_sample_posterior(mppi_handle_t h, uint32_t solve_idx, const float* loc_
 /* `_state_seq_batch[top_indices]` (mppi.py:481): re-roll the k local samples idx_dev[k] from the
  * resident noise instead of materialising S[N][T+1][ds] -> states_out_dev[k][T+1][ds]. */
 int mppi_rollout_samples(mppi_handle_t h, const int64_t* idx_dev, int k, float* states_out_dev, void* stream);
-/* get_top_samples (mppi.py:462-487) in one call: the k (<= 1024) samples of the last solve with the largest
+/* get_top_samples (mppi.py:462-487) in one call: the k (any 1 <= k <= num_samples) samples of the last solve with the largest
  * weight = the smallest cost (radix select on the device), sorted by descending weight, their state
+ * (k <= 1024: one block sorts the candidates in LDS; larger k: a multi-pass bitonic sort in HBM), their state
  * trajectories re-rolled around the mean that solve sampled (states_out_dev [k][T+1][ds]) and their softmax
  * weights softmax(-c/lambda)_i (weights_out_dev [k]).  lambda = the temperature of that solve.  On a shard this
  * ranks the shard's own samples (weights still use the global normalisation); see the two calls below. */

@@ -64,7 +64,8 @@ struct MppiSolver {
     float* solve_stats = nullptr;    // {min c, sum e, sum e^2, sum e*c} over all shards of the last finalize
     unsigned* topk_hist = nullptr;   // [3][TOPK_BINS] + 2 counters, kept zeroed between calls
     TopkSel* topk_sel = nullptr;     // [3]
-    unsigned long long* topk_cand = nullptr;  // [TOPK_MAX]
+    unsigned long long* topk_cand = nullptr;  // [topk_cap] (a power of two >= TOPK_MAX: the large-k sort pads to it)
+    size_t topk_cap = 0;
     // peer-to-peer exchange of the shard summaries (mppi_p2p_*): off unless connected and enabled
     unsigned long long* p2p_local = nullptr;       // this rank's exchange buffer (fine-grained, IPC-exported)
     unsigned long long** p2p_peers_dev = nullptr;  // device array [world] of every rank's buffer as mapped here
@@ -175,7 +176,8 @@ struct StageTimer {
 
 int math_level(mppi_handle_t h);
 // dispatch on (model, math level); level 2 exists for the models whose trigonometric arguments are bounded by the model
-// itself (wrapped headings, clamped pole angle / position): all but the pendulum, whose angle is free
+// itself (wrapped headings, clamped pole angle / position): all but the pendulum, whose angle is free, and the
+// MuJoCo-style cart-pole, whose open-loop instability amplifies the hardware sin/cos error 20-fold
 #define MPPI_DISPATCH_HW(MODEL_, CALL)                                                                \
         case MODEL_: if (ml_ == 2) { CALL(MODEL_, 2); } else if (ml_ == 1) { CALL(MODEL_, 1); } else { CALL(MODEL_, 0); } break;
 #define MPPI_DISPATCH_NOHW(MODEL_, CALL)                                                              \
@@ -190,7 +192,7 @@ int math_level(mppi_handle_t h);
         MPPI_DISPATCH_HW(MPPI_MODEL_MOUNTAINCAR, CALL)                                                \
         MPPI_DISPATCH_HW(MPPI_MODEL_NAV2D, CALL)                                                      \
         MPPI_DISPATCH_HW(MPPI_MODEL_RACING, CALL)                                                     \
-        MPPI_DISPATCH_HW(MPPI_MODEL_MJCARTPOLE, CALL)                                                 \
+        MPPI_DISPATCH_NOHW(MPPI_MODEL_MJCARTPOLE, CALL)                                               \
         MPPI_DISPATCH_HW(MPPI_MODEL_GOALZONE, CALL)                                                   \
         }                                                                                             \
     } while (0)
@@ -409,6 +411,7 @@ int mppi_create(const MppiConfig* cfg, mppi_handle_t* out) {
     HIP_TRY(h, hipMemset(h->topk_hist, 0, sizeof(unsigned) * (3 * TOPK_BINS + 2)));
     HIP_TRY(h, hipMalloc(&h->topk_sel, sizeof(TopkSel) * 3));
     HIP_TRY(h, hipMalloc(&h->topk_cand, sizeof(unsigned long long) * TOPK_MAX));
+    h->topk_cap = TOPK_MAX;
     const int max_blocks = 2048;
     HIP_TRY(h, hipMalloc(&h->partials, sizeof(float) * (size_t)max_blocks * h->colsp));
     HIP_TRY(h, hipMalloc(&h->heads, sizeof(float) * (size_t)max_blocks * 4));
@@ -1378,10 +1381,24 @@ int mppi_rollout_samples(mppi_handle_t h, const int64_t* idx_dev, int k, float* 
     return MPPI_OK;
 }
 
+// candidate buffer for k words, padded to a power of two (the large-k sort works on 2^m words)
+static int topk_reserve(mppi_handle_t h, int k) {
+    size_t need = TOPK_MAX;
+    while (need < (size_t)k) need <<= 1;
+    if (need <= h->topk_cap) return MPPI_OK;
+    HIP_TRY(h, hipDeviceSynchronize());
+    (void)hipFree(h->topk_cand);
+    h->topk_cand = nullptr; h->topk_cap = 0;
+    HIP_TRY(h, hipMalloc(&h->topk_cand, sizeof(unsigned long long) * need));
+    h->topk_cap = need;
+    return MPPI_OK;
+}
+
 // radix select of this handle's k smallest costs -> h->topk_cand (unordered, global indices)
 static int topk_select(mppi_handle_t h, int k, hipStream_t s) {
-    if (k < 1 || k > TOPK_MAX || k > h->d.N) return fail(h, MPPI_E_INVALID, "top samples: need 1 <= k <= min(1024, num_samples)");
+    if (k < 1 || k > h->d.N) return fail(h, MPPI_E_INVALID, "top samples: need 1 <= k <= num_samples");
     if (h->d.sample_offset + h->d.N >= ((int64_t)1 << 32)) return fail(h, MPPI_E_INVALID, "top samples: global sample indices must be < 2^32");
+    if (int rc = topk_reserve(h, k)) return rc;
     const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((h->d.N + BLOCK * 8 - 1) / (BLOCK * 8), 1024));
     unsigned* hist = h->topk_hist;
     unsigned* counters = h->topk_hist + 3 * TOPK_BINS;
@@ -1394,7 +1411,24 @@ static int topk_select(mppi_handle_t h, int k, hipStream_t s) {
     return MPPI_OK;
 }
 
-// sort k candidates, weigh and re-roll them; `clean` also resets the select state (after topk_select)
+// ascending sort of the k > TOPK_MAX candidate words at h->topk_cand (see topk_sort_local_kernel)
+static int topk_sort_large(mppi_handle_t h, int k, hipStream_t s) {
+    int P = TOPK_MAX;
+    while (P < k) P <<= 1;
+    if (P > k) hipLaunchKernelGGL(topk_pad_kernel, dim3((unsigned)((P - k + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, h->topk_cand, k, P);
+    hipLaunchKernelGGL(topk_sort_local_kernel<true>, dim3((unsigned)(P / TOPK_MAX)), dim3(TOPK_MAX), 0, s, h->topk_cand, 0);
+    for (int size = 2 * TOPK_MAX; size <= P; size <<= 1) {
+        for (int stride = size >> 1; stride >= TOPK_MAX; stride >>= 1)
+            hipLaunchKernelGGL(topk_sort_global_kernel, dim3((unsigned)((P / 2 + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, h->topk_cand,
+                               P, size, stride);
+        hipLaunchKernelGGL(topk_sort_local_kernel<false>, dim3((unsigned)(P / TOPK_MAX)), dim3(TOPK_MAX), 0, s, h->topk_cand, size);
+    }
+    HIP_TRY(h, hipGetLastError());
+    return MPPI_OK;
+}
+
+// sort k candidates, weigh and re-roll them; `clean` also resets the select state (after topk_select).  `cand` is
+// h->topk_cand when k > TOPK_MAX (sorted in place).
 static int topk_rollout(mppi_handle_t h, const unsigned long long* cand, int k, float lambda, float* states_out,
                         float* weights_out, bool clean, bool need_local, hipStream_t s) {
     const bool gen = h->noise_regen && !h->injected;
@@ -1403,12 +1437,23 @@ static int topk_rollout(mppi_handle_t h, const unsigned long long* cand, int k, 
         return fail(h, MPPI_E_STATE, "candidates of other shards can only be re-rolled from regenerated noise (noise_regen = 1, no injection)");
     unsigned* hist = clean ? h->topk_hist : nullptr;
     unsigned* counters = clean ? h->topk_hist + 3 * TOPK_BINS : nullptr;
+    if (k <= TOPK_MAX) {
 #define CALL_TOPK(MODEL, FASTV)                                                                       \
-    hipLaunchKernelGGL((topk_rollout_kernel<MODEL, FASTV>), dim3(1), dim3(TOPK_MAX), 0, s, cand, k, h->noise, gen,  \
+    hipLaunchKernelGGL((topk_rollout_kernel<MODEL, FASTV, false>), dim3(1), dim3(TOPK_MAX), 0, s, cand, k, h->noise, gen,  \
                        h->mean_used, h->x0_used, h->solve_stats, lambda, states_out, weights_out, hist, counters,  \
                        h->d, h->gen, h->ctx)
-    MPPI_DISPATCH(h, CALL_TOPK);
+        MPPI_DISPATCH(h, CALL_TOPK);
 #undef CALL_TOPK
+    } else {
+        if (int rc = topk_sort_large(h, k, s)) return rc;
+        const unsigned grid = (unsigned)((k + WAVE - 1) / WAVE);
+#define CALL_TOPK_SORTED(MODEL, FASTV)                                                                \
+    hipLaunchKernelGGL((topk_rollout_kernel<MODEL, FASTV, true>), dim3(grid), dim3(WAVE), 0, s, (const unsigned long long*)h->topk_cand, \
+                       k, h->noise, gen, h->mean_used, h->x0_used, h->solve_stats, lambda, states_out, weights_out, hist,  \
+                       counters, h->d, h->gen, h->ctx)
+        MPPI_DISPATCH(h, CALL_TOPK_SORTED);
+#undef CALL_TOPK_SORTED
+    }
     HIP_TRY(h, hipGetLastError());
     return MPPI_OK;
 }
@@ -1433,11 +1478,17 @@ int mppi_top_candidates(mppi_handle_t h, int k, uint64_t* cand_out_dev, void* st
 
 int mppi_rollout_candidates(mppi_handle_t h, const uint64_t* cand_dev, int k, float lambda, float* states_out,
                             float* weights_out, void* stream) {
-    if (!h || !cand_dev || !states_out || !weights_out || !(lambda > 0.0f) || k < 1 || k > TOPK_MAX)
+    if (!h || !cand_dev || !states_out || !weights_out || !(lambda > 0.0f) || k < 1)
         return fail(h, MPPI_E_INVALID, "bad rollout_candidates arguments");
     if (int rc = check_ready(h)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if (k > TOPK_MAX) {  // the large-k sort works in place on the handle's padded buffer
+        if (int rc = topk_reserve(h, k)) return rc;
+        HIP_TRY(h, hipMemcpyAsync(h->topk_cand, cand_dev, sizeof(uint64_t) * (size_t)k, hipMemcpyDeviceToDevice, s));
+        return topk_rollout(h, h->topk_cand, k, lambda, states_out, weights_out, false, false, s);
+    }
     return topk_rollout(h, reinterpret_cast<const unsigned long long*>(cand_dev), k, lambda, states_out, weights_out, false,
-                        false, (hipStream_t)stream);
+                        false, s);
 }
 
 // ---- in-library collective: RCCL all_gather of the shard summaries on the solve's stream (SURVEY 8e variant A)

@@ -1408,7 +1408,9 @@ __global__ __launch_bounds__(BLOCK) void topk_collect_kernel(const float* __rest
     }
 }
 
-template <int MODEL, int FAST>
+// SORTED = false: ONE block sorts the k <= TOPK_MAX candidates itself (bitonic in LDS) before re-rolling them;
+// SORTED = true: `cand` is already ascending (topk_sort_* below: any k) and the grid's threads take one candidate each.
+template <int MODEL, int FAST, bool SORTED>
 __global__ __launch_bounds__(TOPK_MAX) void topk_rollout_kernel(const unsigned long long* __restrict__ cand, int k,
                                                                 const float4* __restrict__ noise, bool gen_noise,
                                                                 const float* __restrict__ mean,
@@ -1420,28 +1422,35 @@ __global__ __launch_bounds__(TOPK_MAX) void topk_rollout_kernel(const unsigned l
                                                                 unsigned* __restrict__ counters, Dims d, GenCtx gen,
                                                                 ModelCtx ctx) {
     constexpr int DS = ModelT<MODEL, FAST>::DS, DC = ModelT<MODEL, FAST>::DC;
-    __shared__ unsigned long long s_key[TOPK_MAX];
-    s_key[threadIdx.x] = (int)threadIdx.x < k ? cand[threadIdx.x] : ~0ull;
-    if (hist) {  // leave the select state clean for the next call
-        for (int b = threadIdx.x; b < 3 * TOPK_BINS; b += TOPK_MAX) hist[b] = 0u;
+    __shared__ unsigned long long s_key[SORTED ? 1 : TOPK_MAX];
+    if (hist && blockIdx.x == 0) {  // leave the select state clean for the next call
+        for (int b = threadIdx.x; b < 3 * TOPK_BINS; b += blockDim.x) hist[b] = 0u;
         if (threadIdx.x < 2) counters[threadIdx.x] = 0u;
     }
-    __syncthreads();
-    for (int size = 2; size <= TOPK_MAX; size <<= 1) {  // bitonic sort, ascending (key, index)
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            const int j = threadIdx.x ^ stride;
-            if (j > (int)threadIdx.x) {
-                const unsigned long long a = s_key[threadIdx.x], b = s_key[j];
-                const bool up = (threadIdx.x & size) == 0;
-                if ((a > b) == up) { s_key[threadIdx.x] = b; s_key[j] = a; }
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long mine;
+    if (!SORTED) {
+        s_key[threadIdx.x] = (int)threadIdx.x < k ? cand[threadIdx.x] : ~0ull;
+        __syncthreads();
+        for (int size = 2; size <= TOPK_MAX; size <<= 1) {  // bitonic sort, ascending (key, index)
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                const int j = threadIdx.x ^ stride;
+                if (j > (int)threadIdx.x) {
+                    const unsigned long long a = s_key[threadIdx.x], b = s_key[j];
+                    const bool up = (threadIdx.x & size) == 0;
+                    if ((a > b) == up) { s_key[threadIdx.x] = b; s_key[j] = a; }
+                }
+                __syncthreads();
             }
-            __syncthreads();
         }
+        if (q >= k) return;
+        mine = s_key[q];
+    } else {
+        if (q >= k) return;
+        mine = cand[q];
     }
-    const int q = threadIdx.x;
-    if (q >= k) return;
-    const uint64_t gi = s_key[q] & 0xFFFFFFFFull;            // global sample index
-    const float c = key_to_float((unsigned)(s_key[q] >> 32));  // its cost
+    const uint64_t gi = mine & 0xFFFFFFFFull;            // global sample index
+    const float c = key_to_float((unsigned)(mine >> 32));  // its cost
     weights[q] = expf((-c) / lambda - (-stats[0]) / lambda) / stats[1];  // softmax(-c/lambda)_i (mppi.py:376)
     const bool inherit = (int64_t)gi < d.inherit_count;
     const int64_t i = (int64_t)gi - d.sample_offset;  // local index: only meaningful when the tiles are read
@@ -1464,6 +1473,43 @@ __global__ __launch_bounds__(TOPK_MAX) void topk_rollout_kernel(const unsigned l
             u[kk] = clampf(m + e, d.u_min[kk], d.u_max[kk]);
         }
     });
+}
+
+// Ascending sort of P = 2^m >= 2048 candidate words in global memory (k > TOPK_MAX; the tail past k holds ~0).  Bitonic:
+// topk_sort_local_kernel<true> sorts every 1024-word chunk completely in LDS (all stages up to 1024, direction by the
+// chunk's position), then for size = 2048, 4096, ... P the strides >= 1024 are one global compare-exchange pass each
+// (topk_sort_global_kernel) and the strides 512 ... 1 of that stage run in LDS again (topk_sort_local_kernel<false>).
+template <bool FULL>
+__global__ __launch_bounds__(TOPK_MAX) void topk_sort_local_kernel(unsigned long long* __restrict__ cand, int size_arg) {
+    __shared__ unsigned long long s_key[TOPK_MAX];
+    const int g = blockIdx.x * TOPK_MAX + threadIdx.x;
+    s_key[threadIdx.x] = cand[g];
+    __syncthreads();
+    for (int size = FULL ? 2 : size_arg; size <= (FULL ? TOPK_MAX : size_arg); size <<= 1) {
+        for (int stride = min(size >> 1, TOPK_MAX >> 1); stride > 0; stride >>= 1) {
+            const int j = threadIdx.x ^ stride;
+            if (j > (int)threadIdx.x) {
+                const unsigned long long a = s_key[threadIdx.x], b = s_key[j];
+                const bool up = (g & size) == 0;
+                if ((a > b) == up) { s_key[threadIdx.x] = b; s_key[j] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    cand[g] = s_key[threadIdx.x];
+}
+__global__ __launch_bounds__(BLOCK) void topk_sort_global_kernel(unsigned long long* __restrict__ cand, int P, int size,
+                                                                 int stride) {
+    const int t = blockIdx.x * BLOCK + threadIdx.x;  // one thread per pair
+    if (t >= P / 2) return;
+    const int i = ((t / stride) * 2 * stride) + (t % stride), j = i + stride;
+    const unsigned long long a = cand[i], b = cand[j];
+    const bool up = (i & size) == 0;
+    if ((a > b) == up) { cand[i] = b; cand[j] = a; }
+}
+__global__ __launch_bounds__(BLOCK) void topk_pad_kernel(unsigned long long* __restrict__ cand, int k, int P) {
+    const int t = k + blockIdx.x * BLOCK + threadIdx.x;
+    if (t < P) cand[t] = ~0ull;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -96,11 +96,12 @@ MPPI_HD float clampf(float x, float lo, float hi) {
 #undef MPPI_MODEL_HWTRIG
 //   mppi::fused_hw — as mppi::fused, with sin/cos of arguments the MODEL bounds — the wrapped headings of the kinematic
 //                  models (racing, nav2d, goal zone: the `CHECK = false` call sites of sincos_f, argument in [-pi, pi))
-//                  and the clamped pole angle / position of the cart-poles and the mountain car (sincos_b, |x| <= 4
+//                  and the clamped pole angle / position of the cart-pole and the mountain car (sincos_b, |x| <= 4
 //                  or the lane is redone) — evaluated by the hardware v_sin_f32 / v_cos_f32 (argument in revolutions):
 //                  measured max abs error 2.7e-7 against 7.8e-8 of the polynomials (scripts/ubench/hw_sincos_acc.hip)
 //                  — below half an ulp of any position beyond 4 m — for 3 instead of 24 instructions per step.
-//                  The pendulum's free angle keeps the exactly reduced polynomials.  Device only.
+//                  The pendulum's free angle and the MuJoCo-style cart-pole keep the exactly reduced polynomials.
+//                  Device only.
 #if defined(__clang__)
 #pragma clang fp contract(fast)
 #endif

@@ -985,31 +985,43 @@ class MPPI(nn.Module):
             order = torch.argsort(top.values, descending=True)
             return self._state_seq_batch_buf[top.indices][order], top.values[order]
         out = torch.empty(num_samples, self._horizon + 1, self._dim_state, device=self._device, dtype=self._dtype)
-        st = self._stream()
-        if num_samples <= 1024:  # one library call: radix select + sort + re-roll + weights
-            w = torch.empty(num_samples, device=self._device, dtype=self._dtype)
-            self._h.call("mppi_top_samples", num_samples, float(self._last_lambda), _ptr(out), _ptr(w), st)
-            return out, w
-        top = torch.topk(self._weights, num_samples)
-        idx = top.indices.to(torch.int64).contiguous()
-        self._h.call("mppi_rollout_samples", _ptr(idx), num_samples, _ptr(out), st)
-        order = torch.argsort(top.values, descending=True)
-        return out[order], top.values[order]
+        w = torch.empty(num_samples, device=self._device, dtype=self._dtype)
+        # one library call for any k: radix select + sort (one block up to 1024, multi-pass beyond) + re-roll + weights
+        self._h.call("mppi_top_samples", num_samples, float(self._last_lambda), _ptr(out), _ptr(w), self._stream())
+        return out, w
 
     def _top_samples_sharded(self, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
-        """Sharded get_top_samples: every rank selects its k best candidates ((cost key << 32) | global index), one
-        all_gather merges them, and — the device noise being a function of the global sample index — every rank
-        re-rolls the k global winners itself: all ranks return the same tensors."""
+        """Sharded get_top_samples: every rank selects its min(k, local) best candidates ((cost key << 32) | global
+        index, padded to k with the largest word), one all_gather merges them, and — the device noise being a function
+        of the global sample index — every rank re-rolls the k global winners itself: all ranks return the same
+        tensors.  Opaque callables keep their state trajectories (like the reference): there the winners' rows are
+        gathered instead of re-rolled."""
         import torch.distributed as dist
 
-        if self._model is None or k > 1024 or k > self._local_samples:
-            raise NotImplementedError("sharded get_top_samples: native models, k <= min(1024, samples per rank)")
         st = self._stream()
-        mine = torch.empty(k, dtype=torch.int64, device=self._device)  # uint64 bit patterns
-        self._h.call("mppi_top_candidates", k, _ptr(mine), st)
+        kk = min(k, self._local_samples)
+        flip = torch.tensor(-(1 << 63), dtype=torch.int64, device=self._device)  # unsigned order through a signed sort
+        if self._model is None:
+            wl = self._weights  # this shard's slice of the global softmax
+            top = torch.topk(wl, kk)
+            mine_w = torch.full((k,), -1.0, device=self._device, dtype=self._dtype)
+            mine_s = torch.zeros(k, self._horizon + 1, self._dim_state, device=self._device, dtype=self._dtype)
+            mine_w[:kk], mine_s[:kk] = top.values, self._state_seq_batch_buf[top.indices]
+            all_w = torch.empty(self._world * k, device=self._device, dtype=self._dtype)
+            all_s = torch.empty(self._world * k, self._horizon + 1, self._dim_state, device=self._device, dtype=self._dtype)
+            dist.all_gather_into_tensor(all_w, mine_w, group=self._pg)
+            dist.all_gather_into_tensor(all_s, mine_s, group=self._pg)
+            best = torch.sort(all_w, descending=True, stable=True)
+            return all_s[best.indices[:k]], best.values[:k]
+        mine = torch.full((k,), -1, dtype=torch.int64, device=self._device)  # uint64 bit patterns; -1 = the largest word
+        if kk == k:
+            self._h.call("mppi_top_candidates", kk, _ptr(mine), st)
+        else:
+            part = torch.empty(kk, dtype=torch.int64, device=self._device)
+            self._h.call("mppi_top_candidates", kk, _ptr(part), st)
+            mine[:kk] = part
         allc = torch.empty(self._world * k, dtype=torch.int64, device=self._device)
         dist.all_gather_into_tensor(allc, mine, group=self._pg)
-        flip = torch.tensor(-(1 << 63), dtype=torch.int64, device=self._device)  # unsigned order through a signed sort
         best = (torch.sort(allc ^ flip).values[:k] ^ flip).contiguous()
         out = torch.empty(k, self._horizon + 1, self._dim_state, device=self._device, dtype=self._dtype)
         w = torch.empty(k, device=self._device, dtype=self._dtype)

@@ -302,10 +302,13 @@ def test_top_samples_match_reference():
 
 
 @pytest.mark.parametrize("N,k,lam", [(1000, 1, 1.0), (4096, 300, 50.0), (777, 777, 500.0), (1 << 20, 300, 1.0),
-                                     (1 << 20, 1024, 2000.0)])
+                                     (1 << 20, 1024, 2000.0), (5000, 1025, 800.0), (1 << 17, 4096, 2000.0),
+                                     (3000, 3000, 500.0), (1 << 16, 40000, 5000.0)])
 def test_device_top_k_selects_the_smallest_costs(N, k, lam):
     """mppi_top_samples (radix select + sort + re-roll on the device) against a host sort of the same costs,
-    the softmax weights, and the index-driven re-roll path; twice, to check the select state is left clean."""
+    the softmax weights, and the index-driven re-roll path; twice, to check the select state is left clean.  Any
+    k <= N like the reference (mppi.py:462-487): up to 1024 candidates are sorted by one block in LDS, more by the
+    multi-pass bitonic sort in HBM (k = 1025, 4096, N = 3000 and 40 000 of 65 536)."""
     solver, ctrl = make_solver("racing", 50, N, lambda_=lam)
     env = _envs["racing"]
     x0 = env._robot_state.clone()
@@ -562,6 +565,7 @@ def _sharded_worker(rank, world, port, q, exchange="nccl"):
         a2, s2 = solver.forward(x0)
         st = solver.last_stats()
         ts, tw = solver.get_top_samples(24)  # sharded: candidates merged across ranks, re-rolled on every rank
+        tsb, twb = solver.get_top_samples(5000)  # more than a rank owns (4096) and more than one block sorts (1024)
         for _ in range(50):  # many back-to-back solves: the exchange buffers alternate, ranks drift apart freely
             a_prev = solver._previous_action_seq.clone()
             idx_last = solver._solve_idx
@@ -574,7 +578,7 @@ def _sharded_worker(rank, world, port, q, exchange="nccl"):
         an, sn = nav.forward(xn)
         q.put((rank, a1.cpu().numpy(), s1.cpu().numpy(), a2.cpu().numpy(), st["sum_e"], st["cmin"],
                ts.cpu().numpy(), tw.cpu().numpy(), a3.cpu().numpy(), an.cpu().numpy(), sn.cpu().numpy(),
-               nav._last_lambda, a_prev.cpu().numpy(), idx_last))
+               nav._last_lambda, a_prev.cpu().numpy(), idx_last, tsb.cpu().numpy(), twb.cpu().numpy()))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -610,6 +614,10 @@ def test_two_rank_sharded_solver_matches_single(exchange):
     a2, _ = single.forward(x0)
     cmin_after_two = single.last_stats()["cmin"]
     ts, tw = single.get_top_samples(24)
+    tsb, twb = single.get_top_samples(5000)
+    for r in res:  # ... also when k exceeds what one rank owns and what one block sorts
+        assert rel_err(r[14], tsb.cpu().numpy()) < 1e-5 and rel_err(r[15], twb.cpu().numpy()) < 1e-5
+    assert np.array_equal(res[0][14], res[1][14]) and np.array_equal(res[0][15], res[1][15])
     for r in res:  # the sharded top samples are the unsharded ones (same global indices, same noise; the warm
         # start they are rolled around differs in the last bits between the sharded and the single combine)
         assert rel_err(r[6], ts.cpu().numpy()) < 1e-5
@@ -663,13 +671,13 @@ def test_racing_full_size_against_oracle():
     check_rel("action_seq_vs_oracle_given_costs", a1.cpu().numpy(), P.weighted_actions(w, mean, eps), TOL)
     assert abs(stats["ess"] - st["ess"]) <= 1e-4 * st["ess"]
     check_rel("state_seq_vs_oracle_rollout", s1.cpu().numpy()[0], P.rollout_single(x0.cpu().numpy(), a1.cpu().numpy()), TOL)
-    # the same costs under a DENSE softmax (lambda = 500: thousands of samples carry weight): the weighted reduction over
+    # the same costs under a DENSE softmax (lambda = 5000: thousands of samples carry weight): the weighted reduction over
     # all 2^20 samples against the oracle's float64 sums
-    dense, cd = make_solver("racing", T, N, lambda_=500.0)
+    dense, cd = make_solver("racing", T, N, lambda_=5000.0)
     cd.set_reference(ref)
     ad, sd = dense.forward(x0)
     assert torch.equal(dense._costs, solver._costs)  # same seed and solve index: the same noise, the same costs
-    wd, std = orc.softmax_weights(c_gpu, 500.0)
+    wd, std = orc.softmax_weights(c_gpu, 5000.0)
     assert std["ess"] > 100
     check_rel("action_seq_vs_oracle_given_costs", ad.cpu().numpy(), P.weighted_actions(wd, mean, eps), TOL)
     parity_report.record("ess_rel_err", abs(dense.last_stats()["ess"] - std["ess"]) / std["ess"], 1e-4)
@@ -1764,6 +1772,15 @@ def _uneven_worker(rank, world, port, q):
             nav.forward(xn)
             a, s = nav.forward(xn)
             out += [a.cpu().numpy(), s.cpu().numpy(), nav._last_lambda]
+        # opaque callables, sharded: get_top_samples with k beyond what a rank owns gathers the winners' stored rows
+        from envs import classic_control as cc
+        from pi_mpc.mppi import MPPI
+
+        gen = MPPI(15, 1001, 2, 1, _untagged(cc.pendulum_dynamics), _untagged(cc.pendulum_cost), torch.tensor([-2.0]),
+                   torch.tensor([2.0]), torch.tensor([1.0]), 5.0, shard_samples=True)
+        gen.forward(torch.tensor([3.0, 0.0]))
+        ts, tw = gen.get_top_samples(400)
+        out += [ts.cpu().numpy(), tw.cpu().numpy()]
         q.put(tuple(out))
         dist.barrier()
     finally:
@@ -1797,3 +1814,16 @@ def test_uneven_shards_match_the_unsharded_solver():
             assert abs(r[base + 2] - nav._last_lambda) <= 1e-4 * nav._last_lambda
             assert rel_err(r[base], a.cpu().numpy()) < 5e-5 and rel_err(r[base + 1], s.cpu().numpy()) < 5e-5
         assert np.array_equal(r[1], res[0][1])  # the ranks agree exactly
+    from envs import classic_control as cc
+    from pi_mpc.mppi import MPPI
+
+    gen = MPPI(15, 1001, 2, 1, _untagged(cc.pendulum_dynamics), _untagged(cc.pendulum_cost), torch.tensor([-2.0]),
+               torch.tensor([2.0]), torch.tensor([1.0]), 5.0)
+    gen.forward(torch.tensor([3.0, 0.0]))
+    ts, tw = gen.get_top_samples(400)
+    for r in res:
+        assert rel_err(r[8], tw.cpu().numpy()) < 1e-5 and r[7].shape == (400, 16, 2)
+        distinct = np.abs(np.diff(tw.cpu().numpy())) > 1e-7 * tw.cpu().numpy()[:-1]  # (ties may come in any order)
+        keep = np.concatenate([[True], distinct]) & np.concatenate([distinct, [True]])
+        assert rel_err(r[7][keep], ts.cpu().numpy()[keep]) < 1e-5
+        assert np.array_equal(r[7], res[0][7])
