@@ -42,6 +42,15 @@ struct MppiSolver {
     LbpsDev* lbps_dev = nullptr;              // grids of the device-resident LBPS search
     float* stats_max = nullptr;               // [STATS_BLOCKS] per-block maximum cost (LBPS: the cost range)
     double lbps_lo = 0.0, lbps_hi = 0.0;      // [lam_min, lam_max] the preset round-0 grid was built for
+    // single-launch solve (solve_fused_kernel): cells the blocks exchange through, its error flag, the solve counter
+    unsigned long long* fused_cells = nullptr;
+    int* fused_error = nullptr;        // mapped pinned
+    int* fused_error_dev = nullptr;
+    unsigned fused_seq = 0;
+    int fused_mode = 1;                // option "fused_solve": 0 = never, 1 = whenever the problem fits (default)
+    int cu_count = 0;
+    double* grid0_dev = nullptr;       // [STATS_L] round-0 grid of the fused ESSPS / LBPS search
+    double grid0_lo = 0.0, grid0_hi = 0.0;
     // the temperature rule mppi_solve applies when called with MPPI_LAMBDA_DEVICE (mppi_set_auto_lambda)
     int auto_rule = 0;
     double auto_param = 0.0, auto_lo = 0.0, auto_hi = 0.0;
@@ -436,6 +445,7 @@ int mppi_create(const MppiConfig* cfg, mppi_handle_t* out) {
             if (int rc = mppi_set_control_limits(h, cfg->u_min, cfg->u_max, cfg->sigmas, md.dc)) return rc;
     }
     if (int rc = mpo_upload(h, 1.0, 0.1, 0.2, false)) return rc;  // mppi.py:191-200
+    HIP_TRY(h, hipDeviceGetAttribute(&h->cu_count, hipDeviceAttributeMultiprocessorCount, cfg->device));
     HIP_TRY(h, hipDeviceSynchronize());
     return MPPI_OK;
 }
@@ -482,6 +492,8 @@ int mppi_destroy(mppi_handle_t h) {
     (void)hipFree(h->map_pad); (void)hipFree(h->stats_part); (void)hipFree(h->noise_std);
     if (h->stats_host) (void)hipHostFree(h->stats_host);
     if (h->live_hint) (void)hipHostFree(h->live_hint);
+    (void)hipFree(h->fused_cells); (void)hipFree(h->grid0_dev);
+    if (h->fused_error) (void)hipHostFree(h->fused_error);
     if (h->comm) (void)rccl().comm_destroy(h->comm);
     (void)hipFree(h->comm_send); (void)hipFree(h->comm_recv);
     for (void* pm : h->p2p_opened) (void)hipIpcCloseMemHandle(pm);
@@ -1017,6 +1029,77 @@ int mppi_finalize(mppi_handle_t h, const float* summaries_dev, int num_shards, f
     return MPPI_OK;
 }
 
+// ---- the single-launch solve (solve_fused_kernel)
+static bool fused_applies(mppi_handle_t h, float lambda) {
+    if (!h->fused_mode || h->cfg.model == MPPI_MODEL_GENERIC || h->mapping != 0) return false;
+    if (!(h->noise_regen && !h->injected && !h->wide)) return false;         // the noise is regenerated in registers
+    if (h->p2p_enabled || h->comm_enabled) return false;                      // sharded solves exchange between devices
+    if (h->d.row > FUSED_MAX_ROW) return false;
+    const int64_t blocks = (h->d.N + FUSED_BLOCK - 1) / FUSED_BLOCK;
+    if (blocks > FUSED_MAX_BLOCKS || blocks > h->cu_count) return false;      // every block must be resident at once
+    if (h->fused_error && *(volatile int*)h->fused_error) return false;       // a poll timed out once: stay on the multi-kernel path
+    if (lambda == MPPI_LAMBDA_DEVICE && h->auto_rule == MPPI_AUTO_MPO && !h->lambda_dev_valid) return false;
+    if (h->timing == 1) return false;                                         // per-stage timing brackets the separate kernels
+    return check_ready(h) == MPPI_OK;
+}
+
+static int solve_fused(mppi_handle_t h, float lambda, float* action_out, float* state_out, float* stats_out, hipStream_t s) {
+    if (!h->fused_cells) {  // first use: set-up path (blocking)
+        const size_t bytes = sizeof(unsigned long long) * FX_PHASES * FUSED_MAX_BLOCKS * FX_CELLS;
+        HIP_TRY(h, hipMalloc(&h->fused_cells, bytes));
+        HIP_TRY(h, hipMemset(h->fused_cells, 0, bytes));
+        HIP_TRY(h, hipMalloc(&h->grid0_dev, sizeof(double) * STATS_L));
+        HIP_TRY(h, hipHostMalloc((void**)&h->fused_error, sizeof(int), hipHostMallocMapped));
+        *h->fused_error = 0;
+        HIP_TRY(h, hipHostGetDevicePointer((void**)&h->fused_error_dev, h->fused_error, 0));
+        HIP_TRY(h, hipDeviceSynchronize());
+    }
+    const bool dev = lambda == MPPI_LAMBDA_DEVICE;
+    int rule = FUSED_RULE_NONE;
+    if (dev && h->auto_rule == MPPI_AUTO_ESSPS) rule = FUSED_RULE_ESSPS;
+    if (dev && h->auto_rule == MPPI_AUTO_LBPS) rule = FUSED_RULE_LBPS;
+    if (rule != FUSED_RULE_NONE && (h->grid0_lo != h->auto_lo || h->grid0_hi != h->auto_hi)) {  // set-up path, blocking
+        double g0[STATS_L];
+        mppi::host::essps_make_grid<STATS_L>(h->auto_lo, h->auto_hi, g0);
+        HIP_TRY(h, hipDeviceSynchronize());
+        HIP_TRY(h, hipMemcpy(h->grid0_dev, g0, sizeof(g0), hipMemcpyHostToDevice));
+        h->grid0_lo = h->auto_lo; h->grid0_hi = h->auto_hi;
+    }
+    if (!dev && !(lambda > 0.0f)) return fail(h, MPPI_E_INVALID, "lambda must be > 0");
+    StageTimer tm(h, 1, s);
+    h->min_slot ^= 1;
+    ++h->fused_seq;
+    if (h->fused_seq == 0) h->fused_seq = 1;
+    double* host_lam = nullptr;
+    HIP_TRY(h, hipHostGetDevicePointer((void**)&host_lam, h->stats_host, 0));
+    host_lam += 8 + STATS_L * 3;
+    FusedArgs A{};
+    A.mean = h->mean; A.x0 = h->x0_cur; A.costs = h->costs;
+    A.min_key = h->min_key + h->min_slot; A.next_min_key = h->min_key + (h->min_slot ^ 1);
+    A.mean_used = h->mean_used; A.x0_used = h->x0_used;
+    A.rule = rule; A.rule_param = h->auto_param; A.lam_min = h->auto_lo; A.lam_max = h->auto_hi;
+    A.lambda_arg = dev ? -1.0f : lambda;
+    A.lambda_dev = h->lambda_dev; A.lambda_host = host_lam; A.grid0 = h->grid0_dev;
+    A.mean_store = h->mean; A.action_out = action_out; A.state_out = state_out; A.stats_out = stats_out;
+    A.stats_keep = h->solve_stats; A.summary_out = h->summary;
+    const SgFilter sg{h->sg_coeffs, h->sg_history, h->sg_window};
+    const FusedCtx fx{h->fused_cells, h->fused_error_dev, h->fused_seq};
+    const unsigned grid = (unsigned)((h->d.N + FUSED_BLOCK - 1) / FUSED_BLOCK);
+#define CALL_FUSED(MODEL, FASTV)                                                                      \
+    do {                                                                                              \
+        const size_t shmem = sizeof(float) * ((size_t)8 * h->d.R + (size_t)h->d.T * ModelT<MODEL, FASTV>::KROW + 2 * (size_t)h->d.row + \
+                                              MPPI_SUMMARY_HEAD + (sg.window ? (size_t)(2 * h->d.T - 1 + 2 * (sg.window / 2)) * h->dc : 0)); \
+        hipLaunchKernelGGL((solve_fused_kernel<MODEL, FASTV>), dim3(grid), dim3(FUSED_BLOCK), shmem, s, A, h->d, h->gen, h->ctx, sg, fx); \
+    } while (0)
+    MPPI_DISPATCH(h, CALL_FUSED);
+#undef CALL_FUSED
+    HIP_TRY(h, hipGetLastError());
+    if (rule != FUSED_RULE_NONE) h->lambda_dev_valid = true;
+    h->last_reduce_blocks = 0;   // no partial rows of a separate reduction exist for this solve
+    h->summary_valid = true;     // ... but its summary does (h->summary)
+    return MPPI_OK;
+}
+
 // The temperature rule mppi_solve applies when it is called with lambda = MPPI_LAMBDA_DEVICE (mppi.py:183-210).
 int mppi_set_auto_lambda(mppi_handle_t h, int rule, double param, double lam_min, double lam_max) {
     if (!h || rule < MPPI_AUTO_NONE || rule > MPPI_AUTO_MPO) return fail(h, MPPI_E_INVALID, "bad temperature rule");
@@ -1038,6 +1121,11 @@ int mppi_solve(mppi_handle_t h, const float* x0_dev, uint32_t solve_idx, float l
         return fail(h, MPPI_E_STATE, "MPPI_LAMBDA_DEVICE: no temperature rule configured (mppi_set_auto_lambda)");
     if (x0_dev) { if (int rc = mppi_bind_state(h, x0_dev)) return rc; }
     if (int rc = mppi_sample(h, solve_idx, stream)) return rc;
+    if (fused_applies(h, lambda)) {
+        if (int rc = solve_fused(h, lambda, action_out_dev, state_seq_out_dev, stats_out_dev, (hipStream_t)stream)) return rc;
+        if (h->auto_rule == MPPI_AUTO_MPO) return mppi_mpo_step_device(h, stream);
+        return MPPI_OK;
+    }
     if (int rc = mppi_rollout_cost(h, stream)) return rc;
     if (dev && h->auto_rule == MPPI_AUTO_ESSPS) {
         if (int rc = mppi_essps_lambda_device(h, h->auto_param, h->auto_lo, h->auto_hi, stream)) return rc;
@@ -1596,6 +1684,10 @@ int mppi_p2p_exchange(mppi_handle_t h, const float* data_dev, float* gathered_ou
     return MPPI_OK;
 }
 
+// 1 once a poll of the single-launch solve timed out on this handle (read without synchronising): that solve's outputs
+// are void (NaN) and the handle has returned to the multi-kernel path
+int mppi_fused_error(mppi_handle_t h) { return (h && h->fused_error) ? *(volatile int*)h->fused_error : 0; }
+
 // 1 if a poll of the exchange buffer ever timed out on this handle (read without synchronising)
 int mppi_p2p_error(mppi_handle_t h) { return (h && h->p2p_error) ? *(volatile int*)h->p2p_error : 0; }
 
@@ -1606,6 +1698,7 @@ int mppi_set_option(mppi_handle_t h, const char* key, int64_t value) {
     if (k == "reduce_blocks") { h->reduce_blocks = (int)std::max<int64_t>(1, std::min<int64_t>(value, 2048)); return MPPI_OK; }
     if (k == "timing") { h->timing = (int)value; return MPPI_OK; }
     if (k == "mapping") { h->mapping = value ? 1 : 0; return MPPI_OK; }
+    if (k == "fused_solve") { h->fused_mode = value ? 1 : 0; return MPPI_OK; }
     if (k == "fold_path") { h->fold_mode = (value >= 0 && value <= 2) ? (int)value : 0; return MPPI_OK; }
     if (k == "exchange_p2p") {  // sharded solves: summaries travel through the peer-to-peer buffer, no collective
         if (value && !h->p2p_connected) return fail(h, MPPI_E_STATE, "exchange_p2p: call mppi_p2p_alloc / mppi_p2p_connect first");

@@ -753,6 +753,105 @@ __global__ __launch_bounds__(BLOCK) void p2p_collect_kernel(P2pCtx x, int len, f
     p2p_collect<BLOCK>(x, len, out, len);
 }
 
+constexpr int FIN_BLOCK = 1024;
+// The tail of a solve once the shard summaries are at hand (block-wide, FIN_BLOCK threads): combine the shards, normalise,
+// Savitzky-Golay step, warm start, outputs, batch-1 rollout.  Shared by finalize_kernel and solve_fused_kernel.
+// s_act [row] and s_yp (filter staging) are LDS; `summaries` may be LDS or global.
+template <int MODEL, int FAST>
+__device__ __forceinline__ void finalize_tail(const float* summaries, int num_shards, float lambda, int row, int T,
+                                              const float* s_x0, float* s_act, float* s_yp,
+                                              float* __restrict__ mean_store, float* __restrict__ action_out,
+                                              float* __restrict__ state_out, float* __restrict__ stats_out,
+                                              float* __restrict__ stats_keep, const SgFilter& sg, const ModelCtx& ctx) {
+    constexpr int DC = ModelT<MODEL, FAST>::DC;
+    const int stride = MPPI_SUMMARY_HEAD + row;
+    float xmax = -INFINITY, cmin = INFINITY;
+    for (int g = 0; g < num_shards; ++g) {
+        const float m = summaries[(int64_t)g * stride];
+        xmax = fmaxf(xmax, (-m) / lambda);
+        cmin = fminf(cmin, m);
+    }
+    float se = 0.f, se2 = 0.f, sec = 0.f;
+    for (int g = 0; g < num_shards; ++g) {
+        const float* sm = summaries + (int64_t)g * stride;
+        const float f = expf((-sm[0]) / lambda - xmax);
+        se = fmaf(f, sm[1], se);
+        se2 = fmaf(f * f, sm[2], se2);
+        sec = fmaf(f, sm[3], sec);
+    }
+    for (int cidx = threadIdx.x; cidx < row; cidx += FIN_BLOCK) {
+        float a = 0.f;
+        for (int g = 0; g < num_shards; ++g) {
+            const float* sm = summaries + (int64_t)g * stride;
+            const float f = expf((-sm[0]) / lambda - xmax);
+            a = fmaf(f, sm[MPPI_SUMMARY_HEAD + cidx], a);
+        }
+        a = a / se;
+        s_act[cidx] = a;
+        if (sg.window == 0) {
+            if (action_out) action_out[cidx] = a;
+            if (mean_store) mean_store[cidx] = a;
+        }
+    }
+    if (threadIdx.x == 0) {
+        if (stats_out) { stats_out[0] = cmin; stats_out[1] = se; stats_out[2] = se2; stats_out[3] = sec; }
+        stats_keep[0] = cmin; stats_keep[1] = se; stats_keep[2] = se2; stats_keep[3] = sec;
+    }
+    __syncthreads();
+    if (sg.window > 0) {
+        // Step 7 (mppi.py:423-443,598-620): Savitzky-Golay smoothing of [history(T-1); a(T)] per control dimension,
+        // symmetric-flip padding by w/2, valid cross-correlation accumulated tap by tap in fp32 (the operation
+        // order of the host statement in pi_mpc/_host.py), keep the last T; then shift a'[0] into the history.
+        const int dcn = row / T, p = sg.window / 2, n = 2 * T - 1;
+        for (int idx = threadIdx.x; idx < n * dcn; idx += FIN_BLOCK) {
+            const int i = idx / dcn, k = idx - i * dcn;
+            s_yp[(p + i) * dcn + k] = i < T - 1 ? sg.history[i * dcn + k] : s_act[(i - (T - 1)) * dcn + k];
+        }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < p * dcn; idx += FIN_BLOCK) {
+            const int j = idx / dcn, k = idx - j * dcn;
+            s_yp[(p - 1 - j) * dcn + k] = s_yp[(p + j) * dcn + k];                  // front: y[p-1], ..., y[0]
+            s_yp[(p + n + j) * dcn + k] = s_yp[(p + n - 1 - j) * dcn + k];          // back:  y[n-1], ..., y[n-p]
+        }
+        __syncthreads();
+        float filt = 0.0f;
+        const int cidx = threadIdx.x;  // row <= FIN_BLOCK is checked on the host for the filter
+        if (cidx < row) {
+            const int t = cidx / dcn, k = cidx - t * dcn;
+            for (int j = 0; j < sg.window; ++j) filt = filt + s_yp[(T - 1 + t + j) * dcn + k] * sg.coeffs[j];
+        }
+        __syncthreads();
+        if (cidx < row) {
+            s_act[cidx] = filt;
+            if (action_out) action_out[cidx] = filt;
+            if (mean_store) mean_store[cidx] = filt;
+        }
+        for (int idx = threadIdx.x; idx < (T - 1) * dcn; idx += FIN_BLOCK) {  // history <- [history[1:]; a'[0]]
+            const int i = idx / dcn, k = idx - i * dcn;
+            sg.history[idx] = i < T - 2 ? s_yp[(p + i + 1) * dcn + k] : 0.0f;
+        }
+        __syncthreads();
+        if (threadIdx.x < dcn && T >= 2) sg.history[(T - 2) * dcn + threadIdx.x] = s_act[threadIdx.x];
+        __syncthreads();
+    }
+    if (!state_out) return;
+    const auto getu = [&](int t, float* u) {
+#pragma unroll
+        for (int k = 0; k < DC; ++k) u[k] = s_act[t * DC + k];
+    };
+    if constexpr (MODEL == MPPI_MODEL_RACING && FAST) {
+        if (T <= 63) {  // the serial part of the batch-1 rollout shrinks to the heading/speed recurrences
+            if (threadIdx.x >= WAVE) return;
+            bool bad = false;
+            ModelT<MODEL, FAST>::rollout_wave(ctx, s_x0, s_act, T, state_out, bad);
+            if (__ballot(bad) != 0ull && threadIdx.x == 0)  // left a fast-path validity range: library math
+                (void)rollout_states<MODEL, 0>(s_x0, T, ctx, state_out, getu);
+            return;
+        }
+    }
+    if (threadIdx.x == 0) rollout_states_checked<MODEL, FAST>(s_x0, T, ctx, state_out, getu);
+}
+
 // Combine shard summaries, normalise, store the warm start, roll the result out with batch 1
 // (mppi.py:381-385,448-452,508-524).
 // `summaries` != nullptr: `num_shards` summary vectors (the all_gathered shards, or this handle's own summary
@@ -763,7 +862,6 @@ __global__ __launch_bounds__(BLOCK) void p2p_collect_kernel(P2pCtx x, int len, f
 // also written to `summary_out` for later readers and the number of live rows to `nlive_out` (mapped host memory:
 // the host's hint for the next solve).  A timed-out peer-to-peer poll voids the outputs (NaN) instead of
 // returning a partial combine.
-constexpr int FIN_BLOCK = 1024;
 template <int MODEL, int FAST>
 __global__ __launch_bounds__(FIN_BLOCK) void finalize_kernel(const float* __restrict__ summaries, int num_shards,
                                                              const float* __restrict__ partials,
@@ -852,91 +950,8 @@ __global__ __launch_bounds__(FIN_BLOCK) void finalize_kernel(const float* __rest
         summaries = s_sum;  // (generic address space: LDS)
         num_shards = 1;
     }
-    float xmax = -INFINITY, cmin = INFINITY;
-    for (int g = 0; g < num_shards; ++g) {
-        const float m = summaries[(int64_t)g * stride];
-        xmax = fmaxf(xmax, (-m) / lambda);
-        cmin = fminf(cmin, m);
-    }
-    float se = 0.f, se2 = 0.f, sec = 0.f;
-    for (int g = 0; g < num_shards; ++g) {
-        const float* sm = summaries + (int64_t)g * stride;
-        const float f = expf((-sm[0]) / lambda - xmax);
-        se = fmaf(f, sm[1], se);
-        se2 = fmaf(f * f, sm[2], se2);
-        sec = fmaf(f, sm[3], sec);
-    }
-    for (int cidx = threadIdx.x; cidx < row; cidx += FIN_BLOCK) {
-        float a = 0.f;
-        for (int g = 0; g < num_shards; ++g) {
-            const float* sm = summaries + (int64_t)g * stride;
-            const float f = expf((-sm[0]) / lambda - xmax);
-            a = fmaf(f, sm[MPPI_SUMMARY_HEAD + cidx], a);
-        }
-        a = a / se;
-        s_act[cidx] = a;
-        if (sg.window == 0) {
-            if (action_out) action_out[cidx] = a;
-            if (mean_store) mean_store[cidx] = a;
-        }
-    }
-    if (threadIdx.x == 0) {
-        if (stats_out) { stats_out[0] = cmin; stats_out[1] = se; stats_out[2] = se2; stats_out[3] = sec; }
-        stats_keep[0] = cmin; stats_keep[1] = se; stats_keep[2] = se2; stats_keep[3] = sec;
-    }
-    __syncthreads();
-    if (sg.window > 0) {
-        // Step 7 (mppi.py:423-443,598-620): Savitzky-Golay smoothing of [history(T-1); a(T)] per control dimension,
-        // symmetric-flip padding by w/2, valid cross-correlation accumulated tap by tap in fp32 (the operation
-        // order of the host statement in pi_mpc/_host.py), keep the last T; then shift a'[0] into the history.
-        const int dcn = row / T, p = sg.window / 2, n = 2 * T - 1;
-        for (int idx = threadIdx.x; idx < n * dcn; idx += FIN_BLOCK) {
-            const int i = idx / dcn, k = idx - i * dcn;
-            s_yp[(p + i) * dcn + k] = i < T - 1 ? sg.history[i * dcn + k] : s_act[(i - (T - 1)) * dcn + k];
-        }
-        __syncthreads();
-        for (int idx = threadIdx.x; idx < p * dcn; idx += FIN_BLOCK) {
-            const int j = idx / dcn, k = idx - j * dcn;
-            s_yp[(p - 1 - j) * dcn + k] = s_yp[(p + j) * dcn + k];                  // front: y[p-1], ..., y[0]
-            s_yp[(p + n + j) * dcn + k] = s_yp[(p + n - 1 - j) * dcn + k];          // back:  y[n-1], ..., y[n-p]
-        }
-        __syncthreads();
-        float filt = 0.0f;
-        const int cidx = threadIdx.x;  // row <= FIN_BLOCK is checked on the host for the filter
-        if (cidx < row) {
-            const int t = cidx / dcn, k = cidx - t * dcn;
-            for (int j = 0; j < sg.window; ++j) filt = filt + s_yp[(T - 1 + t + j) * dcn + k] * sg.coeffs[j];
-        }
-        __syncthreads();
-        if (cidx < row) {
-            s_act[cidx] = filt;
-            if (action_out) action_out[cidx] = filt;
-            if (mean_store) mean_store[cidx] = filt;
-        }
-        for (int idx = threadIdx.x; idx < (T - 1) * dcn; idx += FIN_BLOCK) {  // history <- [history[1:]; a'[0]]
-            const int i = idx / dcn, k = idx - i * dcn;
-            sg.history[idx] = i < T - 2 ? s_yp[(p + i + 1) * dcn + k] : 0.0f;
-        }
-        __syncthreads();
-        if (threadIdx.x < dcn && T >= 2) sg.history[(T - 2) * dcn + threadIdx.x] = s_act[threadIdx.x];
-        __syncthreads();
-    }
-    if (!state_out) return;
-    const auto getu = [&](int t, float* u) {
-#pragma unroll
-        for (int k = 0; k < DC; ++k) u[k] = s_act[t * DC + k];
-    };
-    if constexpr (MODEL == MPPI_MODEL_RACING && FAST) {
-        if (T <= 63) {  // the serial part of the batch-1 rollout shrinks to the heading/speed recurrences
-            if (threadIdx.x >= WAVE) return;
-            bool bad = false;
-            ModelT<MODEL, FAST>::rollout_wave(ctx, s_x0, s_act, T, state_out, bad);
-            if (__ballot(bad) != 0ull && threadIdx.x == 0)  // left a fast-path validity range: library math
-                (void)rollout_states<MODEL, 0>(s_x0, T, ctx, state_out, getu);
-            return;
-        }
-    }
-    if (threadIdx.x == 0) rollout_states_checked<MODEL, FAST>(s_x0, T, ctx, state_out, getu);
+    finalize_tail<MODEL, FAST>(summaries, num_shards, lambda, row, T, s_x0, s_act, s_yp, mean_store, action_out, state_out,
+                               stats_out, stats_keep, sg, ctx);
 }
 
 // Softmax statistics of the cost vector for one temperature — the device half of the auto-lambda
@@ -1244,6 +1259,365 @@ __global__ __launch_bounds__(WAVE) void mpo_step_kernel(const float* __restrict_
         *temp_dev = s.temperature();
         lambda_host[0] = lam; lambda_host[1] = used;
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// MPPI.forward() as ONE launch (mppi.py:223-460) for N <= 1024 x (number of CUs): a cooperative kernel.
+//
+// The multi-kernel solve of a small or medium problem is a chain of 3-9 dependent, latency-bound launches (launch + the
+// first load of data another XCD just wrote ~ 4-5 us each; a captured hipGraph replays the same chain:
+// profiles/r03_experiments.md).  Here every block of 1024 threads owns 1024 trajectories (one per thread: the whole
+// problem is resident at once, at most one block per CU) and the blocks talk through CELLS in HBM instead of kernel
+// boundaries: an 8-byte word {fp32 value, 32-bit solve number} written with ONE relaxed agent-scope store and polled with
+// agent-scope loads, so that data and "ready" cannot be seen apart and no fence or grid barrier is needed (the protocol
+// of the peer-to-peer exchange, P2pCtx).  Hops per solve:
+//   1. every block publishes its minimum cost; every block reads all of them                     -> global minimum
+//   2. ESSPS / LBPS only, per round: every block publishes its 96 partial sums of the 32-temperature statistics
+//      (+ its maximum cost); block 0 combines them, runs the scalar step of the search and broadcasts the next grid or
+//      the temperature                                                                                (2 hops per round)
+//   3. every block with a non-zero weight publishes its partial row sum_i e_i U_i and {sum e, sum e^2, sum e c};
+//      block 0 folds them and runs the tail of the solve (normalise, filter, warm start, batch-1 rollout).
+// Costs, the minimum, the statistics and therefore the temperature are BIT-IDENTICAL to the multi-kernel path (same
+// device functions, same partition into 1024-cost chunks, same summation order); the weighted row is summed in a
+// different order (per block instead of per reduce-grid block), i.e. equal to rounding.
+// A poll that does not complete within ~2 s (a block that never became resident: the device is shared with another
+// cooperative kernel) raises *error, voids the outputs and returns — no hang.
+constexpr int FUSED_BLOCK = 1024;
+constexpr int FUSED_MAX_BLOCKS = 256;
+constexpr int FUSED_MAX_ROW = 128;
+constexpr int FX_CELLS = FUSED_MAX_ROW + 8;  // per (phase, block): >= 4 + row, >= 97
+enum { FX_MIN = 0, FX_STATS = 1 /* +2*round */, FX_BCAST = 2 /* +2*round */, FX_ROW = 7, FX_PHASES = 8 };
+enum { FUSED_RULE_NONE = 0, FUSED_RULE_ESSPS = 1, FUSED_RULE_LBPS = 2 };
+struct FusedCtx {
+    unsigned long long* cells;  // [FX_PHASES][FUSED_MAX_BLOCKS][FX_CELLS]
+    int* error;                 // mapped host flag
+    unsigned seq;               // this solve's number (never 0)
+};
+__device__ __forceinline__ unsigned long long* fx_cell(const FusedCtx& x, int phase, int b, int j) {
+    return x.cells + ((size_t)phase * FUSED_MAX_BLOCKS + b) * FX_CELLS + j;
+}
+__device__ __forceinline__ void fx_put(const FusedCtx& x, int phase, int b, int j, float v) {
+    __hip_atomic_store(fx_cell(x, phase, b, j), ((unsigned long long)x.seq << 32) | (unsigned long long)__float_as_uint(v),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float fx_get(const FusedCtx& x, int phase, int b, int j, long long t0, bool& timed_out) {
+    const unsigned long long* p = fx_cell(x, phase, b, j);
+    unsigned long long cell = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0;
+    while ((unsigned)(cell >> 32) != x.seq) {
+        if ((++spins & 255u) == 0u && wall_clock64() - t0 > 200000000ll) { timed_out = true; break; }  // 100 MHz: 2 s
+        __builtin_amdgcn_s_sleep(1);
+        cell = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return __uint_as_float((unsigned)cell);
+}
+
+struct FusedArgs {
+    const float* mean;      // warm start [row] (read), then overwritten through mean_store
+    const float* x0;        // [ds]
+    float* costs;           // [N]
+    unsigned* min_key;      // slot this solve's minimum goes to (later queries read it)
+    unsigned* next_min_key; // the other slot, reset for the next multi-kernel rollout (it accumulates with atomicMin)
+    float* mean_used;       // snapshots for later re-rolls (get_top_samples)
+    float* x0_used;
+    int rule;               // FUSED_RULE_*
+    double rule_param, lam_min, lam_max;
+    float lambda_arg;       // rule == NONE: > 0, or MPPI_LAMBDA_DEVICE = read *lambda_dev
+    float* lambda_dev;      // device copy of the temperature (written by ESSPS / LBPS)
+    double* lambda_host;    // mapped host [2]
+    const double* grid0;    // device [32]: preset round-0 grid over [lam_min, lam_max]
+    float* mean_store;
+    float* action_out;
+    float* state_out;
+    float* stats_out;
+    float* stats_keep;
+    float* summary_out;     // [4 + row] the shard summary, for later readers
+};
+
+template <int MODEL, int FAST>
+__global__ __launch_bounds__(FUSED_BLOCK) void solve_fused_kernel(FusedArgs A, Dims d, GenCtx gen, ModelCtx ctx,
+                                                                  SgFilter sg, FusedCtx fx) {
+    using M = ModelT<MODEL, FAST>;
+    constexpr int NWV = FUSED_BLOCK / WAVE;
+    constexpr bool UC = FAST != 0;
+    __shared__ float s_c[FUSED_BLOCK];             // this block's costs
+    __shared__ float s_e[FUSED_BLOCK];             // ... and weights
+    __shared__ float s_p[NWV][STATS_L][3];
+    __shared__ float s_w[NWV][4];                  // per-wave scalars
+    __shared__ double s_scratch[STATS_COMB_GROUPS * STATS_L * 3];  // statistics combine / row partials (aliased)
+    __shared__ double s_sumd[STATS_L * 3];
+    __shared__ double s_vald[STATS_L], s_gridd[STATS_L];
+    __shared__ float s_lams[STATS_L];
+    __shared__ float s_bc[4];                      // broadcast scalars: [0] lambda, [1] done flag, [2] cmin
+    __shared__ int s_flag;
+    __shared__ float s_x0[MPPI_MAX_DIM_STATE];
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];  // [8R] mean groups, [T*KROW] step rows, then the tail's staging
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, b = blockIdx.x, G = gridDim.x;
+    const long long t0 = wall_clock64();
+    bool timed_out = false;
+
+    // ---- stage the wave-uniform per-step inputs (like rollout_cost_kernel)
+    float4* s_mean4 = reinterpret_cast<float4*>(s_dyn);
+    float* s_ktab = s_dyn + 8 * d.R;
+    for (int f = tid; f < 4 * d.R; f += FUSED_BLOCK) {
+        const float m = f < d.row ? A.mean[f] : 0.0f;
+        s_dyn[f] = m;
+        s_dyn[4 * d.R + f] = 0.0f;
+        if (b == 0 && f < d.row) A.mean_used[f] = m;
+    }
+    for (int f = tid; f < d.T * M::KROW; f += FUSED_BLOCK) s_ktab[f] = ctx.ref[f];
+    if (tid < M::DS) { s_x0[tid] = A.x0[tid]; if (b == 0) A.x0_used[tid] = A.x0[tid]; }
+    __syncthreads();
+
+    // ---- step 1-3: one trajectory per thread
+    const int64_t i = (int64_t)b * FUSED_BLOCK + tid;
+    const uint64_t gi = (uint64_t)(d.sample_offset + i);
+    const bool inherit = (d.sample_offset + i) < d.inherit_count;
+    float total = INFINITY;
+    if (i < d.N) {
+        bool bad = false;
+        const float4* mp = inherit ? s_mean4 : s_mean4 + d.R;
+        total = trajectory_cost<MODEL, FAST, true, UC>(nullptr, gi, gen, mp, s_ktab, s_x0, d, ctx, bad);
+        if (FAST) {
+            if (bad) {
+                bool ignore = false;
+                total = trajectory_cost<MODEL, 0, true, false>(nullptr, gi, gen, mp, s_ktab, s_x0, d, ctx, ignore);
+            }
+        }
+        A.costs[i] = total;
+    }
+    // ---- hop 1: the global minimum
+    {
+        const float wm = wave_min(total);
+        if (lane == 0) s_w[wid][0] = wm;
+        __syncthreads();
+        if (tid == 0) {
+            float m = s_w[0][0];
+#pragma unroll
+            for (int w = 1; w < NWV; ++w) m = fminf(m, s_w[w][0]);
+            fx_put(fx, FX_MIN, b, 0, m);
+        }
+        float gm = INFINITY;
+        for (int b2 = tid; b2 < G; b2 += FUSED_BLOCK) gm = fminf(gm, fx_get(fx, FX_MIN, b2, 0, t0, timed_out));
+        gm = wave_min(gm);
+        __syncthreads();
+        if (lane == 0) s_w[wid][0] = gm;
+        __syncthreads();
+        if (tid == 0) {
+            float m = s_w[0][0];
+#pragma unroll
+            for (int w = 1; w < NWV; ++w) m = fminf(m, s_w[w][0]);
+            s_bc[2] = m;
+            if (b == 0) { *A.min_key = float_to_key(m); *A.next_min_key = 0xFFFFFFFFu; }
+        }
+        __syncthreads();
+    }
+    const float cmin = s_bc[2];
+
+    // ---- step 4: the temperature
+    float lambda = A.lambda_arg > 0.0f ? A.lambda_arg : *A.lambda_dev;
+    if (A.rule != FUSED_RULE_NONE) {
+        const int rounds = A.rule == FUSED_RULE_ESSPS ? 2 : LBPS_ROUNDS;
+        s_c[tid] = i < d.N ? total : 3.0e38f;
+        float cmaxv = i < d.N ? total : -INFINITY;
+        if (A.rule == FUSED_RULE_LBPS) {
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) cmaxv = fmaxf(cmaxv, __shfl_xor(cmaxv, m));
+            if (lane == 0) s_w[wid][1] = cmaxv;
+        }
+        __syncthreads();
+        for (int r = 0; r < rounds; ++r) {
+            // statistics of this block's 1024 costs for the 32 temperatures of round r (stats_multi_kernel's arithmetic)
+            const int l = tid & (STATS_L - 1), chunk = tid >> 5;
+            const float lam_l = r == 0 ? (float)A.grid0[l] : s_lams[l];
+            const float inv_lam = 1.0f / lam_l;
+            float se = 0.0f, se2 = 0.0f, sec = 0.0f;
+            const float* cc = s_c + chunk * 32;
+#pragma unroll 8
+            for (int j = 0; j < 32; ++j) {
+                const float c = cc[j];
+                const float e = expf((cmin - c) * inv_lam);
+                se += e;
+                se2 = fmaf(e, e, se2);
+                sec = fmaf(e, c, sec);
+            }
+            se += __shfl_xor(se, 32); se2 += __shfl_xor(se2, 32); sec += __shfl_xor(sec, 32);
+            if (lane < STATS_L) { s_p[wid][lane][0] = se; s_p[wid][lane][1] = se2; s_p[wid][lane][2] = sec; }
+            __syncthreads();
+            if (tid < STATS_L * 3) {
+                float v = 0.0f;
+#pragma unroll
+                for (int w = 0; w < NWV; ++w) v += (&s_p[w][0][0])[tid];
+                fx_put(fx, FX_STATS + 2 * r, b, tid, v);
+            }
+            if (tid == STATS_L * 3 && A.rule == FUSED_RULE_LBPS && r == 0) {
+                float v = s_w[0][1];
+#pragma unroll
+                for (int w = 1; w < NWV; ++w) v = fmaxf(v, s_w[w][1]);
+                fx_put(fx, FX_STATS, b, STATS_L * 3, v);
+            }
+            if (b == 0) {
+                // combine: column sums over the blocks in stats_combine_columns' order (thread (quad, g): rows g, g+40, ...)
+                constexpr int COLS = STATS_L * 3, QUADS = COLS / 4, GROUPS = STATS_COMB_GROUPS;
+                const int quad = tid % QUADS, g = tid / QUADS;
+                if (g < GROUPS) {
+                    double v[4] = {0.0, 0.0, 0.0, 0.0};
+                    for (int bb = g; bb < G; bb += GROUPS)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) v[c] += (double)fx_get(fx, FX_STATS + 2 * r, bb, 4 * quad + c, t0, timed_out);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) s_scratch[g * COLS + 4 * quad + c] = v[c];
+                }
+                if (A.rule == FUSED_RULE_LBPS && r == 0) {  // the cost range (once)
+                    float m = -INFINITY;
+                    if (tid >= FUSED_BLOCK - WAVE) {  // the last wave is idle in the combine above
+                        for (int bb = lane; bb < G; bb += WAVE) m = fmaxf(m, fx_get(fx, FX_STATS, bb, COLS, t0, timed_out));
+#pragma unroll
+                        for (int q = 32; q >= 1; q >>= 1) m = fmaxf(m, __shfl_xor(m, q));
+                        if (lane == 0) s_bc[3] = m;
+                    }
+                }
+                __syncthreads();
+                if (tid < COLS) {
+                    double v = 0.0;
+                    for (int q = 0; q < GROUPS; ++q) v += s_scratch[q * COLS + tid];
+                    s_sumd[tid] = v;
+                }
+                __syncthreads();
+                if (tid < WAVE) {  // the scalar step: one wave (essps_select_kernel / lbps_select_kernel)
+                    const int j = tid;
+                    if (j < STATS_L) {
+                        if (r == 0) s_gridd[j] = A.grid0[j];
+                        if (A.rule == FUSED_RULE_ESSPS) s_vald[j] = s_sumd[3 * j] * s_sumd[3 * j] / s_sumd[3 * j + 1];
+                        else s_vald[j] = mppi::host::lbps_objective(
+                            mppi::host::SoftmaxStats{(double)cmin, (double)s_bc[3], s_sumd[3 * j], s_sumd[3 * j + 1], s_sumd[3 * j + 2]},
+                            A.rule_param);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    if (j == 0) {
+                        double lo = A.lam_min, hi = A.lam_max, lam = 0.0;
+                        bool have;
+                        if (A.rule == FUSED_RULE_ESSPS) {
+                            if (r == 0) have = mppi::host::essps_round0<STATS_L>(s_gridd, s_vald, A.rule_param, A.lam_min, A.lam_max, lo, hi, lam);
+                            else { lam = mppi::host::essps_round1<STATS_L>(s_gridd, s_vald, A.rule_param); have = true; }
+                        } else {
+                            mppi::host::lbps_grid_step<STATS_L>(s_gridd, s_vald, r == rounds - 1, lo, hi, lam);
+                            have = r == rounds - 1;
+                        }
+                        s_sumd[0] = lo; s_sumd[1] = hi;
+                        s_flag = have ? 1 : 0;
+                        if (have) {
+                            *A.lambda_dev = (float)lam;
+                            A.lambda_host[0] = lam; A.lambda_host[1] = lam;
+                            fx_put(fx, FX_BCAST + 2 * r, 0, STATS_L + 1, (float)lam);
+                        }
+                        fx_put(fx, FX_BCAST + 2 * r, 0, STATS_L, have ? 1.0f : 0.0f);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    if (!s_flag && j < STATS_L) {  // the next grid, one point per lane
+                        const double gj = mppi::host::essps_grid_point<STATS_L>(s_sumd[0], s_sumd[1], j);
+                        s_gridd[j] = gj;
+                        fx_put(fx, FX_BCAST + 2 * r, 0, j, (float)gj);
+                    }
+                }
+            }
+            // every block: the broadcast of round r
+            if (tid == 0) {
+                const float done = fx_get(fx, FX_BCAST + 2 * r, 0, STATS_L, t0, timed_out);
+                s_bc[1] = done;
+                if (done != 0.0f) s_bc[0] = fx_get(fx, FX_BCAST + 2 * r, 0, STATS_L + 1, t0, timed_out);
+            }
+            __syncthreads();
+            if (s_bc[1] != 0.0f) { lambda = s_bc[0]; break; }
+            if (tid < STATS_L) s_lams[tid] = fx_get(fx, FX_BCAST + 2 * r, 0, tid, t0, timed_out);
+            __syncthreads();
+        }
+    }
+
+    // ---- steps 5-6: weights and this block's share of sum_i e_i U_i
+    const float xmax = (-cmin) / lambda;
+    const float e = i < d.N ? expf((-total) / lambda - xmax) : 0.0f;
+    s_e[tid] = e;
+    {
+        const float cz = e != 0.0f ? total : 0.0f;
+        const float se = wave_sum(e), se2 = wave_sum(e * e), sec = wave_sum(e * cz);
+        if (lane == 0) { s_w[wid][0] = se; s_w[wid][1] = se2; s_w[wid][2] = sec; }
+    }
+    __syncthreads();
+    float bse = 0.0f, bse2 = 0.0f, bsec = 0.0f;
+#pragma unroll
+    for (int w = 0; w < NWV; ++w) { bse += s_w[w][0]; bse2 += s_w[w][1]; bsec += s_w[w][2]; }
+    const bool block_live = bse != 0.0f;  // block-uniform
+    if (block_live) {
+        int RP = 1;
+        while (RP < d.R) RP <<= 1;  // float4 groups per row, rounded up to a power of two (<= 32)
+        const int r = tid & (RP - 1), slice = tid / RP, nsl = FUSED_BLOCK / RP;
+        float* s_part = reinterpret_cast<float*>(s_scratch);  // [nsl][4 * RP]
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        if (r < d.R) {
+            for (int sidx = slice; sidx < FUSED_BLOCK; sidx += nsl) {
+                const float es = s_e[sidx];
+                if (es != 0.0f) {
+                    const int64_t i2 = (int64_t)b * FUSED_BLOCK + sidx;
+                    const uint64_t gi2 = (uint64_t)(d.sample_offset + i2);
+                    const float4 n4 = gen_noise4(gi2, r, gen, d);
+                    const float4 m4 = ((d.sample_offset + i2) < d.inherit_count) ? s_mean4[r] : s_mean4[d.R + r];
+                    const float nv[4] = {n4.x, n4.y, n4.z, n4.w}, mv[4] = {m4.x, m4.y, m4.z, m4.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int k = ctrl_index(j, d.dc);
+                        acc[j] = fmaf(es, clampf(mv[j] + nv[j], d.u_min[k], d.u_max[k]), acc[j]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s_part[slice * 4 * RP + 4 * r + j] = acc[j];
+        __syncthreads();
+        if (tid < d.row) {
+            float v = 0.0f;
+            for (int sl = 0; sl < nsl; ++sl) v += s_part[sl * 4 * RP + tid];
+            fx_put(fx, FX_ROW, b, MPPI_SUMMARY_HEAD + tid, v);
+        }
+        if (tid == FUSED_BLOCK - 1) { fx_put(fx, FX_ROW, b, 1, bse); fx_put(fx, FX_ROW, b, 2, bse2); fx_put(fx, FX_ROW, b, 3, bsec); }
+    }
+    if (tid == FUSED_BLOCK - 2) fx_put(fx, FX_ROW, b, 0, block_live ? 1.0f : 0.0f);
+    if (b != 0) {
+        if (timed_out) *fx.error = 1;
+        return;
+    }
+
+    // ---- block 0: fold the live blocks' rows (ascending), then the tail of the solve
+    __syncthreads();
+    float* s_act = s_dyn + 8 * d.R + d.T * M::KROW;  // [row]
+    float* s_sum = s_act + d.row;                     // [4 + row]
+    float* s_yp = s_sum + MPPI_SUMMARY_HEAD + d.row;  // filter staging
+    unsigned char* s_livef = reinterpret_cast<unsigned char*>(s_c);  // (the costs are not needed any more)
+    for (int b2 = tid; b2 < G; b2 += FUSED_BLOCK) s_livef[b2] = fx_get(fx, FX_ROW, b2, 0, t0, timed_out) != 0.0f ? 1 : 0;
+    __syncthreads();
+    if (tid < d.row + 3) {
+        const int cell = tid < d.row ? MPPI_SUMMARY_HEAD + tid : 1 + (tid - d.row);
+        float v = 0.0f;
+        for (int b2 = 0; b2 < G; ++b2)
+            if (s_livef[b2]) v += fx_get(fx, FX_ROW, b2, cell, t0, timed_out);
+        s_sum[cell] = v;
+        if (A.summary_out) A.summary_out[cell] = v;
+    }
+    if (tid == 0) { s_sum[0] = cmin; if (A.summary_out) A.summary_out[0] = cmin; }
+    s_flag = 0;
+    __syncthreads();
+    if (timed_out) s_flag = 1;
+    __syncthreads();
+    if (s_flag) {  // a block is missing: no partial answer leaves this kernel
+        const float nanv = __uint_as_float(0x7fc00000u);
+        for (int c = tid; c < d.row; c += FUSED_BLOCK) if (A.action_out) A.action_out[c] = nanv;
+        for (int c = tid; c < (d.T + 1) * M::DS; c += FUSED_BLOCK) if (A.state_out) A.state_out[c] = nanv;
+        if (tid < 4 && A.stats_out) A.stats_out[tid] = nanv;
+        if (tid == 0) *fx.error = 1;
+        return;
+    }
+    finalize_tail<MODEL, FAST>(s_sum, 1, lambda, d.row, d.T, s_x0, s_act, s_yp, A.mean_store, A.action_out, A.state_out,
+                               A.stats_out, A.stats_keep, sg, ctx);
 }
 
 // `_weights` (mppi.py:376) given the global min cost and sum e.

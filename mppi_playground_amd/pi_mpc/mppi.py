@@ -299,6 +299,7 @@ class MPPI(nn.Module):
                           and not (use_sg_filter and not self._sg_on_device)
                           and (self._auto_lambda is None or self._rule_on_device is not None))
         self._last_lambda = None
+        self._fused_error_seen = False
         self._injected = None
         self._mean_of_last_solve = self._previous_action_seq
         self._state_seq_batch_buf = None
@@ -734,6 +735,10 @@ class MPPI(nn.Module):
             h.call("mppi_set_state", x0h.ctypes.data_as(C.c_void_p), 0, st)
             x0p = None
         self._refresh_model_inputs()
+        if not self._fused_error_seen and h.lib.mppi_fused_error(h.h):
+            self._fused_error_seen = True  # (from now on the library stays on the multi-kernel path)
+            raise _capi.MppiError("a single-launch solve timed out waiting for one of its blocks (is the GPU shared with another "
+                                  "cooperative kernel?): its outputs are void; later solves use the multi-kernel path")
         self._mean_of_last_solve = self._previous_action_seq
         if self._auto_lambda is None:
             lam = float(self._lambda_value)

@@ -1827,3 +1827,56 @@ def test_uneven_shards_match_the_unsharded_solver():
         keep = np.concatenate([[True], distinct]) & np.concatenate([distinct, [True]])
         assert rel_err(r[7][keep], ts.cpu().numpy()[keep]) < 1e-5
         assert np.array_equal(r[7], res[0][7])
+
+
+# ------------------------------------------------------------------------------ the single-launch solve
+@pytest.mark.parametrize("model,T,N,lam,kw", [
+    ("pendulum", 50, 1000, "ESSPS", {}), ("pendulum", 15, 256, "LBPS", {}), ("pendulum", 15, 1000, "MPO", {}),
+    ("racing", 25, 4000, 1.0, {}), ("racing", 50, 5000, 300.0, dict(exploration=0.2, use_sg_filter=True)),
+    ("nav2d", 50, 65536, "ESSPS", {}), ("nav2d", 30, 3000, "LBPS", dict(use_sg_filter=True, sg_window_size=7, sg_poly_order=2)),
+    ("cartpole", 64, 262144, "ESSPS", dict(use_sg_filter=True)), ("mountaincar", 100, 1025, 0.1, {}),
+    ("goalzone", 30, 3000, 1.0, {}), ("mjcartpole", 50, 1000, 1.0, {}), ("cartpole", 10, 100, 0.001, {})])
+def test_single_launch_solve_equals_the_multi_kernel_path(model, T, N, lam, kw):
+    """mppi_solve as ONE cooperative kernel (solve_fused_kernel, the default whenever the problem is resident at once)
+    against the same solve as separate launches (option fused_solve = 0), closed loop over the warm start: costs,
+    minimum and the searched temperature bit-identical, action and state sequences equal to the rounding of the two
+    summation orders; the queries that read the solve's state afterwards (top samples, weights) agree as well."""
+    fused, cf = make_solver(model, T, N, lambda_=lam, **kw)
+    multi, cm = make_solver(model, T, N, lambda_=lam, **kw)
+    multi.set_option("fused_solve", 0)
+    assert fused._one_call and multi._one_call
+    x0 = {"pendulum": [3.0, 0.0], "racing": None, "nav2d": [-9.0, -9.0, 0.785], "cartpole": [0.01, 0.0, 0.02, 0.0],
+          "mountaincar": [-0.5, 0.0], "mjcartpole": [0.0, 0.0, 0.05, 0.0],
+          "goalzone": None}[model]
+    if model == "racing":
+        env = _envs["racing"]
+        state = env.reset().clone()
+        ref, _ = cf.calc_ref_trajectory(state, env.racing_center_path, 0, T, DL=0.1, lookahead_distance=3,
+                                        reference_path_interval=0.85)
+        cf.set_reference(ref)
+        cm.set_reference(ref)
+    elif model == "goalzone":
+        from helpers import goalzone_env_fixture
+        state = torch.from_numpy(np.asarray(goalzone_env_fixture()["x0"], np.float32)).cuda()
+    else:
+        state = torch.tensor(x0).cuda()
+    for k in range(4):
+        a1, s1 = fused.forward(state)
+        a2, s2 = multi.forward(state)
+        assert not fused._h.lib.mppi_fused_error(fused._h.h)
+        if k == 0:  # same inputs: everything up to the weighted sums is the same arithmetic
+            assert torch.equal(fused._costs, multi._costs)
+            assert fused._last_lambda == multi._last_lambda
+            assert fused.last_stats()["cmin"] == multi.last_stats()["cmin"]
+        else:  # the warm starts differ in their last bits from here on
+            assert rel_err(fused._costs.cpu().numpy(), multi._costs.cpu().numpy()) < 1e-5
+            assert abs(fused._last_lambda - multi._last_lambda) <= 1e-4 * multi._last_lambda
+        tol = 2e-6 * (1 + 4 * k)
+        check_rel("single_launch_action_seq_vs_multi_kernel", a1.cpu().numpy(), a2.cpu().numpy(), tol)
+        check_rel("single_launch_state_seq_vs_multi_kernel", s1.cpu().numpy(), s2.cpu().numpy(), tol if model != "mjcartpole" else 50 * tol)
+        assert abs(fused.last_stats()["ess"] - multi.last_stats()["ess"]) <= 1e-4 * multi.last_stats()["ess"]
+    kq = min(N, 50)
+    ts1, tw1 = fused.get_top_samples(kq)
+    ts2, tw2 = multi.get_top_samples(kq)
+    assert rel_err(tw1.cpu().numpy(), tw2.cpu().numpy()) < 1e-4 and ts1.shape == ts2.shape
+    check_rel("weights_vs_oracle", fused._weights.cpu().numpy(), orc.softmax_weights(fused._costs.cpu().numpy(), fused._last_lambda)[0], TOL)
