@@ -1861,19 +1861,19 @@ def test_single_launch_solve_equals_the_multi_kernel_path(model, T, N, lam, kw):
     else:
         state = torch.tensor(x0).cuda()
     for k in range(4):
+        if k:  # both solve from the SAME warm start / filter history every tick (the fused solver's), so that each tick
+            # compares the two paths on identical inputs instead of two diverging closed loops
+            multi.set_warm_start(fused._previous_action_seq.cpu().numpy(),
+                                 fused._actions_history_for_sg if kw.get("use_sg_filter") else None)
         a1, s1 = fused.forward(state)
         a2, s2 = multi.forward(state)
         assert not fused._h.lib.mppi_fused_error(fused._h.h)
-        if k == 0:  # same inputs: everything up to the weighted sums is the same arithmetic
-            assert torch.equal(fused._costs, multi._costs)
-            assert fused._last_lambda == multi._last_lambda
-            assert fused.last_stats()["cmin"] == multi.last_stats()["cmin"]
-        else:  # the warm starts differ in their last bits from here on
-            assert rel_err(fused._costs.cpu().numpy(), multi._costs.cpu().numpy()) < 1e-5
-            assert abs(fused._last_lambda - multi._last_lambda) <= 1e-4 * multi._last_lambda
-        tol = 2e-6 * (1 + 4 * k)
-        check_rel("single_launch_action_seq_vs_multi_kernel", a1.cpu().numpy(), a2.cpu().numpy(), tol)
-        check_rel("single_launch_state_seq_vs_multi_kernel", s1.cpu().numpy(), s2.cpu().numpy(), tol if model != "mjcartpole" else 50 * tol)
+        # everything up to the weighted sums is the same arithmetic in the same order
+        assert torch.equal(fused._costs, multi._costs)
+        assert fused._last_lambda == multi._last_lambda, (k, fused._last_lambda, multi._last_lambda)
+        assert fused.last_stats()["cmin"] == multi.last_stats()["cmin"]
+        check_rel("single_launch_action_seq_vs_multi_kernel", a1.cpu().numpy(), a2.cpu().numpy(), 2e-6)
+        check_rel("single_launch_state_seq_vs_multi_kernel", s1.cpu().numpy(), s2.cpu().numpy(), 2e-6 if model != "mjcartpole" else 1e-4)
         assert abs(fused.last_stats()["ess"] - multi.last_stats()["ess"]) <= 1e-4 * multi.last_stats()["ess"]
     kq = min(N, 50)
     ts1, tw1 = fused.get_top_samples(kq)
