@@ -47,7 +47,7 @@ struct MppiSolver {
     int* fused_error = nullptr;        // mapped pinned
     int* fused_error_dev = nullptr;
     unsigned fused_seq = 0;
-    int fused_mode = 1;                // option "fused_solve": 0 = never, 1 = whenever the problem fits (default)
+    int fused_mode = 0;                // option "fused_solve": 0 = never (default until it is faster), 1 = whenever the problem fits
     int cu_count = 0;
     double* grid0_dev = nullptr;       // [STATS_L] round-0 grid of the fused ESSPS / LBPS search
     double grid0_lo = 0.0, grid0_hi = 0.0;

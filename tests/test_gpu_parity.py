@@ -425,6 +425,7 @@ def test_regenerated_noise_equals_materialised_tiles(model, T, N):
     for regen in (1, 0):
         solver, ctrl = make_solver(model, T, N, lambda_=50.0 if model in ("racing", "nav2d") else 1.0)
         solver.set_option("noise_regen", regen)
+        solver.set_option("fused_solve", 0)  # (the single-launch solve sums the weighted rows in another order)
         if ctrl is not None:
             env = _envs["racing"]
             ref, _ = ctrl.calc_ref_trajectory(env._robot_state, env.racing_center_path, 0, T, DL=0.1,
@@ -1842,6 +1843,7 @@ def test_single_launch_solve_equals_the_multi_kernel_path(model, T, N, lam, kw):
     minimum and the searched temperature bit-identical, action and state sequences equal to the rounding of the two
     summation orders; the queries that read the solve's state afterwards (top samples, weights) agree as well."""
     fused, cf = make_solver(model, T, N, lambda_=lam, **kw)
+    fused.set_option("fused_solve", 1)
     multi, cm = make_solver(model, T, N, lambda_=lam, **kw)
     multi.set_option("fused_solve", 0)
     assert fused._one_call and multi._one_call
