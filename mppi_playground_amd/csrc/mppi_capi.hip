@@ -1035,8 +1035,7 @@ static bool fused_applies(mppi_handle_t h, float lambda) {
     if (!(h->noise_regen && !h->injected && !h->wide)) return false;         // the noise is regenerated in registers
     if (h->p2p_enabled || h->comm_enabled) return false;                      // sharded solves exchange between devices
     if (h->d.row > FUSED_MAX_ROW) return false;
-    const int64_t blocks = (h->d.N + FUSED_BLOCK - 1) / FUSED_BLOCK;
-    if (blocks > FUSED_MAX_BLOCKS || blocks > h->cu_count) return false;      // every block must be resident at once
+    if (h->d.N > (int64_t)FUSED_BLOCK * std::min(FUSED_MAX_BLOCKS, h->cu_count)) return false;  // every block must be resident at once
     if (h->fused_error && *(volatile int*)h->fused_error) return false;       // a poll timed out once: stay on the multi-kernel path
     if (lambda == MPPI_LAMBDA_DEVICE && h->auto_rule == MPPI_AUTO_MPO && !h->lambda_dev_valid) return false;
     if (h->timing == 1) return false;                                         // per-stage timing brackets the separate kernels
@@ -1084,7 +1083,10 @@ static int solve_fused(mppi_handle_t h, float lambda, float* action_out, float* 
     A.stats_keep = h->solve_stats; A.summary_out = h->summary;
     const SgFilter sg{h->sg_coeffs, h->sg_history, h->sg_window};
     const FusedCtx fx{h->fused_cells, h->fused_error_dev, h->fused_seq};
-    const unsigned grid = (unsigned)((h->d.N + FUSED_BLOCK - 1) / FUSED_BLOCK);
+    // G = min(#CUs, ceil(N / 256)) blocks, each owning spb (a multiple of 64, <= 1024) consecutive trajectories
+    const int64_t gmax = std::min(FUSED_MAX_BLOCKS, h->cu_count);
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(gmax, (h->d.N + 255) / 256));
+    A.spb = (int)(((h->d.N + grid - 1) / grid + 63) / 64 * 64);
 #define CALL_FUSED(MODEL, FASTV)                                                                      \
     do {                                                                                              \
         const size_t shmem = sizeof(float) * ((size_t)8 * h->d.R + (size_t)h->d.T * ModelT<MODEL, FASTV>::KROW + 2 * (size_t)h->d.row + \

@@ -1266,20 +1266,23 @@ __global__ __launch_bounds__(WAVE) void mpo_step_kernel(const float* __restrict_
 //
 // The multi-kernel solve of a small or medium problem is a chain of 3-9 dependent, latency-bound launches (launch + the
 // first load of data another XCD just wrote ~ 4-5 us each; a captured hipGraph replays the same chain:
-// profiles/r03_experiments.md).  Here every block of 1024 threads owns 1024 trajectories (one per thread: the whole
-// problem is resident at once, at most one block per CU) and the blocks talk through CELLS in HBM instead of kernel
-// boundaries: an 8-byte word {fp32 value, 32-bit solve number} written with ONE relaxed agent-scope store and polled with
-// agent-scope loads, so that data and "ready" cannot be seen apart and no fence or grid barrier is needed (the protocol
-// of the peer-to-peer exchange, P2pCtx).  Hops per solve:
-//   1. every block publishes its minimum cost; every block reads all of them                     -> global minimum
-//   2. ESSPS / LBPS only, per round: every block publishes its 96 partial sums of the 32-temperature statistics
-//      (+ its maximum cost); block 0 combines them, runs the scalar step of the search and broadcasts the next grid or
-//      the temperature                                                                                (2 hops per round)
-//   3. every block with a non-zero weight publishes its partial row sum_i e_i U_i and {sum e, sum e^2, sum e c};
-//      block 0 folds them and runs the tail of the solve (normalise, filter, warm start, batch-1 rollout).
-// Costs, the minimum, the statistics and therefore the temperature are BIT-IDENTICAL to the multi-kernel path (same
-// device functions, same partition into 1024-cost chunks, same summation order); the weighted row is summed in a
-// different order (per block instead of per reduce-grid block), i.e. equal to rounding.
+// profiles/r03_experiments.md).  Here the whole problem is resident at once — G = min(#CUs, ceil(N/256)) blocks of 1024
+// threads, block b owning `spb` consecutive trajectories (one per thread of its first spb/64 waves: small problems
+// spread over many CUs as lone waves, exactly like the stand-alone rollout kernel; the other waves of a block only help
+// with the exchanges) — and the blocks talk through CELLS in HBM instead of kernel boundaries: an 8-byte word
+// {fp32 value, 32-bit solve number} written with ONE relaxed agent-scope store and polled with agent-scope loads, so that
+// data and "ready" cannot be seen apart and no fence or grid barrier is needed (the protocol of the peer-to-peer
+// exchange, P2pCtx).  A round trip through a cell costs about as much as a kernel boundary (~2.5 us), so the exchanges
+// are arranged in as few DEPENDENT round trips as possible and every reader issues all its loads before it looks at the
+// first one (fx_get_many):
+//   1. every block publishes its minimum cost; every block reads all of them                              (1 round trip)
+//   2. ESSPS / LBPS only, per round: every block publishes the 96 partial sums of its 32-temperature statistics (+ its
+//      maximum cost); block 0 combines them (fixed order, double), runs the scalar step of the search (host_search.hpp,
+//      the code of essps_select_kernel / lbps_select_kernel) and broadcasts the next grid or the temperature  (2-3 each)
+//   3. every block publishes its partial row sum_i e_i U_i and {sum e, sum e^2, sum e c} (zeros without a weight);
+//      block 0 folds them (fixed order) and runs the tail of the solve: normalise, filter, warm start, batch-1 rollout.
+// Costs and the minimum are BIT-IDENTICAL to the multi-kernel path (same device functions); the statistics and the
+// weighted row are summed over another partition, i.e. the temperature and the action agree to rounding.  Deterministic.
 // A poll that does not complete within ~2 s (a block that never became resident: the device is shared with another
 // cooperative kernel) raises *error, voids the outputs and returns — no hang.
 constexpr int FUSED_BLOCK = 1024;
@@ -1300,9 +1303,8 @@ __device__ __forceinline__ void fx_put(const FusedCtx& x, int phase, int b, int 
     __hip_atomic_store(fx_cell(x, phase, b, j), ((unsigned long long)x.seq << 32) | (unsigned long long)__float_as_uint(v),
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ float fx_get(const FusedCtx& x, int phase, int b, int j, long long t0, bool& timed_out) {
-    const unsigned long long* p = fx_cell(x, phase, b, j);
-    unsigned long long cell = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ __forceinline__ float fx_wait(const FusedCtx& x, const unsigned long long* p, unsigned long long cell, long long t0,
+                                         bool& timed_out) {
     unsigned spins = 0;
     while ((unsigned)(cell >> 32) != x.seq) {
         if ((++spins & 255u) == 0u && wall_clock64() - t0 > 200000000ll) { timed_out = true; break; }  // 100 MHz: 2 s
@@ -1310,6 +1312,22 @@ __device__ __forceinline__ float fx_get(const FusedCtx& x, int phase, int b, int
         cell = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     return __uint_as_float((unsigned)cell);
+}
+__device__ __forceinline__ float fx_get(const FusedCtx& x, int phase, int b, int j, long long t0, bool& timed_out) {
+    const unsigned long long* p = fx_cell(x, phase, b, j);
+    return fx_wait(x, p, __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), t0, timed_out);
+}
+// cell j of blocks b0, b0 + bstep, ... (n <= K of them): ALL loads are issued before the first tag is looked at, so the
+// K cells cost one round trip, not K
+template <int K>
+__device__ __forceinline__ void fx_get_many(const FusedCtx& x, int phase, int b0, int bstep, int n, int j, float (&out)[K],
+                                            long long t0, bool& timed_out) {
+    unsigned long long c[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+        if (k < n) c[k] = __hip_atomic_load(fx_cell(x, phase, b0 + k * bstep, j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int k = 0; k < K; ++k) out[k] = k < n ? fx_wait(x, fx_cell(x, phase, b0 + k * bstep, j), c[k], t0, timed_out) : 0.0f;
 }
 
 struct FusedArgs {
@@ -1320,6 +1338,7 @@ struct FusedArgs {
     unsigned* next_min_key; // the other slot, reset for the next multi-kernel rollout (it accumulates with atomicMin)
     float* mean_used;       // snapshots for later re-rolls (get_top_samples)
     float* x0_used;
+    int spb;                // trajectories per block (a multiple of 64, <= 1024)
     int rule;               // FUSED_RULE_*
     double rule_param, lam_min, lam_max;
     float lambda_arg;       // rule == NONE: > 0, or MPPI_LAMBDA_DEVICE = read *lambda_dev
@@ -1340,15 +1359,20 @@ __global__ __launch_bounds__(FUSED_BLOCK) void solve_fused_kernel(FusedArgs A, D
     using M = ModelT<MODEL, FAST>;
     constexpr int NWV = FUSED_BLOCK / WAVE;
     constexpr bool UC = FAST != 0;
-    __shared__ float s_c[FUSED_BLOCK];             // this block's costs
-    __shared__ float s_e[FUSED_BLOCK];             // ... and weights
+    constexpr int KG = 16;                         // cells a thread keeps in flight per round trip
+    constexpr int COLS = STATS_L * 3;              // 96 statistics columns
+    constexpr int SPARTS = FUSED_BLOCK / COLS;     // 10 row groups of the statistics combine
+    constexpr int CW = FX_CELLS;                   // column slots of the row fold (>= 4 + row)
+    constexpr int RPARTS = FUSED_BLOCK / CW;       // 7 row groups of the row fold
+    __shared__ float s_c[FUSED_BLOCK];             // this block's costs (padded), later its weights
     __shared__ float s_p[NWV][STATS_L][3];
     __shared__ float s_w[NWV][4];                  // per-wave scalars
-    __shared__ double s_scratch[STATS_COMB_GROUPS * STATS_L * 3];  // statistics combine / row partials (aliased)
-    __shared__ double s_sumd[STATS_L * 3];
+    __shared__ double s_scratch[2048];             // statistics combine [SPARTS][COLS] doubles; aliased: row partials, 4096 floats
+    __shared__ float s_fold[RPARTS][CW];           // block 0's row fold
+    __shared__ double s_sumd[COLS];
     __shared__ double s_vald[STATS_L], s_gridd[STATS_L];
-    __shared__ float s_lams[STATS_L];
-    __shared__ float s_bc[4];                      // broadcast scalars: [0] lambda, [1] done flag, [2] cmin
+    __shared__ float s_lams[STATS_L + 2];
+    __shared__ float s_bc[4];                      // [2] global minimum, [3] global maximum
     __shared__ int s_flag;
     __shared__ float s_x0[MPPI_MAX_DIM_STATE];
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];  // [8R] mean groups, [T*KROW] step rows, then the tail's staging
@@ -1369,12 +1393,13 @@ __global__ __launch_bounds__(FUSED_BLOCK) void solve_fused_kernel(FusedArgs A, D
     if (tid < M::DS) { s_x0[tid] = A.x0[tid]; if (b == 0) A.x0_used[tid] = A.x0[tid]; }
     __syncthreads();
 
-    // ---- step 1-3: one trajectory per thread
-    const int64_t i = (int64_t)b * FUSED_BLOCK + tid;
-    const uint64_t gi = (uint64_t)(d.sample_offset + i);
-    const bool inherit = (d.sample_offset + i) < d.inherit_count;
+    // ---- steps 1-3: one trajectory per thread of the block's first spb/64 waves
+    const int64_t i = (int64_t)b * A.spb + tid;
+    const bool mine = tid < A.spb && i < d.N;
     float total = INFINITY;
-    if (i < d.N) {
+    if (mine) {
+        const uint64_t gi = (uint64_t)(d.sample_offset + i);
+        const bool inherit = (d.sample_offset + i) < d.inherit_count;
         bool bad = false;
         const float4* mp = inherit ? s_mean4 : s_mean4 + d.R;
         total = trajectory_cost<MODEL, FAST, true, UC>(nullptr, gi, gen, mp, s_ktab, s_x0, d, ctx, bad);
@@ -1386,28 +1411,35 @@ __global__ __launch_bounds__(FUSED_BLOCK) void solve_fused_kernel(FusedArgs A, D
         }
         A.costs[i] = total;
     }
-    // ---- hop 1: the global minimum
+    // ---- hop 1: the global minimum (and, for LBPS, maximum)
     {
         const float wm = wave_min(total);
-        if (lane == 0) s_w[wid][0] = wm;
+        float wx = mine ? total : -INFINITY;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) wx = fmaxf(wx, __shfl_xor(wx, m));
+        if (lane == 0) { s_w[wid][0] = wm; s_w[wid][1] = wx; }
         __syncthreads();
         if (tid == 0) {
-            float m = s_w[0][0];
+            float m = s_w[0][0], mx = s_w[0][1];
 #pragma unroll
-            for (int w = 1; w < NWV; ++w) m = fminf(m, s_w[w][0]);
+            for (int w = 1; w < NWV; ++w) { m = fminf(m, s_w[w][0]); mx = fmaxf(mx, s_w[w][1]); }
             fx_put(fx, FX_MIN, b, 0, m);
+            fx_put(fx, FX_MIN, b, 1, mx);
         }
-        float gm = INFINITY;
-        for (int b2 = tid; b2 < G; b2 += FUSED_BLOCK) gm = fminf(gm, fx_get(fx, FX_MIN, b2, 0, t0, timed_out));
+        float gm = INFINITY, gx = -INFINITY;
+        if (tid < G) gm = fx_get(fx, FX_MIN, tid, 0, t0, timed_out);                                   // G <= 256
+        else if (tid >= 512 && tid - 512 < G) gx = fx_get(fx, FX_MIN, tid - 512, 1, t0, timed_out);
         gm = wave_min(gm);
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) gx = fmaxf(gx, __shfl_xor(gx, m));
         __syncthreads();
-        if (lane == 0) s_w[wid][0] = gm;
+        if (lane == 0) { s_w[wid][0] = gm; s_w[wid][1] = gx; }
         __syncthreads();
         if (tid == 0) {
-            float m = s_w[0][0];
+            float m = s_w[0][0], mx = s_w[0][1];
 #pragma unroll
-            for (int w = 1; w < NWV; ++w) m = fminf(m, s_w[w][0]);
-            s_bc[2] = m;
+            for (int w = 1; w < NWV; ++w) { m = fminf(m, s_w[w][0]); mx = fmaxf(mx, s_w[w][1]); }
+            s_bc[2] = m; s_bc[3] = mx;
             if (b == 0) { *A.min_key = float_to_key(m); *A.next_min_key = 0xFFFFFFFFu; }
         }
         __syncthreads();
@@ -1418,69 +1450,52 @@ __global__ __launch_bounds__(FUSED_BLOCK) void solve_fused_kernel(FusedArgs A, D
     float lambda = A.lambda_arg > 0.0f ? A.lambda_arg : *A.lambda_dev;
     if (A.rule != FUSED_RULE_NONE) {
         const int rounds = A.rule == FUSED_RULE_ESSPS ? 2 : LBPS_ROUNDS;
-        s_c[tid] = i < d.N ? total : 3.0e38f;
-        float cmaxv = i < d.N ? total : -INFINITY;
-        if (A.rule == FUSED_RULE_LBPS) {
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) cmaxv = fmaxf(cmaxv, __shfl_xor(cmaxv, m));
-            if (lane == 0) s_w[wid][1] = cmaxv;
-        }
+        s_c[tid] = mine ? total : 3.0e38f;  // padding: e = exp(-inf) = 0 and 0 * c = 0
         __syncthreads();
         for (int r = 0; r < rounds; ++r) {
-            // statistics of this block's 1024 costs for the 32 temperatures of round r (stats_multi_kernel's arithmetic)
+            // statistics of this block's costs for the 32 temperatures of round r (stats_multi_kernel's arithmetic)
             const int l = tid & (STATS_L - 1), chunk = tid >> 5;
             const float lam_l = r == 0 ? (float)A.grid0[l] : s_lams[l];
             const float inv_lam = 1.0f / lam_l;
             float se = 0.0f, se2 = 0.0f, sec = 0.0f;
-            const float* cc = s_c + chunk * 32;
+            if (chunk * 32 < A.spb) {  // (wave-uniform: chunks past the block's trajectories hold padding only)
+                const float* cc = s_c + chunk * 32;
 #pragma unroll 8
-            for (int j = 0; j < 32; ++j) {
-                const float c = cc[j];
-                const float e = expf((cmin - c) * inv_lam);
-                se += e;
-                se2 = fmaf(e, e, se2);
-                sec = fmaf(e, c, sec);
+                for (int j = 0; j < 32; ++j) {
+                    const float c = cc[j];
+                    const float e = expf((cmin - c) * inv_lam);
+                    se += e;
+                    se2 = fmaf(e, e, se2);
+                    sec = fmaf(e, c, sec);
+                }
             }
             se += __shfl_xor(se, 32); se2 += __shfl_xor(se2, 32); sec += __shfl_xor(sec, 32);
             if (lane < STATS_L) { s_p[wid][lane][0] = se; s_p[wid][lane][1] = se2; s_p[wid][lane][2] = sec; }
             __syncthreads();
-            if (tid < STATS_L * 3) {
+            if (tid < COLS) {
                 float v = 0.0f;
 #pragma unroll
                 for (int w = 0; w < NWV; ++w) v += (&s_p[w][0][0])[tid];
                 fx_put(fx, FX_STATS + 2 * r, b, tid, v);
             }
-            if (tid == STATS_L * 3 && A.rule == FUSED_RULE_LBPS && r == 0) {
-                float v = s_w[0][1];
-#pragma unroll
-                for (int w = 1; w < NWV; ++w) v = fmaxf(v, s_w[w][1]);
-                fx_put(fx, FX_STATS, b, STATS_L * 3, v);
-            }
             if (b == 0) {
-                // combine: column sums over the blocks in stats_combine_columns' order (thread (quad, g): rows g, g+40, ...)
-                constexpr int COLS = STATS_L * 3, QUADS = COLS / 4, GROUPS = STATS_COMB_GROUPS;
-                const int quad = tid % QUADS, g = tid / QUADS;
-                if (g < GROUPS) {
-                    double v[4] = {0.0, 0.0, 0.0, 0.0};
-                    for (int bb = g; bb < G; bb += GROUPS)
+                // combine: thread (col, part) sums blocks part, part + SPARTS, ... in ascending order, KG cells in flight
+                const int col = tid % COLS, part = tid / COLS;
+                if (part < SPARTS) {
+                    double v = 0.0;
+                    for (int b0 = part; b0 < G; b0 += KG * SPARTS) {
+                        float vals[KG];
+                        const int n = min(KG, (G - b0 + SPARTS - 1) / SPARTS);
+                        fx_get_many<KG>(fx, FX_STATS + 2 * r, b0, SPARTS, n, col, vals, t0, timed_out);
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) v[c] += (double)fx_get(fx, FX_STATS + 2 * r, bb, 4 * quad + c, t0, timed_out);
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) s_scratch[g * COLS + 4 * quad + c] = v[c];
-                }
-                if (A.rule == FUSED_RULE_LBPS && r == 0) {  // the cost range (once)
-                    float m = -INFINITY;
-                    if (tid >= FUSED_BLOCK - WAVE) {  // the last wave is idle in the combine above
-                        for (int bb = lane; bb < G; bb += WAVE) m = fmaxf(m, fx_get(fx, FX_STATS, bb, COLS, t0, timed_out));
-#pragma unroll
-                        for (int q = 32; q >= 1; q >>= 1) m = fmaxf(m, __shfl_xor(m, q));
-                        if (lane == 0) s_bc[3] = m;
+                        for (int k = 0; k < KG; ++k) v += (double)vals[k];
                     }
+                    s_scratch[part * COLS + col] = v;
                 }
                 __syncthreads();
                 if (tid < COLS) {
                     double v = 0.0;
-                    for (int q = 0; q < GROUPS; ++q) v += s_scratch[q * COLS + tid];
+                    for (int q = 0; q < SPARTS; ++q) v += s_scratch[q * COLS + tid];
                     s_sumd[tid] = v;
                 }
                 __syncthreads();
@@ -1509,35 +1524,30 @@ __global__ __launch_bounds__(FUSED_BLOCK) void solve_fused_kernel(FusedArgs A, D
                         if (have) {
                             *A.lambda_dev = (float)lam;
                             A.lambda_host[0] = lam; A.lambda_host[1] = lam;
-                            fx_put(fx, FX_BCAST + 2 * r, 0, STATS_L + 1, (float)lam);
                         }
+                        fx_put(fx, FX_BCAST + 2 * r, 0, STATS_L + 1, have ? (float)lam : 0.0f);
                         fx_put(fx, FX_BCAST + 2 * r, 0, STATS_L, have ? 1.0f : 0.0f);
                     }
                     __builtin_amdgcn_wave_barrier();
-                    if (!s_flag && j < STATS_L) {  // the next grid, one point per lane
-                        const double gj = mppi::host::essps_grid_point<STATS_L>(s_sumd[0], s_sumd[1], j);
-                        s_gridd[j] = gj;
+                    if (j < STATS_L) {  // the next grid, one point per lane (zeros once the temperature is known)
+                        double gj = 0.0;
+                        if (!s_flag) { gj = mppi::host::essps_grid_point<STATS_L>(s_sumd[0], s_sumd[1], j); s_gridd[j] = gj; }
                         fx_put(fx, FX_BCAST + 2 * r, 0, j, (float)gj);
                     }
                 }
             }
-            // every block: the broadcast of round r
-            if (tid == 0) {
-                const float done = fx_get(fx, FX_BCAST + 2 * r, 0, STATS_L, t0, timed_out);
-                s_bc[1] = done;
-                if (done != 0.0f) s_bc[0] = fx_get(fx, FX_BCAST + 2 * r, 0, STATS_L + 1, t0, timed_out);
-            }
+            // every block: the broadcast of round r, 34 cells read side by side
+            if (tid < STATS_L + 2) s_lams[tid] = fx_get(fx, FX_BCAST + 2 * r, 0, tid, t0, timed_out);
             __syncthreads();
-            if (s_bc[1] != 0.0f) { lambda = s_bc[0]; break; }
-            if (tid < STATS_L) s_lams[tid] = fx_get(fx, FX_BCAST + 2 * r, 0, tid, t0, timed_out);
-            __syncthreads();
+            if (s_lams[STATS_L] != 0.0f) { lambda = s_lams[STATS_L + 1]; break; }
         }
+        __syncthreads();
     }
 
     // ---- steps 5-6: weights and this block's share of sum_i e_i U_i
     const float xmax = (-cmin) / lambda;
-    const float e = i < d.N ? expf((-total) / lambda - xmax) : 0.0f;
-    s_e[tid] = e;
+    const float e = mine ? expf((-total) / lambda - xmax) : 0.0f;
+    s_c[tid] = e;
     {
         const float cz = e != 0.0f ? total : 0.0f;
         const float se = wave_sum(e), se2 = wave_sum(e * e), sec = wave_sum(e * cz);
@@ -1547,18 +1557,17 @@ __global__ __launch_bounds__(FUSED_BLOCK) void solve_fused_kernel(FusedArgs A, D
     float bse = 0.0f, bse2 = 0.0f, bsec = 0.0f;
 #pragma unroll
     for (int w = 0; w < NWV; ++w) { bse += s_w[w][0]; bse2 += s_w[w][1]; bsec += s_w[w][2]; }
-    const bool block_live = bse != 0.0f;  // block-uniform
-    if (block_live) {
+    {
         int RP = 1;
         while (RP < d.R) RP <<= 1;  // float4 groups per row, rounded up to a power of two (<= 32)
         const int r = tid & (RP - 1), slice = tid / RP, nsl = FUSED_BLOCK / RP;
-        float* s_part = reinterpret_cast<float*>(s_scratch);  // [nsl][4 * RP]
+        float* s_part = reinterpret_cast<float*>(s_scratch);  // [nsl][4 * RP] = 4096 floats
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        if (r < d.R) {
-            for (int sidx = slice; sidx < FUSED_BLOCK; sidx += nsl) {
-                const float es = s_e[sidx];
+        if (bse != 0.0f && r < d.R) {
+            for (int sidx = slice; sidx < A.spb; sidx += nsl) {
+                const float es = s_c[sidx];
                 if (es != 0.0f) {
-                    const int64_t i2 = (int64_t)b * FUSED_BLOCK + sidx;
+                    const int64_t i2 = (int64_t)b * A.spb + sidx;
                     const uint64_t gi2 = (uint64_t)(d.sample_offset + i2);
                     const float4 n4 = gen_noise4(gi2, r, gen, d);
                     const float4 m4 = ((d.sample_offset + i2) < d.inherit_count) ? s_mean4[r] : s_mean4[d.R + r];
@@ -1581,27 +1590,38 @@ __global__ __launch_bounds__(FUSED_BLOCK) void solve_fused_kernel(FusedArgs A, D
         }
         if (tid == FUSED_BLOCK - 1) { fx_put(fx, FX_ROW, b, 1, bse); fx_put(fx, FX_ROW, b, 2, bse2); fx_put(fx, FX_ROW, b, 3, bsec); }
     }
-    if (tid == FUSED_BLOCK - 2) fx_put(fx, FX_ROW, b, 0, block_live ? 1.0f : 0.0f);
     if (b != 0) {
         if (timed_out) *fx.error = 1;
         return;
     }
 
-    // ---- block 0: fold the live blocks' rows (ascending), then the tail of the solve
-    __syncthreads();
+    // ---- block 0: fold the blocks' rows in ascending order, then the tail of the solve
     float* s_act = s_dyn + 8 * d.R + d.T * M::KROW;  // [row]
     float* s_sum = s_act + d.row;                     // [4 + row]
     float* s_yp = s_sum + MPPI_SUMMARY_HEAD + d.row;  // filter staging
-    unsigned char* s_livef = reinterpret_cast<unsigned char*>(s_c);  // (the costs are not needed any more)
-    for (int b2 = tid; b2 < G; b2 += FUSED_BLOCK) s_livef[b2] = fx_get(fx, FX_ROW, b2, 0, t0, timed_out) != 0.0f ? 1 : 0;
+    {
+        const int col = tid % CW, part = tid / CW;    // cell slot (1 .. 3 + row are used), row group
+        if (part < RPARTS) {
+            float v = 0.0f;
+            if (col >= 1 && col < MPPI_SUMMARY_HEAD + d.row) {
+                for (int b0 = part; b0 < G; b0 += KG * RPARTS) {
+                    float vals[KG];
+                    const int n = min(KG, (G - b0 + RPARTS - 1) / RPARTS);
+                    fx_get_many<KG>(fx, FX_ROW, b0, RPARTS, n, col, vals, t0, timed_out);
+#pragma unroll
+                    for (int k = 0; k < KG; ++k) v += vals[k];
+                }
+            }
+            s_fold[part][col] = v;
+        }
+    }
     __syncthreads();
-    if (tid < d.row + 3) {
-        const int cell = tid < d.row ? MPPI_SUMMARY_HEAD + tid : 1 + (tid - d.row);
+    if (tid >= 1 && tid < MPPI_SUMMARY_HEAD + d.row) {
         float v = 0.0f;
-        for (int b2 = 0; b2 < G; ++b2)
-            if (s_livef[b2]) v += fx_get(fx, FX_ROW, b2, cell, t0, timed_out);
-        s_sum[cell] = v;
-        if (A.summary_out) A.summary_out[cell] = v;
+#pragma unroll
+        for (int q = 0; q < RPARTS; ++q) v += s_fold[q][tid];
+        s_sum[tid] = v;
+        if (A.summary_out) A.summary_out[tid] = v;
     }
     if (tid == 0) { s_sum[0] = cmin; if (A.summary_out) A.summary_out[0] = cmin; }
     s_flag = 0;

@@ -1870,12 +1870,17 @@ def test_single_launch_solve_equals_the_multi_kernel_path(model, T, N, lam, kw):
         a1, s1 = fused.forward(state)
         a2, s2 = multi.forward(state)
         assert not fused._h.lib.mppi_fused_error(fused._h.h)
-        # everything up to the weighted sums is the same arithmetic in the same order
+        # the rollout is the same arithmetic; the sums behind the temperature and the action run over another partition
         assert torch.equal(fused._costs, multi._costs)
-        assert fused._last_lambda == multi._last_lambda, (k, fused._last_lambda, multi._last_lambda)
         assert fused.last_stats()["cmin"] == multi.last_stats()["cmin"]
-        check_rel("single_launch_action_seq_vs_multi_kernel", a1.cpu().numpy(), a2.cpu().numpy(), 2e-6)
-        check_rel("single_launch_state_seq_vs_multi_kernel", s1.cpu().numpy(), s2.cpu().numpy(), 2e-6 if model != "mjcartpole" else 1e-4)
+        if lam == "LBPS":  # (flat to fp32 rounding around its minimum: see same_lbps_minimum)
+            assert same_lbps_minimum(fused._costs.cpu().numpy(), fused._last_lambda, multi._last_lambda)
+        else:
+            assert abs(fused._last_lambda - multi._last_lambda) <= 1e-6 * multi._last_lambda, (k, fused._last_lambda, multi._last_lambda)
+        dl = abs(fused._last_lambda - multi._last_lambda) / multi._last_lambda
+        tol = 2e-6 + 20 * dl
+        check_rel("single_launch_action_seq_vs_multi_kernel", a1.cpu().numpy(), a2.cpu().numpy(), tol)
+        check_rel("single_launch_state_seq_vs_multi_kernel", s1.cpu().numpy(), s2.cpu().numpy(), tol if model != "mjcartpole" else 50 * tol)
         assert abs(fused.last_stats()["ess"] - multi.last_stats()["ess"]) <= 1e-4 * multi.last_stats()["ess"]
     kq = min(N, 50)
     ts1, tw1 = fused.get_top_samples(kq)
