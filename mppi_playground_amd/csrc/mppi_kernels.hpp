@@ -1308,7 +1308,7 @@ __device__ __forceinline__ float fx_wait(const FusedCtx& x, const unsigned long 
     unsigned spins = 0;
     while ((unsigned)(cell >> 32) != x.seq) {
         if ((++spins & 255u) == 0u && wall_clock64() - t0 > 200000000ll) { timed_out = true; break; }  // 100 MHz: 2 s
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(4);  // back off: thousands of lanes poll while the last blocks are still rolling out
         cell = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     return __uint_as_float((unsigned)cell);
@@ -1359,7 +1359,7 @@ __global__ __launch_bounds__(FUSED_BLOCK) void solve_fused_kernel(FusedArgs A, D
     using M = ModelT<MODEL, FAST>;
     constexpr int NWV = FUSED_BLOCK / WAVE;
     constexpr bool UC = FAST != 0;
-    constexpr int KG = 16;                         // cells a thread keeps in flight per round trip
+    constexpr int KG = 32;                         // cells a thread keeps in flight: every gather is ONE round trip (G <= 256)
     constexpr int COLS = STATS_L * 3;              // 96 statistics columns
     constexpr int SPARTS = FUSED_BLOCK / COLS;     // 10 row groups of the statistics combine
     constexpr int CW = FX_CELLS;                   // column slots of the row fold (>= 4 + row)
@@ -1525,19 +1525,23 @@ __global__ __launch_bounds__(FUSED_BLOCK) void solve_fused_kernel(FusedArgs A, D
                             *A.lambda_dev = (float)lam;
                             A.lambda_host[0] = lam; A.lambda_host[1] = lam;
                         }
-                        fx_put(fx, FX_BCAST + 2 * r, 0, STATS_L + 1, have ? (float)lam : 0.0f);
-                        fx_put(fx, FX_BCAST + 2 * r, 0, STATS_L, have ? 1.0f : 0.0f);
+                        s_lams[STATS_L + 1] = have ? (float)lam : 0.0f;
+                        s_lams[STATS_L] = have ? 1.0f : 0.0f;
                     }
                     __builtin_amdgcn_wave_barrier();
                     if (j < STATS_L) {  // the next grid, one point per lane (zeros once the temperature is known)
                         double gj = 0.0;
                         if (!s_flag) { gj = mppi::host::essps_grid_point<STATS_L>(s_sumd[0], s_sumd[1], j); s_gridd[j] = gj; }
-                        fx_put(fx, FX_BCAST + 2 * r, 0, j, (float)gj);
+                        s_lams[j] = (float)gj;
                     }
                 }
+                __syncthreads();
+                // broadcast: every block gets its OWN copy of the 34 cells (nobody polls a shared address)
+                for (int q = tid; q < G * (STATS_L + 2); q += FUSED_BLOCK)
+                    fx_put(fx, FX_BCAST + 2 * r, q / (STATS_L + 2), q % (STATS_L + 2), s_lams[q % (STATS_L + 2)]);
+            } else {
+                if (tid < STATS_L + 2) s_lams[tid] = fx_get(fx, FX_BCAST + 2 * r, b, tid, t0, timed_out);
             }
-            // every block: the broadcast of round r, 34 cells read side by side
-            if (tid < STATS_L + 2) s_lams[tid] = fx_get(fx, FX_BCAST + 2 * r, 0, tid, t0, timed_out);
             __syncthreads();
             if (s_lams[STATS_L] != 0.0f) { lambda = s_lams[STATS_L + 1]; break; }
         }
