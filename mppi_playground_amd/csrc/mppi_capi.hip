@@ -47,7 +47,7 @@ struct MppiSolver {
     int* fused_error = nullptr;        // mapped pinned
     int* fused_error_dev = nullptr;
     unsigned fused_seq = 0;
-    int fused_mode = 0;                // option "fused_solve": 0 = never (default until it is faster), 1 = whenever the problem fits
+    int fused_mode = 1;                // option "fused_solve": 0 = never, 1 = small problems (default), 2 = whenever resident
     int cu_count = 0;
     double* grid0_dev = nullptr;       // [STATS_L] round-0 grid of the fused ESSPS / LBPS search
     double grid0_lo = 0.0, grid0_hi = 0.0;
@@ -1030,8 +1030,13 @@ int mppi_finalize(mppi_handle_t h, const float* summaries_dev, int num_shards, f
 }
 
 // ---- the single-launch solve (solve_fused_kernel)
+static constexpr int64_t FUSED_AUTO_MAX_SAMPLES = 4096;
 static bool fused_applies(mppi_handle_t h, float lambda) {
     if (!h->fused_mode || h->cfg.model == MPPI_MODEL_GENERIC || h->mapping != 0) return false;
+    // measured (profiles/r03_experiments.md): a cell round trip costs about as much as a kernel boundary, so the single
+    // launch wins where the exchanges are few and small — up to a few thousand samples (the reference examples' sizes:
+    // 39 vs 49 us at N = 1000 with ESSPS, 22 vs 28 us for racing at N = 4000) — and is on par or slower beyond
+    if (h->fused_mode == 1 && h->d.N > FUSED_AUTO_MAX_SAMPLES) return false;
     if (!(h->noise_regen && !h->injected && !h->wide)) return false;         // the noise is regenerated in registers
     if (h->p2p_enabled || h->comm_enabled) return false;                      // sharded solves exchange between devices
     if (h->d.row > FUSED_MAX_ROW) return false;
@@ -1700,7 +1705,7 @@ int mppi_set_option(mppi_handle_t h, const char* key, int64_t value) {
     if (k == "reduce_blocks") { h->reduce_blocks = (int)std::max<int64_t>(1, std::min<int64_t>(value, 2048)); return MPPI_OK; }
     if (k == "timing") { h->timing = (int)value; return MPPI_OK; }
     if (k == "mapping") { h->mapping = value ? 1 : 0; return MPPI_OK; }
-    if (k == "fused_solve") { h->fused_mode = value ? 1 : 0; return MPPI_OK; }
+    if (k == "fused_solve") { h->fused_mode = value < 0 ? 0 : value > 2 ? 2 : (int)value; return MPPI_OK; }
     if (k == "fold_path") { h->fold_mode = (value >= 0 && value <= 2) ? (int)value : 0; return MPPI_OK; }
     if (k == "exchange_p2p") {  // sharded solves: summaries travel through the peer-to-peer buffer, no collective
         if (value && !h->p2p_connected) return fail(h, MPPI_E_STATE, "exchange_p2p: call mppi_p2p_alloc / mppi_p2p_connect first");

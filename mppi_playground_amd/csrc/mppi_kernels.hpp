@@ -1308,7 +1308,7 @@ __device__ __forceinline__ float fx_wait(const FusedCtx& x, const unsigned long 
     unsigned spins = 0;
     while ((unsigned)(cell >> 32) != x.seq) {
         if ((++spins & 255u) == 0u && wall_clock64() - t0 > 200000000ll) { timed_out = true; break; }  // 100 MHz: 2 s
-        __builtin_amdgcn_s_sleep(4);  // back off: thousands of lanes poll while the last blocks are still rolling out
+        __builtin_amdgcn_s_sleep(2);
         cell = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     return __uint_as_float((unsigned)cell);

@@ -34,7 +34,7 @@ rows += [("racing4000", "racing T=25 N=4000 lambda=1 (the example's size)", 0, 0
          ("racing256k", "racing T=50 N=262144 lambda=1", 0, 0, racing(262144, 50), env.reset().clone())]
 for key, label, work, b_alg, make, x0 in rows:
     out = []
-    for fused in (0, 1):
+    for fused in (0, 2):
         s = make()
         s.set_option("fused_solve", fused)
         out.append(_time_solver(torch, s, x0, n=200, warm=30) * 1e6)

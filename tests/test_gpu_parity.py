@@ -1843,7 +1843,7 @@ def test_single_launch_solve_equals_the_multi_kernel_path(model, T, N, lam, kw):
     minimum and the searched temperature bit-identical, action and state sequences equal to the rounding of the two
     summation orders; the queries that read the solve's state afterwards (top samples, weights) agree as well."""
     fused, cf = make_solver(model, T, N, lambda_=lam, **kw)
-    fused.set_option("fused_solve", 1)
+    fused.set_option("fused_solve", 2)  # (1, the default, takes the single launch up to 4096 samples only)
     multi, cm = make_solver(model, T, N, lambda_=lam, **kw)
     multi.set_option("fused_solve", 0)
     assert fused._one_call and multi._one_call
