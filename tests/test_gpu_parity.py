@@ -1154,6 +1154,7 @@ def test_device_sg_filter_equals_the_host_statement():
     for model, T, N, kw in (("cartpole", 64, 1024, dict()), ("cartpole", 12, 256, dict(sg_window_size=9, sg_poly_order=4)),
                             ("nav2d", 30, 512, dict(sg_window_size=7, sg_poly_order=2))):
         dev, _ = make_solver(model, T, N, lambda_=1.0, use_sg_filter=True, **kw)
+        dev.set_option("fused_solve", 0)  # (bit-identity is a statement about the same summation order: multi-kernel path)
         host, _ = make_solver(model, T, N, lambda_=1.0, use_sg_filter=True, sg_filter="host", **kw)
         assert dev._sg_on_device and not host._sg_on_device
         x = torch.tensor([0.01, 0.0, 0.02, 0.0]) if model == "cartpole" else torch.tensor([-9.0, -9.0, 0.785])
@@ -1446,7 +1447,11 @@ def test_reference_side_binding_is_self_sufficient():
         mc = MODEL_CFG[model]
         for essps in (False, True):
             ours, _ = make_solver(model, T, N, lambda_="ESSPS" if essps else 0.7)
+            ours.set_option("fused_solve", 0)  # (the single launch sums in another order: compare like with like)
             hips = [rb.HipForward(_capi.LIB_PATH, model, T, N, mc["u_min"], mc["u_max"], mc["sigmas"], seed=42) for _ in range(2)]
+            for hp in hips:
+                hp.lib.mppi_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+                assert hp.lib.mppi_set_option(hp.h, b"fused_solve", 0) == 0
             states = [torch.tensor(x0, device="cuda") for _ in range(3)]
             for tick in range(4):
                 a0, s0 = ours.forward(states[0])
