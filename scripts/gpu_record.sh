@@ -3,7 +3,7 @@
 # rocprofv3 kernel trace + separate PMC passes for C3 (regen / tiles) and for the dense-weight configs C2 / C5.
 # Usage: bash scripts/gpu_record.sh [tag]   (writes gpurun_out/prof_<tag>/, default tag r2)
 set -u
-TAG=${1:-r2}
+TAG=${1:-r3}
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -14,11 +14,15 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smok
 timeout 900 python bench.py > gpurun_out/bench.log 2>&1; tail -c 600 gpurun_out/bench.log; echo
 timeout 300 python bench.py --steps 100 --warmup 20 --noise-regen 0 --no-cpu-baseline --no-extras > gpurun_out/bench_tiles.log 2>&1
 # the N > 1 path on this one GPU: ranks share the device, gloo instead of RCCL (RCCL needs one device per rank)
-for spec in "2 nccl" "2 p2p" "8 nccl" "8 p2p"; do
+# (the timed run takes the requested transport — "auto" falls back to the torch.distributed all_gather here, because RCCL
+# cannot put two ranks on one device — and then times the other transports behind the wall-clock guard: `exchange_alt`)
+for spec in "2 auto" "2 p2p" "8 auto"; do
   set -- $spec
   MPPI_BENCH_ONE_DEVICE=1 MPPI_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus $1 --exchange $2 --steps 20 --warmup 5 > gpurun_out/bench_dry_g$1_$2.log 2>&1
   echo "dry run --gpus $1 --exchange $2: rc=$? $(tail -1 gpurun_out/bench_dry_g$1_$2.log | cut -c1-160)"
 done
+MASTER_PORT=29543 timeout 300 python scripts/nccl_single_rank.py 2>&1 | grep -E "forced exchange|RCCL all_gather" > gpurun_out/nccl_single_rank.txt
+timeout 300 python scripts/fused_timing.py 2>&1 | grep -v amdgpu.ids > gpurun_out/fused_timing.txt
 cd /tmp
 B="python $R/bench.py --no-cpu-baseline --no-extras"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $P -o kt -- $B --steps 30 --warmup 5 > $R/gpurun_out/rocprof_kt.log 2>&1
