@@ -148,7 +148,8 @@ class MPPI(nn.Module):
         self._auto_lambda_stats = auto_lambda_stats
         self._graph_callables = bool(graph_callables)
         self._graph = None           # captured loops (generic path)
-        self._graph_b1 = None        # captured batch-1 rollout of the solution (generic path)
+        self._graph_b1 = None        # captured batch-1 rollout of the solution (generic path); False = not capturable
+        self._graph_info_keys = None
         self._graph_state = "off" if not graph_callables else "warmup"  # warmup -> capture -> replay | failed
         if essps_search not in ("device", "grid", "brentq"):
             raise ValueError("essps_search must be 'device', 'grid' or 'brentq'")
@@ -780,6 +781,7 @@ class MPPI(nn.Module):
         U = self._perturbed_action_seqs_buf
         self._h.call("mppi_export_noise", None, _ptr(U), self._stream())
         if self._graph_state == "replay":
+            self._check_replay_info(info)
             self._graph.replay()
         elif self._graph_state == "capture":
             self._capture_callables(info)
@@ -812,19 +814,44 @@ class MPPI(nn.Module):
 
     def _states_prediction_graphed(self) -> torch.Tensor:
         """Step 8 (the batch-1 rollout of the solution through the user's dynamics, T launch-bound calls) as a second
-        captured graph on static buffers; returns a fresh tensor like the eager path."""
+        captured graph on static buffers; returns a fresh tensor like the eager path.  A dynamics that cannot be captured
+        at batch 1 keeps the eager rollout (warned once), like the N-sample loops."""
+        import warnings
+
         if self._graph_b1 is None:
             self._b1_actions = torch.empty(1, self._horizon, self._dim_control, device=self._device, dtype=self._dtype)
             self._b1_actions.copy_(self._action_out)
-            self._states_prediction(self._x0_tensor, self._b1_actions)  # warm-up at batch 1
-            torch.cuda.synchronize(self._device)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._b1_states = self._states_prediction(self._x0_tensor, self._b1_actions)
-            self._graph_b1 = g
+            try:
+                side = torch.cuda.Stream(device=self._device)
+                side.wait_stream(torch.cuda.current_stream(self._device))
+                with torch.cuda.stream(side):  # warm-up at batch 1 on the stream the capture will use
+                    self._states_prediction(self._x0_tensor, self._b1_actions)
+                torch.cuda.current_stream(self._device).wait_stream(side)
+                torch.cuda.synchronize(self._device)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side):
+                    self._b1_states = self._states_prediction(self._x0_tensor, self._b1_actions)
+                self._graph_b1 = g
+            except Exception as e:  # noqa: BLE001  not capturable at batch 1: stay eager for this step
+                torch.cuda.synchronize(self._device)
+                self._graph_b1 = False
+                warnings.warn(f"graph_callables: the batch-1 rollout of the solution could not be captured "
+                              f"({type(e).__name__}); it stays on the eager loop")
+        if self._graph_b1 is False:
+            return self._states_prediction(self._x0_tensor, self._action_out.repeat(1, 1, 1))
         self._b1_actions.copy_(self._action_out)
         self._graph_b1.replay()
         return self._b1_states.clone()
+
+    def recapture(self) -> None:
+        """graph_callables: drop the captured loops; the next solve runs eagerly (warm-up) and the one after captures
+        again.  Call it after REBINDING anything the callables read (a new tensor object for a reference path, a
+        changed Python scalar): a replay reads the storage that was captured — update tensors in place (`copy_`) to
+        change what a captured graph sees without recapturing."""
+        if self._graph_callables:
+            self._graph = self._graph_b1 = None
+            self._graph_info_keys = None
+            self._graph_state = "warmup"
 
     def _capture_callables(self, info: Dict) -> None:
         """Capture _callable_loops into a hipGraph and run it once; on failure fall back to the eager loops for good."""
@@ -832,11 +859,16 @@ class MPPI(nn.Module):
 
         try:
             torch.cuda.synchronize(self._device)
+            side = torch.cuda.Stream(device=self._device)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, stream=side):
                 self._callable_loops(info)
             self._graph = g
             self._graph_state = "replay"
+            # what the caller's dict held besides the solver's own four keys when the loops were captured: a replay cannot
+            # see later changes of it (see _check_replay_info)
+            self._graph_info_keys = {k: id(v) for k, v in info.items()
+                                     if k not in ("prev_state", "prev_action", "initial_state", "t")}
             g.replay()
         except Exception as e:  # not capturable (host sync, data-dependent shapes, ...): stay eager
             self._graph, self._graph_state = None, "failed"
@@ -844,6 +876,19 @@ class MPPI(nn.Module):
             warnings.warn(f"graph_callables: the dynamics / cost_func loops could not be captured ({type(e).__name__}: "
                           f"{str(e).splitlines()[0] if str(e) else ''}); staying on the eager loops")
             self._callable_loops(info)
+
+    def _check_replay_info(self, info: Dict) -> None:
+        """A replayed graph ignores the `info` dict it is handed: the solver's own keys are views of the static buffers
+        (filled in below like the eager loop leaves them), but entries the CALLER put there were read at capture time.  If
+        those changed identity since, the replay would silently use the old objects: refuse instead."""
+        now = {k: id(v) for k, v in info.items() if k not in ("prev_state", "prev_action", "initial_state", "t")}
+        if now != self._graph_info_keys:
+            raise RuntimeError("graph_callables: the caller's entries of `info` changed since the loops were captured "
+                               f"({sorted(set(now) ^ set(self._graph_info_keys)) or sorted(now)}); update tensors in place "
+                               "or call solver.recapture()")
+        U, S = self._perturbed_action_seqs_buf, self._state_seq_batch_buf  # what the eager loop leaves in the dict
+        info["prev_state"], info["prev_action"] = S[:, -2, :], U[:, max(self._horizon - 2, 0), :]
+        info["initial_state"], info["t"] = S[:, 0, :], self._horizon - 1
 
     def _states_prediction(self, state: torch.Tensor, action_seqs: torch.Tensor) -> torch.Tensor:
         """src/pi_mpc/mppi.py:508-524 with the user's dynamics."""

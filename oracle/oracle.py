@@ -129,6 +129,7 @@ class Problem:
         N, T, ds, dc = self.N, self.T, self.ds, self.dc
         x0, mean, eps = _f32(x0), _f32(mean), _f32(eps)
         assert eps.shape == (N, T, dc) and mean.shape == (T, dc) and x0.shape == (ds,)
+        assert self.model != "racing" or self.p.ref_path, "racing: set the reference window first (set_ref_path)"
         U = np.empty((N, T, dc), np.float32) if want_U else None
         S = np.empty((N, T + 1, ds), np.float32) if want_S else None
         stage = np.empty((N, T), np.float32) if want_stage else None

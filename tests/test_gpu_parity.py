@@ -1576,6 +1576,18 @@ def test_generic_path_hipgraph_capture_of_the_callables():
                 times.append((time.perf_counter() - t0) / 20 * 1e3)
             print(f"generic {model} N={N} T={T}: eager loops {times[0]:.2f} ms/solve, hipGraph replay {times[1]:.2f} ms/solve")
             assert times[1] < times[0]
+            # a replay fills the caller's dict like the eager loop leaves it ...
+            info = {}
+            graph.forward(xg, info)
+            assert set(info) == {"prev_state", "prev_action", "initial_state", "t"} and info["t"] == T - 1
+            # ... and refuses entries of the caller's that it cannot have seen at capture time
+            with pytest.raises(RuntimeError, match="recapture"):
+                graph.forward(xg, {"weights_table": torch.ones(3, device="cuda")})
+            graph.recapture()
+            assert graph._graph_state == "warmup"
+            a_w, _ = graph.forward(xg)   # eager warm-up
+            a_c, _ = graph.forward(xg)   # captures again
+            assert graph._graph_state == "replay" and torch.isfinite(a_c).all()
         else:
             assert graph._graph_state == "failed" and warned
 
