@@ -1301,8 +1301,8 @@ __global__ __launch_bounds__(FIN_BLOCK) void sparse_tail_kernel(const float* __r
     __shared__ int s_wcnt[NWV];
     __shared__ unsigned s_list[NT];
     __shared__ float s_e[SPT_SUB * WAVE];
-    __shared__ float s_part[4 * NT];
-    __shared__ float s_red[NWV][3];
+    __shared__ double s_part[4 * NT];  // (double: a dense softmax walks thousands of samples per thread)
+    __shared__ double s_red[NWV][3];
     __shared__ float s_x0[MPPI_MAX_DIM_STATE];
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];  // [8R] mean groups (+ zeros), [row] action, [4+row] summary, filter staging
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -1315,8 +1315,8 @@ __global__ __launch_bounds__(FIN_BLOCK) void sparse_tail_kernel(const float* __r
     int RP = 1;
     while (RP < d.R) RP <<= 1;
     const int r = tid & (RP - 1), slot = tid / RP, nsl = NT / RP;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    float se = 0.f, se2 = 0.f, sec = 0.f;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    double se = 0.0, se2 = 0.0, sec = 0.0;
     int nlive_total = 0;
     for (int64_t sweep0 = 0; sweep0 < d.tiles; sweep0 += (int64_t)MAXCH * NT) {
         // ---- 1. this sweep's tile minima, all loads in flight together
@@ -1329,9 +1329,13 @@ __global__ __launch_bounds__(FIN_BLOCK) void sparse_tail_kernel(const float* __r
         if (tid < MAXCH) s_any[tid] = 0u;
         __syncthreads();
         unsigned mine = 0u;
+        // a tile MAY hold a weight iff its minimum does: exp(x) != 0 in fp32 needs x > -104, and x = (-c)/lambda - max is
+        // within a few ulps of (cmin - c)/lambda: the cheap test keeps a superset (a flagged tile whose weights all turn
+        // out exactly zero adds nothing); the exact weights are formed per sample below
+        const float inv_lam = 1.0f / lambda;
 #pragma unroll
         for (int ch = 0; ch < MAXCH; ++ch) {
-            const bool live = expf((-tm[ch]) / lambda - xmax) != 0.0f;  // exp(-inf) = 0 for the padding
+            const bool live = (cmin - tm[ch]) * inv_lam >= -105.0f;  // -inf for the padding
             if (live) mine |= 1u << ch;
             if (__ballot(live) != 0ull && lane == 0) atomicOr(&s_any[ch], 1u);
         }
@@ -1357,7 +1361,7 @@ __global__ __launch_bounds__(FIN_BLOCK) void sparse_tail_kernel(const float* __r
                     const float c = i < d.N ? costs[i] : INFINITY;
                     const float e = expf((-c) / lambda - xmax);
                     s_e[p] = e;
-                    if (e != 0.0f) { se += e; se2 = fmaf(e, e, se2); sec = fmaf(e, c, sec); }
+                    if (e != 0.0f) { se += (double)e; se2 += (double)e * (double)e; sec += (double)e * (double)c; }
                 }
                 __syncthreads();
                 if (r < d.R) {
@@ -1372,7 +1376,7 @@ __global__ __launch_bounds__(FIN_BLOCK) void sparse_tail_kernel(const float* __r
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
                                 const int k = ctrl_index(j, d.dc);
-                                acc[j] = fmaf(es, clampf(mv[j] + nv[j], d.u_min[k], d.u_max[k]), acc[j]);
+                                acc[j] += (double)es * (double)clampf(mv[j] + nv[j], d.u_min[k], d.u_max[k]);
                             }
                         }
                     }
@@ -1387,22 +1391,23 @@ __global__ __launch_bounds__(FIN_BLOCK) void sparse_tail_kernel(const float* __r
     float* s_yp = s_sum + MPPI_SUMMARY_HEAD + d.row;
 #pragma unroll
     for (int j = 0; j < 4; ++j) s_part[slot * 4 * RP + 4 * r + j] = acc[j];
-    se = wave_sum(se); se2 = wave_sum(se2); sec = wave_sum(sec);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { se += __shfl_xor(se, m); se2 += __shfl_xor(se2, m); sec += __shfl_xor(sec, m); }
     if (lane == 0) { s_red[wid][0] = se; s_red[wid][1] = se2; s_red[wid][2] = sec; }
     __syncthreads();
     if (tid < d.row) {
-        float v = 0.0f;
+        double v = 0.0;
         for (int sl = 0; sl < nsl; ++sl) v += s_part[sl * 4 * RP + tid];
-        s_sum[MPPI_SUMMARY_HEAD + tid] = v;
-        if (summary_out) summary_out[MPPI_SUMMARY_HEAD + tid] = v;
+        s_sum[MPPI_SUMMARY_HEAD + tid] = (float)v;
+        if (summary_out) summary_out[MPPI_SUMMARY_HEAD + tid] = (float)v;
     }
     if (tid >= NT - 3) {
         const int q = tid - (NT - 3);
-        float v = 0.0f;
+        double v = 0.0;
 #pragma unroll
         for (int w = 0; w < NWV; ++w) v += s_red[w][q];
-        s_sum[1 + q] = v;
-        if (summary_out) summary_out[1 + q] = v;
+        s_sum[1 + q] = (float)v;
+        if (summary_out) summary_out[1 + q] = (float)v;
     }
     if (tid == 0) {
         s_sum[0] = cmin;
