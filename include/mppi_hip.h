@@ -386,12 +386,7 @@ int mppi_p2p_error(mppi_handle_t h);
  * the north star's literal wavefront-per-trajectory rollout (comparison only, ~20x slower); "reduce_blocks" grid of the weighted
  * reduction; "fold_path" who sums the reduction's partial rows: 0 = by the live-row count of earlier solves (default),
  * 1 = inside mppi_finalize whenever the rows fit its LDS, 2 = always the separate summarize kernel (both use the same
- * summation tree: results are bit-identical); "sparse_tail" 1 (default) = mppi_solve runs steps 5-8 (weights, weighted
- * mean, normalisation, filter, warm start, batch-1 rollout) as ONE block after the rollout kernel whenever the previous
- * solve's softmax was sharp (few tiles of 64 trajectories carried any weight: the rollout kernel leaves per-tile minima,
- * so the block scans 4 B per tile instead of the costs) — one kernel boundary instead of two, exact for any weights, equal
- * to the two-kernel path to the rounding of the summation order; 0 = always mppi_weights_reduce + mppi_finalize;
- * "fused_solve" (see mppi_fused_error); "timing" (see mppi_get_timing). */
+ * summation tree: results are bit-identical); "timing" (see mppi_get_timing). */
 int mppi_set_option(mppi_handle_t h, const char* key, int64_t value);
 /* Device time per stage from HIP event pairs recorded on the caller's stream around every stage call
  * since the last drain (no host synchronisation while recording): out[0..3] = mean ms of

@@ -29,8 +29,6 @@ struct MppiSolver {
     // device buffers
     float4* noise = nullptr;
     float* costs = nullptr;
-    float* tile_min = nullptr;     // [tiles] minimum cost of every 64-trajectory tile (written by the rollout kernel)
-    int sparse_tail = 1;           // option "sparse_tail": mppi_solve may run steps 5-8 as one block (sparse_tail_kernel)
     unsigned* min_key = nullptr;   // two slots, toggled per rollout (no memset between solves)
     int min_slot = 0;
     float* x0 = nullptr;           // owned copy of the state ...
@@ -402,7 +400,6 @@ int mppi_create(const MppiConfig* cfg, mppi_handle_t* out) {
     HIP_TRY(h, hipMalloc(&h->noise, noise_bytes));
     HIP_TRY(h, hipMemset(h->noise, 0, noise_bytes));
     HIP_TRY(h, hipMalloc(&h->costs, sizeof(float) * (size_t)d.N));
-    HIP_TRY(h, hipMalloc(&h->tile_min, sizeof(float) * (size_t)d.tiles));
     HIP_TRY(h, hipMalloc(&h->min_key, 2 * sizeof(unsigned)));
     HIP_TRY(h, hipMemset(h->min_key, 0xFF, 2 * sizeof(unsigned)));
     const size_t x0_floats = (size_t)std::max(md.ds, MPPI_MAX_DIM_STATE);
@@ -438,7 +435,7 @@ int mppi_create(const MppiConfig* cfg, mppi_handle_t* out) {
     HIP_TRY(h, hipMalloc(&h->essps_dev, sizeof(EsspsDev)));
     HIP_TRY(h, hipMalloc(&h->lambda_dev, sizeof(float)));
     HIP_TRY(h, hipHostMalloc((void**)&h->live_hint, sizeof(int), hipHostMallocMapped));
-    *h->live_hint = 1 << 30;  // "dense" until a solve has reported how many rows / tiles carried weight
+    *h->live_hint = 0;
     HIP_TRY(h, hipHostGetDevicePointer((void**)&h->live_hint_dev, h->live_hint, 0));
     std::memset(&h->ctx, 0, sizeof(h->ctx));
     if (h->wide) {
@@ -483,7 +480,7 @@ int mppi_set_control_limits(mppi_handle_t h, const float* u_min, const float* u_
 
 int mppi_destroy(mppi_handle_t h) {
     if (!h) return MPPI_E_INVALID;
-    (void)hipFree(h->noise); (void)hipFree(h->costs); (void)hipFree(h->tile_min); (void)hipFree(h->min_key); (void)hipFree(h->x0);
+    (void)hipFree(h->noise); (void)hipFree(h->costs); (void)hipFree(h->min_key); (void)hipFree(h->x0);
     (void)hipFree(h->x0_used); (void)hipFree(h->coltab); (void)hipFree(h->lams_dev); (void)hipFree(h->essps_dev);
     (void)hipFree(h->lambda_dev); (void)hipFree(h->mpo_dev); (void)hipFree(h->mpo_temp_dev); (void)hipFree(h->lbps_dev);
     (void)hipFree(h->stats_max);
@@ -895,10 +892,10 @@ int mppi_rollout_cost(mppi_handle_t h, void* stream) {
         constexpr bool UCV = FASTV != 0;  /* the FAST kernels exist in the u_in_bounds form only (see use_fast) */ \
         if (gen)                                                                                      \
             hipLaunchKernelGGL((rollout_cost_kernel<MODEL, FASTV, true, UCV>), dim3(grid), dim3(BLOCK), shmem, s, \
-                               h->noise, h->mean, h->x0_cur, h->costs, mk, mk_next, h->mean_used, h->x0_used, h->tile_min, h->d, h->gen, h->ctx); \
+                               h->noise, h->mean, h->x0_cur, h->costs, mk, mk_next, h->mean_used, h->x0_used, h->d, h->gen, h->ctx); \
         else                                                                                          \
             hipLaunchKernelGGL((rollout_cost_kernel<MODEL, FASTV, false, UCV>), dim3(grid), dim3(BLOCK), shmem, s, \
-                               h->noise, h->mean, h->x0_cur, h->costs, mk, mk_next, h->mean_used, h->x0_used, h->tile_min, h->d, h->gen, h->ctx); \
+                               h->noise, h->mean, h->x0_cur, h->costs, mk, mk_next, h->mean_used, h->x0_used, h->d, h->gen, h->ctx); \
     } while (0)
     MPPI_DISPATCH(h, CALL_ROLLOUT);
 #undef CALL_ROLLOUT
@@ -1032,40 +1029,6 @@ int mppi_finalize(mppi_handle_t h, const float* summaries_dev, int num_shards, f
     return MPPI_OK;
 }
 
-// ---- steps 5-8 as one block when the softmax is sharp (sparse_tail_kernel)
-static bool sparse_tail_applies(mppi_handle_t h, float lambda) {
-    if (!h->sparse_tail || h->cfg.model == MPPI_MODEL_GENERIC || h->mapping != 0) return false;
-    if (!(h->noise_regen && !h->injected && !h->wide)) return false;
-    if (h->p2p_enabled || h->comm_enabled) return false;      // sharded solves need the shard summary before the exchange
-    if (h->d.row > FUSED_MAX_ROW) return false;
-    if (lambda == MPPI_LAMBDA_DEVICE && h->auto_rule != MPPI_AUTO_MPO) return false;  // ESSPS / LBPS aim at a dense softmax
-    // few rows / tiles carried weight in the previous solve (written by the last tail kernel to mapped host memory, read
-    // without synchronising: it only steers which of two exact paths runs)
-    return *(volatile int*)h->live_hint <= FOLD_IN_FINALIZE_MAX_ROWS;
-}
-
-static int solve_sparse_tail(mppi_handle_t h, float lambda, float* action_out, float* state_out, float* stats_out, hipStream_t s) {
-    const float* lam_dev = nullptr;
-    if (int rc = resolve_lambda(h, lambda, &lam_dev)) return rc;
-    StageTimer tm(h, 3, s);
-    const SgFilter sg{h->sg_coeffs, h->sg_history, h->sg_window};
-    const unsigned* mk = h->min_key + h->min_slot;
-#define CALL_SPT(MODEL, FASTV)                                                                        \
-    do {                                                                                              \
-        const size_t shmem = sizeof(float) * ((size_t)8 * h->d.R + 2 * (size_t)h->d.row + MPPI_SUMMARY_HEAD +  \
-                                              (sg.window ? (size_t)(2 * h->d.T - 1 + 2 * (sg.window / 2)) * h->dc : 0)); \
-        hipLaunchKernelGGL((sparse_tail_kernel<MODEL, FASTV>), dim3(1), dim3(FIN_BLOCK), shmem, s, (const float*)h->tile_min, \
-                           (const float*)h->costs, mk, (const float*)h->mean, h->x0_cur, lambda, lam_dev, h->mean, action_out, \
-                           state_out, stats_out, h->solve_stats, h->summary, h->live_hint_dev, sg, h->d, h->gen, h->ctx); \
-    } while (0)
-    MPPI_DISPATCH(h, CALL_SPT);
-#undef CALL_SPT
-    HIP_TRY(h, hipGetLastError());
-    h->last_reduce_blocks = 0;
-    h->summary_valid = true;
-    return MPPI_OK;
-}
-
 // ---- the single-launch solve (solve_fused_kernel)
 static constexpr int64_t FUSED_AUTO_MAX_SAMPLES = 4096;
 static bool fused_applies(mppi_handle_t h, float lambda) {
@@ -1176,12 +1139,8 @@ int mppi_solve(mppi_handle_t h, const float* x0_dev, uint32_t solve_idx, float l
     } else if (dev && h->auto_rule == MPPI_AUTO_LBPS) {
         if (int rc = mppi_lbps_lambda_device(h, h->auto_param, h->auto_lo, h->auto_hi, stream)) return rc;
     }
-    if (sparse_tail_applies(h, lambda)) {
-        if (int rc = solve_sparse_tail(h, lambda, action_out_dev, state_seq_out_dev, stats_out_dev, (hipStream_t)stream)) return rc;
-    } else {
-        if (int rc = mppi_weights_reduce(h, lambda, nullptr, stream)) return rc;
-        if (int rc = mppi_finalize(h, nullptr, 1, lambda, 1, action_out_dev, state_seq_out_dev, stats_out_dev, stream)) return rc;
-    }
+    if (int rc = mppi_weights_reduce(h, lambda, nullptr, stream)) return rc;
+    if (int rc = mppi_finalize(h, nullptr, 1, lambda, 1, action_out_dev, state_seq_out_dev, stats_out_dev, stream)) return rc;
     // MPO: the dual steps after every solve, whatever temperature this solve's weights were given (mppi.py:387-398)
     if (h->auto_rule == MPPI_AUTO_MPO) return mppi_mpo_step_device(h, stream);
     return MPPI_OK;
@@ -1746,7 +1705,6 @@ int mppi_set_option(mppi_handle_t h, const char* key, int64_t value) {
     if (k == "reduce_blocks") { h->reduce_blocks = (int)std::max<int64_t>(1, std::min<int64_t>(value, 2048)); return MPPI_OK; }
     if (k == "timing") { h->timing = (int)value; return MPPI_OK; }
     if (k == "mapping") { h->mapping = value ? 1 : 0; return MPPI_OK; }
-    if (k == "sparse_tail") { h->sparse_tail = value ? 1 : 0; return MPPI_OK; }
     if (k == "fused_solve") { h->fused_mode = value < 0 ? 0 : value > 2 ? 2 : (int)value; return MPPI_OK; }
     if (k == "fold_path") { h->fold_mode = (value >= 0 && value <= 2) ? (int)value : 0; return MPPI_OK; }
     if (k == "exchange_p2p") {  // sharded solves: summaries travel through the peer-to-peer buffer, no collective

@@ -259,8 +259,7 @@ __global__ __launch_bounds__(BLOCK) MPPI_ROLLOUT_ATTR void rollout_cost_kernel(c
                                                              unsigned* __restrict__ min_key,
                                                              unsigned* __restrict__ next_min_key,
                                                              float* __restrict__ mean_used,
-                                                             float* __restrict__ x0_used,
-                                                             float* __restrict__ tile_min, Dims d, GenCtx gen,
+                                                             float* __restrict__ x0_used, Dims d, GenCtx gen,
                                                              ModelCtx ctx) {
     using M = ModelT<MODEL, FAST>;
     __shared__ float s_min[BLOCK / WAVE];
@@ -304,10 +303,7 @@ __global__ __launch_bounds__(BLOCK) MPPI_ROLLOUT_ATTR void rollout_cost_kernel(c
         else total = INFINITY;
     }
     const float wm = wave_min(total);
-    if (lane == 0) {
-        s_min[wid] = wm;
-        if (tile < d.tiles) tile_min[tile] = wm;  // 4 B per 64 trajectories: what sparse_tail_kernel scans instead of costs[N]
-    }
+    if (lane == 0) s_min[wid] = wm;
     __syncthreads();
     if (threadIdx.x == 0) {
         float m = s_min[0];
@@ -1263,160 +1259,6 @@ __global__ __launch_bounds__(WAVE) void mpo_step_kernel(const float* __restrict_
         *temp_dev = s.temperature();
         lambda_host[0] = lam; lambda_host[1] = used;
     }
-}
-
-// ------------------------------------------------------------------------------------------
-// Steps 5-8 in ONE block when the softmax is sharp (mppi.py:376-385,423-452): weights, weighted mean, normalisation,
-// filter, warm start and batch-1 rollout after a single kernel boundary instead of two (weights_reduce + finalize: each
-// ~2.5 us of launch and a dependent round of loads; at C3 the pair is 21 us of a 150 us solve for one or two tiles that
-// carry any weight).  The rollout kernel leaves the minimum cost of every 64-trajectory tile (4 B per tile: 64 KB at
-// N = 2^20 instead of 4 MB of costs); a tile whose minimum has weight exp((-c)/lambda - max) == 0 in fp32 holds no
-// sample with a weight, exactly, so this block
-//   1. loads all tile minima at once (16 per thread at C3), flags the live tiles, compacts them per chunk of 1024,
-//   2. for the live tiles only: loads the 64 costs, forms the weights, regenerates the noise of those trajectories
-//      (thread = (float4 group, slot); slots walk the live (tile, sample) pairs) and accumulates e_i U_i,
-//   3. folds the slots in fixed order, sums the statistics and runs finalize_tail.
-// Exact for any weights; FAST only while few tiles are live (the host takes this path when the previous solve reported
-// few live tiles / rows through *live_hint, and goes back to the two-kernel path when this kernel reports many).
-// Same arithmetic per sample as weights_reduce_kernel; the sums run in another order (equal to rounding).
-constexpr int SPT_SUB = 32;  // live tiles per pass (their 2048 weights are staged in LDS)
-template <int MODEL, int FAST>
-__global__ __launch_bounds__(FIN_BLOCK) void sparse_tail_kernel(const float* __restrict__ tile_min,
-                                                                const float* __restrict__ costs,
-                                                                const unsigned* __restrict__ min_key,
-                                                                const float* __restrict__ mean,
-                                                                const float* __restrict__ x0, float lambda_arg,
-                                                                const float* __restrict__ lambda_dev,
-                                                                float* __restrict__ mean_store,
-                                                                float* __restrict__ action_out,
-                                                                float* __restrict__ state_out,
-                                                                float* __restrict__ stats_out,
-                                                                float* __restrict__ stats_keep,
-                                                                float* __restrict__ summary_out,
-                                                                int* __restrict__ nlive_out, SgFilter sg, Dims d,
-                                                                GenCtx gen, ModelCtx ctx) {
-    using M = ModelT<MODEL, FAST>;
-    constexpr int NT = FIN_BLOCK, NWV = NT / WAVE, MAXCH = 16;  // 16 x 1024 tiles per sweep (N = 2^20 in one sweep)
-    __shared__ unsigned s_any[MAXCH];
-    __shared__ int s_wcnt[NWV];
-    __shared__ unsigned s_list[NT];
-    __shared__ float s_e[SPT_SUB * WAVE];
-    __shared__ double s_part[4 * NT];  // (double: a dense softmax walks thousands of samples per thread)
-    __shared__ double s_red[NWV][3];
-    __shared__ float s_x0[MPPI_MAX_DIM_STATE];
-    extern __shared__ __attribute__((aligned(16))) float s_dyn[];  // [8R] mean groups (+ zeros), [row] action, [4+row] summary, filter staging
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const float lambda = lambda_dev ? *lambda_dev : lambda_arg;
-    const float cmin = key_to_float(*min_key);
-    const float xmax = (-cmin) / lambda;
-    float4* s_mean4 = reinterpret_cast<float4*>(s_dyn);
-    for (int f = tid; f < 4 * d.R; f += NT) { s_dyn[f] = f < d.row ? mean[f] : 0.0f; s_dyn[4 * d.R + f] = 0.0f; }
-    if (tid < M::DS) s_x0[tid] = x0[tid];
-    int RP = 1;
-    while (RP < d.R) RP <<= 1;
-    const int r = tid & (RP - 1), slot = tid / RP, nsl = NT / RP;
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    double se = 0.0, se2 = 0.0, sec = 0.0;
-    int nlive_total = 0;
-    for (int64_t sweep0 = 0; sweep0 < d.tiles; sweep0 += (int64_t)MAXCH * NT) {
-        // ---- 1. this sweep's tile minima, all loads in flight together
-        float tm[MAXCH];
-#pragma unroll
-        for (int ch = 0; ch < MAXCH; ++ch) {
-            const int64_t t = sweep0 + (int64_t)ch * NT + tid;
-            tm[ch] = t < d.tiles ? tile_min[t] : INFINITY;
-        }
-        if (tid < MAXCH) s_any[tid] = 0u;
-        __syncthreads();
-        unsigned mine = 0u;
-        // a tile MAY hold a weight iff its minimum does: exp(x) != 0 in fp32 needs x > -104, and x = (-c)/lambda - max is
-        // within a few ulps of (cmin - c)/lambda: the cheap test keeps a superset (a flagged tile whose weights all turn
-        // out exactly zero adds nothing); the exact weights are formed per sample below
-        const float inv_lam = 1.0f / lambda;
-#pragma unroll
-        for (int ch = 0; ch < MAXCH; ++ch) {
-            const bool live = (cmin - tm[ch]) * inv_lam >= -105.0f;  // -inf for the padding
-            if (live) mine |= 1u << ch;
-            if (__ballot(live) != 0ull && lane == 0) atomicOr(&s_any[ch], 1u);
-        }
-        __syncthreads();
-        for (int ch = 0; ch < MAXCH; ++ch) {
-            if (!s_any[ch]) continue;  // block-uniform
-            // ---- compact the live tiles of this chunk, ascending
-            const bool f = (mine >> ch) & 1u;
-            const unsigned long long mask = __ballot(f);
-            if (lane == 0) s_wcnt[wid] = __popcll(mask);
-            __syncthreads();
-            int off = 0, cnt = 0;
-#pragma unroll
-            for (int w = 0; w < NWV; ++w) { const int c = s_wcnt[w]; if (w < wid) off += c; cnt += c; }
-            if (f) s_list[off + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned)(sweep0 + (int64_t)ch * NT + tid);
-            __syncthreads();
-            nlive_total += cnt;
-            // ---- 2. the live tiles, SPT_SUB at a time
-            for (int t0 = 0; t0 < cnt; t0 += SPT_SUB) {
-                const int nt = min(SPT_SUB, cnt - t0), npairs = nt * WAVE;
-                for (int p = tid; p < npairs; p += NT) {
-                    const int64_t i = (int64_t)s_list[t0 + (p >> 6)] * WAVE + (p & 63);
-                    const float c = i < d.N ? costs[i] : INFINITY;
-                    const float e = expf((-c) / lambda - xmax);
-                    s_e[p] = e;
-                    if (e != 0.0f) { se += (double)e; se2 += (double)e * (double)e; sec += (double)e * (double)c; }
-                }
-                __syncthreads();
-                if (r < d.R) {
-                    for (int p = slot; p < npairs; p += nsl) {
-                        const float es = s_e[p];
-                        if (es != 0.0f) {
-                            const int64_t i = (int64_t)s_list[t0 + (p >> 6)] * WAVE + (p & 63);
-                            const uint64_t gi = (uint64_t)(d.sample_offset + i);
-                            const float4 n4 = gen_noise4(gi, r, gen, d);
-                            const float4 m4 = ((d.sample_offset + i) < d.inherit_count) ? s_mean4[r] : s_mean4[d.R + r];
-                            const float nv[4] = {n4.x, n4.y, n4.z, n4.w}, mv[4] = {m4.x, m4.y, m4.z, m4.w};
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                const int k = ctrl_index(j, d.dc);
-                                acc[j] += (double)es * (double)clampf(mv[j] + nv[j], d.u_min[k], d.u_max[k]);
-                            }
-                        }
-                    }
-                }
-                __syncthreads();
-            }
-        }
-    }
-    // ---- 3. fold the slots (ascending), sum the statistics, run the tail
-    float* s_act = s_dyn + 8 * d.R;
-    float* s_sum = s_act + d.row;
-    float* s_yp = s_sum + MPPI_SUMMARY_HEAD + d.row;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) s_part[slot * 4 * RP + 4 * r + j] = acc[j];
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) { se += __shfl_xor(se, m); se2 += __shfl_xor(se2, m); sec += __shfl_xor(sec, m); }
-    if (lane == 0) { s_red[wid][0] = se; s_red[wid][1] = se2; s_red[wid][2] = sec; }
-    __syncthreads();
-    if (tid < d.row) {
-        double v = 0.0;
-        for (int sl = 0; sl < nsl; ++sl) v += s_part[sl * 4 * RP + tid];
-        s_sum[MPPI_SUMMARY_HEAD + tid] = (float)v;
-        if (summary_out) summary_out[MPPI_SUMMARY_HEAD + tid] = (float)v;
-    }
-    if (tid >= NT - 3) {
-        const int q = tid - (NT - 3);
-        double v = 0.0;
-#pragma unroll
-        for (int w = 0; w < NWV; ++w) v += s_red[w][q];
-        s_sum[1 + q] = (float)v;
-        if (summary_out) summary_out[1 + q] = (float)v;
-    }
-    if (tid == 0) {
-        s_sum[0] = cmin;
-        if (summary_out) summary_out[0] = cmin;
-        if (nlive_out) *nlive_out = nlive_total;
-    }
-    __syncthreads();
-    finalize_tail<MODEL, FAST>(s_sum, 1, lambda, d.row, d.T, s_x0, s_act, s_yp, mean_store, action_out, state_out, stats_out,
-                               stats_keep, sg, ctx);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -426,7 +426,6 @@ def test_regenerated_noise_equals_materialised_tiles(model, T, N):
         solver, ctrl = make_solver(model, T, N, lambda_=50.0 if model in ("racing", "nav2d") else 1.0)
         solver.set_option("noise_regen", regen)
         solver.set_option("fused_solve", 0)  # (the single-launch solve sums the weighted rows in another order)
-        solver.set_option("sparse_tail", 0)  # (... and so does the one-block tail of a sharp softmax)
         if ctrl is not None:
             env = _envs["racing"]
             ref, _ = ctrl.calc_ref_trajectory(env._robot_state, env.racing_center_path, 0, T, DL=0.1,
@@ -1905,38 +1904,3 @@ def test_single_launch_solve_equals_the_multi_kernel_path(model, T, N, lam, kw):
     ts2, tw2 = multi.get_top_samples(kq)
     assert rel_err(tw1.cpu().numpy(), tw2.cpu().numpy()) < 1e-4 and ts1.shape == ts2.shape
     check_rel("weights_vs_oracle", fused._weights.cpu().numpy(), orc.softmax_weights(fused._costs.cpu().numpy(), fused._last_lambda)[0], TOL)
-
-
-def test_sparse_tail_equals_the_two_kernel_path_and_follows_the_density():
-    """Steps 5-8 as one block (sparse_tail_kernel: tile minima -> live tiles -> weights, weighted mean, tail) against
-    weights_reduce + finalize on the same inputs every tick, racing at N = 2^17 and N = 2^20: costs identical, action /
-    state sequences equal to the rounding of the summation order; the path follows the density of the softmax through
-    *live_hint — dense first solve, sharp lambda = 1 from the second on, back to the two-kernel path one solve after the
-    temperature is raised to a dense 5000 (that solve itself is still exact), and sparse again afterwards."""
-    for N in (1 << 17, 1 << 20):
-        one, c1 = make_solver("racing", 50, N, lambda_=1.0)
-        two, c2 = make_solver("racing", 50, N, lambda_=1.0)
-        two.set_option("sparse_tail", 0)
-        env = _envs["racing"]
-        x0 = env.reset().clone()
-        ref, _ = c1.calc_ref_trajectory(x0, env.racing_center_path, 0, 50, DL=0.1, lookahead_distance=3,
-                                        reference_path_interval=0.85)
-        c1.set_reference(ref)
-        c2.set_reference(ref)
-        lams = [1.0, 1.0, 1.0, 5000.0, 5000.0, 1.0, 1.0]
-        for k, lam in enumerate(lams):
-            if k:
-                two.set_warm_start(one._previous_action_seq.cpu().numpy())
-            one._lambda = two._lambda = lam
-            a1, s1 = one.forward(x0)
-            a2, s2 = two.forward(x0)
-            assert torch.equal(one._costs, two._costs)
-            check_rel("sparse_tail_action_seq_vs_two_kernels", a1.cpu().numpy(), a2.cpu().numpy(), 2e-6)
-            check_rel("sparse_tail_state_seq_vs_two_kernels", s1.cpu().numpy(), s2.cpu().numpy(), 2e-6)
-            st1, st2 = one.last_stats(), two.last_stats()
-            assert st1["cmin"] == st2["cmin"] and abs(st1["ess"] - st2["ess"]) <= 1e-4 * st2["ess"]
-            assert (st1["ess"] > 100) == (lam == 5000.0)
-        # later queries read the solve's state the same way after either tail
-        ts1, tw1 = one.get_top_samples(16)
-        ts2, tw2 = two.get_top_samples(16)
-        assert torch.equal(ts1, ts2) and rel_err(tw1.cpu().numpy(), tw2.cpu().numpy()) < 1e-5
