@@ -538,6 +538,7 @@ int mppi_set_model_params(mppi_handle_t h, const float* p, int n) {
         const float L = p[MPPI_RP_L];
         uint32_t bits; std::memcpy(&bits, &L, 4);
         h->ctx.inv_L = (L > 0.0f && (bits & 0x7fffffu) != 0x7fffffu) ? 1.0f / L : 0.0f;
+        h->ctx.unit_L = L == 1.0f ? 1 : 0;
     }
     h->params_set = true;
     refresh_pad(h, nullptr);  // the padded grid depends on the position clamp limits

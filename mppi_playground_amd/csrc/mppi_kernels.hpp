@@ -152,7 +152,8 @@ __device__ __forceinline__ float4 noise_group(const float4* __restrict__ np, int
 // which scalar (SMEM) loads — out of order, lgkmcnt(0) only — do not allow.
 // UC: the solver's clamp range lies inside the model's own action clamp (compile-time so that the
 // second clamp disappears).
-template <int MODEL, int FAST, bool GEN, bool UC>
+// VAR: a launch-uniform model variant the kernel has branched on OUTSIDE the horizon loop (racing: unit wheel base).
+template <int MODEL, int FAST, bool GEN, bool UC, bool VAR = false>
 __device__ __forceinline__ float trajectory_cost(const float4* __restrict__ np, uint64_t gi, const GenCtx& gen,
                                                  const float4* mean4, const float* ktab,
                                                  const float* __restrict__ x0, const Dims& d, const ModelCtx& ctx,
@@ -192,7 +193,8 @@ __device__ __forceinline__ float trajectory_cost(const float4* __restrict__ np, 
 #pragma unroll
         for (int k = 0; k < DC; ++k) u[k] = clampf(mv[k] + ev[k], lo[k], hi[k]);
         float sn[DS], ss[DS];
-        M::step(ctx, s, u, sn, ss, bad, UC, FAST != 0);
+        if constexpr (MODEL == MPPI_MODEL_RACING) M::step(ctx, s, u, sn, ss, bad, UC, FAST != 0, VAR);
+        else M::step(ctx, s, u, sn, ss, bad, UC, FAST != 0);
         acc += M::cost(ctx, kcur, ss, u, pu, bad);
 #pragma unroll
         for (int k = 0; k < DC; ++k) { pl[k] = pu[k]; pu[k] = u[k]; }
@@ -292,7 +294,11 @@ __global__ __launch_bounds__(BLOCK) MPPI_ROLLOUT_ATTR void rollout_cost_kernel(c
         const float4* np = noise + tile * d.R * 64 + lane;
         bool bad = false;
         const float4* mp = inherit ? s_mean4 : s_mean4 + d.R;
-        total = trajectory_cost<MODEL, FAST, GEN, UC>(np, gi, gen, mp, s_ktab, x0, d, ctx, bad);
+        // (racing, fast math: the unit wheel base of the reference is a launch-uniform branch around two copies of the loop)
+        if (MODEL == MPPI_MODEL_RACING && FAST != 0 && ctx.unit_L)
+            total = trajectory_cost<MODEL, FAST, GEN, UC, true>(np, gi, gen, mp, s_ktab, x0, d, ctx, bad);
+        else
+            total = trajectory_cost<MODEL, FAST, GEN, UC>(np, gi, gen, mp, s_ktab, x0, d, ctx, bad);
         if (FAST) {
             if (bad) {  // a fast path left its validity range: redo this lane with the library math
                 bool ignore = false;
@@ -1402,7 +1408,10 @@ __global__ __launch_bounds__(FUSED_BLOCK) void solve_fused_kernel(FusedArgs A, D
         const bool inherit = (d.sample_offset + i) < d.inherit_count;
         bool bad = false;
         const float4* mp = inherit ? s_mean4 : s_mean4 + d.R;
-        total = trajectory_cost<MODEL, FAST, true, UC>(nullptr, gi, gen, mp, s_ktab, s_x0, d, ctx, bad);
+        if (MODEL == MPPI_MODEL_RACING && FAST != 0 && ctx.unit_L)
+            total = trajectory_cost<MODEL, FAST, true, UC, true>(nullptr, gi, gen, mp, s_ktab, s_x0, d, ctx, bad);
+        else
+            total = trajectory_cost<MODEL, FAST, true, UC>(nullptr, gi, gen, mp, s_ktab, s_x0, d, ctx, bad);
         if (FAST) {
             if (bad) {
                 bool ignore = false;

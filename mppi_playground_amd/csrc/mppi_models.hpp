@@ -50,6 +50,7 @@ struct ModelCtx {
     int32_t ref_rows;
     int32_t tan_small;     // steer bounds within [-0.25, 0.25]: polynomial tan is valid
     float inv_L;           // racing: RN(1/L) for the Markstein division by the wheel base (0 = unusable)
+    int32_t unit_L;        // racing: the wheel base is exactly 1 (the reference's value): the division disappears
     int32_t u_in_bounds;   // the solver's [u_min, u_max] lies inside the model's own action clamp
     int32_t wrap_safe;     // per-step heading increments are < pi: wrapped angles stay in the narrow range
 };
