@@ -1904,3 +1904,44 @@ def test_single_launch_solve_equals_the_multi_kernel_path(model, T, N, lam, kw):
     ts2, tw2 = multi.get_top_samples(kq)
     assert rel_err(tw1.cpu().numpy(), tw2.cpu().numpy()) < 1e-4 and ts1.shape == ts2.shape
     check_rel("weights_vs_oracle", fused._weights.cpu().numpy(), orc.softmax_weights(fused._costs.cpu().numpy(), fused._last_lambda)[0], TOL)
+
+
+@pytest.mark.parametrize("model,T,N,expl", [("pendulum", 1, 1, 0.0), ("pendulum", 1, 5, 0.0), ("pendulum", 2, 64, 0.5),
+                                            ("pendulum", 7, 65, 1.0), ("racing", 1, 3, 0.0), ("racing", 3, 130, 0.3),
+                                            ("nav2d", 2, 1, 0.0), ("nav2d", 30, 255, 0.1), ("nav2d", 64, 257, 0.0),
+                                            ("cartpole", 64, 1023, 0.0), ("mountaincar", 128, 4096, 0.0),
+                                            ("goalzone", 5, 1025, 0.2)])
+def test_single_launch_solve_at_edge_sizes_against_oracle(model, T, N, expl):
+    """The default path of small problems (solve_fused_kernel, one cooperative launch) at ragged sizes — one sample,
+    one step, sizes around the 64-trajectory tiles and the 256-per-block split, the widest row it takes (T*dc = 128), an
+    exploration split through a block — against the ORACLE on the device-drawn noise: costs, action and state sequence."""
+    lam = 0.7
+    solver, ctrl = make_solver(model, T, N, lambda_=lam, exploration=expl)
+    assert solver._one_call
+    if model == "racing":
+        env = _envs["racing"]
+        x0 = env.reset().clone()
+        ref, _ = ctrl.calc_ref_trajectory(x0, env.racing_center_path, 0, T, DL=0.1, lookahead_distance=3,
+                                          reference_path_interval=0.85)
+        ctrl.set_reference(ref)
+        ref_np = ref.numpy()
+    else:
+        from helpers import goalzone_env_fixture
+        x0 = {"pendulum": [3.0, 0.1], "nav2d": [-9.0, -9.0, 0.785], "cartpole": [0.01, 0.0, 0.02, 0.0],
+              "mountaincar": [-0.5, 0.0], "goalzone": list(np.asarray(goalzone_env_fixture()["x0"], np.float32))}[model]
+        x0 = torch.tensor(x0, dtype=torch.float32).cuda()
+        ref_np = None
+    mean = np.zeros((T, solver._dim_control), np.float32)
+    P = oracle_problem(model, N, T, expl, ref_path=ref_np)
+    for k in range(2):
+        a, s = solver.forward(x0)
+        assert not solver._h.lib.mppi_fused_error(solver._h.h)
+        c_gpu = solver._costs.cpu().numpy()
+        eps = solver._action_noises.cpu().numpy()
+        r = P.rollout_cost(x0.cpu().numpy(), mean, eps, want_margin=True)
+        check_costs(c_gpu, r)
+        w, st = orc.softmax_weights(c_gpu, lam)
+        check_rel("action_seq_vs_oracle_given_costs", a.cpu().numpy(), P.weighted_actions(w, mean, eps), TOL)
+        check_rel("state_seq_vs_oracle_rollout", s.cpu().numpy()[0], P.rollout_single(x0.cpu().numpy(), a.cpu().numpy()), TOL)
+        assert abs(solver.last_stats()["ess"] - st["ess"]) <= 1e-4 * st["ess"]
+        mean = a.cpu().numpy()  # the warm start of the next solve
