@@ -14,9 +14,9 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smok
 timeout 900 python bench.py > gpurun_out/bench.log 2>&1; tail -c 600 gpurun_out/bench.log; echo
 timeout 300 python bench.py --steps 100 --warmup 20 --noise-regen 0 --no-cpu-baseline --no-extras > gpurun_out/bench_tiles.log 2>&1
 # the N > 1 path on this one GPU: ranks share the device, gloo instead of RCCL (RCCL needs one device per rank)
-# (the timed run takes the requested transport — "auto" falls back to the torch.distributed all_gather here, because RCCL
-# cannot put two ranks on one device — and then times the other transports behind the wall-clock guard: `exchange_alt`)
-for spec in "2 auto" "2 p2p" "8 auto"; do
+# ("all" times every transport with the full K steps and reports the best complete run; RCCL cannot put two ranks on one
+# device, so the in-library communicator shows up as an error entry under `transports` here)
+for spec in "2 all" "2 nccl" "8 all"; do
   set -- $spec
   MPPI_BENCH_ONE_DEVICE=1 MPPI_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus $1 --exchange $2 --steps 20 --warmup 5 > gpurun_out/bench_dry_g$1_$2.log 2>&1
   echo "dry run --gpus $1 --exchange $2: rc=$? $(tail -1 gpurun_out/bench_dry_g$1_$2.log | cut -c1-160)"
