@@ -101,7 +101,7 @@ typedef struct MppiConfig {
 const char* mppi_version(void);
 /* Integer version of THIS header's function signatures; bindings compare it with the constant they were written
  * against and refuse a stale library (a changed argument list would otherwise be called with shifted arguments). */
-#define MPPI_ABI_VERSION 6
+#define MPPI_ABI_VERSION 7
 int mppi_abi_version(void);
 /* Number of visible HIP devices (0 => the product cannot run; callers must fail loudly). */
 int mppi_device_count(void);
@@ -243,7 +243,7 @@ int mppi_solve(mppi_handle_t h, const float* x0_dev, uint32_t solve_idx, float l
                float* state_seq_out_dev, float* stats_out_dev, void* stream);
 /* mppi_solve as a SINGLE LAUNCH.  For small problems (option "fused_solve" = 1, the default: num_samples <= 4096, the
  * sizes of the reference's examples) whose noise is regenerated in registers, with T*dim_control <= 128 and no sharding,
- * mppi_solve runs ONE cooperative kernel instead of 3-9 dependent launches: min(#CUs, ceil(N/256)) blocks exchange their
+ * mppi_solve runs ONE cooperative kernel instead of 3-9 dependent launches: min(#CUs, ceil(N/64)) blocks exchange their
  * minima, the partial sums of the temperature search and their partial weighted rows through 8-byte {value, solve
  * number} cells in HBM (relaxed agent-scope stores, polled), block 0 runs the scalar steps and the tail of the solve.
  * Costs and minimum are bit-identical to the multi-kernel path; temperature, action and state sequences equal to
@@ -274,16 +274,23 @@ int mppi_softmax_stats(mppi_handle_t h, float lambda, double* out5_host, void* s
 int mppi_softmax_stats_multi(mppi_handle_t h, const float* lambdas_host, int count, double* out_host, void* stream);
 /* ESSPS (mppi.py:351-370): lambda in [lam_min, lam_max] with ESS(lambda) = target_ess (end-point rules of
  * mppi.py:361-364), searched on the host from two 32-temperature passes of mppi_softmax_stats_multi and an
- * inverse cubic interpolation (within ~1e-7 relative of scipy's brentq on the same statistics).  Unsharded
- * handles; synchronises twice. */
+ * inverse polynomial interpolation (within ~1e-7 relative of scipy's brentq on the same statistics).  From the second
+ * search of a handle on, the first grid is clustered around the previous root (with the end points and a sparse cover
+ * of the rest of the range); when the root is found well inside the cluster and the interpolation has visibly converged
+ * there (polynomials of two orders agree to 1e-5) the search ends after ONE pass (~1e-6 relative), otherwise the
+ * bracket is refined by the second grid as in a cold search.  Option "essps_cold" makes the next search cold.
+ * Unsharded handles; synchronises once or twice. */
 int mppi_essps_lambda(mppi_handle_t h, double target_ess, double lam_min, double lam_max, double* lambda_out_host,
                       void* stream);
 /* The same search with NO host synchronisation: both statistics passes and both scalar steps (end-point rules /
- * refined grid, root interpolation) run as kernels on `stream`, and the temperature stays in device memory.  Pass
+ * refined grid, root interpolation) run as kernels on `stream` (the second pair returns at once when the first grid
+ * was enough), the first grid of the NEXT search is left in device memory, and so is the temperature.  Pass
  * MPPI_LAMBDA_DEVICE as the `lambda` of mppi_weights_reduce / mppi_finalize to use it; mppi_get_lambda reads it back
  * (synchronises the stream).  Identical arithmetic to mppi_essps_lambda (both call csrc/host_search.hpp). */
 #define MPPI_LAMBDA_DEVICE (-1.0f)
 int mppi_essps_lambda_device(mppi_handle_t h, double target_ess, double lam_min, double lam_max, void* stream);
+/* Passes over the costs the last device-resident search took (ESSPS: 1 or 2; LBPS: 3); 0 = none yet.  Synchronises. */
+int mppi_search_passes(mppi_handle_t h, void* stream);
 /* The temperature a device-resident rule left in HBM, and (lambda_used_out_host != NULL) the one the last solve's weights
  * used — the same value for ESSPS / LBPS, the previous one for MPO (mppi.py:387-398 updates it AFTER the weights).
  * Synchronises `stream` (pass the stream the solve was enqueued on). */
@@ -381,8 +388,10 @@ int mppi_p2p_connect(mppi_handle_t h, const void* ipc_handles_host, const int32_
 int mppi_p2p_exchange(mppi_handle_t h, const float* data_dev, float* gathered_out_dev, void* stream);
 int mppi_p2p_error(mppi_handle_t h);
 
-/* Tuning knobs (not in the reference): "math" 0 = library sin/cos/tan/fmod/div, 1 = range-checked
- * fast paths (default); "noise_regen" (see mppi_sample); "mapping" 0 = lane per trajectory (default), 1 =
+/* Tuning knobs (not in the reference): "math" 0 = library sin/cos/tan/fmod/div, 1 = range-checked polynomial
+ * fast paths, 2 = 1 + the hardware sin/cos for model-bounded arguments (default); "fused_solve" (see mppi_fused_error);
+ * "essps_cold" (any value): the next ESSPS search of this handle starts from the geometric grid instead of the one
+ * clustered around its last root; "noise_regen" (see mppi_sample); "mapping" 0 = lane per trajectory (default), 1 =
  * the north star's literal wavefront-per-trajectory rollout (comparison only, ~20x slower); "reduce_blocks" grid of the weighted
  * reduction; "fold_path" who sums the reduction's partial rows: 0 = by the live-row count of earlier solves (default),
  * 1 = inside mppi_finalize whenever the rows fit its LDS, 2 = always the separate summarize kernel (both use the same

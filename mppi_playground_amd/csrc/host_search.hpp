@@ -130,7 +130,7 @@ bool lbps_lambda(S&& stats, double delta, double lam_min, double lam_max, double
 // ---------------------------------------------------------------------------------------------------------
 // ESSPS (mppi.py:351-370,559-566): the root of ESS(lambda) = target on [lam_min, lam_max] with the reference's
 // end-point rules, from two geometric grids of P temperatures (ONE pass over the costs on the device per grid) and an
-// inverse cubic interpolation in (ESS, log lambda).  Same algorithm as pi_mpc/_host.py::essps_lambda_grid (within
+// inverse polynomial interpolation in (ESS, log lambda).  Same algorithm as pi_mpc/_host.py::essps_lambda_grid (within
 // ~1e-7 relative of scipy's brentq on the same statistics).  The search is written as three steps so that the host
 // loop below (statistics read back per grid) and the device-resident chain in mppi_kernels.hpp (essps_select_kernel:
 // no read-back at all) run the very same arithmetic.
@@ -153,51 +153,152 @@ MPPI_SEARCH_HD int essps_bracket(const double* ess, double target_ess) {
     for (int j = 0; j < P; ++j) if (ess[j] >= target_ess) { i = j; break; }
     return i < 1 ? 1 : i;
 }
-// round 0 (mppi.py:361-364): true when an end-point rule decided (lam_out set), else [lo, hi] = the bracket
+// The ESSPS steps work on the grid in the LOG domain: every grid is generated from lg[j] = log(grid[j]) anyway, the
+// interpolation needs exactly those logs, and its result is log(root), which is what the next first grid is built
+// around — so no step takes a logarithm of a grid value again (the scalar step is one lane of one wave on the device:
+// a double-precision log there costs as much as the rest of it).
+struct EsspsRange {  // [lam_min, lam_max] and its logs
+    double lam_min, lam_max, lmin, lmax;
+};
+MPPI_SEARCH_HD EsspsRange essps_range(double lam_min, double lam_max) { return EsspsRange{lam_min, lam_max, log(lam_min), log(lam_max)}; }
+struct EsspsRoot {   // the result of a search: lambda, log(lambda), and whether the next first grid may be clustered around it
+    double lam, log_lam;
+    bool warm;
+};
+// point j of the geometric grid over [lo, hi] given llo = log(lo), lhi = log(hi) (end points exact)
 template <int P>
-MPPI_SEARCH_HD bool essps_round0(const double* grid, const double* ess, double target_ess, double lam_min, double lam_max,
-                                 double& lo, double& hi, double& lam_out) {
-    if (target_ess <= ess[0]) { lam_out = lam_min; return true; }
-    if (target_ess >= ess[P - 1]) { lam_out = lam_max; return true; }
-    const int i = essps_bracket<P>(ess, target_ess);
-    lo = grid[i - 1]; hi = grid[i];
+MPPI_SEARCH_HD void essps_point(double lo, double hi, double llo, double lhi, int j, double& g, double& lg) {
+    if (j == 0) { g = lo; lg = llo; return; }
+    if (j == P - 1) { g = hi; lg = lhi; return; }
+    lg = llo + (lhi - llo) * (double)j / (double)(P - 1);
+    g = exp(lg);
+}
+// Warm start.  In a control loop the temperature moves little from solve to solve, so the FIRST grid of a search is
+// clustered around the previous solve's root: ESSPS_CLUSTER points geometric over [prev / F, prev * F] (F = 1.5: 3.9 %
+// apart), and the other P - ESSPS_CLUSTER spread geometrically over the rest of [lam_min, lam_max] on either side in
+// proportion to its log-length (the end points themselves always included: the reference's end-point rules need ESS
+// there).  If the six grid points around the root are all close neighbours and the interpolation has visibly
+// converged there, the search is over after ONE pass over the costs; anywhere else (first solve, a jump of the
+// temperature, a target of a few samples out of very many) the bracket — never wider than ~1/10 of the log-range — is
+// refined by a second grid exactly as in a cold search.  Same root either way (to ~1e-6 relative).
+constexpr double ESSPS_LOG_WARM_FACTOR = 0.4054651081081644;  // log(1.5)
+constexpr double ESSPS_LOG_FINE_RATIO = 0.04879016416943205;  // log(1.05): a spacing this narrow can be interpolated right away
+constexpr int ESSPS_CLUSTER = 22;
+MPPI_SEARCH_HD bool essps_warm(bool have_prev, double log_prev, const EsspsRange& r) {
+    return have_prev && log_prev - ESSPS_LOG_WARM_FACTOR > r.lmin + 1.0e-3 && log_prev + ESSPS_LOG_WARM_FACTOR < r.lmax - 1.0e-3;
+}
+template <int P>
+MPPI_SEARCH_HD void essps_first_point(bool have_prev, double log_prev, const EsspsRange& r, int j, double& g, double& lg) {
+    static_assert(P >= ESSPS_CLUSTER + 2, "grid too small for the clustered first grid");
+    if (!essps_warm(have_prev, log_prev, r)) { essps_point<P>(r.lam_min, r.lam_max, r.lmin, r.lmax, j, g, lg); return; }
+    if (j == 0) { g = r.lam_min; lg = r.lmin; return; }
+    if (j == P - 1) { g = r.lam_max; lg = r.lmax; return; }
+    constexpr int S = P - ESSPS_CLUSTER;  // points outside the cluster, >= 1 on each side
+    const double clo = log_prev - ESSPS_LOG_WARM_FACTOR, chi = log_prev + ESSPS_LOG_WARM_FACTOR;
+    int nb = (int)((double)S * (clo - r.lmin) / ((clo - r.lmin) + (r.lmax - chi)) + 0.5);
+    nb = nb < 1 ? 1 : (nb > S - 1 ? S - 1 : nb);
+    const int na = S - nb;
+    if (j < nb) lg = r.lmin + (clo - r.lmin) * (double)j / (double)nb;
+    else if (j < nb + ESSPS_CLUSTER) lg = clo + (chi - clo) * (double)(j - nb) / (double)(ESSPS_CLUSTER - 1);
+    else lg = chi + (r.lmax - chi) * (double)(j - (nb + ESSPS_CLUSTER - 1)) / (double)na;
+    g = exp(lg);
+}
+template <int P>
+MPPI_SEARCH_HD void essps_first_grid(bool have_prev, double log_prev, const EsspsRange& r, double* grid, double* lgrid) {
+    for (int j = 0; j < P; ++j) essps_first_point<P>(have_prev, log_prev, r, j, grid[j], lgrid[j]);
+}
+// the Lagrange form of log(lambda) as a function of ESS at ESS = target through the NPT grid points j0 .. j0+NPT-1:
+// term a of the sum (one division per point) ...
+template <int NPT>
+MPPI_SEARCH_HD double essps_poly_term(const double* lgrid, const double* ess, double target_ess, int j0, int a) {
+    double num = 1.0, den = 1.0;
+    for (int b = 0; b < NPT; ++b)
+        if (b != a) { num *= target_ess - ess[j0 + b]; den *= ess[j0 + a] - ess[j0 + b]; }
+    return num / den * lgrid[j0 + a];
+}
+// ... and the sum in ascending order (the device's scalar step computes the terms on NPT lanes and adds them in the same
+// order: mppi_kernels.hpp, essps_round0_wave); false when ESS is not strictly increasing over the points
+template <int NPT>
+MPPI_SEARCH_HD bool essps_poly(const double* lgrid, const double* ess, double target_ess, int j0, double& log_lam) {
+    bool increasing = true;
+    for (int a = 0; a < NPT - 1; ++a) increasing = increasing && ess[j0 + a + 1] > ess[j0 + a];
+    if (!increasing) return false;
+    double x = 0.0;
+    for (int a = 0; a < NPT; ++a) x += essps_poly_term<NPT>(lgrid, ess, target_ess, j0, a);
+    log_lam = x;
+    return true;
+}
+// the root inside the bracket [grid[i-1], grid[i]]: the polynomial through ESSPS_NPT points (three either side of the root
+// away from the grid's ends), or linear interpolation when ESS is not strictly increasing there or the polynomial leaves
+// the bracket
+constexpr int ESSPS_NPT = 6;
+MPPI_SEARCH_HD EsspsRoot essps_linear(const double* grid, const double* ess, double target_ess, int i) {
+    const double lo = grid[i - 1], hi = grid[i], e0 = ess[i - 1], e1 = ess[i];
+    const double lam = (e1 == e0) ? 0.5 * (lo + hi) : lo + (hi - lo) * (target_ess - e0) / (e1 - e0);
+    return EsspsRoot{lam, log(lam), true};
+}
+MPPI_SEARCH_HD EsspsRoot essps_interpolate(const double* grid, const double* lgrid, const double* ess, double target_ess, int i, int j0) {
+    double x;
+    if (essps_poly<ESSPS_NPT>(lgrid, ess, target_ess, j0, x) && x >= lgrid[i - 1] && x <= lgrid[i]) return EsspsRoot{exp(x), x, true};
+    return essps_linear(grid, ess, target_ess, i);
+}
+// round 0 (mppi.py:361-364): true when the search is over (root set) — an end-point rule decided, or the
+// ESSPS_NPT grid points around the root are all close neighbours (a clustered first grid, or a narrow
+// [lam_min, lam_max]) AND the interpolation has visibly converged there: the polynomials through the six and through
+// the inner four points agree to ESSPS_AGREE (ESS(lambda) varies on the scale lambda / (c - c_min) of the samples
+// that carry the weight, which can be short against the cluster's spacing when the target is a few samples out of
+// very many) — else i = the bracket [grid[i-1], grid[i]] for the second grid
+constexpr double ESSPS_AGREE = 1.0e-5;
+template <int P>
+MPPI_SEARCH_HD bool essps_round0(const double* lgrid, const double* ess, double target_ess, const EsspsRange& r, int& i, EsspsRoot& root) {
+    static_assert(P >= 2 * ESSPS_NPT, "grid too small");
+    if (target_ess <= ess[0]) { root = EsspsRoot{r.lam_min, r.lmin, false}; return true; }
+    if (target_ess >= ess[P - 1]) { root = EsspsRoot{r.lam_max, r.lmax, false}; return true; }
+    i = essps_bracket<P>(ess, target_ess);
+    constexpr int H = ESSPS_NPT / 2;
+    if (i >= H && i <= P - H) {
+        bool fine = true;
+        for (int k = i - H; k < i + H - 1; ++k) fine = fine && lgrid[k + 1] - lgrid[k] <= ESSPS_LOG_FINE_RATIO;
+        double x6, x4;
+        if (fine && essps_poly<ESSPS_NPT>(lgrid, ess, target_ess, i - H, x6) && essps_poly<4>(lgrid, ess, target_ess, i - 2, x4) &&
+            x6 >= lgrid[i - 1] && x6 <= lgrid[i] && fabs(x6 - x4) <= ESSPS_AGREE) {
+            root = EsspsRoot{exp(x6), x6, true};
+            return true;
+        }
+    }
     return false;
 }
-// round 1: bracket on the refined grid, then the Lagrange form of log(lambda) as a function of ESS at ESS = target
-// through the four grid points around the root (linear interpolation when ESS is not strictly increasing there)
+// round 1: bracket on the refined grid, then the polynomial through the grid points around the root
 template <int P>
-MPPI_SEARCH_HD double essps_round1(const double* grid, const double* ess, double target_ess) {
-    static_assert(P >= 4, "grid too small for the cubic");
+MPPI_SEARCH_HD EsspsRoot essps_round1(const double* grid, const double* lgrid, const double* ess, double target_ess) {
+    static_assert(P >= ESSPS_NPT, "grid too small for the interpolation");
     const int i = essps_bracket<P>(ess, target_ess);
-    const double lo = grid[i - 1], hi = grid[i];
-    const int j0 = (i - 2 < 0 ? 0 : (i - 2 > P - 4 ? P - 4 : i - 2));
-    bool increasing = true;
-    for (int a = 0; a < 3; ++a) increasing = increasing && ess[j0 + a + 1] > ess[j0 + a];
-    if (increasing) {
-        double x = 0.0;
-        for (int a = 0; a < 4; ++a) {
-            double w = 1.0;
-            for (int b = 0; b < 4; ++b)
-                if (b != a) w *= (target_ess - ess[j0 + b]) / (ess[j0 + a] - ess[j0 + b]);
-            x += w * log(grid[j0 + a]);
-        }
-        const double lam = exp(x);
-        if (lam >= lo && lam <= hi) return lam;
-    }
-    const double e0 = ess[i - 1], e1 = ess[i];
-    return (e1 == e0) ? 0.5 * (lo + hi) : lo + (hi - lo) * (target_ess - e0) / (e1 - e0);
+    constexpr int H = ESSPS_NPT / 2;
+    const int j0 = (i - H < 0 ? 0 : (i - H > P - ESSPS_NPT ? P - ESSPS_NPT : i - H));
+    return essps_interpolate(grid, lgrid, ess, target_ess, i, j0);
 }
 // host loop: ess_grid(lams[P], ess_out[P]) -> bool evaluates ESS for P temperatures (one device pass + read-back)
+// (prev: the root of the previous search on this solver — `warm` false = none — replaced by this search's)
 template <int P, class G>
-bool essps_lambda(G&& ess_grid, double target_ess, double lam_min, double lam_max, double& lam_out) {
-    double grid[P], ess[P], lo = lam_min, hi = lam_max;
-    essps_make_grid<P>(lo, hi, grid);
+bool essps_lambda(G&& ess_grid, double target_ess, double lam_min, double lam_max, double& lam_out, EsspsRoot& prev) {
+    double grid[P], lgrid[P], ess[P];
+    const EsspsRange r = essps_range(lam_min, lam_max);
+    essps_first_grid<P>(prev.warm, prev.log_lam, r, grid, lgrid);
     if (!ess_grid(grid, ess)) return false;
-    if (essps_round0<P>(grid, ess, target_ess, lam_min, lam_max, lo, hi, lam_out)) return true;
-    essps_make_grid<P>(lo, hi, grid);
-    if (!ess_grid(grid, ess)) return false;
-    lam_out = essps_round1<P>(grid, ess, target_ess);
+    int i = 1;
+    if (!essps_round0<P>(lgrid, ess, target_ess, r, i, prev)) {
+        const double lo = grid[i - 1], hi = grid[i], llo = lgrid[i - 1], lhi = lgrid[i];
+        for (int j = 0; j < P; ++j) essps_point<P>(lo, hi, llo, lhi, j, grid[j], lgrid[j]);
+        if (!ess_grid(grid, ess)) return false;
+        prev = essps_round1<P>(grid, lgrid, ess, target_ess);
+    }
+    lam_out = prev.lam;
     return true;
+}
+template <int P, class G>
+bool essps_lambda(G&& ess_grid, double target_ess, double lam_min, double lam_max, double& lam_out) {  // cold
+    EsspsRoot none{0.0, 0.0, false};
+    return essps_lambda<P>(ess_grid, target_ess, lam_min, lam_max, lam_out, none);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -49,7 +49,7 @@ struct MppiSolver {
     unsigned fused_seq = 0;
     int fused_mode = 1;                // option "fused_solve": 0 = never, 1 = small problems (default), 2 = whenever resident
     int cu_count = 0;
-    double* grid0_dev = nullptr;       // [STATS_L] round-0 grid of the fused ESSPS / LBPS search
+    double* grid0_dev = nullptr;       // [STATS_L] round-0 grid of the fused LBPS search (ESSPS: essps_dev->grid0)
     double grid0_lo = 0.0, grid0_hi = 0.0;
     // the temperature rule mppi_solve applies when called with MPPI_LAMBDA_DEVICE (mppi_set_auto_lambda)
     int auto_rule = 0;
@@ -105,11 +105,14 @@ struct MppiSolver {
     float* heads = nullptr;
     float* summary = nullptr;
     float* stats_part = nullptr;     // [STATS_BLOCKS][max(4, STATS_L*3)]
-    double* stats_host = nullptr;    // mapped pinned [8 + STATS_L*3 + 1]: single-lambda stats, grid stats, device-searched lambda
+    double* stats_host = nullptr;    // mapped pinned [8 + STATS_L*3 + 3]: single-lambda stats, grid stats, device-searched lambda (next, used), its passes
     float* lams_dev = nullptr;       // [3][STATS_L]: caller's grid, ESSPS round-0 grid (preset), ESSPS round-1 grid (device-written)
     EsspsDev* essps_dev = nullptr;   // state of the device-resident ESSPS search
     float* lambda_dev = nullptr;     // the temperature that search left on the device (MPPI_LAMBDA_DEVICE)
-    double essps_lo = 0.0, essps_hi = 0.0;  // [lam_min, lam_max] the preset round-0 grid was built for
+    double essps_lo = 0.0, essps_hi = 0.0;  // [lam_min, lam_max] the device search's first grid was built for
+    mppi::host::EsspsRange essps_range{};   // ... with its logs
+    mppi::host::EsspsRoot essps_prev_host{0.0, 0.0, false};  // mppi_essps_lambda: last root (warm start of the next search) ...
+    double essps_prev_lo = 0.0, essps_prev_hi = 0.0;          // ... and the range it was searched in
     bool lambda_dev_valid = false;
     uint8_t* map_cells[2] = {nullptr, nullptr};
     uint8_t* map_pad = nullptr;      // padded (and, for racing, summed) grid of the FAST lookup
@@ -426,7 +429,7 @@ int mppi_create(const MppiConfig* cfg, mppi_handle_t* out) {
     HIP_TRY(h, hipMalloc(&h->heads, sizeof(float) * (size_t)max_blocks * 4));
     HIP_TRY(h, hipMalloc(&h->summary, sizeof(float) * (size_t)(MPPI_SUMMARY_HEAD + d.row)));
     HIP_TRY(h, hipMalloc(&h->stats_part, sizeof(float) * STATS_L * 3 * STATS_BLOCKS));
-    HIP_TRY(h, hipHostMalloc((void**)&h->stats_host, sizeof(double) * (8 + STATS_L * 3 + 2), hipHostMallocMapped));
+    HIP_TRY(h, hipHostMalloc((void**)&h->stats_host, sizeof(double) * (8 + STATS_L * 3 + 3), hipHostMallocMapped));
     HIP_TRY(h, hipMalloc(&h->mpo_dev, sizeof(mppi::host::MpoState)));
     HIP_TRY(h, hipMalloc(&h->mpo_temp_dev, sizeof(float)));
     HIP_TRY(h, hipMalloc(&h->lbps_dev, sizeof(LbpsDev)));
@@ -1048,13 +1051,31 @@ static bool fused_applies(mppi_handle_t h, float lambda) {
     return check_ready(h) == MPPI_OK;
 }
 
+// The state of the device-resident ESSPS search for [lam_min, lam_max]: a cold (geometric) first grid; after that every
+// finished search leaves the first grid of the next one behind (host_search.hpp: essps_first_grid).  Set-up path, blocking.
+static int essps_prepare(mppi_handle_t h, double lam_min, double lam_max) {
+    if (h->essps_lo == lam_min && h->essps_hi == lam_max) return MPPI_OK;
+    EsspsDev st{};
+    float lamf[STATS_L];
+    h->essps_range = mppi::host::essps_range(lam_min, lam_max);
+    mppi::host::essps_first_grid<STATS_L>(false, 0.0, h->essps_range, st.grid0, st.lgrid0);
+    for (int j = 0; j < STATS_L; ++j) { lamf[j] = (float)st.grid0[j]; st.grid1[j] = st.grid0[j]; st.lgrid1[j] = st.lgrid0[j]; }
+    HIP_TRY(h, hipDeviceSynchronize());
+    HIP_TRY(h, hipMemcpy(h->lams_dev + STATS_L, lamf, sizeof(lamf), hipMemcpyHostToDevice));
+    // (round 1's grid is rewritten by every search; a valid one for the searches that end after round 0)
+    HIP_TRY(h, hipMemcpy(h->lams_dev + 2 * STATS_L, lamf, sizeof(lamf), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->essps_dev, &st, sizeof(st), hipMemcpyHostToDevice));
+    h->essps_lo = lam_min; h->essps_hi = lam_max;
+    return MPPI_OK;
+}
+
 static int solve_fused(mppi_handle_t h, float lambda, float* action_out, float* state_out, float* stats_out, hipStream_t s) {
     if (!h->fused_cells) {  // first use: set-up path (blocking)
         const size_t bytes = sizeof(unsigned long long) * FX_PHASES * FUSED_MAX_BLOCKS * FX_CELLS;
         HIP_TRY(h, hipMalloc(&h->fused_cells, bytes));
         HIP_TRY(h, hipMemset(h->fused_cells, 0, bytes));
         HIP_TRY(h, hipMalloc(&h->grid0_dev, sizeof(double) * STATS_L));
-        HIP_TRY(h, hipHostMalloc((void**)&h->fused_error, sizeof(int), hipHostMallocMapped));
+        HIP_TRY(h, hipHostMalloc((void**)&h->fused_error, sizeof(int) * 32, hipHostMallocMapped));
         *h->fused_error = 0;
         HIP_TRY(h, hipHostGetDevicePointer((void**)&h->fused_error_dev, h->fused_error, 0));
         HIP_TRY(h, hipDeviceSynchronize());
@@ -1063,7 +1084,9 @@ static int solve_fused(mppi_handle_t h, float lambda, float* action_out, float* 
     int rule = FUSED_RULE_NONE;
     if (dev && h->auto_rule == MPPI_AUTO_ESSPS) rule = FUSED_RULE_ESSPS;
     if (dev && h->auto_rule == MPPI_AUTO_LBPS) rule = FUSED_RULE_LBPS;
-    if (rule != FUSED_RULE_NONE && (h->grid0_lo != h->auto_lo || h->grid0_hi != h->auto_hi)) {  // set-up path, blocking
+    if (rule == FUSED_RULE_ESSPS)
+        if (int rc = essps_prepare(h, h->auto_lo, h->auto_hi)) return rc;
+    if (rule == FUSED_RULE_LBPS && (h->grid0_lo != h->auto_lo || h->grid0_hi != h->auto_hi)) {  // set-up path, blocking
         double g0[STATS_L];
         mppi::host::essps_make_grid<STATS_L>(h->auto_lo, h->auto_hi, g0);
         HIP_TRY(h, hipDeviceSynchronize());
@@ -1084,15 +1107,24 @@ static int solve_fused(mppi_handle_t h, float lambda, float* action_out, float* 
     A.mean_used = h->mean_used; A.x0_used = h->x0_used;
     A.rule = rule; A.rule_param = h->auto_param; A.lam_min = h->auto_lo; A.lam_max = h->auto_hi;
     A.lambda_arg = dev ? -1.0f : lambda;
-    A.lambda_dev = h->lambda_dev; A.lambda_host = host_lam; A.grid0 = h->grid0_dev;
+    A.lambda_dev = h->lambda_dev; A.lambda_host = host_lam;
+    A.grid0 = rule == FUSED_RULE_ESSPS ? h->essps_dev->grid0 : h->grid0_dev;
+    A.lams0 = h->lams_dev + STATS_L;
+    A.essps = h->essps_dev; A.range = h->essps_range;
     A.mean_store = h->mean; A.action_out = action_out; A.state_out = state_out; A.stats_out = stats_out;
     A.stats_keep = h->solve_stats; A.summary_out = h->summary;
     const SgFilter sg{h->sg_coeffs, h->sg_history, h->sg_window};
     const FusedCtx fx{h->fused_cells, h->fused_error_dev, h->fused_seq};
-    // G = min(#CUs, ceil(N / 256)) blocks, each owning spb (a multiple of 64, <= 1024) consecutive trajectories
+    // G = min(#CUs, ceil(N / 64)) blocks, each owning spb (a multiple of 64, <= 1024) consecutive trajectories: ONE wave
+    // of rollouts per block as long as there are CUs left (the rest of its 1024 threads share the block's reductions and
+    // the regeneration of its weighted noise rows, which a block of 256 trajectories spends ~5 us on)
     const int64_t gmax = std::min(FUSED_MAX_BLOCKS, h->cu_count);
-    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(gmax, (h->d.N + 255) / 256));
+    unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(gmax, (h->d.N + 63) / 64));
+    // up to FUSED_AUTO_MAX_SAMPLES trajectories: at most FUSED_SMALL_BLOCKS blocks, which then need neither the hop for the
+    // global minimum nor the broadcast of the temperature (solve_fused_kernel: `small`)
+    if (h->d.N <= FUSED_AUTO_MAX_SAMPLES) grid = std::min<unsigned>(grid, (unsigned)FUSED_SMALL_BLOCKS);
     A.spb = (int)(((h->d.N + grid - 1) / grid + 63) / 64 * 64);
+    grid = (unsigned)((h->d.N + A.spb - 1) / A.spb);  // (no block without trajectories)
 #define CALL_FUSED(MODEL, FASTV)                                                                      \
     do {                                                                                              \
         const size_t shmem = sizeof(float) * ((size_t)8 * h->d.R + (size_t)h->d.T * ModelT<MODEL, FASTV>::KROW + 2 * (size_t)h->d.row + \
@@ -1229,18 +1261,7 @@ int mppi_essps_lambda_device(mppi_handle_t h, double target_ess, double lam_min,
     if (!h || !(lam_min > 0.0) || !(lam_max > lam_min) || !(target_ess > 0.0))
         return fail(h, MPPI_E_INVALID, "bad essps arguments");
     hipStream_t s = (hipStream_t)stream;
-    if (h->essps_lo != lam_min || h->essps_hi != lam_max) {  // (re)build the round-0 grid: setup path, blocking
-        EsspsDev st{};
-        float lamf[STATS_L];
-        mppi::host::essps_make_grid<STATS_L>(lam_min, lam_max, st.grid0);
-        for (int j = 0; j < STATS_L; ++j) { lamf[j] = (float)st.grid0[j]; st.grid1[j] = st.grid0[j]; }
-        HIP_TRY(h, hipDeviceSynchronize());
-        HIP_TRY(h, hipMemcpy(h->lams_dev + STATS_L, lamf, sizeof(lamf), hipMemcpyHostToDevice));
-        // (round 1's grid is rewritten by every search; a valid one for the searches an end-point rule cuts short)
-        HIP_TRY(h, hipMemcpy(h->lams_dev + 2 * STATS_L, lamf, sizeof(lamf), hipMemcpyHostToDevice));
-        HIP_TRY(h, hipMemcpy(h->essps_dev, &st, sizeof(st), hipMemcpyHostToDevice));
-        h->essps_lo = lam_min; h->essps_hi = lam_max;
-    }
+    if (int rc = essps_prepare(h, lam_min, lam_max)) return rc;
     const unsigned* mk = h->min_key + h->min_slot;
     const int blocks = stats_blocks(h);
     double* host_lam = nullptr;
@@ -1251,11 +1272,11 @@ int mppi_essps_lambda_device(mppi_handle_t h, double target_ess, double lam_min,
     hipLaunchKernelGGL(stats_multi_kernel, dim3(blocks), dim3(STATS_THREADS), 0, s, h->costs, h->d.N, mk, (const float*)lams0,
                        h->stats_part, (const int32_t*)nullptr, (float*)nullptr);
     hipLaunchKernelGGL(essps_select_kernel<0>, dim3(1), dim3(1024), 0, s, (const float*)h->stats_part, blocks, target_ess,
-                       lam_min, lam_max, h->essps_dev, lams1, h->lambda_dev, host_lam);
+                       h->essps_range, h->essps_dev, lams1, lams0, h->lambda_dev, host_lam);
     hipLaunchKernelGGL(stats_multi_kernel, dim3(blocks), dim3(STATS_THREADS), 0, s, h->costs, h->d.N, mk, (const float*)lams1,
                        h->stats_part, (const int32_t*)&h->essps_dev->done, (float*)nullptr);
     hipLaunchKernelGGL(essps_select_kernel<1>, dim3(1), dim3(1024), 0, s, (const float*)h->stats_part, blocks, target_ess,
-                       lam_min, lam_max, h->essps_dev, lams1, h->lambda_dev, host_lam);
+                       h->essps_range, h->essps_dev, lams1, lams0, h->lambda_dev, host_lam);
     HIP_TRY(h, hipGetLastError());
     h->lambda_dev_valid = true;
     return MPPI_OK;
@@ -1270,6 +1291,14 @@ int mppi_get_lambda(mppi_handle_t h, double* lambda_out_host, double* lambda_use
     *lambda_out_host = h->stats_host[8 + STATS_L * 3];
     if (lambda_used_out_host) *lambda_used_out_host = h->stats_host[8 + STATS_L * 3 + 1];
     return MPPI_OK;
+}
+
+// Passes over the costs (32-temperature grids) the last device-resident ESSPS / LBPS search took: ESSPS 1 when an
+// end-point rule decided or the warm-started first grid was enough, else 2; LBPS always LBPS_ROUNDS.  Synchronises.
+int mppi_search_passes(mppi_handle_t h, void* stream) {
+    if (!h || !h->lambda_dev_valid) return 0;
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return 0;
+    return (int)h->stats_host[8 + STATS_L * 3 + 2];
 }
 
 // LBPS with no host synchronisation (mppi.py:341-349): LBPS_ROUNDS x (32-temperature statistics pass -> one-block
@@ -1321,7 +1350,7 @@ int mppi_lbps_lambda_device(mppi_handle_t h, double delta, double lam_min, doubl
 
 // ESSPS temperature (mppi.py:351-370,559-566): the root of ESS(lambda) = target on [lam_min, lam_max] with the
 // reference's end-point rules, found on the host from device statistics — two 32-point geometric grids
-// (mppi_softmax_stats_multi: one pass over the costs each) and an inverse cubic interpolation in
+// (mppi_softmax_stats_multi: one pass over the costs each) and an inverse polynomial interpolation in
 // (ESS, log lambda): host::essps_lambda in host_search.hpp.  Same algorithm as pi_mpc/_host.py::essps_lambda_grid
 // (which sharded solvers use, with an all_gather per grid); kept in the library so that the single-GPU solve has no
 // interpreter work per probe.
@@ -1331,6 +1360,7 @@ int mppi_essps_lambda(mppi_handle_t h, double target_ess, double lam_min, double
         return fail(h, MPPI_E_INVALID, "bad essps arguments");
     constexpr int P = STATS_L;
     int rc = MPPI_OK;
+    if (h->essps_prev_lo != lam_min || h->essps_prev_hi != lam_max) h->essps_prev_host.warm = false;  // another range: a cold search
     const bool ok = mppi::host::essps_lambda<P>(
         [&](const double* grid, double* ess) {
             float lamf[P];
@@ -1341,7 +1371,9 @@ int mppi_essps_lambda(mppi_handle_t h, double target_ess, double lam_min, double
             for (int j = 0; j < P; ++j) ess[j] = raw[3 * j] * raw[3 * j] / raw[3 * j + 1];
             return true;
         },
-        target_ess, lam_min, lam_max, *lambda_out);
+        target_ess, lam_min, lam_max, *lambda_out, h->essps_prev_host);
+    h->essps_prev_lo = lam_min; h->essps_prev_hi = lam_max;
+    if (!ok) h->essps_prev_host.warm = false;
     return ok ? MPPI_OK : rc;
 }
 
@@ -1694,6 +1726,14 @@ int mppi_p2p_exchange(mppi_handle_t h, const float* data_dev, float* gathered_ou
 
 // 1 once a poll of the single-launch solve timed out on this handle (read without synchronising): that solve's outputs
 // are void (NaN) and the handle has returned to the multi-kernel path
+#ifdef MPPI_FUSED_TRACE
+extern "C" int mppi_debug_fused_trace(mppi_handle_t h, int* out10) {  // (out: 24 ints)  // 10 ns ticks since block 0 started, per phase boundary
+    if (!h || !h->fused_error) return MPPI_E_STATE;
+    (void)hipDeviceSynchronize();
+    for (int k = 0; k < 24; ++k) { out10[k] = h->fused_error[1 + k]; h->fused_error[1 + k] = 0; }
+    return MPPI_OK;
+}
+#endif
 int mppi_fused_error(mppi_handle_t h) { return (h && h->fused_error) ? *(volatile int*)h->fused_error : 0; }
 
 // 1 if a poll of the exchange buffer ever timed out on this handle (read without synchronising)
@@ -1706,6 +1746,11 @@ int mppi_set_option(mppi_handle_t h, const char* key, int64_t value) {
     if (k == "reduce_blocks") { h->reduce_blocks = (int)std::max<int64_t>(1, std::min<int64_t>(value, 2048)); return MPPI_OK; }
     if (k == "timing") { h->timing = (int)value; return MPPI_OK; }
     if (k == "mapping") { h->mapping = value ? 1 : 0; return MPPI_OK; }
+    if (k == "essps_cold") {  // the next ESSPS search (device chain and host loop) starts from the geometric grid
+        h->essps_lo = h->essps_hi = 0.0;
+        h->essps_prev_host.warm = false;
+        return MPPI_OK;
+    }
     if (k == "fused_solve") { h->fused_mode = value < 0 ? 0 : value > 2 ? 2 : (int)value; return MPPI_OK; }
     if (k == "fold_path") { h->fold_mode = (value >= 0 && value <= 2) ? (int)value : 0; return MPPI_OK; }
     if (k == "exchange_p2p") {  // sharded solves: summaries travel through the peer-to-peer buffer, no collective

@@ -1131,50 +1131,114 @@ __global__ __launch_bounds__(1024) void stats_multi_combine_kernel(const float* 
 // mppi_essps_lambda calls) — round 0 applies the end-point rules or writes the refined grid for the second pass,
 // round 1 interpolates the root.  The temperature ends up in `lambda_out` (device, fp32: what weights_reduce_kernel
 // and finalize_kernel read) and in mapped host memory (double) for whoever asks later; the host never waits.
+// The scalar steps of the search with the lanes of ONE wave sharing the work (call with all 64 lanes active; every lane
+// returns the same values).  Same arithmetic and the same order of the sums as host::essps_round0 / essps_round1, which
+// one lane would take ~3 us for (32 dependent LDS reads for the bracket, 10 double divisions and ~100 dependent double
+// multiplications for the two polynomials): the bracket is a ballot, every polynomial term has its own lane.
+template <int P>
+__device__ __forceinline__ int essps_bracket_wave(const double* ess, double target_ess, int lane) {
+    const unsigned long long above = __ballot(lane < P && ess[lane < P ? lane : 0] >= target_ess);
+    const int i = above ? __ffsll((long long)above) - 1 : P - 1;
+    return i < 1 ? 1 : i;
+}
+template <int P>
+__device__ __forceinline__ bool essps_round0_wave(const double* lgrid, const double* ess, double target_ess,
+                                                  const mppi::host::EsspsRange& r, int lane, int& i, mppi::host::EsspsRoot& root) {
+    using namespace mppi::host;
+    if (target_ess <= ess[0]) { root = EsspsRoot{r.lam_min, r.lmin, false}; return true; }
+    if (target_ess >= ess[P - 1]) { root = EsspsRoot{r.lam_max, r.lmax, false}; return true; }
+    i = essps_bracket_wave<P>(ess, target_ess, lane);
+    constexpr int H = ESSPS_NPT / 2;
+    if (i < H || i > P - H) return false;
+    bool ok = true;  // lanes 0 .. NPT-2 own one pair of neighbours each: close, and ESS strictly increasing
+    if (lane < ESSPS_NPT - 1) {
+        const int k = i - H + lane;
+        ok = lgrid[k + 1] - lgrid[k] <= ESSPS_LOG_FINE_RATIO && ess[k + 1] > ess[k];
+    }
+    if (!__all(ok)) return false;
+    double term = 0.0;  // lanes 0..5: the terms of the six-point polynomial, lanes 8..11: of the four-point one
+    if (lane < ESSPS_NPT) term = essps_poly_term<ESSPS_NPT>(lgrid, ess, target_ess, i - H, lane);
+    else if (lane >= 8 && lane < 12) term = essps_poly_term<4>(lgrid, ess, target_ess, i - 2, lane - 8);
+    double x6 = 0.0, x4 = 0.0;
+#pragma unroll
+    for (int a = 0; a < ESSPS_NPT; ++a) x6 += __shfl(term, a);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) x4 += __shfl(term, 8 + a);
+    if (x6 >= lgrid[i - 1] && x6 <= lgrid[i] && fabs(x6 - x4) <= ESSPS_AGREE) {
+        root = EsspsRoot{exp(x6), x6, true};
+        return true;
+    }
+    return false;
+}
+template <int P>
+__device__ __forceinline__ mppi::host::EsspsRoot essps_round1_wave(const double* grid, const double* lgrid, const double* ess,
+                                                                   double target_ess, int lane) {
+    using namespace mppi::host;
+    const int i = essps_bracket_wave<P>(ess, target_ess, lane);
+    constexpr int H = ESSPS_NPT / 2;
+    const int j0 = (i - H < 0 ? 0 : (i - H > P - ESSPS_NPT ? P - ESSPS_NPT : i - H));
+    bool ok = true;
+    if (lane < ESSPS_NPT - 1) ok = ess[j0 + lane + 1] > ess[j0 + lane];
+    if (__all(ok)) {
+        const double term = lane < ESSPS_NPT ? essps_poly_term<ESSPS_NPT>(lgrid, ess, target_ess, j0, lane) : 0.0;
+        double x = 0.0;
+#pragma unroll
+        for (int a = 0; a < ESSPS_NPT; ++a) x += __shfl(term, a);
+        if (x >= lgrid[i - 1] && x <= lgrid[i]) return EsspsRoot{exp(x), x, true};
+    }
+    return essps_linear(grid, ess, target_ess, i);
+}
 struct EsspsDev {
-    double grid0[STATS_L];  // round-0 temperatures: geometric over [lam_min, lam_max], written once by the host
-    double grid1[STATS_L];  // round-1 temperatures: the refined grid round 0 wrote (`lams` holds their fp32 casts)
-    double lo, hi;          // bracket after round 0
-    double lam;             // result
-    int32_t done, pad;      // an end-point rule of round 0 already decided
+    // first grid of the NEXT search and its logs: geometric over [lam_min, lam_max] at first (host), then rewritten by
+    // every finished search around its root (host_search.hpp: essps_first_grid)
+    double grid0[STATS_L], lgrid0[STATS_L];
+    double grid1[STATS_L], lgrid1[STATS_L];  // the refined grid round 0 wrote (`lams` holds the fp32 casts)
+    double lam;                              // result
+    int32_t done, pad;                       // round 0 already finished the search
 };
 template <int ROUND>
 __global__ __launch_bounds__(1024) void essps_select_kernel(const float* __restrict__ part, int nblocks, double target_ess,
-                                                            double lam_min, double lam_max, EsspsDev* __restrict__ st,
-                                                            float* __restrict__ lams, float* __restrict__ lambda_out,
+                                                            mppi::host::EsspsRange range, EsspsDev* __restrict__ st,
+                                                            float* __restrict__ lams, float* __restrict__ lams0,
+                                                            float* __restrict__ lambda_out,
                                                             double* __restrict__ lambda_host) {
     __shared__ double s_acc[STATS_COMB_GROUPS * STATS_L * 3];
     __shared__ double s_sum[STATS_L * 3];
-    __shared__ double s_ess[STATS_L];
-    __shared__ double s_bracket[2];
-    __shared__ int s_have;
+    __shared__ double s_ess[STATS_L], s_grid[STATS_L], s_lgrid[STATS_L];
     stats_combine_columns(part, nblocks, s_acc, s_sum);
     if (threadIdx.x >= WAVE) return;  // the scalar step: one wave, lane j owns temperature j where that helps
     if (ROUND == 1 && st->done) return;
     const int j = threadIdx.x;
-    if (j < STATS_L) s_ess[j] = s_sum[3 * j] * s_sum[3 * j] / s_sum[3 * j + 1];  // 32 double divisions, one per lane
+    if (j < STATS_L) {
+        s_ess[j] = s_sum[3 * j] * s_sum[3 * j] / s_sum[3 * j + 1];  // 32 double divisions, one per lane
+        s_grid[j] = ROUND == 0 ? st->grid0[j] : st->grid1[j];
+        s_lgrid[j] = ROUND == 0 ? st->lgrid0[j] : st->lgrid1[j];
+    }
     __builtin_amdgcn_wave_barrier();
-    if (ROUND == 0) {
-        if (j == 0) {
-            double lo = lam_min, hi = lam_max, lam = 0.0;
-            const bool have = mppi::host::essps_round0<STATS_L>(st->grid0, s_ess, target_ess, lam_min, lam_max, lo, hi, lam);
-            st->done = have ? 1 : 0;
-            st->lo = lo; st->hi = hi;
-            s_bracket[0] = lo; s_bracket[1] = hi;
-            s_have = have ? 1 : 0;
-            if (have) { st->lam = lam; *lambda_out = (float)lam; lambda_host[0] = lam; lambda_host[1] = lam; }
+    mppi::host::EsspsRoot root{0.0, 0.0, false};  // (wave-uniform from here on)
+    int i = 1;
+    bool have = true;
+    if (ROUND == 0) have = essps_round0_wave<STATS_L>(s_lgrid, s_ess, target_ess, range, j, i, root);
+    else root = essps_round1_wave<STATS_L>(s_grid, s_lgrid, s_ess, target_ess, j);
+    if (j == 0) {
+        if (ROUND == 0) st->done = have ? 1 : 0;
+        if (have) {
+            st->lam = root.lam;
+            *lambda_out = (float)root.lam;
+            lambda_host[0] = root.lam; lambda_host[1] = root.lam; lambda_host[2] = (double)(ROUND + 1);
         }
-        __builtin_amdgcn_wave_barrier();
-        if (!s_have && j < STATS_L) {  // the refined grid, one point (two logs + one exp in double) per lane
-            const double gj = mppi::host::essps_grid_point<STATS_L>(s_bracket[0], s_bracket[1], j);
-            st->grid1[j] = gj;
-            lams[j] = (float)gj;
+    }
+    if (j < STATS_L) {  // one grid point (an exp in double) per lane
+        double g, lg;
+        if (have) {  // the search is over: the next one starts from a grid around this root
+            mppi::host::essps_first_point<STATS_L>(root.warm, root.log_lam, range, j, g, lg);
+            st->grid0[j] = g; st->lgrid0[j] = lg;
+            lams0[j] = (float)g;
+        } else {     // the refined grid over the bracket
+            mppi::host::essps_point<STATS_L>(s_grid[i - 1], s_grid[i], s_lgrid[i - 1], s_lgrid[i], j, g, lg);
+            st->grid1[j] = g; st->lgrid1[j] = lg;
+            lams[j] = (float)g;
         }
-    } else if (j == 0) {
-        const double lam = mppi::host::essps_round1<STATS_L>(st->grid1, s_ess, target_ess);
-        st->lam = lam;
-        *lambda_out = (float)lam;
-        lambda_host[0] = lam; lambda_host[1] = lam;
     }
 }
 
@@ -1225,7 +1289,7 @@ __global__ __launch_bounds__(1024) void lbps_select_kernel(const float* __restri
         double lo, hi, lam;
         mppi::host::lbps_grid_step<STATS_L>(s_grid, s_obj, LAST, lo, hi, lam);
         s_bracket[0] = lo; s_bracket[1] = hi;
-        if (LAST) { *lambda_out = (float)lam; lambda_host[0] = lam; lambda_host[1] = lam; }
+        if (LAST) { *lambda_out = (float)lam; lambda_host[0] = lam; lambda_host[1] = lam; lambda_host[2] = (double)LBPS_ROUNDS; }
     }
     __builtin_amdgcn_wave_barrier();
     if (!LAST && j < STATS_L) {
@@ -1272,7 +1336,7 @@ __global__ __launch_bounds__(WAVE) void mpo_step_kernel(const float* __restrict_
 //
 // The multi-kernel solve of a small or medium problem is a chain of 3-9 dependent, latency-bound launches (launch + the
 // first load of data another XCD just wrote ~ 4-5 us each; a captured hipGraph replays the same chain:
-// profiles/r03_experiments.md).  Here the whole problem is resident at once — G = min(#CUs, ceil(N/256)) blocks of 1024
+// profiles/r03_experiments.md).  Here the whole problem is resident at once — G = min(#CUs, ceil(N/64)) blocks of 1024
 // threads, block b owning `spb` consecutive trajectories (one per thread of its first spb/64 waves: small problems
 // spread over many CUs as lone waves, exactly like the stand-alone rollout kernel; the other waves of a block only help
 // with the exchanges) — and the blocks talk through CELLS in HBM instead of kernel boundaries: an 8-byte word
@@ -1294,6 +1358,7 @@ __global__ __launch_bounds__(WAVE) void mpo_step_kernel(const float* __restrict_
 constexpr int FUSED_BLOCK = 1024;
 constexpr int FUSED_MAX_BLOCKS = 256;
 constexpr int FUSED_MAX_ROW = 128;
+constexpr int FUSED_SMALL_BLOCKS = 32;       // up to this many blocks no hop is spent on the global minimum or on a broadcast
 constexpr int FX_CELLS = FUSED_MAX_ROW + 8;  // per (phase, block): >= 4 + row, >= 97
 enum { FX_MIN = 0, FX_STATS = 1 /* +2*round */, FX_BCAST = 2 /* +2*round */, FX_ROW = 7, FX_PHASES = 8 };
 enum { FUSED_RULE_NONE = 0, FUSED_RULE_ESSPS = 1, FUSED_RULE_LBPS = 2 };
@@ -1336,6 +1401,12 @@ __device__ __forceinline__ void fx_get_many(const FusedCtx& x, int phase, int b0
     for (int k = 0; k < K; ++k) out[k] = k < n ? fx_wait(x, fx_cell(x, phase, b0 + k * bstep, j), c[k], t0, timed_out) : 0.0f;
 }
 
+// -DMPPI_FUSED_TRACE (experiments only): block 0 stamps the 100 MHz clock at its phase boundaries into error[1 + k]
+#ifdef MPPI_FUSED_TRACE
+#define FX_TRACE(k) do { if (b == 0 && tid == 0) s_trace[k] = (int)(wall_clock64() - t0); } while (0)  // (dumped at the end)
+#else
+#define FX_TRACE(k) do { } while (0)
+#endif
 struct FusedArgs {
     const float* mean;      // warm start [row] (read), then overwritten through mean_store
     const float* x0;        // [ds]
@@ -1350,7 +1421,10 @@ struct FusedArgs {
     float lambda_arg;       // rule == NONE: > 0, or MPPI_LAMBDA_DEVICE = read *lambda_dev
     float* lambda_dev;      // device copy of the temperature (written by ESSPS / LBPS)
     double* lambda_host;    // mapped host [2]
-    const double* grid0;    // device [32]: preset round-0 grid over [lam_min, lam_max]
+    double* grid0;          // device [32]: round-0 grid (ESSPS: essps->grid0, rewritten around the root for the next search; LBPS: fixed)
+    EsspsDev* essps;        // ESSPS: the search state shared with the multi-kernel path (first grid of the next search + logs)
+    mppi::host::EsspsRange range;
+    float* lams0;           // ESSPS: fp32 copy of grid0 for the multi-kernel path's statistics pass (kept in step)
     float* mean_store;
     float* action_out;
     float* state_out;
@@ -1366,6 +1440,7 @@ __global__ __launch_bounds__(FUSED_BLOCK) void solve_fused_kernel(FusedArgs A, D
     constexpr int NWV = FUSED_BLOCK / WAVE;
     constexpr bool UC = FAST != 0;
     constexpr int KG = 32;                         // cells a thread keeps in flight: every gather is ONE round trip (G <= 256)
+    constexpr int KS = 5;                          // ... with few blocks (G <= 32 over >= 7 thread groups)
     constexpr int COLS = STATS_L * 3;              // 96 statistics columns
     constexpr int SPARTS = FUSED_BLOCK / COLS;     // 10 row groups of the statistics combine
     constexpr int CW = FX_CELLS;                   // column slots of the row fold (>= 4 + row)
@@ -1376,11 +1451,16 @@ __global__ __launch_bounds__(FUSED_BLOCK) void solve_fused_kernel(FusedArgs A, D
     __shared__ double s_scratch[2048];             // statistics combine [SPARTS][COLS] doubles; aliased: row partials, 4096 floats
     __shared__ float s_fold[RPARTS][CW];           // block 0's row fold
     __shared__ double s_sumd[COLS];
-    __shared__ double s_vald[STATS_L], s_gridd[STATS_L];
+    __shared__ double s_vald[STATS_L], s_gridd[STATS_L], s_lgridd[STATS_L];
     __shared__ float s_lams[STATS_L + 2];
-    __shared__ float s_bc[4];                      // [2] global minimum, [3] global maximum
+    __shared__ float s_bc[4];                      // [0] block minimum, [1] block maximum, [2] global minimum, [3] global maximum
+    __shared__ float s_ref[2][FUSED_SMALL_BLOCKS]; // few blocks: the blocks' reference costs / their maxima or rescale factors
     __shared__ int s_flag;
     __shared__ float s_x0[MPPI_MAX_DIM_STATE];
+#ifdef MPPI_FUSED_TRACE
+    __shared__ int s_trace[24];
+    if (threadIdx.x < 24) s_trace[threadIdx.x] = 0;
+#endif
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];  // [8R] mean groups, [T*KROW] step rows, then the tail's staging
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, b = blockIdx.x, G = gridDim.x;
     const long long t0 = wall_clock64();
@@ -1397,7 +1477,13 @@ __global__ __launch_bounds__(FUSED_BLOCK) void solve_fused_kernel(FusedArgs A, D
     }
     for (int f = tid; f < d.T * M::KROW; f += FUSED_BLOCK) s_ktab[f] = ctx.ref[f];
     if (tid < M::DS) { s_x0[tid] = A.x0[tid]; if (b == 0) A.x0_used[tid] = A.x0[tid]; }
+    if (A.rule != FUSED_RULE_NONE && tid >= FUSED_BLOCK - STATS_L) {  // the search's first grid (its loads hide behind the rollout)
+        const int j = tid - (FUSED_BLOCK - STATS_L);
+        s_gridd[j] = A.grid0[j];
+        if (A.rule == FUSED_RULE_ESSPS) s_lgridd[j] = A.essps->lgrid0[j];
+    }
     __syncthreads();
+    FX_TRACE(0);
 
     // ---- steps 1-3: one trajectory per thread of the block's first spb/64 waves
     const int64_t i = (int64_t)b * A.spb + tid;
@@ -1420,7 +1506,12 @@ __global__ __launch_bounds__(FUSED_BLOCK) void solve_fused_kernel(FusedArgs A, D
         }
         A.costs[i] = total;
     }
-    // ---- hop 1: the global minimum (and, for LBPS, maximum)
+    FX_TRACE(1);
+    // ---- the block's minimum and maximum; hop 1 (G > FUSED_SMALL_BLOCKS only): the global ones
+    // With few blocks no hop is spent on the minimum: a block's exponents are taken relative to its OWN minimum
+    // (`cref`), which it publishes next to its sums, and whoever adds the blocks' sums rescales them by
+    // exp((c_min - cref_b) / lambda) — the combine of the shard summaries (finalize_tail) applied to blocks.
+    const bool small = G <= FUSED_SMALL_BLOCKS;
     {
         const float wm = wave_min(total);
         float wx = mine ? total : -INFINITY;
@@ -1432,47 +1523,61 @@ __global__ __launch_bounds__(FUSED_BLOCK) void solve_fused_kernel(FusedArgs A, D
             float m = s_w[0][0], mx = s_w[0][1];
 #pragma unroll
             for (int w = 1; w < NWV; ++w) { m = fminf(m, s_w[w][0]); mx = fmaxf(mx, s_w[w][1]); }
-            fx_put(fx, FX_MIN, b, 0, m);
-            fx_put(fx, FX_MIN, b, 1, mx);
+            s_bc[0] = m; s_bc[1] = mx;
+            s_bc[2] = m; s_bc[3] = mx;  // (small: until the first gather knows better)
+            if (!small) { fx_put(fx, FX_MIN, b, 0, m); fx_put(fx, FX_MIN, b, 1, mx); }
         }
-        float gm = INFINITY, gx = -INFINITY;
-        if (tid < G) gm = fx_get(fx, FX_MIN, tid, 0, t0, timed_out);                                   // G <= 256
-        else if (tid >= 512 && tid - 512 < G) gx = fx_get(fx, FX_MIN, tid - 512, 1, t0, timed_out);
-        gm = wave_min(gm);
+        if (!small) {
+            float gm = INFINITY, gx = -INFINITY;
+            if (tid < G) gm = fx_get(fx, FX_MIN, tid, 0, t0, timed_out);                                   // G <= 256
+            else if (tid >= 512 && tid - 512 < G) gx = fx_get(fx, FX_MIN, tid - 512, 1, t0, timed_out);
+            gm = wave_min(gm);
 #pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) gx = fmaxf(gx, __shfl_xor(gx, m));
-        __syncthreads();
-        if (lane == 0) { s_w[wid][0] = gm; s_w[wid][1] = gx; }
-        __syncthreads();
-        if (tid == 0) {
-            float m = s_w[0][0], mx = s_w[0][1];
+            for (int m = 32; m >= 1; m >>= 1) gx = fmaxf(gx, __shfl_xor(gx, m));
+            __syncthreads();
+            if (lane == 0) { s_w[wid][0] = gm; s_w[wid][1] = gx; }
+            __syncthreads();
+            if (tid == 0) {
+                float m = s_w[0][0], mx = s_w[0][1];
 #pragma unroll
-            for (int w = 1; w < NWV; ++w) { m = fminf(m, s_w[w][0]); mx = fmaxf(mx, s_w[w][1]); }
-            s_bc[2] = m; s_bc[3] = mx;
-            if (b == 0) { *A.min_key = float_to_key(m); *A.next_min_key = 0xFFFFFFFFu; }
+                for (int w = 1; w < NWV; ++w) { m = fminf(m, s_w[w][0]); mx = fmaxf(mx, s_w[w][1]); }
+                s_bc[2] = m; s_bc[3] = mx;
+            }
         }
         __syncthreads();
     }
-    const float cmin = s_bc[2];
+    // what this block's exponents are relative to: the global minimum once it is known (a block without trajectories
+    // publishes +inf as its reference — a factor 0 wherever its zeros are added — and uses 0 itself)
+    float cref = s_bc[2], cpub = s_bc[2];
+    if (!(cref < INFINITY)) cref = 0.0f;
+    bool cmin_known = !small;
+    FX_TRACE(2);
 
     // ---- step 4: the temperature
-    float lambda = A.lambda_arg > 0.0f ? A.lambda_arg : *A.lambda_dev;
+    float lambda = A.lambda_arg;
+    if (A.rule == FUSED_RULE_NONE && !(lambda > 0.0f)) lambda = *A.lambda_dev;  // (MPO: the dual's temperature)
     if (A.rule != FUSED_RULE_NONE) {
         const int rounds = A.rule == FUSED_RULE_ESSPS ? 2 : LBPS_ROUNDS;
         s_c[tid] = mine ? total : 3.0e38f;  // padding: e = exp(-inf) = 0 and 0 * c = 0
         __syncthreads();
+        FX_TRACE(14);
         for (int r = 0; r < rounds; ++r) {
             // statistics of this block's costs for the 32 temperatures of round r (stats_multi_kernel's arithmetic)
-            const int l = tid & (STATS_L - 1), chunk = tid >> 5;
-            const float lam_l = r == 0 ? (float)A.grid0[l] : s_lams[l];
+            // (thread = temperature l x one of 32 runs of spb/32 consecutive costs: every thread of the block works)
+#ifdef MPPI_FUSED_TRACE_REPEAT
+          for (int rep = 0; rep < 2; ++rep) {  // experiment: the same code twice — is the first pass slow because it is cold?
+            if (rep == 1) { __syncthreads(); if (r == 0) FX_TRACE(19); }
+#endif
+            const int l = tid & (STATS_L - 1), chunk = tid >> 5, per = A.spb >> 5;
+            const float lam_l = r == 0 ? (float)s_gridd[l] : s_lams[l];
             const float inv_lam = 1.0f / lam_l;
             float se = 0.0f, se2 = 0.0f, sec = 0.0f;
-            if (chunk * 32 < A.spb) {  // (wave-uniform: chunks past the block's trajectories hold padding only)
-                const float* cc = s_c + chunk * 32;
-#pragma unroll 8
-                for (int j = 0; j < 32; ++j) {
+            {
+                const float* cc = s_c + chunk * per;
+#pragma unroll 2
+                for (int j = 0; j < per; ++j) {
                     const float c = cc[j];
-                    const float e = expf((cmin - c) * inv_lam);
+                    const float e = expf((cref - c) * inv_lam);
                     se += e;
                     se2 = fmaf(e, e, se2);
                     sec = fmaf(e, c, sec);
@@ -1480,85 +1585,150 @@ __global__ __launch_bounds__(FUSED_BLOCK) void solve_fused_kernel(FusedArgs A, D
             }
             se += __shfl_xor(se, 32); se2 += __shfl_xor(se2, 32); sec += __shfl_xor(sec, 32);
             if (lane < STATS_L) { s_p[wid][lane][0] = se; s_p[wid][lane][1] = se2; s_p[wid][lane][2] = sec; }
+            if (r == 0) FX_TRACE(15);
             __syncthreads();
+            if (r == 0) FX_TRACE(16);
+#ifdef MPPI_FUSED_TRACE_REPEAT
+            if (rep == 1) break;
+          }
+#endif
             if (tid < COLS) {
                 float v = 0.0f;
 #pragma unroll
                 for (int w = 0; w < NWV; ++w) v += (&s_p[w][0][0])[tid];
                 fx_put(fx, FX_STATS + 2 * r, b, tid, v);
+            } else if (small && tid == COLS) {
+                fx_put(fx, FX_STATS + 2 * r, b, COLS, cpub);
+                fx_put(fx, FX_STATS + 2 * r, b, COLS + 1, s_bc[1]);
             }
-            if (b == 0) {
+            if (r == 0) FX_TRACE(10);
+            if (small || b == 0) {  // (few blocks: EVERY block gathers and runs the scalar step itself — no broadcast hop)
+                if (small) {        // the blocks' reference costs first: the global minimum / maximum
+                    if (tid < G) s_ref[0][tid] = fx_get(fx, FX_STATS + 2 * r, tid, COLS, t0, timed_out);
+                    else if (tid >= WAVE && tid - WAVE < G) s_ref[1][tid - WAVE] = fx_get(fx, FX_STATS + 2 * r, tid - WAVE, COLS + 1, t0, timed_out);
+                    __syncthreads();
+                    if (wid < 2) {
+                        float v = lane < G ? s_ref[wid][lane] : (wid == 0 ? INFINITY : -INFINITY);
+#pragma unroll
+                        for (int m = 32; m >= 1; m >>= 1) v = wid == 0 ? fminf(v, __shfl_xor(v, m)) : fmaxf(v, __shfl_xor(v, m));
+                        if (lane == 0) s_bc[2 + wid] = v;
+                    }
+                    __syncthreads();
+                }
                 // combine: thread (col, part) sums blocks part, part + SPARTS, ... in ascending order, KG cells in flight
                 const int col = tid % COLS, part = tid / COLS;
                 if (part < SPARTS) {
                     double v = 0.0;
-                    for (int b0 = part; b0 < G; b0 += KG * SPARTS) {
-                        float vals[KG];
-                        const int n = min(KG, (G - b0 + SPARTS - 1) / SPARTS);
-                        fx_get_many<KG>(fx, FX_STATS + 2 * r, b0, SPARTS, n, col, vals, t0, timed_out);
+                    const float gmin = s_bc[2];
+                    const float lam_c = r == 0 ? (float)s_gridd[col / 3] : s_lams[col / 3];
+                    const float inv_c = 1.0f / lam_c;
+                    if (small) {  // <= KS blocks per thread; sums relative to the block's reference -> relative to the global minimum
+                        float vals[KS];
+                        const int n = min(KS, (G - part + SPARTS - 1) / SPARTS);
+                        fx_get_many<KS>(fx, FX_STATS + 2 * r, part, SPARTS, n, col, vals, t0, timed_out);
 #pragma unroll
-                        for (int k = 0; k < KG; ++k) v += (double)vals[k];
+                        for (int k = 0; k < KS; ++k)
+                            if (k < n) {
+                                const float f = expf((gmin - s_ref[0][part + k * SPARTS]) * inv_c);
+                                v += (double)vals[k] * (double)(col % 3 == 1 ? f * f : f);
+                            }
+                    } else {
+                        for (int b0 = part; b0 < G; b0 += KG * SPARTS) {
+                            float vals[KG];
+                            const int n = min(KG, (G - b0 + SPARTS - 1) / SPARTS);
+                            fx_get_many<KG>(fx, FX_STATS + 2 * r, b0, SPARTS, n, col, vals, t0, timed_out);
+#pragma unroll
+                            for (int k = 0; k < KG; ++k) v += (double)vals[k];
+                        }
                     }
                     s_scratch[part * COLS + col] = v;
                 }
                 __syncthreads();
+                if (r == 0) FX_TRACE(11);
                 if (tid < COLS) {
                     double v = 0.0;
                     for (int q = 0; q < SPARTS; ++q) v += s_scratch[q * COLS + tid];
                     s_sumd[tid] = v;
                 }
                 __syncthreads();
+                if (r == 0) FX_TRACE(12);
                 if (tid < WAVE) {  // the scalar step: one wave (essps_select_kernel / lbps_select_kernel)
                     const int j = tid;
                     if (j < STATS_L) {
-                        if (r == 0) s_gridd[j] = A.grid0[j];
                         if (A.rule == FUSED_RULE_ESSPS) s_vald[j] = s_sumd[3 * j] * s_sumd[3 * j] / s_sumd[3 * j + 1];
                         else s_vald[j] = mppi::host::lbps_objective(
-                            mppi::host::SoftmaxStats{(double)cmin, (double)s_bc[3], s_sumd[3 * j], s_sumd[3 * j + 1], s_sumd[3 * j + 2]},
+                            mppi::host::SoftmaxStats{(double)s_bc[2], (double)s_bc[3], s_sumd[3 * j], s_sumd[3 * j + 1], s_sumd[3 * j + 2]},
                             A.rule_param);
                     }
                     __builtin_amdgcn_wave_barrier();
-                    if (j == 0) {
-                        double lo = A.lam_min, hi = A.lam_max, lam = 0.0;
-                        bool have;
-                        if (A.rule == FUSED_RULE_ESSPS) {
-                            if (r == 0) have = mppi::host::essps_round0<STATS_L>(s_gridd, s_vald, A.rule_param, A.lam_min, A.lam_max, lo, hi, lam);
-                            else { lam = mppi::host::essps_round1<STATS_L>(s_gridd, s_vald, A.rule_param); have = true; }
-                        } else {
-                            mppi::host::lbps_grid_step<STATS_L>(s_gridd, s_vald, r == rounds - 1, lo, hi, lam);
-                            have = r == rounds - 1;
+                    if (r == 0) FX_TRACE(17);
+                    double lam = 0.0, gj = 0.0, lgj = 0.0;
+                    bool have;
+                    if (A.rule == FUSED_RULE_ESSPS) {
+                        mppi::host::EsspsRoot root{0.0, 0.0, false};  // (wave-uniform)
+                        int i = 1;
+                        have = true;
+                        if (r == 0) have = essps_round0_wave<STATS_L>(s_lgridd, s_vald, A.rule_param, A.range, j, i, root);
+                        else root = essps_round1_wave<STATS_L>(s_gridd, s_lgridd, s_vald, A.rule_param, j);
+                        lam = root.lam;
+                        if (j < STATS_L) {  // the next grid, one point per lane
+                            if (!have) {
+                                const double lo = s_gridd[i - 1], hi = s_gridd[i], llo = s_lgridd[i - 1], lhi = s_lgridd[i];
+                                mppi::host::essps_point<STATS_L>(lo, hi, llo, lhi, j, gj, lgj);
+                                __builtin_amdgcn_wave_barrier();
+                                s_gridd[j] = gj; s_lgridd[j] = lgj;
+                            } else if (b == 0) {  // the next ESSPS search starts around this root
+                                double g0, lg0;
+                                mppi::host::essps_first_point<STATS_L>(root.warm, root.log_lam, A.range, j, g0, lg0);
+                                A.essps->grid0[j] = g0; A.essps->lgrid0[j] = lg0;
+                                A.lams0[j] = (float)g0;
+                            }
                         }
-                        s_sumd[0] = lo; s_sumd[1] = hi;
-                        s_flag = have ? 1 : 0;
-                        if (have) {
+                    } else {
+                        if (j == 0) {
+                            double lo = A.lam_min, hi = A.lam_max;
+                            mppi::host::lbps_grid_step<STATS_L>(s_gridd, s_vald, r == rounds - 1, lo, hi, lam);
+                            s_sumd[0] = lo; s_sumd[1] = hi; s_sumd[2] = lam;
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        have = r == rounds - 1;
+                        lam = s_sumd[2];
+                        if (!have && j < STATS_L) {
+                            gj = mppi::host::essps_grid_point<STATS_L>(s_sumd[0], s_sumd[1], j);
+                            s_gridd[j] = gj;
+                        }
+                    }
+                    if (j < STATS_L) s_lams[j] = have ? 0.0f : (float)gj;  // (zeros once the temperature is known)
+                    if (j == 0) {
+                        if (have && b == 0) {
                             *A.lambda_dev = (float)lam;
-                            A.lambda_host[0] = lam; A.lambda_host[1] = lam;
+                            A.lambda_host[0] = lam; A.lambda_host[1] = lam; A.lambda_host[2] = (double)(r + 1);
                         }
                         s_lams[STATS_L + 1] = have ? (float)lam : 0.0f;
                         s_lams[STATS_L] = have ? 1.0f : 0.0f;
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    if (j < STATS_L) {  // the next grid, one point per lane (zeros once the temperature is known)
-                        double gj = 0.0;
-                        if (!s_flag) { gj = mppi::host::essps_grid_point<STATS_L>(s_sumd[0], s_sumd[1], j); s_gridd[j] = gj; }
-                        s_lams[j] = (float)gj;
+                        if (r == 0) FX_TRACE(18);
                     }
                 }
                 __syncthreads();
+                if (r == 0) FX_TRACE(13);
                 // broadcast: every block gets its OWN copy of the 34 cells (nobody polls a shared address)
-                for (int q = tid; q < G * (STATS_L + 2); q += FUSED_BLOCK)
-                    fx_put(fx, FX_BCAST + 2 * r, q / (STATS_L + 2), q % (STATS_L + 2), s_lams[q % (STATS_L + 2)]);
+                if (!small)
+                    for (int q = tid; q < G * (STATS_L + 2); q += FUSED_BLOCK)
+                        fx_put(fx, FX_BCAST + 2 * r, q / (STATS_L + 2), q % (STATS_L + 2), s_lams[q % (STATS_L + 2)]);
             } else {
                 if (tid < STATS_L + 2) s_lams[tid] = fx_get(fx, FX_BCAST + 2 * r, b, tid, t0, timed_out);
             }
             __syncthreads();
+            FX_TRACE(3 + r);
+            if (small) { cref = cpub = s_bc[2]; cmin_known = true; }  // (every block has seen all the minima by now)
             if (s_lams[STATS_L] != 0.0f) { lambda = s_lams[STATS_L + 1]; break; }
         }
         __syncthreads();
     }
+    FX_TRACE(6);
 
-    // ---- steps 5-6: weights and this block's share of sum_i e_i U_i
-    const float xmax = (-cmin) / lambda;
+    // ---- steps 5-6: weights (relative to cref) and this block's share of sum_i e_i U_i
+    const float xmax = (-cref) / lambda;
     const float e = mine ? expf((-total) / lambda - xmax) : 0.0f;
     s_c[tid] = e;
     {
@@ -1596,13 +1766,25 @@ __global__ __launch_bounds__(FUSED_BLOCK) void solve_fused_kernel(FusedArgs A, D
 #pragma unroll
         for (int j = 0; j < 4; ++j) s_part[slice * 4 * RP + 4 * r + j] = acc[j];
         __syncthreads();
-        if (tid < d.row) {
+        {   // fold the slices in two steps (fixed order): W = 4 RP columns x Q = 1024 / W groups of nsl / Q = 4 slices each
+            const int W = 4 * RP, Q = FUSED_BLOCK / W, c = tid & (W - 1), q = tid / W;
+            float* s_half = &s_p[0][0][0];  // [Q][W] = 1024 floats (the statistics' staging is free by now)
             float v = 0.0f;
-            for (int sl = 0; sl < nsl; ++sl) v += s_part[sl * 4 * RP + tid];
-            fx_put(fx, FX_ROW, b, MPPI_SUMMARY_HEAD + tid, v);
+            for (int sl = q; sl < nsl; sl += Q) v += s_part[sl * W + c];
+            s_half[q * W + c] = v;
+            __syncthreads();
+            if (tid < d.row) {
+                float t = 0.0f;
+                for (int g = 0; g < Q; ++g) t += s_half[g * W + tid];
+                fx_put(fx, FX_ROW, b, MPPI_SUMMARY_HEAD + tid, t);
+            }
         }
-        if (tid == FUSED_BLOCK - 1) { fx_put(fx, FX_ROW, b, 1, bse); fx_put(fx, FX_ROW, b, 2, bse2); fx_put(fx, FX_ROW, b, 3, bsec); }
+        if (tid == FUSED_BLOCK - 1) {
+            fx_put(fx, FX_ROW, b, 0, cpub);
+            fx_put(fx, FX_ROW, b, 1, bse); fx_put(fx, FX_ROW, b, 2, bse2); fx_put(fx, FX_ROW, b, 3, bsec);
+        }
     }
+    FX_TRACE(7);
     if (b != 0) {
         if (timed_out) *fx.error = 1;
         return;
@@ -1612,22 +1794,49 @@ __global__ __launch_bounds__(FUSED_BLOCK) void solve_fused_kernel(FusedArgs A, D
     float* s_act = s_dyn + 8 * d.R + d.T * M::KROW;  // [row]
     float* s_sum = s_act + d.row;                     // [4 + row]
     float* s_yp = s_sum + MPPI_SUMMARY_HEAD + d.row;  // filter staging
+    const bool rescale = small && !cmin_known;  // the blocks' exponents are relative to their own minima
+    float cmin = cref;
+    if (rescale) {  // finalize_tail's combine of shard summaries, applied to the blocks: f_b = exp((-cref_b)/lambda - max)
+        if (tid < G) s_ref[0][tid] = fx_get(fx, FX_ROW, tid, 0, t0, timed_out);
+        __syncthreads();
+        if (wid == 0) {
+            float v = lane < G ? s_ref[0][lane] : INFINITY;
+            v = wave_min(v);
+            if (lane == 0) s_bc[2] = v;
+            if (lane < G) s_ref[1][lane] = expf((-s_ref[0][lane]) / lambda - (-v) / lambda);
+        }
+        __syncthreads();
+        cmin = s_bc[2];
+    }
     {
         const int col = tid % CW, part = tid / CW;    // cell slot (1 .. 3 + row are used), row group
         if (part < RPARTS) {
             float v = 0.0f;
             if (col >= 1 && col < MPPI_SUMMARY_HEAD + d.row) {
-                for (int b0 = part; b0 < G; b0 += KG * RPARTS) {
-                    float vals[KG];
-                    const int n = min(KG, (G - b0 + RPARTS - 1) / RPARTS);
-                    fx_get_many<KG>(fx, FX_ROW, b0, RPARTS, n, col, vals, t0, timed_out);
+                if (small) {
+                    float vals[KS];
+                    const int n = min(KS, (G - part + RPARTS - 1) / RPARTS);
+                    fx_get_many<KS>(fx, FX_ROW, part, RPARTS, n, col, vals, t0, timed_out);
 #pragma unroll
-                    for (int k = 0; k < KG; ++k) v += vals[k];
+                    for (int k = 0; k < KS; ++k)
+                        if (k < n) {
+                            const float f = rescale ? s_ref[1][part + k * RPARTS] : 1.0f;
+                            v = rescale ? fmaf(col == 2 ? f * f : f, vals[k], v) : v + vals[k];
+                        }
+                } else {
+                    for (int b0 = part; b0 < G; b0 += KG * RPARTS) {
+                        float vals[KG];
+                        const int n = min(KG, (G - b0 + RPARTS - 1) / RPARTS);
+                        fx_get_many<KG>(fx, FX_ROW, b0, RPARTS, n, col, vals, t0, timed_out);
+#pragma unroll
+                        for (int k = 0; k < KG; ++k) v += vals[k];
+                    }
                 }
             }
             s_fold[part][col] = v;
         }
     }
+    if (tid == 0) { *A.min_key = float_to_key(cmin); *A.next_min_key = 0xFFFFFFFFu; }
     __syncthreads();
     if (tid >= 1 && tid < MPPI_SUMMARY_HEAD + d.row) {
         float v = 0.0f;
@@ -1639,6 +1848,7 @@ __global__ __launch_bounds__(FUSED_BLOCK) void solve_fused_kernel(FusedArgs A, D
     if (tid == 0) { s_sum[0] = cmin; if (A.summary_out) A.summary_out[0] = cmin; }
     s_flag = 0;
     __syncthreads();
+    FX_TRACE(8);
     if (timed_out) s_flag = 1;
     __syncthreads();
     if (s_flag) {  // a block is missing: no partial answer leaves this kernel
@@ -1651,6 +1861,10 @@ __global__ __launch_bounds__(FUSED_BLOCK) void solve_fused_kernel(FusedArgs A, D
     }
     finalize_tail<MODEL, FAST>(s_sum, 1, lambda, d.row, d.T, s_x0, s_act, s_yp, A.mean_store, A.action_out, A.state_out,
                                A.stats_out, A.stats_keep, sg, ctx);
+    FX_TRACE(9);
+#ifdef MPPI_FUSED_TRACE
+    if (tid == 0) for (int k = 0; k < 24; ++k) fx.error[1 + k] = s_trace[k];
+#endif
 }
 
 // `_weights` (mppi.py:376) given the global min cost and sum e.

@@ -69,46 +69,102 @@ def essps_lambda_stats(stats, target_ess: float, lam_min: float, lam_max: float)
     return brentq(lambda lam: ess_from_stats(stats(lam)) - target_ess, lam_min, lam_max)
 
 
-def essps_lambda_grid(stats_multi, target_ess: float, lam_min: float, lam_max: float, points: int = 32,
-                      rounds: int = 2) -> float:
-    """The same root as essps_lambda_stats (ESS(lambda) = target, ESS increasing in lambda), bracketed on
-    geometric grids: `stats_multi(lams)` evaluates ESS for up to 32 temperatures in ONE pass over the costs, so
-    two round trips shrink the bracket from [lam_min, lam_max] to a ratio of (lam_max/lam_min)**(1/31**2)
-    (1.007 for [0.01, 10]) and an inverse cubic interpolation in (ESS, log lambda) through the four grid points
-    around it lands within ~1e-7 relative of brentq's answer over the whole range — instead of ~18 sequential
-    probes, each a device round trip."""
+ESSPS_LOG_WARM_FACTOR = math.log(1.5)  # csrc/host_search.hpp: the same constants, the same steps
+ESSPS_LOG_FINE_RATIO = math.log(1.05)
+ESSPS_CLUSTER = 22
+ESSPS_NPT = 6
+ESSPS_AGREE = 1.0e-5
+
+
+def essps_first_grid(lam_prev, lam_min: float, lam_max: float, points: int = 32):
+    """First grid of a search and its logs (csrc/host_search.hpp::essps_first_point): geometric over [lam_min, lam_max], or —
+    given the previous root well inside the range — ESSPS_CLUSTER points over [prev/1.5, prev*1.5] and the rest spread over
+    what is left on either side in proportion to its log-length, the end points included."""
     lo, hi = float(lam_min), float(lam_max)
-    grid = ess = None
-    i = 1
-    for rnd in range(rounds):
-        grid = lo * (hi / lo) ** (np.arange(points) / (points - 1.0))  # geometric
-        grid[0], grid[-1] = lo, hi
-        ess = np.asarray(stats_multi(grid), np.float64)
-        if rnd == 0:  # same end-point rules as the reference (mppi.py:361-364)
-            if target_ess <= ess[0]:
-                return lam_min
-            if target_ess >= ess[-1]:
-                return lam_max
-        above = np.nonzero(ess >= target_ess)[0]
-        i = max(int(above[0]) if len(above) else points - 1, 1)
-        lo, hi = float(grid[i - 1]), float(grid[i])
-    j0 = min(max(i - 2, 0), points - 4)
-    xs, ys = np.log(grid[j0:j0 + 4]), ess[j0:j0 + 4]
-    if points >= 4 and np.all(np.diff(ys) > 0):  # Lagrange form of x(y) at y = target
-        x = 0.0
-        for a in range(4):
-            w = 1.0
-            for b in range(4):
-                if b != a:
-                    w *= (target_ess - ys[b]) / (ys[a] - ys[b])
-            x += w * xs[a]
-        lam = float(np.exp(x))
-        if lo <= lam <= hi:
-            return lam
-    e0, e1 = float(ess[i - 1]), float(ess[i])
+    lmin, lmax = math.log(lo), math.log(hi)
+    lf = ESSPS_LOG_WARM_FACTOR
+    lp = math.log(lam_prev) if lam_prev is not None and lam_prev > 0.0 else None
+    warm = lp is not None and points >= ESSPS_CLUSTER + 2 and lp - lf > lmin + 1e-3 and lp + lf < lmax - 1e-3
+    j = np.arange(points, dtype=np.float64)
+    if not warm:
+        lg = lmin + (lmax - lmin) * j / (points - 1.0)
+    else:
+        s = points - ESSPS_CLUSTER
+        clo, chi = lp - lf, lp + lf
+        nb = min(max(int(s * (clo - lmin) / ((clo - lmin) + (lmax - chi)) + 0.5), 1), s - 1)
+        na = s - nb
+        below = lmin + (clo - lmin) * j / nb
+        cluster = clo + (chi - clo) * (j - nb) / (ESSPS_CLUSTER - 1)
+        above = chi + (lmax - chi) * (j - (nb + ESSPS_CLUSTER - 1)) / na
+        lg = np.where(j < nb, below, np.where(j < nb + ESSPS_CLUSTER, cluster, above))
+    lg[0], lg[-1] = lmin, lmax
+    grid = np.exp(lg)
+    grid[0], grid[-1] = lo, hi
+    return grid, lg
+
+
+def _essps_poly(lgrid, ess, target_ess, j0, npt):
+    """Lagrange form of log(lambda)(ESS) at ESS = target through grid points j0 .. j0+npt-1; None unless ESS increases."""
+    xs, ys = lgrid[j0:j0 + npt], ess[j0:j0 + npt]
+    if not np.all(np.diff(ys) > 0):
+        return None
+    x = 0.0
+    for a in range(npt):
+        num = den = 1.0
+        for b in range(npt):
+            if b != a:
+                num *= target_ess - ys[b]
+                den *= ys[a] - ys[b]
+        x += num / den * xs[a]
+    return float(x)
+
+
+def _essps_interpolate(grid, lgrid, ess, target_ess, i, j0):
+    x = _essps_poly(lgrid, ess, target_ess, j0, ESSPS_NPT)
+    if x is not None and lgrid[i - 1] <= x <= lgrid[i]:
+        return math.exp(x)
+    lo, hi, e0, e1 = float(grid[i - 1]), float(grid[i]), float(ess[i - 1]), float(ess[i])
     if e1 == e0:
         return 0.5 * (lo + hi)
     return lo + (hi - lo) * (target_ess - e0) / (e1 - e0)
+
+
+def essps_lambda_grid(stats_multi, target_ess: float, lam_min: float, lam_max: float, points: int = 32,
+                      lam_prev=None) -> float:
+    """The same root as essps_lambda_stats (ESS(lambda) = target, ESS increasing in lambda), bracketed on
+    geometric grids: `stats_multi(lams)` evaluates ESS for up to 32 temperatures in ONE pass over the costs, so
+    two round trips shrink the bracket from [lam_min, lam_max] to a ratio of (lam_max/lam_min)**(1/31**2)
+    (1.007 for [0.01, 10]) and an inverse polynomial interpolation in (ESS, log lambda) through the six grid points
+    around it lands within ~1e-7 relative of brentq's answer over the whole range — instead of ~18 sequential
+    probes, each a device round trip.  With `lam_prev` (the previous solve's root) the first grid is clustered around
+    it (essps_first_grid) and ONE round trip is enough whenever the root has not left the cluster and the
+    interpolation has visibly converged there (~1e-6 relative).  Same steps as csrc/host_search.hpp::essps_lambda."""
+    assert points >= 2 * ESSPS_NPT
+    grid, lgrid = essps_first_grid(lam_prev, lam_min, lam_max, points)
+    ess = np.asarray(stats_multi(grid), np.float64)
+    if target_ess <= ess[0]:  # same end-point rules as the reference (mppi.py:361-364)
+        return lam_min
+    if target_ess >= ess[-1]:
+        return lam_max
+
+    def bracket(ess):
+        above = np.nonzero(ess >= target_ess)[0]
+        return max(int(above[0]) if len(above) else points - 1, 1)
+
+    i = bracket(ess)
+    h = ESSPS_NPT // 2
+    if h <= i <= points - h and np.all(np.diff(lgrid[i - h:i + h]) <= ESSPS_LOG_FINE_RATIO):
+        x6, x4 = _essps_poly(lgrid, ess, target_ess, i - h, ESSPS_NPT), _essps_poly(lgrid, ess, target_ess, i - 2, 4)
+        if x6 is not None and x4 is not None and lgrid[i - 1] <= x6 <= lgrid[i] and abs(x6 - x4) <= ESSPS_AGREE:
+            return math.exp(x6)  # the first grid was fine around the root and the interpolation has converged: one pass
+    lo, hi, llo, lhi = float(grid[i - 1]), float(grid[i]), float(lgrid[i - 1]), float(lgrid[i])
+    lgrid = llo + (lhi - llo) * np.arange(points) / (points - 1.0)
+    lgrid[0], lgrid[-1] = llo, lhi
+    grid = np.exp(lgrid)
+    grid[0], grid[-1] = lo, hi
+    ess = np.asarray(stats_multi(grid), np.float64)
+    i = bracket(ess)
+    return _essps_interpolate(grid, lgrid, ess, target_ess, i, min(max(i - ESSPS_NPT // 2, 0), points - ESSPS_NPT))
 
 
 def lbps_lambda_stats(stats, delta: float, lam_min: float, lam_max: float) -> float:

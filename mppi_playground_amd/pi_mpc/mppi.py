@@ -77,12 +77,13 @@ class MPPI(nn.Module):
             auto_lambda_stats: "device" (default) evaluates the softmax sums of the ESSPS/LBPS/MPO searches
                 on the GPU (mppi_softmax_stats; the root-finders stay on the host), "host" copies
                 costs[N] to the CPU and evaluates them in numpy like the reference does.
-            essps_search: with device statistics, "device" (default) and "grid" bracket the ESSPS root with two
-                32-temperature geometric grids (one pass over the costs each) and an inverse cubic
+            essps_search: with device statistics, "device" (default) and "grid" bracket the ESSPS root with
+                32-temperature grids (one pass over the costs each: two geometric ones, or ONE clustered around the
+                previous solve's root when the temperature has moved < 1.5x) and an inverse polynomial
                 interpolation — "device" runs the scalar steps of that search as kernels too, so the solve never
                 waits for the host (the temperature stays in HBM; reading `_lambda` fetches it), "grid" reads the
                 statistics back after each pass; "brentq" probes one lambda at a time like the reference's scipy
-                call.  All return the same root (to ~1e-7 relative).  Sharded solvers combine the shards'
+                call.  All return the same root (to ~1e-6 relative).  Sharded solvers combine the shards'
                 statistics on the host ("device" behaves like "grid" there).
             lbps_search: with device statistics on one GPU, "device" (default) replaces the reference's ~25 dependent Brent
                 probes by three 32-temperature grids + a parabola, all as kernels (no host wait; within 1e-3 relative of
@@ -202,6 +203,7 @@ class MPPI(nn.Module):
         self._lambda_pending = False  # the temperature of the last solve still lives on the device only
         self._lambda_stream = None    # ... and this is the stream that solve was enqueued on
         self._lambda_override = None  # MPO on the device: a temperature assigned to `_lambda` by the caller
+        self._essps_prev = None       # root of the last host-side ESSPS grid search (warm start of the next one)
         self._used_known = True       # `_last_lambda_value` already holds the last solve's temperature
         self._lambda_value = self._last_lambda_value = None
         self._h = None
@@ -572,6 +574,8 @@ class MPPI(nn.Module):
                                                 dtype=self._dtype)
         self._h.call("mppi_set_mean", _ptr(self._previous_action_seq), 1, self._stream())
         self._actions_history_for_sg = np.zeros((self._horizon - 1, self._dim_control), np.float32)
+        self._essps_prev = None  # the next ESSPS search starts cold (no grid clustered around the last temperature)
+        self._h.call("mppi_set_option", b"essps_cold", 1)
 
     @property
     def _actions_history_for_sg(self) -> np.ndarray:
@@ -661,11 +665,13 @@ class MPPI(nn.Module):
             self._lambda = lam_out.value
         elif self._auto_lambda == "ESSPS":
             self._lambda = ((_host.essps_lambda_grid(self._ess_grid, self._essps_target_ess, self._lambda_min,
-                                                     self._lambda_max) if self._essps_search != "brentq" else
+                                                     self._lambda_max, lam_prev=self._essps_prev)
+                             if self._essps_search != "brentq" else
                              _host.essps_lambda_stats(self._softmax_stats, self._essps_target_ess, self._lambda_min,
                                                       self._lambda_max)) if on_dev else
                             _host.essps_lambda(costs_host, self._essps_target_ess, self._lambda_min,
                                                self._lambda_max))
+            self._essps_prev = float(self._lambda)  # the next grid search starts around it (one exchange instead of two)
         if self._lambda_pending:
             lam = _capi.LAMBDA_DEVICE  # weights_reduce / finalize read the temperature from device memory
             self._used_known = False

@@ -67,7 +67,8 @@ def search_lib():
         _search.search_lbps.argtypes = [vp, i, d, d, d, vp, vp]
         _search.search_lbps_grid.argtypes = [vp, i, d, d, d, vp]
         _search.search_fminbound_poly.argtypes = [d, d, d, d, d, vp, vp]
-        _search.search_essps.argtypes = [vp, i, d, d, d, vp]
+        _search.search_essps.argtypes = [vp, i, d, d, d, d, vp, vp]
+        _search.search_essps_first_grid.argtypes = [d, d, d, vp]
         _search.search_mpo.argtypes = [vp, i, i, d, d, d, vp]
     return _search
 
@@ -92,11 +93,17 @@ def fminbound_poly(a, b, c, lo, hi):
     return out.value, nf.value
 
 
-def essps(costs, target, lo, hi):
+def essps(costs, target, lo, hi, lam_prev=0.0, with_passes=False):
     c = np.ascontiguousarray(costs, np.float32)
-    out = C.c_double(0)
-    assert search_lib().search_essps(_p(c), len(c), target, lo, hi, C.byref(out)) == 0
-    return out.value
+    out, passes = C.c_double(0), C.c_int(0)
+    assert search_lib().search_essps(_p(c), len(c), target, lo, hi, lam_prev, C.byref(out), C.byref(passes)) == 0
+    return (out.value, passes.value) if with_passes else out.value
+
+
+def essps_first_grid(lam_prev, lo, hi):
+    g = np.zeros(32, np.float64)
+    assert search_lib().search_essps_first_grid(lam_prev, lo, hi, _p(g)) == 0
+    return g
 
 
 def mpo(cost_rows, lam0=1.0, epsilon=0.1, lr=0.2):

@@ -57,13 +57,25 @@ int search_fminbound_poly(double a, double b, double c, double lo, double hi, do
                      lo, hi, 1e-5, 500, *xmin, nfev) ? 0 : -1;
 }
 
-int search_essps(const float* costs, int n, double target, double lo, double hi, double* lam_out) {
-    return essps_lambda<32>(
-               [&](const double* grid, double* ess) {
-                   for (int j = 0; j < 32; ++j) ess[j] = stats_of(costs, n, (double)(float)grid[j]).ess();
-                   return true;
-               },
-               target, lo, hi, *lam_out) ? 0 : -1;
+// lam_prev > 0: warm start from the previous root; passes_out = number of grids (passes over the costs) the search took
+int search_essps(const float* costs, int n, double target, double lo, double hi, double lam_prev, double* lam_out,
+                 int* passes_out) {
+    int passes = 0;
+    EsspsRoot prev{lam_prev, lam_prev > 0.0 ? std::log(lam_prev) : 0.0, lam_prev > 0.0};
+    const bool ok = essps_lambda<32>(
+        [&](const double* grid, double* ess) {
+            ++passes;
+            for (int j = 0; j < 32; ++j) ess[j] = stats_of(costs, n, (double)(float)grid[j]).ess();
+            return true;
+        },
+        target, lo, hi, *lam_out, prev);
+    if (passes_out) *passes_out = passes;
+    return ok ? 0 : -1;
+}
+int search_essps_first_grid(double lam_prev, double lo, double hi, double* grid32) {
+    double lg[32];
+    essps_first_grid<32>(lam_prev > 0.0, lam_prev > 0.0 ? std::log(lam_prev) : 0.0, essps_range(lo, hi), grid32, lg);
+    return 0;
 }
 
 // `steps` MPO updates, each on its own cost vector costs[s][n]; lambdas_out[s] = exp(logT) after step s

@@ -375,3 +375,35 @@ def test_lbps_grid_search_finds_the_brent_minimum_on_random_costs():
         assert f <= f_ref + 1e-6 * abs(f_ref), (i, lam, res.x, f, f_ref)
         if abs(lam - res.x) > 2e-3 * res.x:  # a different temperature only where the objective is no worse
             assert f <= f_ref + 1e-7 * abs(f_ref), (i, lam, res.x)
+
+
+def test_essps_warm_start_lands_on_the_same_root():
+    """The clustered first grid (host_search.hpp::essps_first_grid, mirrored by _host.essps_first_grid): same points in C++
+    and numpy, sorted, end points exact; a search warm-started from anywhere gives the reference's lambda (the fixtures'
+    brentq roots) — in ONE pass over the costs when the previous root is within the cluster, in two otherwise."""
+    import emul
+
+    for prev in (0.0, 0.02, 0.3, 1.0, 2.5, 6.5, 9.9):
+        for lo, hi in ((0.01, 10.0), (1e-3, 1e3), (0.5, 2.0)):
+            gc, gp = emul.essps_first_grid(prev, lo, hi), _host.essps_first_grid(prev, lo, hi)[0]
+            assert np.allclose(gc, gp, rtol=1e-14, atol=0)
+            assert gc[0] == lo and gc[-1] == hi and np.all(np.diff(gc) > 0)
+            if prev and lo * 1.6 < prev < hi / 1.6:  # warm: the cluster is there, and no gap is wider than ~1/10 of the log-range
+                near = (gc > prev / 1.51) & (gc < prev * 1.51)
+                assert near.sum() == 22 and np.max(gc[near][1:] / gc[near][:-1]) < 1.05
+                assert np.max(np.log(gc[1:] / gc[:-1])) <= np.log(hi / lo) / 8
+    one_pass = 0
+    for name in ("pendulum_T50_N1000_essps", "nav2d_T50_N512_essps", "cartpole_T64_N1024_essps_sg",
+                 "nav2d_T30_N4096_essps", "racing_T25_N1024_essps"):
+        g, cfg = load(name), CASES[name]
+        for k in range(int(g["K"])):
+            c, want = g[f"costs_{k}"], float(g[f"lambda_{k}"])
+            multi = lambda lams, c=c: np.array([_host.ess_from_stats(_np_stats(c)(l)) for l in lams])  # noqa: E731
+            for f in (1.0, 0.97, 1.2, 0.7, 1.49, 0.1, 3.0, 30.0):
+                lam, passes = emul.essps(c, cfg["N"] / 10, 0.01, 10.0, lam_prev=want * f, with_passes=True)
+                assert abs(lam - want) <= 1e-5 * want, (name, k, f, lam, want)
+                lam_py = _host.essps_lambda_grid(multi, cfg["N"] / 10, 0.01, 10.0, lam_prev=want * f)
+                assert abs(lam_py - lam) <= 2e-6 * lam, (name, k, f, lam_py, lam)
+                one_pass += passes == 1
+                assert passes in (1, 2) and (passes == 2 or lam in (0.01, 10.0) or 1 / 1.5 < f < 1.5), (name, k, f, passes)
+    assert one_pass > 20  # (a sharp ESS curve — few samples — may fail the convergence check and take the second grid)
