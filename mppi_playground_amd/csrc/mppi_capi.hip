@@ -1075,7 +1075,7 @@ static int solve_fused(mppi_handle_t h, float lambda, float* action_out, float* 
         HIP_TRY(h, hipMalloc(&h->fused_cells, bytes));
         HIP_TRY(h, hipMemset(h->fused_cells, 0, bytes));
         HIP_TRY(h, hipMalloc(&h->grid0_dev, sizeof(double) * STATS_L));
-        HIP_TRY(h, hipHostMalloc((void**)&h->fused_error, sizeof(int) * 32, hipHostMallocMapped));
+        HIP_TRY(h, hipHostMalloc((void**)&h->fused_error, sizeof(int) * 64, hipHostMallocMapped));
         *h->fused_error = 0;
         HIP_TRY(h, hipHostGetDevicePointer((void**)&h->fused_error_dev, h->fused_error, 0));
         HIP_TRY(h, hipDeviceSynchronize());
@@ -1727,10 +1727,11 @@ int mppi_p2p_exchange(mppi_handle_t h, const float* data_dev, float* gathered_ou
 // 1 once a poll of the single-launch solve timed out on this handle (read without synchronising): that solve's outputs
 // are void (NaN) and the handle has returned to the multi-kernel path
 #ifdef MPPI_FUSED_TRACE
-extern "C" int mppi_debug_fused_trace(mppi_handle_t h, int* out10) {  // (out: 24 ints)  // 10 ns ticks since block 0 started, per phase boundary
+extern "C" int mppi_debug_fused_trace(mppi_handle_t h, int* out10) {  // (out: 56 ints)  // 10 ns ticks since block 0 started, per phase boundary
     if (!h || !h->fused_error) return MPPI_E_STATE;
     (void)hipDeviceSynchronize();
     for (int k = 0; k < 24; ++k) { out10[k] = h->fused_error[1 + k]; h->fused_error[1 + k] = 0; }
+    for (int k = 0; k < 32; ++k) out10[24 + k] = h->fused_error[32 + k];
     return MPPI_OK;
 }
 #endif

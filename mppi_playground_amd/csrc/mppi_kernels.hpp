@@ -1355,7 +1355,7 @@ __global__ __launch_bounds__(WAVE) void mpo_step_kernel(const float* __restrict_
 // weighted row are summed over another partition, i.e. the temperature and the action agree to rounding.  Deterministic.
 // A poll that does not complete within ~2 s (a block that never became resident: the device is shared with another
 // cooperative kernel) raises *error, voids the outputs and returns — no hang.
-constexpr int FUSED_BLOCK = 1024;
+constexpr int FUSED_BLOCK = 512;
 constexpr int FUSED_MAX_BLOCKS = 256;
 constexpr int FUSED_MAX_ROW = 128;
 constexpr int FUSED_SMALL_BLOCKS = 32;       // up to this many blocks no hop is spent on the global minimum or on a broadcast
@@ -1433,6 +1433,77 @@ struct FusedArgs {
     float* summary_out;     // [4 + row] the shard summary, for later readers
 };
 
+// The scalar step of a search round of the single-launch solve, for ONE wave (lane j): statistics sums -> ESS / LBPS
+// objective per temperature -> essps_round0/1 (wave-parallel) or lbps_grid_step -> the next grid or the temperature, left
+// in s_lams[0..31] (next grid as fp32, zeros once the temperature is known), s_lams[32] (1 = known), s_lams[33] (it).
+// NOT inlined: its double-precision code (and what the compiler would hoist out of the rounds loop for it) stays out of
+// the register budget and the loop pre-header of solve_fused_kernel, where all the other waves would execute it too.
+struct FusedRule {  // (by value: a reference to the kernel's argument block would have to be spilled to scratch memory for the call)
+    int rule;
+    double rule_param, lam_min, lam_max;
+    mppi::host::EsspsRange range;
+    EsspsDev* essps;
+    float* lams0;
+    float* lambda_dev;
+    double* lambda_host;
+};
+__device__ __noinline__ void fused_scalar_step(FusedRule A, int r, int rounds, bool first_block, int j, double* s_sumd,
+                                               double* s_vald, double* s_gridd, double* s_lgridd, float* s_lams, const float* s_bc) {
+    if (j < STATS_L) {
+        if (A.rule == FUSED_RULE_ESSPS) s_vald[j] = s_sumd[3 * j] * s_sumd[3 * j] / s_sumd[3 * j + 1];
+        else s_vald[j] = mppi::host::lbps_objective(
+            mppi::host::SoftmaxStats{(double)s_bc[2], (double)s_bc[3], s_sumd[3 * j], s_sumd[3 * j + 1], s_sumd[3 * j + 2]},
+            A.rule_param);
+    }
+    __builtin_amdgcn_wave_barrier();
+    double lam = 0.0, gj = 0.0, lgj = 0.0;
+    bool have;
+    if (A.rule == FUSED_RULE_ESSPS) {
+        mppi::host::EsspsRoot root{0.0, 0.0, false};  // (wave-uniform)
+        int i = 1;
+        have = true;
+        if (r == 0) have = essps_round0_wave<STATS_L>(s_lgridd, s_vald, A.rule_param, A.range, j, i, root);
+        else root = essps_round1_wave<STATS_L>(s_gridd, s_lgridd, s_vald, A.rule_param, j);
+        lam = root.lam;
+        if (j < STATS_L) {  // the next grid, one point per lane
+            if (!have) {
+                const double lo = s_gridd[i - 1], hi = s_gridd[i], llo = s_lgridd[i - 1], lhi = s_lgridd[i];
+                mppi::host::essps_point<STATS_L>(lo, hi, llo, lhi, j, gj, lgj);
+                __builtin_amdgcn_wave_barrier();
+                s_gridd[j] = gj; s_lgridd[j] = lgj;
+            } else if (first_block) {  // the next ESSPS search starts around this root
+                double g0, lg0;
+                mppi::host::essps_first_point<STATS_L>(root.warm, root.log_lam, A.range, j, g0, lg0);
+                A.essps->grid0[j] = g0; A.essps->lgrid0[j] = lg0;
+                A.lams0[j] = (float)g0;
+            }
+        }
+    } else {
+        if (j == 0) {
+            double lo = A.lam_min, hi = A.lam_max;
+            mppi::host::lbps_grid_step<STATS_L>(s_gridd, s_vald, r == rounds - 1, lo, hi, lam);
+            s_sumd[0] = lo; s_sumd[1] = hi; s_sumd[2] = lam;
+        }
+        __builtin_amdgcn_wave_barrier();
+        have = r == rounds - 1;
+        lam = s_sumd[2];
+        if (!have && j < STATS_L) {
+            gj = mppi::host::essps_grid_point<STATS_L>(s_sumd[0], s_sumd[1], j);
+            s_gridd[j] = gj;
+        }
+    }
+    if (j < STATS_L) s_lams[j] = have ? 0.0f : (float)gj;  // (zeros once the temperature is known)
+    if (j == 0) {
+        if (have && first_block) {
+            *A.lambda_dev = (float)lam;
+            s_vald[0] = lam; s_vald[1] = (double)(r + 1);  // (block 0 copies them to the host's mirror at the very end of the kernel:
+                                                           // a store to host memory holds up every later wait on memory of this wave)
+        }
+        s_lams[STATS_L + 1] = have ? (float)lam : 0.0f;
+        s_lams[STATS_L] = have ? 1.0f : 0.0f;
+    }
+}
+
 template <int MODEL, int FAST>
 __global__ __launch_bounds__(FUSED_BLOCK) void solve_fused_kernel(FusedArgs A, Dims d, GenCtx gen, ModelCtx ctx,
                                                                   SgFilter sg, FusedCtx fx) {
@@ -1440,7 +1511,7 @@ __global__ __launch_bounds__(FUSED_BLOCK) void solve_fused_kernel(FusedArgs A, D
     constexpr int NWV = FUSED_BLOCK / WAVE;
     constexpr bool UC = FAST != 0;
     constexpr int KG = 32;                         // cells a thread keeps in flight: every gather is ONE round trip (G <= 256)
-    constexpr int KS = 5;                          // ... with few blocks (G <= 32 over >= 7 thread groups)
+    constexpr int KS = (FUSED_SMALL_BLOCKS + FUSED_BLOCK / FX_CELLS - 1) / (FUSED_BLOCK / FX_CELLS);                          // ... with few blocks (G <= 32 over >= 7 thread groups)
     constexpr int COLS = STATS_L * 3;              // 96 statistics columns
     constexpr int SPARTS = FUSED_BLOCK / COLS;     // 10 row groups of the statistics combine
     constexpr int CW = FX_CELLS;                   // column slots of the row fold (>= 4 + row)
@@ -1459,6 +1530,7 @@ __global__ __launch_bounds__(FUSED_BLOCK) void solve_fused_kernel(FusedArgs A, D
     __shared__ float s_x0[MPPI_MAX_DIM_STATE];
 #ifdef MPPI_FUSED_TRACE
     __shared__ int s_trace[24];
+    __shared__ int s_wtrace[16][2];  // (per wave: start / end of the round-0 statistics)
     if (threadIdx.x < 24) s_trace[threadIdx.x] = 0;
 #endif
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];  // [8R] mean groups, [T*KROW] step rows, then the tail's staging
@@ -1530,7 +1602,7 @@ __global__ __launch_bounds__(FUSED_BLOCK) void solve_fused_kernel(FusedArgs A, D
         if (!small) {
             float gm = INFINITY, gx = -INFINITY;
             if (tid < G) gm = fx_get(fx, FX_MIN, tid, 0, t0, timed_out);                                   // G <= 256
-            else if (tid >= 512 && tid - 512 < G) gx = fx_get(fx, FX_MIN, tid - 512, 1, t0, timed_out);
+            else if (tid >= FUSED_BLOCK / 2 && tid - FUSED_BLOCK / 2 < G) gx = fx_get(fx, FX_MIN, tid - FUSED_BLOCK / 2, 1, t0, timed_out);
             gm = wave_min(gm);
 #pragma unroll
             for (int m = 32; m >= 1; m >>= 1) gx = fmaxf(gx, __shfl_xor(gx, m));
@@ -1564,11 +1636,10 @@ __global__ __launch_bounds__(FUSED_BLOCK) void solve_fused_kernel(FusedArgs A, D
         for (int r = 0; r < rounds; ++r) {
             // statistics of this block's costs for the 32 temperatures of round r (stats_multi_kernel's arithmetic)
             // (thread = temperature l x one of 32 runs of spb/32 consecutive costs: every thread of the block works)
-#ifdef MPPI_FUSED_TRACE_REPEAT
-          for (int rep = 0; rep < 2; ++rep) {  // experiment: the same code twice — is the first pass slow because it is cold?
-            if (rep == 1) { __syncthreads(); if (r == 0) FX_TRACE(19); }
+#ifdef MPPI_FUSED_TRACE
+            if (b == 0 && r == 0 && lane == 0) s_wtrace[wid][0] = (int)(wall_clock64() - t0);
 #endif
-            const int l = tid & (STATS_L - 1), chunk = tid >> 5, per = A.spb >> 5;
+            const int l = tid & (STATS_L - 1), chunk = tid >> 5, per = A.spb / (FUSED_BLOCK / STATS_L);
             const float lam_l = r == 0 ? (float)s_gridd[l] : s_lams[l];
             const float inv_lam = 1.0f / lam_l;
             float se = 0.0f, se2 = 0.0f, sec = 0.0f;
@@ -1586,12 +1657,11 @@ __global__ __launch_bounds__(FUSED_BLOCK) void solve_fused_kernel(FusedArgs A, D
             se += __shfl_xor(se, 32); se2 += __shfl_xor(se2, 32); sec += __shfl_xor(sec, 32);
             if (lane < STATS_L) { s_p[wid][lane][0] = se; s_p[wid][lane][1] = se2; s_p[wid][lane][2] = sec; }
             if (r == 0) FX_TRACE(15);
+#ifdef MPPI_FUSED_TRACE
+            if (b == 0 && r == 0 && lane == 0) s_wtrace[wid][1] = (int)(wall_clock64() - t0);
+#endif
             __syncthreads();
             if (r == 0) FX_TRACE(16);
-#ifdef MPPI_FUSED_TRACE_REPEAT
-            if (rep == 1) break;
-          }
-#endif
             if (tid < COLS) {
                 float v = 0.0f;
 #pragma unroll
@@ -1653,61 +1723,10 @@ __global__ __launch_bounds__(FUSED_BLOCK) void solve_fused_kernel(FusedArgs A, D
                 __syncthreads();
                 if (r == 0) FX_TRACE(12);
                 if (tid < WAVE) {  // the scalar step: one wave (essps_select_kernel / lbps_select_kernel)
-                    const int j = tid;
-                    if (j < STATS_L) {
-                        if (A.rule == FUSED_RULE_ESSPS) s_vald[j] = s_sumd[3 * j] * s_sumd[3 * j] / s_sumd[3 * j + 1];
-                        else s_vald[j] = mppi::host::lbps_objective(
-                            mppi::host::SoftmaxStats{(double)s_bc[2], (double)s_bc[3], s_sumd[3 * j], s_sumd[3 * j + 1], s_sumd[3 * j + 2]},
-                            A.rule_param);
-                    }
-                    __builtin_amdgcn_wave_barrier();
                     if (r == 0) FX_TRACE(17);
-                    double lam = 0.0, gj = 0.0, lgj = 0.0;
-                    bool have;
-                    if (A.rule == FUSED_RULE_ESSPS) {
-                        mppi::host::EsspsRoot root{0.0, 0.0, false};  // (wave-uniform)
-                        int i = 1;
-                        have = true;
-                        if (r == 0) have = essps_round0_wave<STATS_L>(s_lgridd, s_vald, A.rule_param, A.range, j, i, root);
-                        else root = essps_round1_wave<STATS_L>(s_gridd, s_lgridd, s_vald, A.rule_param, j);
-                        lam = root.lam;
-                        if (j < STATS_L) {  // the next grid, one point per lane
-                            if (!have) {
-                                const double lo = s_gridd[i - 1], hi = s_gridd[i], llo = s_lgridd[i - 1], lhi = s_lgridd[i];
-                                mppi::host::essps_point<STATS_L>(lo, hi, llo, lhi, j, gj, lgj);
-                                __builtin_amdgcn_wave_barrier();
-                                s_gridd[j] = gj; s_lgridd[j] = lgj;
-                            } else if (b == 0) {  // the next ESSPS search starts around this root
-                                double g0, lg0;
-                                mppi::host::essps_first_point<STATS_L>(root.warm, root.log_lam, A.range, j, g0, lg0);
-                                A.essps->grid0[j] = g0; A.essps->lgrid0[j] = lg0;
-                                A.lams0[j] = (float)g0;
-                            }
-                        }
-                    } else {
-                        if (j == 0) {
-                            double lo = A.lam_min, hi = A.lam_max;
-                            mppi::host::lbps_grid_step<STATS_L>(s_gridd, s_vald, r == rounds - 1, lo, hi, lam);
-                            s_sumd[0] = lo; s_sumd[1] = hi; s_sumd[2] = lam;
-                        }
-                        __builtin_amdgcn_wave_barrier();
-                        have = r == rounds - 1;
-                        lam = s_sumd[2];
-                        if (!have && j < STATS_L) {
-                            gj = mppi::host::essps_grid_point<STATS_L>(s_sumd[0], s_sumd[1], j);
-                            s_gridd[j] = gj;
-                        }
-                    }
-                    if (j < STATS_L) s_lams[j] = have ? 0.0f : (float)gj;  // (zeros once the temperature is known)
-                    if (j == 0) {
-                        if (have && b == 0) {
-                            *A.lambda_dev = (float)lam;
-                            A.lambda_host[0] = lam; A.lambda_host[1] = lam; A.lambda_host[2] = (double)(r + 1);
-                        }
-                        s_lams[STATS_L + 1] = have ? (float)lam : 0.0f;
-                        s_lams[STATS_L] = have ? 1.0f : 0.0f;
-                        if (r == 0) FX_TRACE(18);
-                    }
+                    fused_scalar_step(FusedRule{A.rule, A.rule_param, A.lam_min, A.lam_max, A.range, A.essps, A.lams0, A.lambda_dev, A.lambda_host},
+                                      r, rounds, b == 0, tid, s_sumd, s_vald, s_gridd, s_lgridd, s_lams, s_bc);
+                    if (r == 0) FX_TRACE(18);
                 }
                 __syncthreads();
                 if (r == 0) FX_TRACE(13);
@@ -1861,9 +1880,11 @@ __global__ __launch_bounds__(FUSED_BLOCK) void solve_fused_kernel(FusedArgs A, D
     }
     finalize_tail<MODEL, FAST>(s_sum, 1, lambda, d.row, d.T, s_x0, s_act, s_yp, A.mean_store, A.action_out, A.state_out,
                                A.stats_out, A.stats_keep, sg, ctx);
+    if (tid == 0 && A.rule != FUSED_RULE_NONE) { A.lambda_host[0] = s_vald[0]; A.lambda_host[1] = s_vald[0]; A.lambda_host[2] = s_vald[1]; }
     FX_TRACE(9);
 #ifdef MPPI_FUSED_TRACE
     if (tid == 0) for (int k = 0; k < 24; ++k) fx.error[1 + k] = s_trace[k];
+    if (tid < 32) fx.error[32 + tid] = s_wtrace[tid >> 1][tid & 1];
 #endif
 }
 
