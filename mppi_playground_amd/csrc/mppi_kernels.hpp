@@ -1438,17 +1438,21 @@ struct FusedArgs {
 // in s_lams[0..31] (next grid as fp32, zeros once the temperature is known), s_lams[32] (1 = known), s_lams[33] (it).
 // NOT inlined: its double-precision code (and what the compiler would hoist out of the rounds loop for it) stays out of
 // the register budget and the loop pre-header of solve_fused_kernel, where all the other waves would execute it too.
-struct FusedRule {  // (by value: a reference to the kernel's argument block would have to be spilled to scratch memory for the call)
-    int rule;
-    double rule_param, lam_min, lam_max;
-    mppi::host::EsspsRange range;
-    EsspsDev* essps;
-    float* lams0;
-    float* lambda_dev;
-    double* lambda_host;
+struct FusedSearchLds {  // the search's staging in LDS (ONE pointer for the call: arguments beyond 32 dwords travel through scratch memory)
+    double sumd[STATS_L * 3];
+    double vald[STATS_L], gridd[STATS_L], lgridd[STATS_L];
+    float lams[STATS_L + 2];
+    float bc[4];  // [0] block minimum, [1] block maximum, [2] global minimum, [3] global maximum
 };
-__device__ __noinline__ void fused_scalar_step(FusedRule A, int r, int rounds, bool first_block, int j, double* s_sumd,
-                                               double* s_vald, double* s_gridd, double* s_lgridd, float* s_lams, const float* s_bc) {
+// (every argument a scalar: 27 dwords, all in registers — a struct by value, like anything beyond 32 dwords, would travel
+// through scratch memory, a store -> load round trip at the head of the call)
+__device__ __noinline__ void fused_scalar_step(int rule, int r, int rounds, bool first_block, int j, double rule_param, double lam_min,
+                                               double lam_max, double range_lmin, double range_lmax, EsspsDev* essps, float* lams0,
+                                               float* lambda_dev, FusedSearchLds* S) {
+    struct { int rule; double rule_param, lam_min, lam_max; mppi::host::EsspsRange range; EsspsDev* essps; float* lams0; float* lambda_dev; }
+        A{rule, rule_param, lam_min, lam_max, mppi::host::EsspsRange{lam_min, lam_max, range_lmin, range_lmax}, essps, lams0, lambda_dev};
+    double* s_sumd = S->sumd; double* s_vald = S->vald; double* s_gridd = S->gridd; double* s_lgridd = S->lgridd;
+    float* s_lams = S->lams; const float* s_bc = S->bc;
     if (j < STATS_L) {
         if (A.rule == FUSED_RULE_ESSPS) s_vald[j] = s_sumd[3 * j] * s_sumd[3 * j] / s_sumd[3 * j + 1];
         else s_vald[j] = mppi::host::lbps_objective(
@@ -1521,10 +1525,10 @@ __global__ __launch_bounds__(FUSED_BLOCK) void solve_fused_kernel(FusedArgs A, D
     __shared__ float s_w[NWV][4];                  // per-wave scalars
     __shared__ double s_scratch[2048];             // statistics combine [SPARTS][COLS] doubles; aliased: row partials, 4096 floats
     __shared__ float s_fold[RPARTS][CW];           // block 0's row fold
-    __shared__ double s_sumd[COLS];
-    __shared__ double s_vald[STATS_L], s_gridd[STATS_L], s_lgridd[STATS_L];
-    __shared__ float s_lams[STATS_L + 2];
-    __shared__ float s_bc[4];                      // [0] block minimum, [1] block maximum, [2] global minimum, [3] global maximum
+    __shared__ FusedSearchLds s_search;
+    double* const s_sumd = s_search.sumd; double* const s_vald = s_search.vald;
+    double* const s_gridd = s_search.gridd; double* const s_lgridd = s_search.lgridd;
+    float* const s_lams = s_search.lams; float* const s_bc = s_search.bc;
     __shared__ float s_ref[2][FUSED_SMALL_BLOCKS]; // few blocks: the blocks' reference costs / their maxima or rescale factors
     __shared__ int s_flag;
     __shared__ float s_x0[MPPI_MAX_DIM_STATE];
@@ -1724,8 +1728,8 @@ __global__ __launch_bounds__(FUSED_BLOCK) void solve_fused_kernel(FusedArgs A, D
                 if (r == 0) FX_TRACE(12);
                 if (tid < WAVE) {  // the scalar step: one wave (essps_select_kernel / lbps_select_kernel)
                     if (r == 0) FX_TRACE(17);
-                    fused_scalar_step(FusedRule{A.rule, A.rule_param, A.lam_min, A.lam_max, A.range, A.essps, A.lams0, A.lambda_dev, A.lambda_host},
-                                      r, rounds, b == 0, tid, s_sumd, s_vald, s_gridd, s_lgridd, s_lams, s_bc);
+                    fused_scalar_step(A.rule, r, rounds, b == 0, tid, A.rule_param, A.lam_min, A.lam_max, A.range.lmin, A.range.lmax, A.essps,
+                                      A.lams0, A.lambda_dev, &s_search);
                     if (r == 0) FX_TRACE(18);
                 }
                 __syncthreads();
