@@ -38,6 +38,6 @@ for key, label, work, b_alg, make, x0 in _other_solvers(torch, np, which=("c1", 
         parts.append(f"| inside search r0 (us from the min hop): costs staged {f[14]:.1f}, sums computed {f[15]:.1f}, block-synced {f[16]:.1f}, " +
                      (f"[first pass done {f[19]:.1f}] " if acc[19] > 0 else "") + f"published {f[10]:.1f}, gathered {f[11]:.1f}, combined {f[12]:.1f}, ESS per lane {f[17]:.1f}, lane-0 step {f[18]:.1f}, next grid + sync {f[13]:.1f}")
     if acc[10] > 0:
-        wt = (acc[24:56].reshape(16, 2) - acc[2])
+        wt = (acc[24:56].reshape(16, 2) - acc[2])[:8]  # (8 waves per block)
         parts.append("| per wave, statistics of round 0 (start -> done, us from the min hop): " + " ".join(f"{a:.1f}->{b:.1f}" for a, b in wt))
     print(f"{label}: {us:.1f} us/solve end to end; block 0 from its start: " + ", ".join(parts) + f" = {prev:.1f} us", flush=True)

@@ -23,6 +23,9 @@ for spec in "2 all" "2 nccl" "8 all"; do
 done
 MASTER_PORT=29543 timeout 300 python scripts/nccl_single_rank.py 2>&1 | grep -E "forced exchange|RCCL all_gather" > gpurun_out/nccl_single_rank.txt
 timeout 300 python scripts/fused_timing.py 2>&1 | grep -v amdgpu.ids > gpurun_out/fused_timing.txt
+timeout 300 python scripts/essps_passes.py 2>&1 | grep -v amdgpu.ids > gpurun_out/essps_passes.txt
+[ -f mppi_playground_amd/csrc/variants/lib_trace.so ] && MPPI_HIP_LIB=mppi_playground_amd/csrc/variants/lib_trace.so timeout 300 python scripts/fused_trace.py 2>&1 | grep -v amdgpu.ids > gpurun_out/fused_trace.txt
+scripts/ubench/icache_cold > gpurun_out/ubench_cold_code.txt 2>&1; scripts/ubench/clock_cost > gpurun_out/ubench_clock_cost.txt 2>&1
 cd /tmp
 B="python $R/bench.py --no-cpu-baseline --no-extras"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $P -o kt -- $B --steps 30 --warmup 5 > $R/gpurun_out/rocprof_kt.log 2>&1

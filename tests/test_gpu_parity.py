@@ -1676,6 +1676,39 @@ def test_essps_device_search_equals_the_host_loop_on_random_costs():
             assert abs(lam_dev.value - lam_host.value) <= 5e-6 * lam_host.value, (name, target, lam_dev.value, lam_host.value)
 
 
+@pytest.mark.parametrize("fused", [0, 2])
+def test_essps_warm_start_in_a_closed_loop(fused):
+    """From the second solve on the device-resident ESSPS search starts from the grid the previous search left around its
+    root: ONE pass over the costs (mppi_search_passes) while the temperature moves slowly, the same temperature as a cold
+    search of the same costs (to the rule's own resolution) and as the reference's brentq on them; reset() /
+    option "essps_cold" bring the next search back to the geometric grid (two passes)."""
+    _need_gpu()
+    from scipy.optimize import brentq
+
+    solver, _ = make_solver("nav2d", 30, 4096, lambda_="ESSPS")
+    solver.set_option("fused_solve", fused)
+    h = solver._h
+    x = torch.tensor([-9.0, -9.0, 0.785]).cuda()
+    passes = []
+    for k in range(12):
+        if k == 8:
+            solver.set_option("essps_cold", 1)
+        a, st = solver.forward(x)
+        passes.append(h.lib.mppi_search_passes(h.h, None))
+        lam = solver._last_lambda
+        c = solver._costs.cpu().numpy().astype(np.float64)
+        ess = lambda l: (lambda e: e.sum() ** 2 / (e * e).sum())(np.exp(-(c - c.min()) / l))  # noqa: E731
+        assert 0.01 < lam < 10.0
+        want = brentq(lambda l: ess(l) - 409.6, 0.01, 10.0, xtol=1e-13)
+        assert abs(lam - want) <= 1e-5 * want, (k, lam, want)
+        x = st[0, 1].clone()
+    assert passes[0] == 2 and passes[8] == 2, passes          # cold searches
+    assert passes[1:8].count(1) >= 4 and passes[9:].count(1) >= 1, passes  # warm ones (the first ticks of a loop move the temperature most)
+    solver.reset()
+    solver.forward(x)
+    assert h.lib.mppi_search_passes(h.h, None) == 2
+
+
 # ------------------------------------------------------------------------------ device-resident racing tick
 def _device_window(solver, ctrl, env, T, state, cind):
     """calc_ref_trajectory through the library: (reference_path [T+1,4], path index)."""
