@@ -242,17 +242,19 @@ int mppi_set_auto_lambda(mppi_handle_t h, int rule, double param, double lam_min
 int mppi_solve(mppi_handle_t h, const float* x0_dev, uint32_t solve_idx, float lambda, float* action_out_dev,
                float* state_seq_out_dev, float* stats_out_dev, void* stream);
 /* mppi_solve as a SINGLE LAUNCH.  For small problems (option "fused_solve" = 1, the default: num_samples <= 4096, the
- * sizes of the reference's examples) whose noise is regenerated in registers, with T*dim_control <= 128 and no sharding,
- * mppi_solve runs ONE cooperative kernel instead of 3-9 dependent launches: min(#CUs, ceil(N/64)) blocks exchange their
- * minima, the partial sums of the temperature search and their partial weighted rows through 8-byte {value, solve
- * number} cells in HBM (relaxed agent-scope stores, polled), block 0 runs the scalar steps and the tail of the solve.
- * Costs and minimum are bit-identical to the multi-kernel path; temperature, action and state sequences equal to
- * rounding (another summation partition).  "fused_solve" = 0 keeps the multi-kernel path, = 2 takes the single launch
- * whenever every block can be resident at once (num_samples <= 1024 x #CUs = 262 144; measured on par or slower than
- * the multi-kernel path beyond a few thousand samples: a cell round trip costs what a kernel boundary costs).  A poll
- * that cannot complete within ~2 s (the device is shared with another cooperative kernel and a block never became
- * resident) voids that solve's outputs (NaN), raises the flag below and returns the handle to the multi-kernel path —
- * it never hangs. */
+ * sizes of the reference's examples; <= 16 384 under a device-resident ESSPS / LBPS search) whose noise is regenerated in
+ * registers, with T*dim_control <= 128 and no sharding, mppi_solve runs ONE cooperative kernel instead of 3-9 dependent
+ * launches: min(#CUs, ceil(N/64)) blocks of 512 threads (at most 32 of them up to 4096 samples) exchange the partial sums
+ * of the temperature search and their partial weighted rows through 8-byte {value, solve number} cells in HBM (relaxed
+ * agent-scope stores, polled); with up to 32 blocks every block runs the search's scalar step itself and no hop is spent
+ * on the global minimum (a block's sums are relative to its own minimum and rescaled where they are added), beyond
+ * block 0 does and broadcasts; block 0 runs the tail of the solve.  Costs and minimum are bit-identical to the
+ * multi-kernel path; temperature, action and state sequences equal to rounding (another summation partition).
+ * "fused_solve" = 0 keeps the multi-kernel path, = 2 takes the single launch whenever every block can be resident at once
+ * (num_samples <= 512 x #CUs = 131 072; measured on par or slower than the multi-kernel path beyond the defaults above:
+ * a cell round trip costs what a kernel boundary costs).  A poll that cannot complete within ~2 s (the device is shared
+ * with another cooperative kernel and a block never became resident) voids that solve's outputs (NaN), raises the flag
+ * below and returns the handle to the multi-kernel path — it never hangs. */
 int mppi_fused_error(mppi_handle_t h);
 /* Step 7 inside mppi_finalize (mppi.py:423-443,598-620): Savitzky-Golay smoothing of [history(T-1); a(T)] per control
  * dimension (symmetric-flip padding, valid cross-correlation, keep the last T), applied whenever mppi_finalize is

@@ -1034,13 +1034,16 @@ int mppi_finalize(mppi_handle_t h, const float* summaries_dev, int num_shards, f
 }
 
 // ---- the single-launch solve (solve_fused_kernel)
-static constexpr int64_t FUSED_AUTO_MAX_SAMPLES = 4096;
+static constexpr int64_t FUSED_AUTO_MAX_SAMPLES = 4096;          // fixed temperature / MPO
+static constexpr int64_t FUSED_AUTO_MAX_SAMPLES_SEARCH = 16384;  // ESSPS / LBPS on the device
 static bool fused_applies(mppi_handle_t h, float lambda) {
     if (!h->fused_mode || h->cfg.model == MPPI_MODEL_GENERIC || h->mapping != 0) return false;
-    // measured (profiles/r03_experiments.md): a cell round trip costs about as much as a kernel boundary, so the single
-    // launch wins where the exchanges are few and small — up to a few thousand samples (the reference examples' sizes:
-    // 39 vs 49 us at N = 1000 with ESSPS, 22 vs 28 us for racing at N = 4000) — and is on par or slower beyond
-    if (h->fused_mode == 1 && h->d.N > FUSED_AUTO_MAX_SAMPLES) return false;
+    // measured (profiles/r03_experiments.md, r03_visitC_fused_crossover.txt): a cell round trip costs about as much as a
+    // kernel boundary, so the single launch wins where it replaces more kernel boundaries than it needs round trips — with
+    // a fixed temperature up to a few thousand samples (27 vs 32 us for racing at N = 1024, 29 vs 32 at 4096, 33 vs 32 at
+    // 8192), under a temperature search further (nav2d ESSPS 32 vs 47 us at N = 1024, 48 vs 52 at 16 384, 51 vs 52 at 32 768)
+    const bool search = lambda == MPPI_LAMBDA_DEVICE && (h->auto_rule == MPPI_AUTO_ESSPS || h->auto_rule == MPPI_AUTO_LBPS);
+    if (h->fused_mode == 1 && h->d.N > (search ? FUSED_AUTO_MAX_SAMPLES_SEARCH : FUSED_AUTO_MAX_SAMPLES)) return false;
     if (!(h->noise_regen && !h->injected && !h->wide)) return false;         // the noise is regenerated in registers
     if (h->p2p_enabled || h->comm_enabled) return false;                      // sharded solves exchange between devices
     if (h->d.row > FUSED_MAX_ROW) return false;
