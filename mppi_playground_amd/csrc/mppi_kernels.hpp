@@ -1332,29 +1332,38 @@ __global__ __launch_bounds__(WAVE) void mpo_step_kernel(const float* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------
-// MPPI.forward() as ONE launch (mppi.py:223-460) for N <= 1024 x (number of CUs): a cooperative kernel.
+// MPPI.forward() as ONE launch (mppi.py:223-460) for N <= 512 x (number of CUs): a cooperative kernel.
 //
 // The multi-kernel solve of a small or medium problem is a chain of 3-9 dependent, latency-bound launches (launch + the
 // first load of data another XCD just wrote ~ 4-5 us each; a captured hipGraph replays the same chain:
-// profiles/r03_experiments.md).  Here the whole problem is resident at once — G = min(#CUs, ceil(N/64)) blocks of 1024
-// threads, block b owning `spb` consecutive trajectories (one per thread of its first spb/64 waves: small problems
-// spread over many CUs as lone waves, exactly like the stand-alone rollout kernel; the other waves of a block only help
-// with the exchanges) — and the blocks talk through CELLS in HBM instead of kernel boundaries: an 8-byte word
+// profiles/r03_experiments.md).  Here the whole problem is resident at once — G = min(#CUs, ceil(N/64)) blocks of 512
+// threads (at most 32 blocks up to 4096 trajectories), block b owning `spb` consecutive trajectories (one per thread of
+// its first spb/64 waves — ONE wave as long as CUs are left: small problems spread over many CUs as lone waves, exactly
+// like the stand-alone rollout kernel; the other waves of a block share its reductions and the regeneration of its
+// weighted noise rows) — and the blocks talk through CELLS in HBM instead of kernel boundaries: an 8-byte word
 // {fp32 value, 32-bit solve number} written with ONE relaxed agent-scope store and polled with agent-scope loads, so that
 // data and "ready" cannot be seen apart and no fence or grid barrier is needed (the protocol of the peer-to-peer
-// exchange, P2pCtx).  A round trip through a cell costs about as much as a kernel boundary (~2.5 us), so the exchanges
-// are arranged in as few DEPENDENT round trips as possible and every reader issues all its loads before it looks at the
-// first one (fx_get_many):
+// exchange, P2pCtx; a device-scope fence per block costs far more than a kernel boundary on this part).  A round trip
+// through a cell costs about as much as a kernel boundary (~2.5 us), so the exchanges are arranged in as few DEPENDENT
+// round trips as possible and every reader issues all its loads before it looks at the first one (fx_get_many):
+//   more than 32 blocks:
 //   1. every block publishes its minimum cost; every block reads all of them                              (1 round trip)
-//   2. ESSPS / LBPS only, per round: every block publishes the 96 partial sums of its 32-temperature statistics (+ its
-//      maximum cost); block 0 combines them (fixed order, double), runs the scalar step of the search (host_search.hpp,
-//      the code of essps_select_kernel / lbps_select_kernel) and broadcasts the next grid or the temperature  (2-3 each)
+//   2. ESSPS / LBPS only, per round: every block publishes the 96 partial sums of its 32-temperature statistics; block 0
+//      combines them (fixed order, double), runs the scalar step of the search (fused_scalar_step: host_search.hpp, the
+//      code of essps_select_kernel / lbps_select_kernel) and broadcasts the next grid or the temperature    (2 each)
 //   3. every block publishes its partial row sum_i e_i U_i and {sum e, sum e^2, sum e c} (zeros without a weight);
 //      block 0 folds them (fixed order) and runs the tail of the solve: normalise, filter, warm start, batch-1 rollout.
+//   up to 32 blocks: hop 1 and the broadcast disappear — a block's exponents are relative to its OWN minimum, published
+//   next to its sums; whoever adds the blocks' sums rescales them by exp((c_min - c_ref,b) / lambda) (finalize_tail's
+//   combine of shard summaries, applied to blocks), and EVERY block gathers the statistics and runs the scalar step
+//   itself (same inputs, same order: the same temperature in every block).
 // Costs and the minimum are BIT-IDENTICAL to the multi-kernel path (same device functions); the statistics and the
 // weighted row are summed over another partition, i.e. the temperature and the action agree to rounding.  Deterministic.
 // A poll that does not complete within ~2 s (a block that never became resident: the device is shared with another
 // cooperative kernel) raises *error, voids the outputs and returns — no hang.
+// 512 threads, not 1024: at 1024 the kernel is capped at 128 VGPRs, spilled to scratch memory, and every wave executed
+// the double-precision invariants the compiler hoisted out of the rounds loop for the scalar step (7 us per round on a
+// 28 us solve; profiles/r03_experiments.md) — hence also fused_scalar_step as a non-inlined function.
 constexpr int FUSED_BLOCK = 512;
 constexpr int FUSED_MAX_BLOCKS = 256;
 constexpr int FUSED_MAX_ROW = 128;
@@ -1415,7 +1424,7 @@ struct FusedArgs {
     unsigned* next_min_key; // the other slot, reset for the next multi-kernel rollout (it accumulates with atomicMin)
     float* mean_used;       // snapshots for later re-rolls (get_top_samples)
     float* x0_used;
-    int spb;                // trajectories per block (a multiple of 64, <= 1024)
+    int spb;                // trajectories per block (a multiple of 64, <= FUSED_BLOCK)
     int rule;               // FUSED_RULE_*
     double rule_param, lam_min, lam_max;
     float lambda_arg;       // rule == NONE: > 0, or MPPI_LAMBDA_DEVICE = read *lambda_dev
