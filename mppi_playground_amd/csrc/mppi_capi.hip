@@ -105,6 +105,7 @@ struct MppiSolver {
     float* heads = nullptr;
     float* summary = nullptr;
     float* stats_part = nullptr;     // [STATS_BLOCKS][max(4, STATS_L*3)]
+    double* stats_host_dev = nullptr;  // the device's view of stats_host
     double* stats_host = nullptr;    // mapped pinned [8 + STATS_L*3 + 3]: single-lambda stats, grid stats, device-searched lambda (next, used), its passes
     float* lams_dev = nullptr;       // [3][STATS_L]: caller's grid, ESSPS round-0 grid (preset), ESSPS round-1 grid (device-written)
     EsspsDev* essps_dev = nullptr;   // state of the device-resident ESSPS search
@@ -430,6 +431,7 @@ int mppi_create(const MppiConfig* cfg, mppi_handle_t* out) {
     HIP_TRY(h, hipMalloc(&h->summary, sizeof(float) * (size_t)(MPPI_SUMMARY_HEAD + d.row)));
     HIP_TRY(h, hipMalloc(&h->stats_part, sizeof(float) * STATS_L * 3 * STATS_BLOCKS));
     HIP_TRY(h, hipHostMalloc((void**)&h->stats_host, sizeof(double) * (8 + STATS_L * 3 + 3), hipHostMallocMapped));
+    HIP_TRY(h, hipHostGetDevicePointer((void**)&h->stats_host_dev, h->stats_host, 0));  // (looked up once: an API call per solve otherwise)
     HIP_TRY(h, hipMalloc(&h->mpo_dev, sizeof(mppi::host::MpoState)));
     HIP_TRY(h, hipMalloc(&h->mpo_temp_dev, sizeof(float)));
     HIP_TRY(h, hipMalloc(&h->lbps_dev, sizeof(LbpsDev)));
@@ -1102,7 +1104,7 @@ static int solve_fused(mppi_handle_t h, float lambda, float* action_out, float* 
     ++h->fused_seq;
     if (h->fused_seq == 0) h->fused_seq = 1;
     double* host_lam = nullptr;
-    HIP_TRY(h, hipHostGetDevicePointer((void**)&host_lam, h->stats_host, 0));
+    host_lam = h->stats_host_dev;
     host_lam += 8 + STATS_L * 3;
     FusedArgs A{};
     A.mean = h->mean; A.x0 = h->x0_cur; A.costs = h->costs;
@@ -1220,7 +1222,7 @@ int mppi_softmax_stats(mppi_handle_t h, float lambda, double* out5_host, void* s
                        (const float*)nullptr, h->stats_part);
     HIP_TRY(h, hipGetLastError());
     double* dev_out = nullptr;
-    HIP_TRY(h, hipHostGetDevicePointer((void**)&dev_out, h->stats_host, 0));
+    dev_out = h->stats_host_dev;
     hipLaunchKernelGGL(stats_combine_kernel, dim3(1), dim3(WAVE), 0, s, h->stats_part, blocks, mk, dev_out);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipStreamSynchronize(s));
@@ -1248,7 +1250,7 @@ int mppi_softmax_stats_multi(mppi_handle_t h, const float* lambdas_host, int cou
                        (const float*)h->lams_dev, h->stats_part, (const int32_t*)nullptr, (float*)nullptr);
     HIP_TRY(h, hipGetLastError());
     double* dev_out = nullptr;
-    HIP_TRY(h, hipHostGetDevicePointer((void**)&dev_out, h->stats_host, 0));
+    dev_out = h->stats_host_dev;
     hipLaunchKernelGGL(stats_multi_combine_kernel, dim3(1), dim3(1024), 0, s, h->stats_part, blocks, dev_out + 8);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipStreamSynchronize(s));
@@ -1268,7 +1270,7 @@ int mppi_essps_lambda_device(mppi_handle_t h, double target_ess, double lam_min,
     const unsigned* mk = h->min_key + h->min_slot;
     const int blocks = stats_blocks(h);
     double* host_lam = nullptr;
-    HIP_TRY(h, hipHostGetDevicePointer((void**)&host_lam, h->stats_host, 0));
+    host_lam = h->stats_host_dev;
     host_lam += 8 + STATS_L * 3;
     float* lams0 = h->lams_dev + STATS_L;
     float* lams1 = h->lams_dev + 2 * STATS_L;
@@ -1331,7 +1333,7 @@ int mppi_lbps_lambda_device(mppi_handle_t h, double delta, double lam_min, doubl
     const unsigned* mk = h->min_key + h->min_slot;
     const int blocks = stats_blocks(h);
     double* host_lam = nullptr;
-    HIP_TRY(h, hipHostGetDevicePointer((void**)&host_lam, h->stats_host, 0));
+    host_lam = h->stats_host_dev;
     host_lam += 8 + STATS_L * 3;
     for (int r = 0; r < LBPS_ROUNDS; ++r) {
         hipLaunchKernelGGL(stats_multi_kernel, dim3(blocks), dim3(STATS_THREADS), 0, s, h->costs, h->d.N, mk,
@@ -1426,7 +1428,7 @@ int mppi_mpo_step_device(mppi_handle_t h, void* stream) {
     const unsigned* mk = h->min_key + h->min_slot;
     const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(STATS_BLOCKS, (h->d.N + BLOCK - 1) / BLOCK));
     double* host_lam = nullptr;
-    HIP_TRY(h, hipHostGetDevicePointer((void**)&host_lam, h->stats_host, 0));
+    host_lam = h->stats_host_dev;
     host_lam += 8 + STATS_L * 3;
     hipLaunchKernelGGL(stats_partial_kernel, dim3(blocks), dim3(BLOCK), 0, s, h->costs, h->d.N, mk, 1.0f,
                        (const float*)h->mpo_temp_dev, h->stats_part);

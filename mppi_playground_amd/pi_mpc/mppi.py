@@ -34,6 +34,17 @@ def _ptr(t: Optional[torch.Tensor]):
 class MPPI(nn.Module):
     """Model Predictive Path Integral control (Williams et al., T-RO 2017) — MI355X-native."""
 
+    # Private state ("_name") never holds Parameters, sub-modules or buffers, so it skips nn.Module's attribute
+    # bookkeeping: forward() assigns about ten such attributes per solve and Module.__setattr__ costs ~1 us each — half of
+    # the host time of a small solve (scripts/host_profile.py).  Properties with setters keep the normal route.
+    _SETTER_PROPERTIES = frozenset(("_lambda", "_last_lambda", "_actions_history_for_sg"))
+
+    def __setattr__(self, name, value):
+        if name[0] == "_" and name not in MPPI._SETTER_PROPERTIES:
+            self.__dict__[name] = value
+        else:
+            super().__setattr__(name, value)
+
     def __init__(
         self,
         horizon: int,
@@ -128,6 +139,7 @@ class MPPI(nn.Module):
             raise ValueError(f"device={dev} is not the current device (cuda:{torch.cuda.current_device()}): select it "
                              "with torch.cuda.set_device() before constructing the solver")
         self._device = torch.device("cuda", torch.cuda.current_device())
+        self._device_index = self._device.index
         self._dtype = dtype
 
         self._horizon = horizon
@@ -348,7 +360,8 @@ class MPPI(nn.Module):
 
     # ------------------------------------------------------------------ helpers
     def _stream(self):
-        return C.c_void_p(torch.cuda.current_stream(self._device).cuda_stream)
+        # (the raw handle of torch's current stream on this device; torch.cuda.current_stream() builds a Stream object: ~4 us)
+        return C.c_void_p(torch._C._cuda_getCurrentRawStream(self._device_index))
 
     def _draw_torch_cpu(self) -> torch.Tensor:
         """`MultivariateNormal(0, diag(sigma^2)).rsample([N])` on torch's CPU generator: bit-identical
@@ -734,7 +747,10 @@ class MPPI(nn.Module):
         """forward() through mppi_solve: the same kernel sequence as the step-by-step path below in one library call
         (native model, device noise, fixed lambda or the device-resident ESSPS search, one GPU)."""
         if torch.is_tensor(state) and state.is_cuda:
-            self._x0_keep = state.detach().to(self._device, self._dtype).contiguous()
+            if state.dtype is self._dtype and state.device == self._device and state.is_contiguous():
+                self._x0_keep = state  # zero-copy as it is (kept alive until the next solve)
+            else:
+                self._x0_keep = state.detach().to(self._device, self._dtype).contiguous()
             x0p = _ptr(self._x0_keep)
         else:
             x0h = np.ascontiguousarray(state.detach().cpu().numpy() if torch.is_tensor(state) else state,
