@@ -1679,9 +1679,9 @@ def test_essps_device_search_equals_the_host_loop_on_random_costs():
 @pytest.mark.parametrize("fused", [0, 2])
 def test_essps_warm_start_in_a_closed_loop(fused):
     """From the second solve on the device-resident ESSPS search starts from the grid the previous search left around its
-    root: ONE pass over the costs (mppi_search_passes) while the temperature moves slowly, the same temperature as a cold
-    search of the same costs (to the rule's own resolution) and as the reference's brentq on them; reset() /
-    option "essps_cold" bring the next search back to the geometric grid (two passes)."""
+    root: ONE pass over the costs (mppi_search_passes) while the temperature moves slowly, and every tick the temperature
+    of the reference's brentq on a float64 evaluation of the same costs (<= 1e-5 relative); reset() / option "essps_cold"
+    bring the next search back to the geometric grid (two passes)."""
     _need_gpu()
     from scipy.optimize import brentq
 
