@@ -339,8 +339,11 @@ int mppi_rollout_samples(mppi_handle_t h, const int64_t* idx_dev, int k, float* 
  * weight = the smallest cost (radix select on the device), sorted by descending weight, their state
  * (k <= 1024: one block sorts the candidates in LDS; larger k: a multi-pass bitonic sort in HBM), their state
  * trajectories re-rolled around the mean that solve sampled (states_out_dev [k][T+1][ds]) and their softmax
- * weights softmax(-c/lambda)_i (weights_out_dev [k]).  lambda = the temperature of that solve.  On a shard this
- * ranks the shard's own samples (weights still use the global normalisation); see the two calls below. */
+ * weights softmax(-c/lambda)_i (weights_out_dev [k]).  lambda = the temperature of that solve, or
+ * MPPI_LAMBDA_DEVICE = the one its finalize step left in device memory (no read-back: the call never waits for the
+ * host).  Up to 4096 samples and k <= 1024 (the reference examples call this every tick with such sizes) the whole
+ * query is ONE launch: a block builds the (cost, index) words of all samples, sorts them in LDS and re-rolls the first k.
+ * On a shard this ranks the shard's own samples (weights still use the global normalisation); see the two calls below. */
 int mppi_top_samples(mppi_handle_t h, int k, float lambda, float* states_out_dev, float* weights_out_dev, void* stream);
 /* The two halves of mppi_top_samples for sharded solvers.  A candidate is (cost key << 32) | GLOBAL sample index; the
  * key is an order-preserving bijection of the fp32 cost, so candidates of all shards can be merged by sorting the

@@ -70,7 +70,7 @@ struct MppiSolver {
     bool injected = false;         // ... because it was injected (cannot be regenerated)
     float* mean = nullptr;
     float* mean_used = nullptr;      // the mean the last rollout sampled around (snapshot taken by the rollout kernel)
-    float* solve_stats = nullptr;    // {min c, sum e, sum e^2, sum e*c} over all shards of the last finalize
+    float* solve_stats = nullptr;    // [8]: {min c, sum e, sum e^2, sum e*c, lambda used} over all shards of the last finalize
     unsigned* topk_hist = nullptr;   // [3][TOPK_BINS] + 2 counters, kept zeroed between calls
     TopkSel* topk_sel = nullptr;     // [3]
     unsigned long long* topk_cand = nullptr;  // [topk_cap] (a power of two >= TOPK_MAX: the large-k sort pads to it)
@@ -418,8 +418,8 @@ int mppi_create(const MppiConfig* cfg, mppi_handle_t* out) {
     HIP_TRY(h, hipMemset(h->mean, 0, sizeof(float) * (size_t)d.row));  // mppi.py:157
     HIP_TRY(h, hipMalloc(&h->mean_used, sizeof(float) * (size_t)d.row));
     HIP_TRY(h, hipMemset(h->mean_used, 0, sizeof(float) * (size_t)d.row));
-    HIP_TRY(h, hipMalloc(&h->solve_stats, sizeof(float) * 4));
-    HIP_TRY(h, hipMemset(h->solve_stats, 0, sizeof(float) * 4));
+    HIP_TRY(h, hipMalloc(&h->solve_stats, sizeof(float) * 8));
+    HIP_TRY(h, hipMemset(h->solve_stats, 0, sizeof(float) * 8));
     HIP_TRY(h, hipMalloc(&h->topk_hist, sizeof(unsigned) * (3 * TOPK_BINS + 2)));
     HIP_TRY(h, hipMemset(h->topk_hist, 0, sizeof(unsigned) * (3 * TOPK_BINS + 2)));
     HIP_TRY(h, hipMalloc(&h->topk_sel, sizeof(TopkSel) * 3));
@@ -1563,7 +1563,7 @@ static int topk_sort_large(mppi_handle_t h, int k, hipStream_t s) {
 // sort k candidates, weigh and re-roll them; `clean` also resets the select state (after topk_select).  `cand` is
 // h->topk_cand when k > TOPK_MAX (sorted in place).
 static int topk_rollout(mppi_handle_t h, const unsigned long long* cand, int k, float lambda, float* states_out,
-                        float* weights_out, bool clean, bool need_local, hipStream_t s) {
+                        float* weights_out, bool clean, bool need_local, hipStream_t s, bool direct = false) {
     const bool gen = h->noise_regen && !h->injected;
     if (!gen && !h->tiles_valid) return fail(h, MPPI_E_STATE, "no noise: solve first");
     if (!gen && !need_local)
@@ -1572,7 +1572,8 @@ static int topk_rollout(mppi_handle_t h, const unsigned long long* cand, int k, 
     unsigned* counters = clean ? h->topk_hist + 3 * TOPK_BINS : nullptr;
     if (k <= TOPK_MAX) {
 #define CALL_TOPK(MODEL, FASTV)                                                                       \
-    hipLaunchKernelGGL((topk_rollout_kernel<MODEL, FASTV, false>), dim3(1), dim3(TOPK_MAX), 0, s, cand, k, h->noise, gen,  \
+    hipLaunchKernelGGL((topk_rollout_kernel<MODEL, FASTV, false>), dim3((unsigned)((k + WAVE - 1) / WAVE)), dim3(TOPK_MAX), 0, s, cand, k, \
+                       direct ? (const float*)h->costs : (const float*)nullptr, direct ? (int)h->d.N : 0, h->noise, gen,  \
                        h->mean_used, h->x0_used, h->solve_stats, lambda, states_out, weights_out, hist, counters,  \
                        h->d, h->gen, h->ctx)
         MPPI_DISPATCH(h, CALL_TOPK);
@@ -1582,8 +1583,8 @@ static int topk_rollout(mppi_handle_t h, const unsigned long long* cand, int k, 
         const unsigned grid = (unsigned)((k + WAVE - 1) / WAVE);
 #define CALL_TOPK_SORTED(MODEL, FASTV)                                                                \
     hipLaunchKernelGGL((topk_rollout_kernel<MODEL, FASTV, true>), dim3(grid), dim3(WAVE), 0, s, (const unsigned long long*)h->topk_cand, \
-                       k, h->noise, gen, h->mean_used, h->x0_used, h->solve_stats, lambda, states_out, weights_out, hist,  \
-                       counters, h->d, h->gen, h->ctx)
+                       k, (const float*)nullptr, 0, h->noise, gen, h->mean_used, h->x0_used, h->solve_stats, lambda, states_out,  \
+                       weights_out, hist, counters, h->d, h->gen, h->ctx)
         MPPI_DISPATCH(h, CALL_TOPK_SORTED);
 #undef CALL_TOPK_SORTED
     }
@@ -1592,9 +1593,15 @@ static int topk_rollout(mppi_handle_t h, const unsigned long long* cand, int k, 
 }
 
 int mppi_top_samples(mppi_handle_t h, int k, float lambda, float* states_out, float* weights_out, void* stream) {
-    if (!h || !states_out || !weights_out || !(lambda > 0.0f)) return fail(h, MPPI_E_INVALID, "bad top_samples arguments");
+    if (!h || !states_out || !weights_out || !(lambda > 0.0f || lambda == MPPI_LAMBDA_DEVICE))
+        return fail(h, MPPI_E_INVALID, "bad top_samples arguments");
     if (int rc = check_ready(h)) return rc;
     hipStream_t s = (hipStream_t)stream;
+    if (h->d.N <= TOPK_DIRECT_MAX && k <= TOPK_MAX) {  // small problems (the reference examples' sizes): ONE launch
+        if (k < 1 || k > h->d.N) return fail(h, MPPI_E_INVALID, "top samples: need 1 <= k <= num_samples");
+        if (h->d.sample_offset + h->d.N >= ((int64_t)1 << 32)) return fail(h, MPPI_E_INVALID, "top samples: global sample indices must be < 2^32");
+        return topk_rollout(h, nullptr, k, lambda, states_out, weights_out, false, true, s, true);
+    }
     if (int rc = topk_select(h, k, s)) return rc;
     return topk_rollout(h, h->topk_cand, k, lambda, states_out, weights_out, true, true, s);
 }
@@ -1611,7 +1618,7 @@ int mppi_top_candidates(mppi_handle_t h, int k, uint64_t* cand_out_dev, void* st
 
 int mppi_rollout_candidates(mppi_handle_t h, const uint64_t* cand_dev, int k, float lambda, float* states_out,
                             float* weights_out, void* stream) {
-    if (!h || !cand_dev || !states_out || !weights_out || !(lambda > 0.0f) || k < 1)
+    if (!h || !cand_dev || !states_out || !weights_out || !(lambda > 0.0f || lambda == MPPI_LAMBDA_DEVICE) || k < 1)
         return fail(h, MPPI_E_INVALID, "bad rollout_candidates arguments");
     if (int rc = check_ready(h)) return rc;
     hipStream_t s = (hipStream_t)stream;

@@ -802,6 +802,7 @@ __device__ __forceinline__ void finalize_tail(const float* summaries, int num_sh
     if (threadIdx.x == 0) {
         if (stats_out) { stats_out[0] = cmin; stats_out[1] = se; stats_out[2] = se2; stats_out[3] = sec; }
         stats_keep[0] = cmin; stats_keep[1] = se; stats_keep[2] = se2; stats_keep[3] = sec;
+        stats_keep[4] = lambda;  // the temperature these weights used (later queries: get_top_samples, _weights)
     }
     __syncthreads();
     if (sg.window > 0) {
@@ -1963,10 +1964,12 @@ struct TopkSel { unsigned prefix, krem; };  // high bits selected so far; how ma
 __device__ __forceinline__ constexpr int topk_shift(int pass) { return pass == 0 ? 21 : pass == 1 ? 10 : 0; }
 __device__ __forceinline__ constexpr int topk_bits(int pass) { return pass == 2 ? 10 : 11; }
 
-// Block-wide (BLOCK threads): the bin whose cumulative count first reaches krem, and the count below that bin.
+// Block-wide (NT threads): the bin whose cumulative count first reaches krem, and the count below that bin.
+template <int NT = BLOCK>
 __device__ __forceinline__ void topk_pick(const unsigned* __restrict__ hist, int nbins, unsigned krem,
-                                          unsigned* __restrict__ s_scan /*[BLOCK + 2]*/, unsigned& bin,
+                                          unsigned* __restrict__ s_scan /*[NT + 2]*/, unsigned& bin,
                                           unsigned& below) {
+    constexpr int BLOCK = NT;  // (shadows the global block size inside this function)
     const int per = (nbins + BLOCK - 1) / BLOCK;
     const int b0 = threadIdx.x * per;
     unsigned loc = 0;
@@ -2063,14 +2066,53 @@ __global__ __launch_bounds__(BLOCK) void topk_collect_kernel(const float* __rest
     }
 }
 
-// SORTED = false: ONE block sorts the k <= TOPK_MAX candidates itself (bitonic in LDS) before re-rolling them;
+// Ascending bitonic sort of one 64-bit word per thread across the block's 1024 threads, NV independent sorts in lockstep
+// (v[r] of thread t = element t of row r).  Strides below 64 are wave shuffles (no barrier); only the 10 stages with a
+// stride >= 64 go through LDS (s_x [NV][1024]) — a plain LDS bitonic sort pays a 1024-thread barrier for each of its 55
+// stages.  first_size = 2: full sort; = 1024: the final merge only (rows that are bitonic already).
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int m) {
+    const unsigned lo = __shfl_xor((unsigned)v, m), hi = __shfl_xor((unsigned)(v >> 32), m);
+    return ((unsigned long long)hi << 32) | lo;
+}
+template <int NV>
+__device__ __forceinline__ void block_bitonic_1024(unsigned long long (&v)[NV], unsigned long long* s_x, int tid, int first_size) {
+    for (int size = first_size; size <= TOPK_MAX; size <<= 1) {
+        const bool up = (tid & size) == 0;  // (size = 1024: every thread)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            unsigned long long o[NV];
+            if (stride >= WAVE) {
+#pragma unroll
+                for (int r = 0; r < NV; ++r) s_x[r * TOPK_MAX + tid] = v[r];
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < NV; ++r) o[r] = s_x[r * TOPK_MAX + (tid ^ stride)];
+                __syncthreads();
+            } else {
+#pragma unroll
+                for (int r = 0; r < NV; ++r) o[r] = shfl_xor_u64(v[r], stride);
+            }
+            const bool keep_min = ((tid & stride) == 0) == up;
+#pragma unroll
+            for (int r = 0; r < NV; ++r) v[r] = keep_min ? (v[r] < o[r] ? v[r] : o[r]) : (v[r] > o[r] ? v[r] : o[r]);
+        }
+    }
+}
+// SORTED = false: every block of the grid (ceil(k / 64) blocks of 1024 threads) selects and sorts the same k <= TOPK_MAX
+//   candidates itself and re-rolls 64 of them with ONE wave (the re-roll is a serial chain of T steps per lane, ~0.36 us per
+//   step: spread over CUs, not stacked on the SIMDs of one).  The candidates are the k words of `cand` (radix select by
+//   topk_hist_kernel / topk_collect_kernel, any N), or — `costs` != nullptr, n_direct <= TOPK_DIRECT_MAX samples: the sizes
+//   of the reference's examples, which call get_top_samples every tick — they are selected from the costs right here (one
+//   row: sorted directly; up to four rows: radix select inside the block): ONE launch instead of five;
 // SORTED = true: `cand` is already ascending (topk_sort_* below: any k) and the grid's threads take one candidate each.
+// lambda <= 0: the temperature the last solve's weights used (stats[4], left by finalize_tail) — no host read-back.
+constexpr int TOPK_DIRECT_MAX = 4096;
 template <int MODEL, int FAST, bool SORTED>
 __global__ __launch_bounds__(TOPK_MAX) void topk_rollout_kernel(const unsigned long long* __restrict__ cand, int k,
+                                                                const float* __restrict__ costs, int n_direct,
                                                                 const float4* __restrict__ noise, bool gen_noise,
                                                                 const float* __restrict__ mean,
                                                                 const float* __restrict__ x0,
-                                                                const float* __restrict__ stats, float lambda,
+                                                                const float* __restrict__ stats, float lambda_arg,
                                                                 float* __restrict__ states,
                                                                 float* __restrict__ weights,
                                                                 unsigned* __restrict__ hist,
@@ -2082,23 +2124,74 @@ __global__ __launch_bounds__(TOPK_MAX) void topk_rollout_kernel(const unsigned l
         for (int b = threadIdx.x; b < 3 * TOPK_BINS; b += blockDim.x) hist[b] = 0u;
         if (threadIdx.x < 2) counters[threadIdx.x] = 0u;
     }
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    const float lambda = lambda_arg > 0.0f ? lambda_arg : stats[4];
+    int q = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long mine;
     if (!SORTED) {
-        s_key[threadIdx.x] = (int)threadIdx.x < k ? cand[threadIdx.x] : ~0ull;
-        __syncthreads();
-        for (int size = 2; size <= TOPK_MAX; size <<= 1) {  // bitonic sort, ascending (key, index)
-            for (int stride = size >> 1; stride > 0; stride >>= 1) {
-                const int j = threadIdx.x ^ stride;
-                if (j > (int)threadIdx.x) {
-                    const unsigned long long a = s_key[threadIdx.x], b = s_key[j];
-                    const bool up = (threadIdx.x & size) == 0;
-                    if ((a > b) == up) { s_key[threadIdx.x] = b; s_key[j] = a; }
+        // row r of the words = samples r * 1024 + t (direct) / the k candidates (one row); padding = the largest word
+        const int tid = threadIdx.x;
+        const int rows = costs ? (n_direct + TOPK_MAX - 1) / TOPK_MAX : 1;
+        unsigned long long v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = r * TOPK_MAX + tid;
+            if (costs) v[r] = i < n_direct ? ((unsigned long long)float_to_key(costs[i]) << 32) | (unsigned long long)(d.sample_offset + i) : ~0ull;
+            else v[r] = (r == 0 && tid < k) ? cand[tid] : ~0ull;
+        }
+        if (rows <= 1) {
+            unsigned long long w1[1] = {v[0]};
+            block_bitonic_1024<1>(w1, s_key, tid, 2);
+            v[0] = w1[0];
+        } else {
+            // 2-4 rows: radix select of the k smallest keys INSIDE the block (three passes of 11 / 11 / 10 bits over the <= 4
+            // keys a thread holds, histogram in LDS: the scheme of topk_hist_kernel / topk_collect_kernel without their four
+            // launches), then one row to sort.  (Sorting all four rows and pruning was measured at ~25 us: 4x the work.)
+            __shared__ unsigned s_hist[TOPK_BINS];
+            __shared__ unsigned s_scan[TOPK_MAX + 2];
+            __shared__ unsigned s_cnt[2];
+            unsigned prefix = 0u, krem = (unsigned)k;
+#pragma unroll
+            for (int pass = 0; pass < 3; ++pass) {
+                const int nb = 1 << topk_bits(pass), shift = topk_shift(pass);
+                for (int b = tid; b < nb; b += TOPK_MAX) s_hist[b] = 0u;
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const unsigned key = (unsigned)(v[r] >> 32);
+                    const bool valid = r * TOPK_MAX + tid < n_direct;
+                    if (valid && (pass == 0 || (key >> (shift + topk_bits(pass))) == prefix)) atomicAdd(&s_hist[(key >> shift) & (nb - 1)], 1u);
                 }
                 __syncthreads();
+                unsigned bin, below;
+                topk_pick<TOPK_MAX>(s_hist, nb, krem, s_scan, bin, below);
+                prefix = (prefix << topk_bits(pass)) | bin;
+                krem -= below;
             }
+            // prefix = the k-th smallest key, krem = how many samples with exactly that key to take
+            if (tid < 2) s_cnt[tid] = 0u;
+            __syncthreads();
+            const unsigned nbelow = (unsigned)k - krem;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const unsigned key = (unsigned)(v[r] >> 32);
+                if (r * TOPK_MAX + tid < n_direct) {
+                    if (key < prefix) s_key[atomicAdd(&s_cnt[0], 1u)] = v[r];
+                    else if (key == prefix) { const unsigned t = atomicAdd(&s_cnt[1], 1u); if (t < krem) s_key[nbelow + t] = v[r]; }
+                }
+            }
+            __syncthreads();
+            unsigned long long w1[1] = {tid < k ? s_key[tid] : ~0ull};
+            __syncthreads();
+            block_bitonic_1024<1>(w1, s_key, tid, 2);
+            v[0] = w1[0];
         }
-        if (q >= k) return;
+        // Every block of the grid has sorted the same words; block b re-rolls candidates 64 b .. 64 b + 63 with ONE wave.
+        // (The re-roll is a serial chain of T steps per lane, ~12 us for a lone wave; k = 300 candidates in the first five
+        // waves of one block put two of them on one SIMD: 25 us.  One wave per block = one CU each.)
+        s_key[tid] = v[0];
+        __syncthreads();
+        q = blockIdx.x * WAVE + tid;
+        if (tid >= WAVE || q >= k) return;
         mine = s_key[q];
     } else {
         if (q >= k) return;

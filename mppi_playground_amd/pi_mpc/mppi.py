@@ -1058,8 +1058,9 @@ class MPPI(nn.Module):
             return self._state_seq_batch_buf[top.indices][order], top.values[order]
         out = torch.empty(num_samples, self._horizon + 1, self._dim_state, device=self._device, dtype=self._dtype)
         w = torch.empty(num_samples, device=self._device, dtype=self._dtype)
-        # one library call for any k: radix select + sort (one block up to 1024, multi-pass beyond) + re-roll + weights
-        self._h.call("mppi_top_samples", num_samples, float(self._last_lambda), _ptr(out), _ptr(w), self._stream())
+        # one library call for any k: radix select + sort (one block up to 1024, multi-pass beyond) + re-roll + weights — ONE
+        # launch up to 4096 samples; the weights use the temperature the solve left on the device (no read-back, no wait)
+        self._h.call("mppi_top_samples", num_samples, _capi.LAMBDA_DEVICE, _ptr(out), _ptr(w), self._stream())
         return out, w
 
     def _top_samples_sharded(self, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -1097,7 +1098,7 @@ class MPPI(nn.Module):
         best = (torch.sort(allc ^ flip).values[:k] ^ flip).contiguous()
         out = torch.empty(k, self._horizon + 1, self._dim_state, device=self._device, dtype=self._dtype)
         w = torch.empty(k, device=self._device, dtype=self._dtype)
-        self._h.call("mppi_rollout_candidates", _ptr(best), k, float(self._last_lambda), _ptr(out), _ptr(w), st)
+        self._h.call("mppi_rollout_candidates", _ptr(best), k, _capi.LAMBDA_DEVICE, _ptr(out), _ptr(w), st)
         return out, w
 
     def get_samples_from_posterior(self, optimal_solution: torch.Tensor, state: torch.Tensor,

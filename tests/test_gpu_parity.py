@@ -303,12 +303,17 @@ def test_top_samples_match_reference():
 
 @pytest.mark.parametrize("N,k,lam", [(1000, 1, 1.0), (4096, 300, 50.0), (777, 777, 500.0), (1 << 20, 300, 1.0),
                                      (1 << 20, 1024, 2000.0), (5000, 1025, 800.0), (1 << 17, 4096, 2000.0),
-                                     (3000, 3000, 500.0), (1 << 16, 40000, 5000.0)])
+                                     (3000, 3000, 500.0), (1 << 16, 40000, 5000.0),
+                                     # the one-launch query of small problems: one row (<= 1024 samples) sorted directly, two
+                                     # to four rows through the radix select inside the block; sizes around the row edges
+                                     (1024, 1024, 500.0), (1025, 7, 50.0), (2048, 1000, 500.0), (2500, 64, 50.0),
+                                     (3000, 300, 50.0), (4096, 1024, 2000.0), (4097, 300, 50.0)])
 def test_device_top_k_selects_the_smallest_costs(N, k, lam):
     """mppi_top_samples (radix select + sort + re-roll on the device) against a host sort of the same costs,
     the softmax weights, and the index-driven re-roll path; twice, to check the select state is left clean.  Any
-    k <= N like the reference (mppi.py:462-487): up to 1024 candidates are sorted by one block in LDS, more by the
-    multi-pass bitonic sort in HBM (k = 1025, 4096, N = 3000 and 40 000 of 65 536)."""
+    k <= N like the reference (mppi.py:462-487): up to 1024 candidates are sorted in LDS, more by the multi-pass bitonic
+    sort in HBM (k = 1025, 4096, N = 3000 and 40 000 of 65 536); up to 4096 samples and k <= 1024 the whole query is one
+    launch (the reference examples' sizes)."""
     solver, ctrl = make_solver("racing", 50, N, lambda_=lam)
     env = _envs["racing"]
     x0 = env._robot_state.clone()
