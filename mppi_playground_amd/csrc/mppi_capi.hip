@@ -1040,7 +1040,7 @@ static constexpr int64_t FUSED_AUTO_MAX_SAMPLES = 4096;          // fixed temper
 static constexpr int64_t FUSED_AUTO_MAX_SAMPLES_SEARCH = 16384;  // ESSPS / LBPS on the device
 static bool fused_applies(mppi_handle_t h, float lambda) {
     if (!h->fused_mode || h->cfg.model == MPPI_MODEL_GENERIC || h->mapping != 0) return false;
-    // measured (profiles/r03_experiments.md, r03_visitC_fused_crossover.txt): a cell round trip costs about as much as a
+    // measured (profiles/r03_experiments.md, r03_visitD_fused_crossover.txt): a cell round trip costs about as much as a
     // kernel boundary, so the single launch wins where it replaces more kernel boundaries than it needs round trips — with
     // a fixed temperature up to a few thousand samples (27 vs 32 us for racing at N = 1024, 29 vs 32 at 4096, 33 vs 32 at
     // 8192), under a temperature search further (nav2d ESSPS 32 vs 47 us at N = 1024, 48 vs 52 at 16 384, 51 vs 52 at 32 768)

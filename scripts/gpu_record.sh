@@ -24,6 +24,9 @@ done
 MASTER_PORT=29543 timeout 300 python scripts/nccl_single_rank.py 2>&1 | grep -E "forced exchange|RCCL all_gather" > gpurun_out/nccl_single_rank.txt
 timeout 300 python scripts/fused_timing.py 2>&1 | grep -v amdgpu.ids > gpurun_out/fused_timing.txt
 timeout 300 python scripts/essps_passes.py 2>&1 | grep -v amdgpu.ids > gpurun_out/essps_passes.txt
+timeout 300 python scripts/top_samples_breakdown.py 2>&1 | grep -v amdgpu.ids > gpurun_out/top_samples_breakdown.txt
+timeout 400 python scripts/fused_crossover.py 2>&1 | grep -v amdgpu.ids > gpurun_out/fused_crossover.txt
+timeout 200 python scripts/host_overhead.py 2>&1 | grep -v amdgpu.ids > gpurun_out/host_overhead.txt
 [ -f mppi_playground_amd/csrc/variants/lib_trace.so ] && MPPI_HIP_LIB=mppi_playground_amd/csrc/variants/lib_trace.so timeout 300 python scripts/fused_trace.py 2>&1 | grep -v amdgpu.ids > gpurun_out/fused_trace.txt
 scripts/ubench/icache_cold > gpurun_out/ubench_cold_code.txt 2>&1; scripts/ubench/clock_cost > gpurun_out/ubench_clock_cost.txt 2>&1
 cd /tmp
