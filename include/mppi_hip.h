@@ -101,7 +101,7 @@ typedef struct MppiConfig {
 const char* mppi_version(void);
 /* Integer version of THIS header's function signatures; bindings compare it with the constant they were written
  * against and refuse a stale library (a changed argument list would otherwise be called with shifted arguments). */
-#define MPPI_ABI_VERSION 7
+#define MPPI_ABI_VERSION 8
 int mppi_abi_version(void);
 /* Number of visible HIP devices (0 => the product cannot run; callers must fail loudly). */
 int mppi_device_count(void);
@@ -177,6 +177,13 @@ int mppi_get_reference(mppi_handle_t h, float* ref_out, int rows, int on_device,
 int mppi_model_step(int model, const float* params_host, int n_params, const float* u_min_host, const float* u_max_host,
                     const float* state_dev, const float* action_dev, float* next_state_dev, const float* goal_xy_host,
                     float goal_threshold, uint8_t* reached_out_dev, void* stream);
+/* `ObstacleMap.compute_cost` / `LaneMap.compute_cost` (src/envs/obstacle_map_2d.py:168-200, src/envs/lane_map_2d.py:90-122)
+ * as one launch, no handle needed — what `env.collision_check` of the examples' loops and cost plugins on the generic path
+ * call: out_dev[i] = map_dev[ix][iy] with (ix, iy) = round_half_even(xy / cell_size + origin) (fp32, the reference's
+ * operation order) when that lies inside the nx x ny grid (row-major float map), else 1.  Point i is the two floats at
+ * xy_dev + i * stride (stride >= 2: e.g. 3 for the x, y of [x, y, theta] state rows). */
+int mppi_grid_lookup(const float* map_dev, int nx, int ny, float cell_size, float origin_x, float origin_y, const float* xy_dev,
+                     int64_t n, int64_t stride, float* out_dev, void* stream);
 
 /* `_previous_action_seq` (mppi.py:157,255,452).  on_device != 0: pointer is a device pointer. */
 int mppi_set_mean(mppi_handle_t h, const float* mean, int on_device, void* stream);

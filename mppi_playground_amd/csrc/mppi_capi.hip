@@ -779,6 +779,15 @@ int mppi_model_step(int model, const float* params_host, int n_params, const flo
     return hipGetLastError() == hipSuccess ? MPPI_OK : MPPI_E_HIP;
 }
 
+int mppi_grid_lookup(const float* map_dev, int nx, int ny, float cell_size, float origin_x, float origin_y, const float* xy_dev,
+                     int64_t n, int64_t stride, float* out_dev, void* stream) {
+    if (!map_dev || !xy_dev || !out_dev || nx < 1 || ny < 1 || !(cell_size > 0.0f) || n < 0 || stride < 2) return MPPI_E_INVALID;
+    if (n == 0) return MPPI_OK;
+    hipLaunchKernelGGL(grid_lookup_kernel, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream, map_dev, nx,
+                       ny, cell_size, origin_x, origin_y, xy_dev, n, stride, out_dev);
+    return hipGetLastError() == hipSuccess ? MPPI_OK : MPPI_E_HIP;
+}
+
 // device <-> device / device -> host copies of small vectors
 static int copy_small(mppi_handle_t h, void* dst, const void* src, size_t bytes, bool dst_dev, bool src_dev, hipStream_t s) {
     if (dst_dev && !src_dev) return upload_small(h, (float*)dst, (const float*)src, bytes / sizeof(float), s);

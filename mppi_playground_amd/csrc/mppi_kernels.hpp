@@ -2260,6 +2260,20 @@ __global__ __launch_bounds__(BLOCK) void topk_pad_kernel(unsigned long long* __r
     if (t < P) cand[t] = ~0ull;
 }
 
+// ObstacleMap.compute_cost / LaneMap.compute_cost (src/envs/obstacle_map_2d.py:168-200, src/envs/lane_map_2d.py:90-122) for
+// callers OUTSIDE the solver — env.collision_check of the examples' loops, cost plugins on the generic path: one thread
+// per point, the reference's arithmetic (fp32 division by the cell size, + origin, round half to even, out of the grid
+// = 1, else the map's value) instead of ~15 torch launches.
+__global__ __launch_bounds__(BLOCK) void grid_lookup_kernel(const float* __restrict__ map, int nx, int ny, float cell_size,
+                                                            float ox, float oy, const float* __restrict__ xy, int64_t n,
+                                                            int64_t stride, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const float qx = rintf(xy[i * stride] / cell_size + ox), qy = rintf(xy[i * stride + 1] / cell_size + oy);
+    const bool inb = qx >= 0.0f && qx < (float)nx && qy >= 0.0f && qy < (float)ny;  // (NaN: out of the grid, like .long() of it)
+    out[i] = inb ? map[(int64_t)qx * ny + (int64_t)qy] : 1.0f;
+}
+
 // ------------------------------------------------------------------------------------------
 // The racing control tick without the host (example/racing.py:161-218,221-266).
 //

@@ -1681,6 +1681,46 @@ def test_essps_device_search_equals_the_host_loop_on_random_costs():
             assert abs(lam_dev.value - lam_host.value) <= 5e-6 * lam_host.value, (name, target, lam_dev.value, lam_host.value)
 
 
+def test_map_lookup_outside_the_solver_is_one_native_launch():
+    """ObstacleMap.compute_cost / LaneMap.compute_cost on device tensors (env.collision_check of the examples' loops,
+    cost plugins on the generic path) go through mppi_grid_lookup: bit-identical to the reference's arithmetic evaluated
+    in numpy float32 (true division, round half to even, out of the grid = 1) for contiguous points, the [:, :, :2]
+    view of state rows, one time step of a state buffer, an irregular view, points outside the grid and NaN."""
+    _need_gpu()
+    env = _envs["racing"]
+    rng = np.random.default_rng(5)
+    for m in (env._obstacle_map, env._lane_map):
+        grid = m._map_torch
+        g = grid.cpu().numpy()
+        cell = np.float32(m._cell_size)
+        org = m._torch_cell_map_origin.cpu().numpy().astype(np.float32)
+
+        def want(p):
+            q = np.rint(p.astype(np.float32) / cell + org)  # float32 throughout; rint = round half to even
+            inb = (q[..., 0] >= 0) & (q[..., 0] < g.shape[0]) & (q[..., 1] >= 0) & (q[..., 1] < g.shape[1])
+            ix = np.where(inb, q[..., 0], 0).astype(np.int64)
+            iy = np.where(inb, q[..., 1], 0).astype(np.int64)
+            return np.where(inb, g[ix, iy], np.float32(1.0)).astype(np.float32)
+
+        lim = 1.2 * max(abs(float(m.x_lim[0])), abs(float(m.x_lim[1])))  # some points outside the map
+        S = torch.from_numpy((rng.uniform(-lim, lim, (257, 31, 4))).astype(np.float32)).cuda()
+        S[3, 4, 0] = float("nan")
+        S[5, 6, 1] = float("inf")
+        # half-integer cell coordinates: the tie cases of the rounding
+        S[7, :, 0] = torch.from_numpy(((np.arange(31) + 0.5 - org[0]) * cell).astype(np.float32)).cuda()
+        cases = {"state rows [:, :, :2]": S[:, :, :2], "contiguous": S[:, :, :2].contiguous(), "one step of a buffer": S[:, 9, None, :2],
+                 "irregular view": S[:, ::3, 1:3], "a single trajectory": S[:1, :, :2]}
+        for name, x in cases.items():
+            got = m.compute_cost(x)
+            assert got.shape == x.shape[:-1] and got.dtype == torch.float32, name
+            assert np.array_equal(got.cpu().numpy(), want(x.cpu().numpy())), name
+    # the env call of the examples' loops
+    st = torch.zeros(1, 26, 4, device="cuda")
+    st[0, :, :2] = torch.from_numpy(rng.uniform(-30, 30, (26, 2)).astype(np.float32)).cuda()
+    c = env.collision_check(state=st)
+    assert c.shape == (1, 26) and bool(((c == 0) | (c == 1)).all())
+
+
 @pytest.mark.parametrize("fused", [0, 2])
 def test_essps_warm_start_in_a_closed_loop(fused):
     """From the second solve on the device-resident ESSPS search starts from the grid the previous search left around its
