@@ -298,6 +298,7 @@ def main():
         ctrl = runs[0]["ctrl"]
         if not args.no_extras:
             out["closed_loop"] = closed_loop(torch, env, ctrl, T, N_total)
+            out["example_loop"] = example_loop(torch)
             out["other_configs"] = other_configs(torch, np)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(np, T, ref_holder["ref"].numpy(), x0.cpu().numpy())
@@ -373,6 +374,32 @@ def closed_loop(torch, env, ctrl, T, N):
             "final_speed_mps": float(state[3]),
             "note": "open-loop `value` above times solves from a fixed state; here the state, the reference window and "
                     "the warm start change every tick"}
+
+
+def example_loop(torch):
+    """The loop of the reference's racing example at ITS sizes (example/racing.py:25-26,221-266: T = 25, N = 4000) minus
+    rendering: controller.update (reference window + solve), env.step, env.collision_check(state_seq) and
+    get_top_samples(300) — the last two are what the reference draws every tick.  No host synchronisation per tick."""
+    from envs.racing_controller import racing_controller
+    from envs.racing_env import RacingEnv
+
+    env = RacingEnv()
+    ctrl = racing_controller(env, horizon=25, num_samples=4000, lambda_=1.0)
+    ctrl.set_cost_map(env._obstacle_map, env._lane_map)
+    state = env.reset()
+    ticks, warm = 200, 20
+    for tick in range(warm + ticks):
+        if tick == warm:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        a, s = ctrl.update(state, env.racing_center_path)
+        state, _ = env.step(a[0, :])
+        env.collision_check(state=s)
+        ctrl.get_top_samples(num_samples=300)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"config": "racing T=25 N=4000 lambda=1 (the reference example's own size): update + env.step + collision_check + "
+                      "get_top_samples(300) per tick", "ticks": ticks, "ms_per_tick": dt / ticks * 1e3, "ticks_per_sec": ticks / dt}
 
 
 def _time_solver(torch, solver, x0, n=50, warm=10):
