@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Soak of the single-launch solve and the one-launch get_top_samples: many back-to-back solves at ragged sizes, closed
+loop, with and without a temperature search; checks that no poll ever timed out (mppi_fused_error), that every output is
+finite and that the last solve still agrees with the multi-kernel path.  Usage (GPU box): python scripts/fused_stress.py [solves]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+import torch
+
+import mppi_playground_amd  # noqa: F401
+from envs.navigation_2d import Navigation2DEnv
+from pi_mpc.mppi import MPPI
+
+n_solves = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
+nav = Navigation2DEnv()
+t = torch.tensor
+total = 0
+t0 = time.perf_counter()
+for N, T, rule in ((1000, 30, "ESSPS"), (3000, 30, "ESSPS"), (4096, 50, 1.0), (777, 13, "LBPS"), (16384, 20, "ESSPS"), (65, 7, 1.0)):
+    s = MPPI(T, N, 3, 2, nav.dynamics, nav.cost_function, nav.u_min, nav.u_max, t([0.5, 0.5]), rule)
+    ref = MPPI(T, N, 3, 2, nav.dynamics, nav.cost_function, nav.u_min, nav.u_max, t([0.5, 0.5]), rule)
+    ref.set_option("fused_solve", 0)
+    x = nav.reset().clone()
+    per = n_solves // 6
+    bad = 0
+    for k in range(per):
+        a, st = s.forward(x)
+        if k % 7 == 0:
+            top, w = s.get_top_samples(min(N, 300))
+        x = st[0, 1].clone() if k % 50 else nav.reset().clone()  # closed loop, restarted now and then
+        if k % 1000 == 999:
+            bad += int(not (torch.isfinite(a).all() and torch.isfinite(st).all() and torch.isfinite(top).all() and torch.isfinite(w).all()))
+    torch.cuda.synchronize()
+    err = s._h.lib.mppi_fused_error(s._h.h)
+    ref.set_warm_start(s._previous_action_seq.cpu().numpy(), None)
+    ref._solve_idx = s._solve_idx  # the same noise identity (the draw is a function of the solve index)
+    a1, _ = s.forward(x)
+    a2, _ = ref.forward(x)
+    d = float((a1 - a2).abs().max() / (a2.abs().max() + 1e-12))
+    total += per
+    print(f"N={N} T={T} lambda={rule}: {per} solves, fused error flag {err}, non-finite checks {bad}, last action vs multi-kernel {d:.1e}", flush=True)
+    assert err == 0 and bad == 0 and d < 1e-4
+print(f"{total} solves in {time.perf_counter() - t0:.1f} s: ok")
