@@ -40,7 +40,7 @@ class MPPI(nn.Module):
     _SETTER_PROPERTIES = frozenset(("_lambda", "_last_lambda", "_actions_history_for_sg"))
 
     def __setattr__(self, name, value):
-        if name[0] == "_" and name not in MPPI._SETTER_PROPERTIES:
+        if name[0] == "_" and name[1:2] != "_" and name not in MPPI._SETTER_PROPERTIES:
             self.__dict__[name] = value
         else:
             super().__setattr__(name, value)
