@@ -2159,7 +2159,21 @@ __global__ __launch_bounds__(TOPK_MAX) void topk_rollout_kernel(const unsigned l
                 for (int r = 0; r < 4; ++r) {
                     const unsigned key = (unsigned)(v[r] >> 32);
                     const bool valid = r * TOPK_MAX + tid < n_direct;
-                    if (valid && (pass == 0 || (key >> (shift + topk_bits(pass))) == prefix)) atomicAdd(&s_hist[(key >> shift) & (nb - 1)], 1u);
+                    const unsigned bin = (key >> shift) & (nb - 1);
+                    if (pass == 0) {
+                        // the top 11 bits of costs of one solve fall into a handful of bins: one atomic per (wave, distinct bin)
+                        // instead of 64 serialised ones on the same LDS word
+                        unsigned long long todo = __ballot(valid);
+                        while (todo) {
+                            const int leader = __ffsll((long long)todo) - 1;
+                            const unsigned b = __shfl(bin, leader);
+                            const unsigned long long same = __ballot(valid && bin == b) & todo;
+                            if ((tid & 63) == leader) atomicAdd(&s_hist[b], (unsigned)__popcll(same));
+                            todo &= ~same;
+                        }
+                    } else if (valid && (key >> (shift + topk_bits(pass))) == prefix) {
+                        atomicAdd(&s_hist[bin], 1u);
+                    }
                 }
                 __syncthreads();
                 unsigned bin, below;
