@@ -176,7 +176,7 @@ __device__ __forceinline__ float trajectory_cost(const float4* __restrict__ np, 
         lo[k] = d.u_min[k]; hi[k] = d.u_max[k];
         asm volatile("" : "+v"(hi[k]));
     }
-    float acc = 0.0f;
+    CostSum<exact_cost_sum(MODEL)> acc;  // sum of the stage costs (mppi.py:333): exactly rounded, or sequential fp32 for racing
     K knext = M::load_k(ktab, 0);
     float4 e = noise_group<GEN>(np, 0, gi, gen, d);
     float4 m4 = mean4[0];
@@ -195,7 +195,7 @@ __device__ __forceinline__ float trajectory_cost(const float4* __restrict__ np, 
         float sn[DS], ss[DS];
         if constexpr (MODEL == MPPI_MODEL_RACING) M::step(ctx, s, u, sn, ss, bad, UC, FAST != 0, VAR);
         else M::step(ctx, s, u, sn, ss, bad, UC, FAST != 0);
-        acc += M::cost(ctx, kcur, ss, u, pu, bad);
+        acc.add(M::cost(ctx, kcur, ss, u, pu, bad));
 #pragma unroll
         for (int k = 0; k < DC; ++k) { pl[k] = pu[k]; pu[k] = u[k]; }
 #pragma unroll
@@ -230,7 +230,7 @@ __device__ __forceinline__ float trajectory_cost(const float4* __restrict__ np, 
             e = e1;
             m4 = m4n;
             const float4* nptr = np + (int64_t)min(r + 2, d.R - 1) * 64;
-            asm volatile("" : "+v"(nptr) : "v"(acc));  // the address "depends" on this iteration's last cost
+            asm volatile("" : "+v"(nptr) : "v"(acc.a));  // the address "depends" on this iteration's last cost
             e1 = *nptr;
         }
     }
@@ -247,7 +247,7 @@ __device__ __forceinline__ float trajectory_cost(const float4* __restrict__ np, 
 #pragma unroll
     for (int k = 0; k < DC; ++k) zero[k] = 0.0f;
     const float term = M::cost(ctx, knext, s, zero, pl, bad);
-    return acc + term;
+    return acc.total(term);
 }
 
 #ifndef MPPI_ROLLOUT_ATTR
@@ -299,12 +299,14 @@ __global__ __launch_bounds__(BLOCK) MPPI_ROLLOUT_ATTR void rollout_cost_kernel(c
             total = trajectory_cost<MODEL, FAST, GEN, UC, true>(np, gi, gen, mp, s_ktab, x0, d, ctx, bad);
         else
             total = trajectory_cost<MODEL, FAST, GEN, UC>(np, gi, gen, mp, s_ktab, x0, d, ctx, bad);
+#ifndef MPPI_AB_NO_REDO  // (A/B knob: bounds what the cold redo path costs the hot loop in registers / code layout)
         if (FAST) {
             if (bad) {  // a fast path left its validity range: redo this lane with the library math
                 bool ignore = false;
                 total = trajectory_cost<MODEL, 0, GEN, false>(np, gi, gen, mp, s_ktab, x0, d, ctx, ignore);
             }
         }
+#endif
         if (i < d.N) costs[i] = total;
         else total = INFINITY;
     }

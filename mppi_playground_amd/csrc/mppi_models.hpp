@@ -78,6 +78,32 @@ MPPI_HD float clampf(float x, float lo, float hi) {
 #endif
 }
 
+// Total cost of a trajectory = sum_t stage cost + terminal cost (mppi.py:333-334: torch.sum(costs, dim=1) + terminal).
+// The order of torch.sum is not part of the reference's contract (a vectorised cascade on the CPU that depends on the
+// ISA, a tree on a GPU), and softmax(-c / lambda) amplifies the last bits of c by |c| / lambda: the reference's own
+// action sequence moves by 2e-5 .. 7e-5 (nav2d, goal zone at lambda = 1) when its costs are re-summed in another valid
+// fp32 order (tests/golden/make_golden.py: the recorded bands).  EXACT = true adds the fp32 stage costs in double
+// and rounds once: the value every fp32 order approximates, so the distance to ANY build of the reference is its
+// own rounding error only.  EXACT = false is the plain sequential fp32 sum (one v_add_f32 per step instead of a
+// conversion + a double add): kept for racing, whose costs / lambda are far from that regime (arg-min at lambda = 1,
+// 1e4-scale obstacle costs over lambda >= 100 in the dense cases: bands <= 6e-6) and whose kernel is VALU-issue bound.
+template <bool EXACT>
+struct CostSum {
+    float a = 0.0f;
+    MPPI_HD void add(float c) { a += c; }
+    MPPI_HD float total(float terminal) const { return a + terminal; }
+};
+template <>
+struct CostSum<true> {
+    double a = 0.0;
+    MPPI_HD void add(float c) { a += (double)c; }
+    MPPI_HD float total(float terminal) const { return (float)(a + (double)terminal); }
+};
+#ifndef MPPI_EXACT_SUM_RACING
+#define MPPI_EXACT_SUM_RACING 0  // (A/B knob of scripts/build_variant.sh: the double accumulator in the racing kernel too)
+#endif
+constexpr bool exact_cost_sum(int model) { return MPPI_EXACT_SUM_RACING || model != MPPI_MODEL_RACING; }
+
 }  // namespace mppi
 
 // The model code is compiled twice:

@@ -63,4 +63,5 @@ class LaneMap:
     def compute_cost(self, x: torch.Tensor) -> torch.Tensor:
         if x.device != self._device or x.dtype != self._dtype:
             x = x.to(self._device, self._dtype)
-        return grid_lookup(self._map_torch, x, self._cell_size, self._torch_cell_map_origin)
+        return grid_lookup(self._map_torch, x, self._cell_size, self._torch_cell_map_origin,
+                           (float(self._cell_map_origin[0]), float(self._cell_map_origin[1])))

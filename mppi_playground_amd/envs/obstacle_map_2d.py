@@ -98,13 +98,14 @@ class ObstacleMap:
         assert self._map_torch is not None
         if x.device != self._device or x.dtype != self._dtype:
             x = x.to(self._device, self._dtype)
-        return grid_lookup(self._map_torch, x, self._cell_size, self._torch_cell_map_origin)
+        return grid_lookup(self._map_torch, x, self._cell_size, self._torch_cell_map_origin,
+                           (float(self._cell_map_origin[0]), float(self._cell_map_origin[1])))
 
     def render(self, *args, **kwargs) -> None:  # UI: out of scope
         return None
 
 
-_native = None  # (library handle, origin cache) once a device lookup has been asked for
+_native = None  # (binding module, library handle) once a device lookup has been asked for
 
 
 def _uniform_point_stride(x: torch.Tensor):
@@ -126,7 +127,7 @@ def _uniform_point_stride(x: torch.Tensor):
     return step
 
 
-def _grid_lookup_device(grid: torch.Tensor, x: torch.Tensor, cell_size: float, origin: torch.Tensor) -> torch.Tensor:
+def _grid_lookup_device(grid: torch.Tensor, x: torch.Tensor, cell_size: float, origin_xy) -> torch.Tensor:
     """The lookup as ONE launch of the library (mppi_grid_lookup: the reference's arithmetic, fp32 division included)
     instead of ~15 torch kernels: env.collision_check runs every tick of the examples' loops, and cost plugins on the
     generic path call it once per step.  Raises when the extension is missing (no silent fallback on a GPU box)."""
@@ -134,12 +135,9 @@ def _grid_lookup_device(grid: torch.Tensor, x: torch.Tensor, cell_size: float, o
     if _native is None:
         from mppi_playground_amd import _capi
 
-        _native = (_capi, _capi.load(), {})
-    capi, lib, origins = _native
-    key = (origin.data_ptr(), origin._version)
-    o = origins.get(key)
-    if o is None:  # (read back once per map: the origin is a constant of the map)
-        o = origins[key] = tuple(float(v) for v in origin.detach().cpu().tolist())
+        _native = (_capi, _capi.load())
+    capi, lib = _native
+    o = origin_xy  # host floats owned by the map object (never a cache keyed on device addresses: those get reused)
     step = _uniform_point_stride(x)
     if step is None:
         x = x.contiguous()
@@ -152,11 +150,14 @@ def _grid_lookup_device(grid: torch.Tensor, x: torch.Tensor, cell_size: float, o
     return out
 
 
-def grid_lookup(grid: torch.Tensor, x: torch.Tensor, cell_size: float, origin: torch.Tensor) -> torch.Tensor:
-    """round-half-even(x / cell + origin) gather with out-of-bound = 1 (shared by both map types)."""
+def grid_lookup(grid: torch.Tensor, x: torch.Tensor, cell_size: float, origin: torch.Tensor, origin_xy=None) -> torch.Tensor:
+    """round-half-even(x / cell + origin) gather with out-of-bound = 1 (shared by both map types).  `origin_xy`: the
+    origin as two host floats (the maps keep it as `_cell_map_origin`); without it the tensor is read back."""
     if (x.is_cuda and grid.is_cuda and x.dtype == torch.float32 and grid.dtype == torch.float32 and grid.is_contiguous()
             and x.shape[-1] == 2 and x.device == grid.device and not x.requires_grad):
-        return _grid_lookup_device(grid, x, cell_size, origin)
+        if origin_xy is None:
+            origin_xy = tuple(float(v) for v in origin.detach().cpu().tolist())
+        return _grid_lookup_device(grid, x, cell_size, origin_xy)
     idx = torch.round(x / cell_size + origin).long()
     ix, iy = idx[..., 0], idx[..., 1]
     oob = (ix < 0) | (ix >= grid.shape[0]) | (iy < 0) | (iy >= grid.shape[1])

@@ -81,6 +81,8 @@ class racing_controller:
             key = (racing_center_path, racing_center_path._version)
             held = self._center_on_device
             if held is None or held[0] is not key[0] or held[1] != key[1]:
+                if self._window_on_device:  # the monotone `ind = max(cind, ind)` carry lives on the device: fetch it first
+                    self._path_index_host = self.solver.path_index
                 self.solver.set_center_path(racing_center_path.detach().cpu().numpy(),
                                             self._window_offsets(T, 0.1, 3, 0.85), self._v_max())
                 self._center_on_device = key

@@ -84,16 +84,115 @@ def pack_bits(m: np.ndarray) -> np.ndarray:
 
 
 class Recorder:
-    """Wraps cost_func to capture the per-call costs the solver sums (mppi.py:307-336)."""
+    """Wraps cost_func to capture the per-call costs the solver sums (mppi.py:307-336).
+
+    `feed`: when set to a tensor [N], the wrapped cost is NOT evaluated: the first call of the solve returns `feed` and
+    the other T calls return zeros, so that `torch.sum(costs, dim=1) + terminal` (mppi.py:333-334) is exactly `feed` and
+    the REFERENCE's own steps 4-8 (temperature rule, softmax, weighted mean, SG filter, batch-1 rollout, warm start:
+    mppi.py:341-460) run on prescribed total costs — the sensitivity probes below."""
 
     def __init__(self, fn):
         self.fn = fn
         self.calls = []
+        self.feed = None
 
     def __call__(self, state, action, info):
+        if self.feed is not None:
+            first = not self.calls
+            self.calls.append(None)
+            return self.feed.clone() if first else torch_zeros_like(self.feed)
         c = self.fn(state, action, info)
         self.calls.append(c.detach().clone())
         return c
+
+
+def torch_zeros_like(t):
+    import torch
+
+    return torch.zeros_like(t)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The reference's OWN sensitivity to fp32 rounding of its costs ("bands").  forward() turns the N total costs into the
+# action sequence through softmax(-c / lambda): a cost change dc moves a weight by w * dc / lambda, so the 1e-5 the
+# north star asks of action_seq / state_seq is a statement about the costs to ~1e-5 * lambda — below one fp32 ulp of the
+# cost for nav2d / goal zone at lambda = 1.  Instead of deriving a tolerance analytically, every fixture records how far
+# the reference's own outputs move when its total costs are replaced by equally valid fp32 evaluations of the same
+# sums.  VARIANTS (index = column of every band array):
+#   0-15  every total cost moved to the next fp32 value up or down (seeded random signs): a 1-ulp change
+#   16     the T stage costs + terminal re-summed in float64, rounded once to fp32 (the exactly rounded sum — what the
+#          HIP kernels compute for every model but racing, mppi_models.hpp: CostSum)
+#   17     the same terms summed sequentially in fp32, t = 0..T-1 then the terminal (another valid fp32 order — the
+#          racing kernel's; torch.sum's own order is a vectorised cascade that depends on the CPU's ISA)
+#   18-23  every stage cost and the terminal moved by one fp32 ulp (seeded signs), then summed by the reference's own
+#          torch.sum(dim=1) + terminal: what a different-but-valid fp32 evaluation of each stage cost would do
+# A band is the maximum over the variants: a sample of the reference's spread under rounding-level changes of its costs
+# (24 probes), against which the tests hold the HIP path's distance to the reference: err <= max(1e-5, band).
+BAND_VARIANTS = tuple(f"ulp_{i}" for i in range(16)) + ("f64sum", "seqsum") + tuple(f"stage_ulp_{i}" for i in range(6))
+
+
+def _variant_costs(v: int, costs, stage, terminal):
+    import torch
+
+    name = BAND_VARIANTS[v]
+    rng = np.random.default_rng(9000 + v)
+    if name.startswith("ulp_"):
+        sign = torch.from_numpy(rng.choice(np.float32([-1.0, 1.0]), size=costs.shape[0]))
+        return torch.nextafter(costs, costs + sign * float("inf"))
+    if name == "f64sum":
+        return (stage.double().sum(dim=1) + terminal.double()).float()
+    if name == "seqsum":
+        acc = torch.zeros_like(terminal)
+        for t in range(stage.shape[1]):
+            acc = acc + stage[:, t]
+        return acc + terminal
+    sign = torch.from_numpy(rng.choice(np.float32([-1.0, 1.0]), size=tuple(stage.shape)))
+    st = torch.nextafter(stage, stage + sign * float("inf"))
+    sign_t = torch.from_numpy(rng.choice(np.float32([-1.0, 1.0]), size=terminal.shape[0]))
+    return torch.sum(st, dim=1) + torch.nextafter(terminal, terminal + sign_t * float("inf"))
+
+
+def _snapshot(solver):
+    import copy
+
+    import torch
+
+    s = dict(prev=solver._previous_action_seq.detach().clone(), hist=solver._actions_history_for_sg.detach().clone(),
+             lam=solver._lambda, auto=solver._auto_lambda, rng=torch.get_rng_state())
+    if hasattr(solver, "optimizer"):  # MPO: the dual and its Adam moments (mppi.py:191-200)
+        s["logT"] = solver.log_temperature.data.clone()
+        s["opt"] = copy.deepcopy(solver.optimizer.state_dict())
+    return s
+
+
+def _restore(solver, s):
+    import copy
+
+    import torch
+
+    solver._previous_action_seq = s["prev"].clone()
+    solver._actions_history_for_sg = s["hist"].clone()
+    solver._lambda, solver._auto_lambda = s["lam"], s["auto"]
+    torch.set_rng_state(s["rng"])
+    if "opt" in s:
+        solver.log_temperature.data.copy_(s["logT"])
+        solver.optimizer.load_state_dict(copy.deepcopy(s["opt"]))
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-30))
+
+
+def _feed_solve(solver, rec, state, costs):
+    rec.calls.clear()
+    rec.feed = costs
+    try:
+        a, s = solver.forward(state=state.clone())
+    finally:
+        rec.feed = None
+        rec.calls.clear()
+    return a.detach().numpy().copy(), s.detach().numpy().copy()
 
 
 ONLY_ROUND2 = len(sys.argv) > 1 and sys.argv[1] == "round2"
@@ -116,6 +215,7 @@ def run_case(name, make_solver, x0, K, next_state, keep_S, before_solve=None, ro
     d = dict(extra)
     d["ctor_eps"] = solver._action_noises.numpy().copy()  # Q2: ctor consumes one draw
     state = torch.as_tensor(np.asarray(x0), dtype=torch.float32)
+    auto = solver._auto_lambda
     for k in range(K):
         if before_solve is not None:
             for kk, vv in before_solve(state, k).items():
@@ -123,6 +223,7 @@ def run_case(name, make_solver, x0, K, next_state, keep_S, before_solve=None, ro
         rec.calls.clear()
         mean_in = solver._previous_action_seq.detach().clone().numpy()
         hist_in = solver._actions_history_for_sg.detach().clone().numpy()
+        pre = _snapshot(solver)
         a, s = solver.forward(state=state.clone())
         calls = list(rec.calls)
         # first T+1 calls belong to the N-sample pass; (no cost calls in the B=1 rollout)
@@ -151,8 +252,58 @@ def run_case(name, make_solver, x0, K, next_state, keep_S, before_solve=None, ro
             d["posterior_after"] = np.int64(k)
             d["posterior_samples"] = ps.detach().numpy().copy()
             d["posterior_states"] = pst.detach().numpy().copy()
+        # ---- per-solve bands: the reference's steps 4-8 re-run on the SAME inputs with perturbed total costs
+        post = _snapshot(solver)
+        lam_used = pre["lam"] if auto == "MPO" else solver._lambda  # the temperature of this solve's weights
+        a_np, s_np = a.detach().numpy(), s.detach().numpy()
+        _restore(solver, pre)  # (sanity: feeding the recorded costs back reproduces the solve bit for bit)
+        a_chk, s_chk = _feed_solve(solver, rec, state, costs)
+        assert np.array_equal(a_chk, a_np) and np.array_equal(s_chk, s_np) and solver._lambda == post["lam"], name
+        nv = len(BAND_VARIANTS)
+        fixed = np.zeros((nv, 2))   # [variant] (action, state) at the temperature the reference used
+        ruled = np.zeros((nv, 3))   # [variant] (action, state, lambda) with the temperature rule re-run
+        for v in range(nv):
+            cv = _variant_costs(v, costs, stage, terminal)
+            _restore(solver, pre)
+            solver._auto_lambda, solver._lambda = None, float(lam_used)
+            av, sv = _feed_solve(solver, rec, state, cv)
+            fixed[v] = _rel(av, a_np), _rel(sv, s_np)
+            if auto is not None:
+                _restore(solver, pre)
+                av, sv = _feed_solve(solver, rec, state, cv)
+                ruled[v] = _rel(av, a_np), _rel(sv, s_np), abs(solver._lambda - post["lam"]) / post["lam"]
+        _restore(solver, post)
+        d[f"band_fixed_{k}"] = fixed
+        if auto is not None:
+            d[f"band_rule_{k}"] = ruled
         state = next_state(state, a, s)
     d["K"] = np.int64(K)
+    # ---- closed-loop bands: the whole K-solve loop re-run per variant (same seed -> same noise; every solve's total
+    # costs replaced by the variant's evaluation of the SAME terms; states, warm start, SG history and the temperature
+    # rule's memory all evolve on their own), compared with the unperturbed loop above
+    cl = np.zeros((K, len(BAND_VARIANTS), 4))  # [solve][variant] (x0, action, state, lambda)
+    for v in range(len(BAND_VARIANTS)):
+        solver2, rec2, _ = make_solver()
+        st2 = torch.as_tensor(np.asarray(x0), dtype=torch.float32)
+        for k in range(K):
+            if before_solve is not None:
+                before_solve(st2, k)
+            rec2.calls.clear()
+            pre = _snapshot(solver2)
+            solver2.forward(state=st2.clone())
+            calls = list(rec2.calls)
+            stage2, term2 = torch.stack(calls[:T], dim=1), calls[T]
+            costs2 = torch.sum(stage2, dim=1) + term2
+            _restore(solver2, pre)
+            av, sv = _feed_solve(solver2, rec2, st2, _variant_costs(v, costs2, stage2, term2))
+            lam_ref = float(d[f"lambda_{k}"])
+            cl[k, v] = (_rel(st2.numpy(), d[f"x0_{k}"]), _rel(av, d[f"action_seq_{k}"]), _rel(sv, d[f"state_seq_{k}"]),
+                        abs(float(solver2._lambda) - lam_ref) / lam_ref)
+            a2, s2 = torch.from_numpy(av), torch.from_numpy(sv)
+            if posterior_after is not None and posterior_after[0] == k:  # keeps the noise stream aligned
+                solver2.get_samples_from_posterior(a2, st2.clone(), posterior_after[1])
+            st2 = next_state(st2, a2, s2)
+    d["band_closed_loop"] = cl
     path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **d)
     print(f"wrote {path}  ({os.path.getsize(path)/1024:.0f} KiB)")

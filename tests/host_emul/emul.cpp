@@ -21,7 +21,7 @@ static float walk(const float* eps_row, const float* mean, const float* x0, int 
     for (int j = 0; j < DS; ++j) s[j] = x0[j];
     if (FAST) M::check_state(ctx, s, bad);
     for (int k = 0; k < DC; ++k) pu[k] = pl[k] = 0.f;
-    float acc = 0.f;
+    CostSum<exact_cost_sum(MODEL)> acc;
     for (int t = 0; t < T; ++t) {
         float u[DC], sn[DS], ss[DS];
         for (int k = 0; k < DC; ++k) {
@@ -30,14 +30,14 @@ static float walk(const float* eps_row, const float* mean, const float* x0, int 
         }
         if (t == 0) for (int k = 0; k < DC; ++k) pu[k] = u[k];
         M::step(ctx, s, u, sn, ss, bad, ctx.u_in_bounds != 0);
-        acc += M::cost(ctx, M::load_k(ctx.ref, t), ss, u, pu, bad);
+        acc.add(M::cost(ctx, M::load_k(ctx.ref, t), ss, u, pu, bad));
         for (int k = 0; k < DC; ++k) { pl[k] = pu[k]; pu[k] = u[k]; }
         for (int j = 0; j < DS; ++j) { if (S_out) S_out[t * DS + j] = ss[j]; s[j] = sn[j]; }
     }
     for (int j = 0; j < DS; ++j) if (S_out) S_out[T * DS + j] = s[j];
     float zero[DC];
     for (int k = 0; k < DC; ++k) zero[k] = 0.f;
-    return acc + M::cost(ctx, M::load_k(ctx.ref, T - 1), s, zero, pl, bad);
+    return acc.total(M::cost(ctx, M::load_k(ctx.ref, T - 1), s, zero, pl, bad));
 }
 
 template <int MODEL>

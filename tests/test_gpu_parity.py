@@ -6,11 +6,14 @@ Tolerances (fp32, north star: 1e-5 relative):
     map-rounding boundary (`margin`, computed by the oracle); at most a handful of boundary samples
     may flip an occupancy cell under <=1.5-ulp sin/cos differences.
   * action_seq / state_seq given the same costs: 1e-5 relative to max-abs.
-  * end-to-end against the reference fixtures (`check_end_to_end`): 1e-5 plus the first-order change of the
-    softmax under the ACTUAL cost differences to the fixture, 2 * sum_i |dw_i| with
-    dw_i = w_i (-(c_gpu_i - c_ref_i)/lambda + sum_j w_j (c_gpu_j - c_ref_j)/lambda) — zero where the softmax is an
-    arg-min (racing at lambda = 1): there the winning sample must be the reference's and the action must equal its
-    clamped action sequence to 1e-6; only a top-2 cost gap under 4 ulps lifts that.
+  * end-to-end against the reference fixtures (`check_end_to_end`): 1e-5, or — where softmax(-c / lambda) amplifies the
+    last bits of the costs beyond that (nav2d, goal zone, pendulum at lambda ~ 1: |c| / lambda ~ 1e3) — the REFERENCE'S
+    OWN measured spread: every fixture records how far the reference's action_seq / state_seq move when its total costs
+    are replaced by equally valid fp32 evaluations of the same sums (24 probes per solve: 1-ulp changes, other summation
+    orders; tests/golden/make_golden.py `band_fixed_k`, `band_rule_k`, `band_closed_loop`).  limit = max(1e-5, band);
+    nothing is derived analytically.  Where the softmax is an arg-min (racing at lambda = 1) the winning sample must be
+    the reference's and the action must equal its clamped action sequence to 1e-6; only a top-2 cost gap under 4 ulps
+    lifts that.
   * automatic temperatures are compared with the reference's on their own terms; the end-to-end check of those
     cases then re-solves with the reference's lambda so that it is not blurred by the search tolerance.
 """
@@ -21,8 +24,8 @@ import pytest
 import torch
 
 import parity_report
-from helpers import (CASES, MODEL_CFG, SOLVER_KW, load, mpo_lambda_tolerance, oracle_problem, orc, rel_err,
-                     same_lbps_minimum, sg_coeffs)
+from helpers import (CASES, MODEL_CFG, SOLVER_KW, band_closed_loop, band_fixed, band_rule_lambda, load, oracle_problem, orc,
+                     rel_err, same_lbps_minimum, sg_coeffs)
 
 pytestmark = pytest.mark.gpu
 
@@ -110,9 +113,19 @@ def check_rel(quantity, got, want, tol):
     return err
 
 
-def check_end_to_end(a, s, c_gpu, lam, g, k, cfg, P, extra=0.0):
-    """Action / state sequence of solve k against the reference fixture (see the module docstring).  `extra`: error
-    already carried by the inputs (closed loops feed their own previous outputs back).  Returns the measured error."""
+def check_banded(quantity, got, want, band, floor=TOL):
+    """rel_err(got, want) <= max(floor, band) where `band` is the reference's own measured spread of that quantity
+    (committed with the fixture); the report keeps the value, the band and whether the plain 1e-5 held."""
+    err = rel_err(got, want)
+    limit = max(floor, band)
+    parity_report.record(quantity, err, limit, reference_band=float(band), within_1e5=bool(err <= TOL))
+    assert err <= limit, f"{quantity}: {err:.2e} > max({floor:.0e}, reference band {band:.2e})"
+    return err
+
+
+def check_end_to_end(a, s, c_gpu, g, k, cfg, band_a, band_s, tag=""):
+    """Action / state sequence of solve k against the reference fixture: 1e-5, or the reference's own measured spread
+    under rounding-level changes of its costs where that is larger (see the module docstring)."""
     from pi_mpc import _host
 
     a_ref, s_ref, c_ref = g[f"action_seq_{k}"], g[f"state_seq_{k}"], g[f"costs_{k}"]
@@ -130,17 +143,18 @@ def check_end_to_end(a, s, c_gpu, lam, g, k, cfg, P, extra=0.0):
                         np.float32(mc["u_max"])).astype(np.float32)
             if cfg.get("use_sg_filter"):
                 U = _host.sg_filter_sequence(g[f"sg_hist_in_{k}"], U, sg_coeffs(cfg))
-            parity_report.record("argmin_action_vs_reference_sample", np.abs(a - U).max() / max(np.abs(U).max(), 1e-30), 1e-6 + extra)
-            assert np.abs(a - U).max() <= (1e-6 + extra) * max(np.abs(U).max(), 1e-30), "action != U[argmin]"
-    dx = (c_gpu.astype(np.float64) - c_ref.astype(np.float64)) / lam
-    dw = w_ref * (-dx + float((w_ref * dx).sum()))
-    tol = TOL + 2.0 * float(np.abs(dw).sum()) + extra
-    err_a = check_rel("action_seq_vs_reference_fixture", a, a_ref, tol)
-    err_s = check_rel("state_seq_vs_reference_fixture", s, s_ref, tol)
-    return max(err_a, err_s)
+            parity_report.record("argmin_action_vs_reference_sample", np.abs(a - U).max() / max(np.abs(U).max(), 1e-30), 1e-6 + band_a)
+            assert np.abs(a - U).max() <= (1e-6 + band_a) * max(np.abs(U).max(), 1e-30), "action != U[argmin]"
+    check_banded("action_seq_vs_reference_fixture" + tag, a, a_ref, band_a)
+    check_banded("state_seq_vs_reference_fixture" + tag, s, s_ref, band_s)
 
 
-LAMBDA_TOL = {"ESSPS": 1e-4, "MPO": 1e-4}  # LBPS: same_lbps_minimum()
+# the library's own search tolerances (the reference-side spread of the temperature comes from the fixture bands):
+# ESSPS: grid + inverse interpolation, checked to 1e-5 against brentq (test_host_logic); LBPS: scipy's bounded Brent stops
+# within xatol = 1e-5 ABSOLUTE + sqrt(eps) of a minimum of the reference's fp32 objective, short of a bound it never
+# evaluates (pendulum: lambda_max = 10 -> 9.9994..9.9998), while the library returns the float64 minimiser to 1e-7
+LBPS_TOL = 1e-3
+LAMBDA_TOL = {"ESSPS": 1e-4}
 
 
 # ------------------------------------------------------------------------------ whole solve vs oracle / golden
@@ -183,15 +197,20 @@ def test_forward_parity(name, math):
         lam = solver._last_lambda
         lam_ref = used_lambda(g, cfg, k)
         if cfg["lambda_"] == "LBPS":
-            assert same_lbps_minimum(c_gpu, lam, lam_ref), (lam, lam_ref)
+            # the reference's own temperature moves by band_rule (nav2d: up to 1e-2) under 1-ulp changes of its costs
+            lim = max(LBPS_TOL, band_rule_lambda(g, k))
+            parity_report.record("lambda_rel_err_LBPS", abs(lam - lam_ref) / lam_ref, lim, reference_band=band_rule_lambda(g, k))
+            assert abs(lam - lam_ref) <= lim * lam_ref, (lam, lam_ref, lim)
+            assert same_lbps_minimum(c_gpu, lam, lam_ref, tol=lim), (lam, lam_ref)  # ... and it is no worse a minimiser
         elif cfg["lambda_"] == "MPO":
             assert lam == lam_ref  # (fed from the fixture below; the rule itself is checked on lambda_next)
             lam_next, lam_next_ref = float(solver._lambda), float(g[f"lambda_{k}"])
-            # (the dual's Adam state is this solver's own: it has seen the reference's cost vectors up to fp32 rounding,
-            # which is all the rule's cancelling gradient needs to move: mpo_lambda_tolerance)
-            tol_mpo = (k + 1) * mpo_lambda_tolerance(c_gpu, lam)
-            parity_report.record("lambda_rel_err_MPO", abs(lam_next - lam_next_ref) / lam_next_ref, tol_mpo)
-            assert abs(lam_next - lam_next_ref) <= tol_mpo * lam_next_ref, (k, lam_next, lam_next_ref, tol_mpo)
+            # the dual's Adam state is this solver's own (it has seen the reference's cost vectors up to fp32 rounding),
+            # so the reference-side spread is the closed-loop band of the temperature, not the one-solve band
+            lim = max(1e-4, band_rule_lambda(g, k), band_closed_loop(g, k)["lam"])
+            parity_report.record("lambda_rel_err_MPO", abs(lam_next - lam_next_ref) / lam_next_ref, lim,
+                                 reference_band=max(band_rule_lambda(g, k), band_closed_loop(g, k)["lam"]))
+            assert abs(lam_next - lam_next_ref) <= lim * lam_next_ref, (k, lam_next, lam_next_ref, lim)
         else:
             if cfg["lambda_"] in LAMBDA_TOL:
                 parity_report.record("lambda_rel_err_" + cfg["lambda_"], abs(lam - lam_ref) / lam_ref, LAMBDA_TOL[cfg["lambda_"]])
@@ -222,7 +241,7 @@ def test_forward_parity(name, math):
         if nflip:  # an occupancy cell flipped under <=1.5-ulp sin/cos differences: the two runs saw different maps
             flipped.append((k, nflip))
         else:
-            check_end_to_end(a, s, c_gpu, lam_ref, g, k, cfg, P)
+            check_end_to_end(a, s, c_gpu, g, k, cfg, *band_fixed(g, k))
     if flipped:  # every other check of every solve ran; the omitted one is reported, not passed over
         pytest.skip(f"{name}: boundary sample(s) flipped a map cell in solve(s) {flipped}; the end-to-end comparison "
                     "with the reference fixture was not applicable there (all other checks passed)")
@@ -240,15 +259,36 @@ def test_identical_seed_closed_loop_matches_reference(name):
     reproduce the reference's noise (bit for bit), temperatures, action and state sequences, warm start and SG
     history included; `get_samples_from_posterior` between two solves draws from the same stream (mppi.py:489-506):
     same samples, same states, and the next solve's noise is the reference's."""
+    _identical_seed_closed_loop(name)
+
+
+@pytest.mark.parametrize("mode", ["host", "brent"])
+@pytest.mark.parametrize("name", ["pendulum_T50_N1000_essps", "cartpole_T64_N1024_essps_sg", "racing_T25_N1024_essps",
+                                  "nav2d_T30_N4096_essps", "nav2d_T50_N512_essps", "pendulum_T15_N256_lbps",
+                                  "nav2d_T30_N512_lbps", "pendulum_T15_N256_mpo", "nav2d_T30_N512_mpo"])
+def test_identical_seed_closed_loop_with_the_temperature_on_the_host(name, mode):
+    """The north star's literal split — auto-lambda on the HOST — through the same identical-seed closed loops:
+    mode "host": `auto_lambda_stats="host"`: costs[N] copied to the CPU and searched with scipy's brentq / bounded Brent /
+    the Adam step in numpy fp32, the reference's own calls (mppi.py:341-370,387-398; pi_mpc/_host.py);
+    mode "brent": the same root-finders inside the library (csrc/host_search.hpp ports of brentq's bracket rule and of
+    scipy's bounded Brent) probing the device-side softmax statistics one temperature at a time."""
+    if mode == "brent" and CASES[name]["lambda_"] == "MPO":
+        pytest.skip("MPO has no search: the device-statistics step is the default path")
+    kw = dict(auto_lambda_stats="host") if mode == "host" else dict(lbps_search="brent", essps_search="brentq")
+    _identical_seed_closed_loop(name, tag="_" + mode, **kw)
+
+
+def _identical_seed_closed_loop(name, tag="", **solver_kw):
     cfg, g = CASES[name], load(name)
     model, T, N = cfg["model"], cfg["T"], cfg["N"]
     kw = {k: cfg[k] for k in SOLVER_KW if k in cfg}
+    kw.update(solver_kw)
     solver, ctrl = make_solver(model, T, N, lambda_=cfg["lambda_"], noise_source="torch_cpu", seed=42, **kw)
     P = oracle_problem(model, N, T, cfg.get("exploration", 0.0))
     state = torch.from_numpy(g["x0_0"])
-    carried = 0.0  # error carried by the warm start / state of our own previous solves
     for k in range(int(g["K"])):
-        assert np.array_equal(state.cpu().numpy(), g[f"x0_{k}"]) or rel_err(state.cpu().numpy(), g[f"x0_{k}"]) < 1e-5 + carried
+        band = band_closed_loop(g, k)  # the reference's own closed loop under rounding-level changes of its costs
+        assert rel_err(state.cpu().numpy(), g[f"x0_{k}"]) <= max(TOL, band["x0"])
         if ctrl is not None:
             env = _envs["racing"]
             ref, ctrl.current_path_index = ctrl.calc_ref_trajectory(state, env.racing_center_path,
@@ -260,17 +300,20 @@ def test_identical_seed_closed_loop_matches_reference(name):
         assert np.abs(solver._action_noises.cpu().numpy() - g[f"eps_{k}"]).max() == 0.0  # same stream, bit for bit
         c = solver._costs.cpu().numpy()
         lam, lam_ref = solver._last_lambda, used_lambda(g, cfg, k)
-        lam_tol = {"ESSPS": 1e-3 if k else 1e-4, "LBPS": 2e-2, "MPO": k * mpo_lambda_tolerance(c, lam_ref)}.get(cfg["lambda_"], 0.0)
-        assert abs(lam - lam_ref) <= lam_tol * lam_ref + 1e-12, (k, lam, lam_ref)
-        # the temperature differs by the search tolerance: its first-order effect on the weights is part of the band
-        w_ref = g[f"weights_{k}"].astype(np.float64)
-        cr = g[f"costs_{k}"].astype(np.float64)
-        dlam = 2.0 * float(np.abs(w_ref * (cr - float((w_ref * cr).sum()))).sum()) * abs(lam - lam_ref) / (lam_ref * lam_ref)
-        carried = check_end_to_end(a.cpu().numpy(), s.cpu().numpy(), c, lam_ref, g, k, cfg, P, extra=2 * carried + dlam)
+        if cfg["lambda_"] in ("ESSPS", "LBPS", "MPO"):
+            kk = k - 1 if cfg["lambda_"] == "MPO" else k  # (MPO: this solve's weights use the temperature solve k-1 left)
+            lam_band = band_closed_loop(g, kk)["lam"] if kk >= 0 else 0.0
+            lim = max({"ESSPS": 1e-4, "LBPS": LBPS_TOL, "MPO": 1e-4}[cfg["lambda_"]], lam_band)
+            parity_report.record("closed_loop_lambda_rel_err_" + cfg["lambda_"] + tag, abs(lam - lam_ref) / lam_ref, lim,
+                                 reference_band=lam_band)
+            assert abs(lam - lam_ref) <= lim * lam_ref, (k, lam, lam_ref, lim)
+        else:
+            assert lam == lam_ref
+        check_end_to_end(a.cpu().numpy(), s.cpu().numpy(), c, g, k, cfg, band["action"], band["state"], tag=tag)
         if "posterior_after" in g.files and int(g["posterior_after"]) == k:
             ps, pst = solver.get_samples_from_posterior(a, state, g["posterior_samples"].shape[0])
-            assert rel_err(ps.cpu().numpy(), g["posterior_samples"]) < TOL + carried
-            assert rel_err(pst.cpu().numpy(), g["posterior_states"]) < TOL + carried
+            assert rel_err(ps.cpu().numpy(), g["posterior_samples"]) <= max(TOL, band["action"])
+            assert rel_err(pst.cpu().numpy(), g["posterior_states"]) <= max(TOL, band["action"], band["state"])
             assert np.abs((ps - a[None]).cpu().numpy() - (g["posterior_samples"] - g[f"action_seq_{k}"][None])).max() < 1e-6
         if ctrl is not None:  # env.step of the reference loop (example/racing.py:233)
             env = _envs["racing"]

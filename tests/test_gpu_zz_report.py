@@ -1,5 +1,8 @@
 """Last module of the GPU session (file order): writes what the parity tests MEASURED to gpurun_out/parity_report.json
-and asserts the headroom — every tolerance is used to at most half, except the quantities named in EXCEPTIONS."""
+and asserts the headroom — every FIXED tolerance is used to at most half, except the quantities named in EXCEPTIONS.
+Quantities whose limit is max(1e-5, the reference's own measured spread) (entries carrying `reference_band`, see
+tests/golden/make_golden.py) are held to that limit as it is: a band is a measurement of the reference, not a tolerance
+of ours, and the report counts how many of those checks hold the plain 1e-5."""
 import os
 
 import pytest
@@ -9,13 +12,8 @@ from helpers import ROOT
 
 pytestmark = pytest.mark.gpu
 
-# quantities that may come closer than 2x to their limit, and why
+# fixed tolerances that may come closer than 2x to their limit, and why
 EXCEPTIONS = {
-    # the band of the end-to-end comparison is DERIVED from the actual cost differences to the fixture (first-order change
-    # of the softmax, see check_end_to_end): it is tight by construction, not a fixed tolerance
-    "action_seq_vs_reference_fixture", "state_seq_vs_reference_fixture",
-    # MPO: bounded by the rule's own conditioning (mpo_lambda_tolerance: one fp32 ulp of the log-sum-exp)
-    "lambda_rel_err_MPO",
     # randomised parameter sets deliberately include maps where many samples sit on cell boundaries
     "map_cell_flips",
 }
@@ -25,12 +23,18 @@ def test_parity_report_and_headroom():
     if not parity_report.entries:
         pytest.skip("no parity measurements in this session (run the whole GPU suite)")
     rep = parity_report.write(os.path.join(ROOT, "gpurun_out", "parity_report.json"))
+    banded = {e["quantity"] for e in parity_report.entries if "reference_band" in e}
     tight = {q: v["worst_fraction_of_limit"] for q, v in rep["summary"].items()
-             if v["worst_fraction_of_limit"] > 0.5 and q not in EXCEPTIONS}
+             if v["worst_fraction_of_limit"] > (1.0 if q in banded else 0.5) and q not in EXCEPTIONS}
     for q, v in sorted(rep["summary"].items()):
-        print(f"{q:44s} n={v['count']:4d}  worst {v['worst']['value']:.3e} of {v['worst']['limit']:.3e} "
-              f"({100 * v['worst_fraction_of_limit']:.1f} %) in {v['worst']['test']}")
-    assert not tight, f"less than 2x headroom: {tight}"
+        extra = ""
+        if q in banded:
+            es = [e for e in parity_report.entries if e["quantity"] == q]
+            n5 = sum(1 for e in es if e.get("within_1e5", e["value"] <= 1e-5))
+            extra = f"  [{n5}/{len(es)} within 1e-5; the rest within the reference's own measured band]"
+        print(f"{q:52s} n={v['count']:4d}  worst {v['worst']['value']:.3e} of {v['worst']['limit']:.3e} "
+              f"({100 * v['worst_fraction_of_limit']:.1f} %) in {v['worst']['test']}{extra}")
+    assert not tight, f"beyond the limit / less than 2x headroom on a fixed tolerance: {tight}"
     # the headline config: how many of the allowed boundary flips C3 really uses
     c3 = [e for e in parity_report.entries if e["quantity"] == "map_cell_flips" and e.get("n") == 1 << 20]
     assert c3 and max(e["value"] for e in c3) <= 20, c3

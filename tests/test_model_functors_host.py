@@ -7,7 +7,8 @@ import numpy as np
 import pytest
 
 import emul
-from helpers import CASES, MODEL_CFG, load, nav2d_env_fixture, oracle_problem, orc, racing_env_fixture, rel_err
+from helpers import (CASES, MODEL_CFG, band_fixed, load, nav2d_env_fixture, oracle_problem, orc, racing_env_fixture, rel_err,
+                     sg_coeffs)
 
 F32 = np.float32
 
@@ -54,6 +55,42 @@ def test_functors_vs_oracle(name, fast):
             assert np.array_equal(S, r["S"])  # library math: same operations as the oracle
         else:
             assert rel_err(S, r["S"]) < 1e-5
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_end_to_end_error_of_the_device_arithmetic_stays_inside_the_reference_bands(name):
+    """Pre-GPU statement of tests/test_gpu_parity.py::check_end_to_end: the device functors' costs (host build, fast
+    math, the kernel's cost summation: exactly rounded, sequential fp32 for racing) -> softmax at the reference's
+    temperature -> weighted mean -> SG -> batch-1 rollout, against the reference fixture: 1e-5, or the reference's own
+    measured spread under rounding-level changes of its costs (band_fixed, tests/golden/make_golden.py)."""
+    import mppi_playground_amd  # noqa: F401  (puts pi_mpc on the path)
+    from pi_mpc import _host
+
+    cfg, g = CASES[name], load(name)
+    m, N, T = cfg["model"], cfg["N"], cfg["T"]
+    mid = orc.MODEL_IDS[m]
+    P = oracle_problem(m, N, T, cfg.get("exploration", 0.0))
+    params, maps, geom = _model_inputs(m)
+    mc = MODEL_CFG[m]
+    for k in range(int(g["K"])):
+        ref = g[f"ref_path_{k}"] if m == "racing" else None
+        if ref is not None:
+            P.set_ref_path(ref)
+        x0, mean, eps = g[f"x0_{k}"], g[f"mean_in_{k}"], g[f"eps_{k}"]
+        c, _, _ = emul.rollout_cost(mid, 1, x0, mean, eps, mc["u_min"], mc["u_max"],
+                                    int(N * (1 - cfg.get("exploration", 0.0))), params, maps, geom, ref)
+        if cfg["lambda_"] == "MPO":  # this solve's weights use the temperature the previous solve left (mppi.py:387-398)
+            lam = 1.0 if k == 0 else float(g[f"lambda_{k - 1}"])
+        else:
+            lam = float(g[f"lambda_{k}"])
+        w, _ = orc.softmax_weights(c, lam)
+        a = P.weighted_actions(w, mean, eps)
+        if cfg.get("use_sg_filter"):
+            a = _host.sg_filter_sequence(g[f"sg_hist_in_{k}"], a, sg_coeffs(cfg))
+        s = P.rollout_single(x0, a)
+        band_a, band_s = band_fixed(g, k)
+        assert rel_err(a, g[f"action_seq_{k}"]) <= max(1e-5, band_a), (k, rel_err(a, g[f"action_seq_{k}"]), band_a)
+        assert rel_err(s, g[f"state_seq_{k}"][0]) <= max(1e-5, band_s), (k, rel_err(s, g[f"state_seq_{k}"][0]), band_s)
 
 
 def _p(a):
