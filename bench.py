@@ -76,6 +76,8 @@ def main():
                     help="1 = regenerate the Philox noise in registers (default), 0 = materialise the noise tiles")
     ap.add_argument("--mapping", type=int, default=0, help="0 = lane per trajectory (default), 1 = the literal "
                     "wavefront-per-trajectory rollout (comparison only)")
+    ap.add_argument("--lazy-state-seq", type=int, default=-1, help="the batch-1 rollout of the solution completed lazily (in an "
+                    "extra block of the next solve's rollout launch): 1 = on, 0 = off, -1 = the solver's default")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip both CPU baselines")
     ap.add_argument("--no-extras", action="store_true", help="skip closed_loop and other_configs")
     ap.add_argument("--workload", choices=("c3", "c2", "c5"), default="c3",
@@ -147,7 +149,8 @@ def main():
         if mode is not None:
             os.environ["MPPI_EXCHANGE"] = mode
         try:
-            ctrl = racing_controller(env, horizon=T, num_samples=N_total, lambda_=1.0, shard_samples=world > 1)
+            dkw = {} if args.lazy_state_seq < 0 else {"lazy_state_seq": bool(args.lazy_state_seq)}
+            ctrl = racing_controller(env, horizon=T, num_samples=N_total, lambda_=1.0, shard_samples=world > 1, **dkw)
         except (_capi.MppiError, RuntimeError) as e:  # the transport's set-up / self-test failed on every rank alike
             return {"exchange": mode, "error": str(e)[:300]}
         ctrl.set_cost_map(env._obstacle_map, env._lane_map)
@@ -173,6 +176,7 @@ def main():
         t0 = time.perf_counter()
         for _ in range(args.steps):
             a, s = solver.forward(x0)
+        solver.join_state_seq()  # (lazy state sequences: all K of them are completed INSIDE the timed region)
         sync()
         dt = time.perf_counter() - t0
         stages = solver.stage_times_ms()
@@ -219,10 +223,14 @@ def main():
         # PMC counters of the dominant kernel for THIS configuration, per launch: collected with rocprofv3 --pmc in
         # separate passes over this same command and committed (profiles/pmc_constants.json names the CSV summaries
         # they were generated from by scripts/pmc_constants.py); a bench run cannot collect counters on itself.
-        traffic, valu, traffic_src = None, None, None
+        traffic, valu, traffic_src, traffic_stale, solve_pmc = None, None, None, None, None
         try:
             if (N_local, T, args.math) == (1 << 20, 50, 2):
+                from mppi_playground_amd import _build
+
                 pc = json.load(open(os.path.join(ROOT, "profiles", "pmc_constants.json")))
+                # counters are per BUILD of the kernels: the file carries the sha256 of the sources it was measured on
+                traffic_stale = pc.get("csrc_sha256") != _build.source_digest()
                 k = pc["rollout_regen" if args.noise_regen else "rollout_tiles"]
                 traffic = int((2 * k["fetch_kb"] + k["write_kb"]) * 1024)  # FETCH_SIZE doubled: gfx950 wide-read correction
                 traffic_src = pc.get("source")
@@ -232,7 +240,13 @@ def main():
                         "frac": k["valu_insts"] / t_roll / peak,
                         "measured_peak_Ginst_per_s": pc.get("valu_issue_ubench", {}).get("mul_add_Ginst_per_s"),
                         "cycles_per_inst_per_simd_at_2p4GHz": 1024 * 2.4e9 * t_roll / k["valu_insts"],
+                        "counters_stale": traffic_stale,
                         "note": "wave64 VALU instructions (SQ_INSTS_VALU, rocprofv3) / live kernel time"}
+                ks = pc.get("solve_regen" if args.noise_regen else "solve_tiles")
+                if ks and ks.get("fetch_kb") is not None:
+                    solve_pmc = {"bytes_moved": int((2 * ks["fetch_kb"] + ks["write_kb"]) * 1024),
+                                 "valu_insts": ks.get("valu_insts"),
+                                 "valu_frac": None if not ks.get("valu_insts") else ks["valu_insts"] / (dev_solve_ms * 1e-3) / peak}
         except Exception:
             pass
         used = best["exchange"]
@@ -257,16 +271,28 @@ def main():
             # HBM peak, as the metric asks; they cannot exceed ~0.45 at this instruction count
             "roofline": {"bound": "valu", "kernel": "rollout_cost_kernel<racing>", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale,
                          "algorithmic_bytes_per_launch": b_alg_rollout, "kernel_ms": stages["rollout_cost"]},
-            "solve_roofline": {"algorithmic_bytes_per_solve": b_alg_solve, "device_ms_per_solve": dev_solve_ms,
-                               "achieved_GBps": b_alg_solve / (dev_solve_ms * 1e-3) / 1e9,
-                               "frac_of_8TBps": b_alg_solve / (dev_solve_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                               "note": "accounting equivalence, not achieved bandwidth: B_alg (SURVEY 8d) prices the noise "
-                                       "as written once and read twice, but it is regenerated in registers and never touches "
-                                       "HBM (roofline.traffic), so this figure can exceed 1"},
+            # the whole solve (every kernel of it): what it MOVES through HBM (PMC, all mppi:: kernels of a solve) and how
+            # much of the VALU issue peak it uses over its device time.  SURVEY 8d's B_alg (three noise-sized terms + the
+            # costs) is kept for reference only: two of its terms never touch HBM in this design (the noise is
+            # regenerated in registers) and at lambda = 1 the third is an arg-min over one or two tiles, so
+            # B_alg / time is not a bandwidth (it exceeded the 8 TB/s peak in round 3); `other_configs.c3_dense`
+            # times the solve whose weighted reduction does touch every tile.
+            "solve_roofline": {"device_ms_per_solve": dev_solve_ms,
+                               "bytes_moved": None if solve_pmc is None else solve_pmc["bytes_moved"],
+                               "moved_GBps": None if solve_pmc is None else solve_pmc["bytes_moved"] / (dev_solve_ms * 1e-3) / 1e9,
+                               "valu_insts": None if solve_pmc is None else solve_pmc["valu_insts"],
+                               "valu_frac": None if solve_pmc is None else solve_pmc["valu_frac"],
+                               "counters_stale": traffic_stale,
+                               "algorithmic_bytes_per_solve_survey_8d": b_alg_solve,
+                               "note": "bytes_moved / valu_insts: rocprofv3 PMC sums over every kernel of one solve "
+                                       "(profiles/pmc_constants.json); the solve is VALU-issue bound, not HBM bound"},
             "stages_ms": {k: stages[k] for k in ("sample", "rollout_cost", "weights_reduce", "finalize")},
         }
+        out["config"]["state_seq"] = ("lazily completed: solve k's batch-1 rollout rides in an extra block of solve k+1's rollout "
+                                      "launch; the last one is completed inside the timed region" if solver._lazy_state else
+                                      "rolled out inside the solve's last kernel")
         if best["exchange_ms"] is not None:
             out["stages_ms"]["exchange_and_handoffs"] = best["exchange_ms"]
             out["exchange_us"] = best["exchange_ms"] * 1e3  # per solve: wall time minus the device stages (instrumented pass)
@@ -363,6 +389,7 @@ def closed_loop(torch, env, ctrl, T, N):
         tc = time.perf_counter()
         t_upd += tb - ta
         t_step += tc - tb
+    ctrl.solver.join_state_seq()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     return {"ticks": ticks, "warmup_ticks": warm, "ms_per_tick": dt / ticks * 1e3, "solves_per_sec": ticks / dt,
@@ -409,6 +436,7 @@ def _time_solver(torch, solver, x0, n=50, warm=10):
     t0 = time.perf_counter()
     for _ in range(n):
         solver.forward(x0)
+    solver.join_state_seq()  # (a lazily completed state sequence of the last solve belongs inside the timed region)
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / n
 
@@ -445,8 +473,24 @@ def _other_solvers(torch, np, which=None):
     return [r for r in rows if which is None or r[0] in which]
 
 
+def _stage_times(torch, solver, x0, n=30):
+    """Per-stage device times (HIP events around each stage's launches) from a separate instrumented pass."""
+    solver.set_option("timing", 1)
+    solver.stage_times_ms()  # drain
+    for _ in range(n):
+        solver.forward(x0)
+    torch.cuda.synchronize()
+    st = solver.stage_times_ms()
+    solver.set_option("timing", 0)
+    return {k: st[k] for k in ("sample", "rollout_cost", "weights_reduce", "finalize")}
+
+
 def other_configs(torch, np):
-    """Solve times of the other BASELINE configs (open loop, 10 warm-up + 50 timed solves each)."""
+    """Solve times of the other BASELINE configs (open loop, 10 warm-up + 50 timed solves each), and the metric's own
+    workload with a DENSE softmax: at lambda = 1 (configs[2], the headline) the racing softmax is an arg-min and the
+    weighted reduction touches one or two of the 16 384 tiles; `c3_dense` (lambda = 5000: ESS of a few thousand) and
+    `c3_essps` (ESS = N / 10) are what a non-degenerate 1 M-sample solve costs — every tile's noise is regenerated a
+    second time and accumulated."""
     out = {}
     for key, label, work, b_alg, make, x0 in _other_solvers(torch, np):
         s = make()
@@ -455,6 +499,28 @@ def other_configs(torch, np):
                     "sample_steps_per_sec": work / dt, "algorithmic_bytes_per_solve": b_alg,
                     "frac_of_8TBps": b_alg / dt / 1e9 / HBM_PEAK_GBS, "lambda": s._last_lambda}
         del s
+    from envs.racing_controller import racing_controller
+    from envs.racing_env import RacingEnv
+
+    env = RacingEnv()
+    x0 = env.reset().clone()
+    n, T = 1 << 20, 50
+    for key, lam, label in (("c3_dense", 5000.0, "C3 racing T=50 N=1048576 lambda=5000 (dense softmax)"),
+                            ("c3_essps", "ESSPS", "C3 racing T=50 N=1048576 ESSPS (target ESS = N/10; device-resident search)")):
+        ctrl = racing_controller(env, horizon=T, num_samples=n, lambda_=lam, **({"lambda_max": 1.0e5} if lam == "ESSPS" else {}))
+        ctrl.set_cost_map(env._obstacle_map, env._lane_map)
+        ref, _ = ctrl.calc_ref_trajectory(x0, env.racing_center_path, 0, T, DL=0.1, lookahead_distance=3,
+                                          reference_path_interval=0.85)
+        ctrl.set_reference(ref)
+        s = ctrl.solver
+        dt = _time_solver(torch, s, x0, n=50, warm=20)
+        st = s.last_stats()
+        stages = _stage_times(torch, s, x0)
+        out[key] = {"config": label, "ms_per_solve": dt * 1e3, "solves_per_sec": 1 / dt, "sample_steps_per_sec": n * T / dt,
+                    "stages_ms": stages, "other_launches_ms": max(dt * 1e3 - sum(stages.values()), 0.0),
+                    "lambda": s._last_lambda, "ess": st["ess"]}
+        del s, ctrl
+        torch.cuda.empty_cache()
     return out
 
 

@@ -101,7 +101,7 @@ typedef struct MppiConfig {
 const char* mppi_version(void);
 /* Integer version of THIS header's function signatures; bindings compare it with the constant they were written
  * against and refuse a stale library (a changed argument list would otherwise be called with shifted arguments). */
-#define MPPI_ABI_VERSION 8
+#define MPPI_ABI_VERSION 9
 int mppi_abi_version(void);
 /* Number of visible HIP devices (0 => the product cannot run; callers must fail loudly). */
 int mppi_device_count(void);
@@ -248,6 +248,21 @@ int mppi_set_auto_lambda(mppi_handle_t h, int rule, double param, double lam_min
  * per solve and no host synchronisation for any temperature rule. */
 int mppi_solve(mppi_handle_t h, const float* x0_dev, uint32_t solve_idx, float lambda, float* action_out_dev,
                float* state_seq_out_dev, float* stats_out_dev, void* stream);
+/* Lazily completed state sequences (mppi_set_option("lazy_state_seq", 1)).  The reference returns `state_seq` — the batch-1
+ * rollout of the solution, mppi.py:448-449,508-524 — with the action sequence, but nothing on a control loop's critical
+ * path needs it: the next solve samples around the mean, env.step applies a[0].  With the option set, mppi_finalize /
+ * mppi_solve of a native model on the multi-kernel path leave those T dependent steps out of the solve's last kernel; the
+ * rollout (same code, same bits) then rides in one extra block of the NEXT mppi_rollout_cost / mppi_solve launch on that
+ * stream — hidden behind its N-sample rollout — or, when somebody wants the state sequence before that, runs as a one-wave
+ * kernel of its own: a reader of state_seq_out_dev calls mppi_join_state_seq(h, serial, its stream) first (no-op when
+ * nothing is pending; the single launch of small problems always rolls out itself).  state_seq_out_dev must stay valid
+ * until then.  mppi_state_seq_serial: the number of the last mppi_finalize and whether its state sequence is pending;
+ * handing that number to mppi_join_state_seq makes a reader of an OLDER solve's sequence launch nothing. */
+int mppi_join_state_seq(mppi_handle_t h, uint32_t serial /* 0 = whatever is pending */, void* stream);
+int mppi_state_seq_serial(mppi_handle_t h, uint32_t* serial_out, int* pending_out);
+/* out2_host = {mean device time of the stand-alone state-sequence kernel [ms] (-1: none), launches} since the last call
+ * (option "timing" = 1). */
+int mppi_get_state_seq_timing(mppi_handle_t h, float* out2_host);
 /* mppi_solve as a SINGLE LAUNCH.  For small problems (option "fused_solve" = 1, the default: num_samples <= 4096, the
  * sizes of the reference's examples; <= 16 384 under a device-resident ESSPS / LBPS search) whose noise is regenerated in
  * registers, with T*dim_control <= 128 and no sharding, mppi_solve runs ONE cooperative kernel instead of 3-9 dependent
@@ -363,6 +378,8 @@ int mppi_top_candidates(mppi_handle_t h, int k, uint64_t* cand_out_dev, void* st
 int mppi_rollout_candidates(mppi_handle_t h, const uint64_t* cand_dev, int k, float lambda, float* states_out_dev,
                             float* weights_out_dev, void* stream);
 
+/* What RCCL reports for this handle's communicator (ncclCommCount, ncclCommUserRank): diagnostics for multi-GPU runs. */
+int mppi_comm_info(mppi_handle_t h, int* count_out, int* rank_out);
 /* In-library collective for sharded solves (variant A: one all_gather of the 4+T*dc-float shard summaries; the
  * reference has no counterpart, src/pi_mpc/mppi.py:102-105 is single-device).  One process per GPU; RCCL is dlopen()ed
  * (librccl.so.1) on first use, so unsharded callers do not need it.

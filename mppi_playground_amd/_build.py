@@ -28,6 +28,19 @@ def deps() -> list:
     return out + [HEADER]
 
 
+def source_digest() -> str:
+    """sha256 over everything the library is compiled from (deps(), in order, file names included): what profiles/
+    pmc_constants.json is keyed on, so that counters measured on another build of the kernels are recognised as stale."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for path in deps():
+        h.update(os.path.basename(path).encode() + b"\0")
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def stale() -> bool:
     if not os.path.exists(LIB):
         return True

@@ -124,13 +124,21 @@ struct MppiSolver {
     int math_fast = 2;
     int reduce_blocks = 512;
     int timing = 0;
-    std::vector<hipEvent_t> ev_pool[4];  // per stage: start0, stop0, start1, stop1, ...
-    size_t ev_used[4] = {0, 0, 0, 0};
+    std::vector<hipEvent_t> ev_pool[5];  // per stage (4 = the deferred state sequence): start0, stop0, start1, stop1, ...
+    size_t ev_used[5] = {0, 0, 0, 0, 0};
     int GPW = 8, nchunks = 1, colsp = 128;  // reduce: float4 groups per wave, column chunks, padded row
     bool summary_valid = false;             // summarize_kernel ran after the last reduce
     int* live_hint = nullptr;               // mapped pinned: partial rows the last fold saw (host-side hint)
     int* live_hint_dev = nullptr;
     int fold_mode = 0;                      // 0: choose by the hint; 1: fold inside finalize when it fits; 2: always summarize
+    // lazily completed state sequence (option "lazy_state_seq"): finalize_kernel leaves {action, start state} in `b1` and
+    // the batch-1 rollout of the solution rides in ONE EXTRA BLOCK of the next rollout kernel on the same stream
+    // (mppi_rollout_cost) — or runs as its own one-wave kernel when somebody asks for it first (mppi_join_state_seq)
+    int lazy_state = 0;
+    float* b1 = nullptr;                    // [row + MPPI_MAX_DIM_STATE]
+    float* pending_state_out = nullptr;     // where the not-yet-rolled-out state sequence of the last solve goes (or null)
+    uint32_t pending_serial = 0;            // which solve that is (mppi_join_state_seq)
+    uint32_t finalize_serial = 0;
     std::string err;
 };
 
@@ -317,6 +325,8 @@ struct RcclApi {
     decltype(&ncclCommDestroy) comm_destroy = nullptr;
     decltype(&ncclAllGather) all_gather = nullptr;
     decltype(&ncclGetErrorString) error_string = nullptr;
+    decltype(&ncclCommCount) comm_count = nullptr;        // optional (diagnostics: mppi_comm_info)
+    decltype(&ncclCommUserRank) comm_user_rank = nullptr;
     bool ok = false;
 };
 const RcclApi& rccl() {
@@ -330,6 +340,8 @@ const RcclApi& rccl() {
         a.comm_destroy = reinterpret_cast<decltype(a.comm_destroy)>(dlsym(lib, "ncclCommDestroy"));
         a.all_gather = reinterpret_cast<decltype(a.all_gather)>(dlsym(lib, "ncclAllGather"));
         a.error_string = reinterpret_cast<decltype(a.error_string)>(dlsym(lib, "ncclGetErrorString"));
+        a.comm_count = reinterpret_cast<decltype(a.comm_count)>(dlsym(lib, "ncclCommCount"));
+        a.comm_user_rank = reinterpret_cast<decltype(a.comm_user_rank)>(dlsym(lib, "ncclCommUserRank"));
         a.ok = a.get_unique_id && a.comm_init_rank && a.comm_destroy && a.all_gather && a.error_string;
         return a;
     }();
@@ -349,6 +361,7 @@ P2pCtx p2p_ctx(mppi_handle_t h) {
 }  // namespace
 
 static int mpo_upload(mppi_handle_t h, double lambda0, double epsilon, double lr, bool lambda_too);
+static int flush_state_seq(mppi_handle_t h, hipStream_t s);
 
 extern "C" {
 
@@ -509,6 +522,7 @@ int mppi_destroy(mppi_handle_t h) {
         if (h->stage_ev[i]) (void)hipEventDestroy(h->stage_ev[i]);
     }
     for (auto& pool : h->ev_pool) for (auto& e : pool) if (e) (void)hipEventDestroy(e);
+    (void)hipFree(h->b1);
     delete h;
     return MPPI_OK;
 }
@@ -518,6 +532,10 @@ int mppi_set_model_params(mppi_handle_t h, const float* p, int n) {
     const int need = h->cfg.model == MPPI_MODEL_RACING ? MPPI_RP_COUNT : h->cfg.model == MPPI_MODEL_NAV2D ? MPPI_NP_COUNT
                      : h->cfg.model == MPPI_MODEL_GOALZONE ? MPPI_GP_COUNT : 0;
     if (n != need) return fail(h, MPPI_E_INVALID, "parameter count does not match the model");
+    if (h->pending_state_out) {  // a lazily completed state sequence belongs to the OLD constants: roll it out first (set-up path)
+        HIP_TRY(h, hipDeviceSynchronize());
+        if (int rc = flush_state_seq(h, nullptr)) return rc;
+    }
     for (int i = 0; i < n; ++i) h->ctx.P[i] = p[i];
     const float* um = h->cfg.u_min; const float* uM = h->cfg.u_max;
     if (h->cfg.model == MPPI_MODEL_GOALZONE) {
@@ -870,6 +888,7 @@ int mppi_rollout_cost(mppi_handle_t h, void* stream) {
     if (int rc = check_ready(h)) return rc;
     hipStream_t s = (hipStream_t)stream;
     if (h->mapping == 1) {  // comparison variant: one wavefront per trajectory, reference-layout noise
+        if (int rc = flush_state_seq(h, s)) return rc;
         if (!h->noise_std) HIP_TRY(h, hipMalloc(&h->noise_std, sizeof(float) * (size_t)h->d.N * h->d.row));
         if (int rc = need_tiles(h, s)) return rc;
         const dim3 cgrid((unsigned)h->d.tiles, (unsigned)((h->d.row + CONV_COLS - 1) / CONV_COLS));
@@ -900,17 +919,24 @@ int mppi_rollout_cost(mppi_handle_t h, void* stream) {
     h->min_slot ^= 1;
     unsigned* mk = h->min_key + h->min_slot;
     unsigned* mk_next = h->min_key + (h->min_slot ^ 1);
-    const unsigned grid = (unsigned)((h->d.tiles + 3) / 4);
+    // a state sequence still pending from the previous solve (option "lazy_state_seq") rides in one extra block of this
+    // launch: its T dependent steps hide behind the N-sample rollout instead of extending the previous solve's tail
+    float* ride = h->pending_state_out;
+    h->pending_state_out = nullptr;
+    const unsigned grid = (unsigned)((h->d.tiles + 3) / 4) + (ride ? 1u : 0u);
 #define CALL_ROLLOUT(MODEL, FASTV)                                                                    \
     do {                                                                                              \
-        const size_t shmem = sizeof(float) * ((size_t)8 * h->d.R + (size_t)h->d.T * ModelT<MODEL, FASTV>::KROW); \
+        const size_t shmem = sizeof(float) * std::max((size_t)8 * h->d.R + (size_t)h->d.T * ModelT<MODEL, FASTV>::KROW, \
+                                                      (size_t)h->d.row + MPPI_MAX_DIM_STATE);         \
         constexpr bool UCV = FASTV != 0;  /* the FAST kernels exist in the u_in_bounds form only (see use_fast) */ \
         if (gen)                                                                                      \
             hipLaunchKernelGGL((rollout_cost_kernel<MODEL, FASTV, true, UCV>), dim3(grid), dim3(BLOCK), shmem, s, \
-                               h->noise, h->mean, h->x0_cur, h->costs, mk, mk_next, h->mean_used, h->x0_used, h->d, h->gen, h->ctx); \
+                               h->noise, h->mean, h->x0_cur, h->costs, mk, mk_next, h->mean_used, h->x0_used, h->d, h->gen, h->ctx, \
+                               (const float*)h->b1, ride);                                           \
         else                                                                                          \
             hipLaunchKernelGGL((rollout_cost_kernel<MODEL, FASTV, false, UCV>), dim3(grid), dim3(BLOCK), shmem, s, \
-                               h->noise, h->mean, h->x0_cur, h->costs, mk, mk_next, h->mean_used, h->x0_used, h->d, h->gen, h->ctx); \
+                               h->noise, h->mean, h->x0_cur, h->costs, mk, mk_next, h->mean_used, h->x0_used, h->d, h->gen, h->ctx, \
+                               (const float*)h->b1, ride);                                           \
     } while (0)
     MPPI_DISPATCH(h, CALL_ROLLOUT);
 #undef CALL_ROLLOUT
@@ -1012,7 +1038,6 @@ int mppi_finalize(mppi_handle_t h, const float* summaries_dev, int num_shards, f
     if (generic && state_out) return fail(h, MPPI_E_INVALID, "generic model: roll the action out with the host dynamics");
     if (!generic) { if (int rc = check_ready(h)) return rc; }
     hipStream_t s = (hipStream_t)stream;
-    StageTimer tm(h, 3, s);
     P2pCtx p2p{};  // seq == 0: off
     if (!summaries_dev) {  // this handle's own reduction (mppi_weights_reduce)
         if (h->last_reduce_blocks < 1) return fail(h, MPPI_E_STATE, "mppi_finalize before mppi_weights_reduce");
@@ -1033,14 +1058,57 @@ int mppi_finalize(mppi_handle_t h, const float* summaries_dev, int num_shards, f
     const size_t shmem = finalize_lds_floats(h, p2p.seq ? p2p.world : 1, sg.window, fold_here) * sizeof(float);
     if (shmem > 64 * 1024) return fail(h, MPPI_E_INVALID, "finalize: horizon too long for the exchange / filter staging");
     const unsigned* mk = h->min_key + h->min_slot;
+    // Option "lazy_state_seq": the batch-1 rollout leaves this kernel (and the solve's critical path).  The kernel writes the
+    // rollout's inputs to h->b1; the rollout itself rides in the next mppi_rollout_cost launch on this stream, or is
+    // launched by mppi_join_state_seq when somebody reads the state sequence first.
+    const bool defer = h->lazy_state && state_out && !generic && h->mapping == 0;
+    if (h->pending_state_out) { if (int rc = flush_state_seq(h, s)) return rc; }  // (an older one nobody picked up)
+    {
+        StageTimer tm(h, 3, s);
 #define CALL_FINALIZE(MODEL, FASTV)                                                                   \
     hipLaunchKernelGGL((finalize_kernel<MODEL, FASTV>), dim3(1), dim3(FIN_BLOCK), shmem, s, summaries_dev, num_shards, \
                        h->partials, h->heads, mk, h->last_reduce_blocks, h->colsp, h->summary, h->live_hint_dev,  \
                        lambda, lam_dev, h->d.row, h->d.T, h->x0_cur, store_mean ? h->mean : (float*)nullptr, action_out,  \
-                       state_out, stats_out, h->solve_stats, sg, p2p, h->ctx)
-    MPPI_DISPATCH(h, CALL_FINALIZE);
+                       defer ? (float*)nullptr : state_out, stats_out, h->solve_stats, sg, p2p, h->ctx,          \
+                       defer ? h->b1 : (float*)nullptr)
+        MPPI_DISPATCH(h, CALL_FINALIZE);
 #undef CALL_FINALIZE
+    }
     HIP_TRY(h, hipGetLastError());
+    ++h->finalize_serial;
+    if (defer) { h->pending_state_out = state_out; h->pending_serial = h->finalize_serial; }
+    return MPPI_OK;
+}
+
+// The pending batch-1 rollout as its own one-wave kernel on `s` (same code and bits as the in-kernel rollout).
+static int flush_state_seq(mppi_handle_t h, hipStream_t s) {
+    if (!h->pending_state_out) return MPPI_OK;
+    float* out = h->pending_state_out;
+    h->pending_state_out = nullptr;
+    const size_t sh1 = sizeof(float) * ((size_t)h->d.row + MPPI_MAX_DIM_STATE);
+    StageTimer tm(h, 4, s);
+#define CALL_STATE_SEQ(MODEL, FASTV)                                                                  \
+    hipLaunchKernelGGL((state_seq_kernel<MODEL, FASTV>), dim3(1), dim3(WAVE), sh1, s, (const float*)h->b1, h->d.row, h->d.T, \
+                       out, h->ctx)
+    MPPI_DISPATCH(h, CALL_STATE_SEQ);
+#undef CALL_STATE_SEQ
+    HIP_TRY(h, hipGetLastError());
+    return MPPI_OK;
+}
+
+// Complete the state sequence of the last mppi_finalize / mppi_solve on `stream` if its rollout is still pending (option
+// "lazy_state_seq"); a no-op otherwise.  `serial` = 0, or the value mppi_state_seq_serial returned right after that solve:
+// a reader of an OLDER solve's state sequence (already completed by a later rollout launch) then launches nothing.
+int mppi_join_state_seq(mppi_handle_t h, uint32_t serial, void* stream) {
+    if (!h) return MPPI_E_INVALID;
+    if (!h->pending_state_out || (serial && serial != h->pending_serial)) return MPPI_OK;
+    return flush_state_seq(h, (hipStream_t)stream);
+}
+// Serial number of the last mppi_finalize (for mppi_join_state_seq), and whether its state sequence is still pending.
+int mppi_state_seq_serial(mppi_handle_t h, uint32_t* serial_out, int* pending_out) {
+    if (!h) return MPPI_E_INVALID;
+    if (serial_out) *serial_out = h->finalize_serial;
+    if (pending_out) *pending_out = h->pending_state_out != nullptr && h->pending_serial == h->finalize_serial;
     return MPPI_OK;
 }
 
@@ -1149,6 +1217,8 @@ static int solve_fused(mppi_handle_t h, float lambda, float* action_out, float* 
 #undef CALL_FUSED
     HIP_TRY(h, hipGetLastError());
     if (rule != FUSED_RULE_NONE) h->lambda_dev_valid = true;
+    // (the single launch rolls the solution out itself; a state sequence still pending from an earlier multi-kernel solve
+    // was completed by mppi_solve before it got here)
     h->last_reduce_blocks = 0;   // no partial rows of a separate reduction exist for this solve
     h->summary_valid = true;     // ... but its summary does (h->summary)
     return MPPI_OK;
@@ -1176,6 +1246,7 @@ int mppi_solve(mppi_handle_t h, const float* x0_dev, uint32_t solve_idx, float l
     if (x0_dev) { if (int rc = mppi_bind_state(h, x0_dev)) return rc; }
     if (int rc = mppi_sample(h, solve_idx, stream)) return rc;
     if (fused_applies(h, lambda)) {
+        if (int rc = flush_state_seq(h, (hipStream_t)stream)) return rc;  // (pending from an earlier multi-kernel solve)
         if (int rc = solve_fused(h, lambda, action_out_dev, state_seq_out_dev, stats_out_dev, (hipStream_t)stream)) return rc;
         if (h->auto_rule == MPPI_AUTO_MPO) return mppi_mpo_step_device(h, stream);
         return MPPI_OK;
@@ -1671,6 +1742,19 @@ int mppi_comm_destroy(mppi_handle_t h) {
 
 // One stand-alone all_gather of data_dev [4 + T*dc] (self-test; every rank calls it the same number of times):
 // gathered_out_dev [world][4 + T*dc].  Synchronises.
+// What RCCL itself says about the communicator of this handle: ncclCommCount / ncclCommUserRank (diagnostics: a
+// multi-GPU bench line records them next to the world size the launcher claims).
+int mppi_comm_info(mppi_handle_t h, int* count_out, int* rank_out) {
+    if (!h || !h->comm) return fail(h, MPPI_E_STATE, "no communicator (mppi_comm_init)");
+    if (!rccl().comm_count || !rccl().comm_user_rank) return fail(h, MPPI_E_STATE, "librccl lacks ncclCommCount / ncclCommUserRank");
+    int c = -1, r = -1;
+    RCCL_TRY(h, rccl().comm_count(h->comm, &c));
+    RCCL_TRY(h, rccl().comm_user_rank(h->comm, &r));
+    if (count_out) *count_out = c;
+    if (rank_out) *rank_out = r;
+    return MPPI_OK;
+}
+
 int mppi_comm_exchange(mppi_handle_t h, const float* data_dev, float* gathered_out_dev, void* stream) {
     if (!h || !data_dev || !gathered_out_dev) return fail(h, MPPI_E_INVALID, "bad comm arguments");
     if (!h->comm) return fail(h, MPPI_E_STATE, "comm: not initialised");
@@ -1774,6 +1858,11 @@ int mppi_set_option(mppi_handle_t h, const char* key, int64_t value) {
         return MPPI_OK;
     }
     if (k == "fused_solve") { h->fused_mode = value < 0 ? 0 : value > 2 ? 2 : (int)value; return MPPI_OK; }
+    if (k == "lazy_state_seq") {  // see mppi_join_state_seq
+        if (value && !h->b1) HIP_TRY(h, hipMalloc(&h->b1, sizeof(float) * ((size_t)h->d.row + MPPI_MAX_DIM_STATE)));
+        h->lazy_state = value ? 1 : 0;
+        return MPPI_OK;
+    }
     if (k == "fold_path") { h->fold_mode = (value >= 0 && value <= 2) ? (int)value : 0; return MPPI_OK; }
     if (k == "exchange_p2p") {  // sharded solves: summaries travel through the peer-to-peer buffer, no collective
         if (value && !h->p2p_connected) return fail(h, MPPI_E_STATE, "exchange_p2p: call mppi_p2p_alloc / mppi_p2p_connect first");
@@ -1787,6 +1876,24 @@ int mppi_set_option(mppi_handle_t h, const char* key, int64_t value) {
     }
     if (k == "noise_regen") { h->noise_regen = value ? 1 : 0; h->tiles_valid = h->tiles_valid && h->injected; return MPPI_OK; }
     return fail(h, MPPI_E_INVALID, "unknown option " + k);
+}
+
+// mean device time [ms] and launch count of the stand-alone state-sequence kernel (mppi_join_state_seq; the rollouts that
+// rode in a rollout launch are not separate kernels) since the last call (option "timing" = 1)
+int mppi_get_state_seq_timing(mppi_handle_t h, float* out2) {
+    if (!h || !out2) return MPPI_E_INVALID;
+    out2[0] = -1.0f; out2[1] = 0.0f;
+    const size_t pairs = h->ev_used[4] / 2;
+    double sum = 0.0;
+    for (size_t p = 0; p < pairs; ++p) {
+        float ms = 0.0f;
+        HIP_TRY(h, hipEventSynchronize(h->ev_pool[4][2 * p + 1]));
+        HIP_TRY(h, hipEventElapsedTime(&ms, h->ev_pool[4][2 * p], h->ev_pool[4][2 * p + 1]));
+        sum += ms;
+    }
+    if (pairs) { out2[0] = (float)(sum / (double)pairs); out2[1] = (float)pairs; }
+    h->ev_used[4] = 0;
+    return MPPI_OK;
 }
 
 int mppi_get_timing(mppi_handle_t h, float* out) {

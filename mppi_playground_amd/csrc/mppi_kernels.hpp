@@ -86,10 +86,13 @@ __device__ __forceinline__ float4 noise_from_bits(const u32x4& x, int r, const D
     for (int j = 0; j < 4; ++j) z[j] *= WIDE ? sig_cols[4 * r + j] : d.sigma[ctrl_index(j, d.dc)];
     return make_float4(z[0], z[1], z[2], z[3]);
 }
+struct KeyPins { uint32_t k0v, k1v, k0w; };  // key words in VGPRs (philox4x32_10: rounds 0 and 1), pinned once by a caller with a hot loop
 template <bool WIDE = false>
 __device__ __forceinline__ float4 gen_noise4(uint64_t gi, int r, const GenCtx& g, const Dims& d,
-                                             const float* __restrict__ sig_cols = nullptr) {
-    const u32x4 x = philox4x32_10((uint32_t)gi, (uint32_t)(gi >> 32), (uint32_t)r, g.solve_idx, g.seed_lo, g.seed_hi);
+                                             const float* __restrict__ sig_cols = nullptr, const KeyPins* pins = nullptr) {
+    const u32x4 x = philox4x32_10((uint32_t)gi, (uint32_t)(gi >> 32), (uint32_t)r, g.solve_idx, g.seed_lo, g.seed_hi,
+                                  pins ? pins->k0v : g.seed_lo, pins ? pins->k1v : g.seed_hi,
+                                  pins ? pins->k0w : g.seed_lo + 0x9E3779B9u);
     float z[4];
     box_muller(x.x, x.y, z[0], z[1]);
     box_muller(x.z, x.w, z[2], z[3]);
@@ -134,8 +137,8 @@ __global__ __launch_bounds__(BLOCK) void posterior_sample_kernel(const float* __
 // One float4 group of a lane's noise row: from the tiles (GEN=false) or regenerated (GEN=true).
 template <bool GEN>
 __device__ __forceinline__ float4 noise_group(const float4* __restrict__ np, int r, uint64_t gi, const GenCtx& g,
-                                              const Dims& d) {
-    if (GEN) return gen_noise4(gi, r, g, d);
+                                              const Dims& d, const KeyPins* pins = nullptr) {
+    if (GEN) return gen_noise4(gi, r, g, d, nullptr, pins);
     return np[(int64_t)r * 64];
 }
 
@@ -153,20 +156,32 @@ __device__ __forceinline__ float4 noise_group(const float4* __restrict__ np, int
 // UC: the solver's clamp range lies inside the model's own action clamp (compile-time so that the
 // second clamp disappears).
 // VAR: a launch-uniform model variant the kernel has branched on OUTSIDE the horizon loop (racing: unit wheel base).
-template <int MODEL, int FAST, bool GEN, bool UC, bool VAR = false>
+// X0OUT (models with EntryGeneral only): the start lies outside the model's position clamp — launch-uniform, x0 is the
+// same for every lane — so the stage cost of step 0 takes the bounds-tested map lookup (every later state is clamped).
+template <int MODEL, int FAST, bool GEN, bool UC, bool VAR = false, bool X0OUT = false>
 __device__ __forceinline__ float trajectory_cost(const float4* __restrict__ np, uint64_t gi, const GenCtx& gen,
                                                  const float4* mean4, const float* ktab,
-                                                 const float* __restrict__ x0, const Dims& d, const ModelCtx& ctx,
+                                                 const float* __restrict__ x0, const Dims& d, const ModelCtx& ctx_in,
                                                  bool& bad) {
     using M = ModelT<MODEL, FAST>;
     using K = typename M::K;
     constexpr int DS = M::DS, DC = M::DC, SPG = 4 / DC;
+    // wave-uniform operands that would otherwise cost a v_mov per use inside the loop (a VALU instruction reads one scalar
+    // register): the model's picks of its launch constants (Model::pin_hot) and the Philox key of round 0
+    ModelCtx ctx = ctx_in;
+    if constexpr (FAST != 0 && EntryGeneral<M>::value) M::pin_hot(ctx);
+    KeyPins pins{gen.seed_lo, gen.seed_hi, gen.seed_lo + 0x9E3779B9u};
+    if (GEN) asm volatile("" : "+v"(pins.k0v), "+v"(pins.k1v), "+v"(pins.k0w));
     float s[DS], pu[DC], pl[DC];
 #pragma unroll
     for (int j = 0; j < DS; ++j) s[j] = x0[j];
     if (FAST) {
-        M::check_state(ctx, s, bad);
-        M::enter(s);  // kinematic models: wrap the heading once; every later heading is a fixed point of that wrap
+        if constexpr (EntryGeneral<M>::value) {
+            M::enter_any(s);  // any finite heading, wrapped once by the reference's own operation (exact)
+        } else {
+            M::check_state(ctx, s, bad);
+            M::enter(s);  // kinematic models: wrap the heading once; every later heading is a fixed point of that wrap
+        }
     }
     // clamp bounds live in VGPRs: v_med3_f32 takes one SGPR operand only, and the compiler would
     // otherwise re-materialise the second bound with a v_mov in every step
@@ -176,9 +191,9 @@ __device__ __forceinline__ float trajectory_cost(const float4* __restrict__ np, 
         lo[k] = d.u_min[k]; hi[k] = d.u_max[k];
         asm volatile("" : "+v"(hi[k]));
     }
-    CostSum<exact_cost_sum(MODEL)> acc;  // sum of the stage costs (mppi.py:333): exactly rounded, or sequential fp32 for racing
+    CostSum<exact_cost_sum(MODEL)> acc;  // sum of the stage costs (mppi.py:333): exactly rounded (racing: sequential fp32)
     K knext = M::load_k(ktab, 0);
-    float4 e = noise_group<GEN>(np, 0, gi, gen, d);
+    float4 e = noise_group<GEN>(np, 0, gi, gen, d, &pins);
     float4 m4 = mean4[0];
     {   // info["prev_action"] of step 0 is U[:, 0] itself (mppi.py:299-301)
         const float e0[4] = {e.x, e.y, e.z, e.w}, m0[4] = {m4.x, m4.y, m4.z, m4.w};
@@ -195,7 +210,8 @@ __device__ __forceinline__ float trajectory_cost(const float4* __restrict__ np, 
         float sn[DS], ss[DS];
         if constexpr (MODEL == MPPI_MODEL_RACING) M::step(ctx, s, u, sn, ss, bad, UC, FAST != 0, VAR);
         else M::step(ctx, s, u, sn, ss, bad, UC, FAST != 0);
-        acc.add(M::cost(ctx, kcur, ss, u, pu, bad));
+        if constexpr (X0OUT) acc.add(M::cost(ctx, kcur, ss, u, pu, bad, t == 0));
+        else acc.add(M::cost(ctx, kcur, ss, u, pu, bad));
 #pragma unroll
         for (int k = 0; k < DC; ++k) { pl[k] = pu[k]; pu[k] = u[k]; }
 #pragma unroll
@@ -207,7 +223,7 @@ __device__ __forceinline__ float trajectory_cost(const float4* __restrict__ np, 
     if (GEN) {
         for (int r = 0; r < full; ++r) {
             const int rn = min(r + 1, d.R - 1);
-            const float4 en = noise_group<GEN>(np, rn, gi, gen, d);  // independent chain, interleaved with the steps
+            const float4 en = noise_group<GEN>(np, rn, gi, gen, d, &pins);  // independent chain, interleaved with the steps
             const float4 m4n = mean4[rn];
             const float ev[4] = {e.x, e.y, e.z, e.w};
             const float mv[4] = {m4.x, m4.y, m4.z, m4.w};
@@ -250,6 +266,40 @@ __device__ __forceinline__ float trajectory_cost(const float4* __restrict__ np, 
     return acc.total(term);
 }
 
+// Total cost of one lane's trajectory: picks the launch-uniform copy of the horizon loop (racing: unit wheel base; a start
+// outside the position clamp) and — for the models whose fast paths have per-lane validity ranges (pendulum, cart-poles,
+// mountain car, goal zone) — redoes a lane that left one with the library math.  Racing and nav2d take any finite start
+// (EntryGeneral) and carry no redo: inlining the library-math walk next to the hot loop cost the racing kernel 18 VGPRs,
+// two waves per SIMD and 3.6 % of its time (profiles/r04_experiments.md).
+template <int MODEL, int FAST, bool GEN, bool UC>
+__device__ __forceinline__ float lane_cost(const float4* __restrict__ np, uint64_t gi, const GenCtx& gen, const float4* mp,
+                                           const float* s_ktab, const float* __restrict__ x0, const Dims& d,
+                                           const ModelCtx& ctx) {
+    using M = ModelT<MODEL, FAST>;
+    bool bad = false;
+    float total;
+    if constexpr (FAST != 0 && EntryGeneral<M>::value) {
+        if (!M::start_in_box(ctx, x0))  // launch-uniform (x0 is shared): the copy whose first stage cost is bounds-tested
+            return trajectory_cost<MODEL, FAST, GEN, UC, false, true>(np, gi, gen, mp, s_ktab, x0, d, ctx, bad);
+    }
+    // (racing, fast math: the unit wheel base of the reference is a launch-uniform branch around two copies of the loop)
+    if (MODEL == MPPI_MODEL_RACING && FAST != 0 && ctx.unit_L)
+        total = trajectory_cost<MODEL, FAST, GEN, UC, true>(np, gi, gen, mp, s_ktab, x0, d, ctx, bad);
+    else
+        total = trajectory_cost<MODEL, FAST, GEN, UC>(np, gi, gen, mp, s_ktab, x0, d, ctx, bad);
+    if constexpr (FAST != 0 && !EntryGeneral<M>::value) {
+        if (bad) {  // a fast path left its validity range: redo this lane with the library math
+            bool ignore = false;
+            total = trajectory_cost<MODEL, 0, GEN, false>(np, gi, gen, mp, s_ktab, x0, d, ctx, ignore);
+        }
+    }
+    return total;
+}
+
+template <int MODEL, int FAST>  // (defined with the solve's tail below)
+__device__ __forceinline__ void batch1_rollout(const ModelCtx& ctx, const float* s_x0, const float* s_act, int T,
+                                               float* __restrict__ state_out);
+
 #ifndef MPPI_ROLLOUT_ATTR
 #define MPPI_ROLLOUT_ATTR  // e.g. __attribute__((amdgpu_waves_per_eu(8))) for occupancy experiments
 #endif
@@ -262,14 +312,27 @@ __global__ __launch_bounds__(BLOCK) MPPI_ROLLOUT_ATTR void rollout_cost_kernel(c
                                                              unsigned* __restrict__ next_min_key,
                                                              float* __restrict__ mean_used,
                                                              float* __restrict__ x0_used, Dims d, GenCtx gen,
-                                                             ModelCtx ctx) {
+                                                             ModelCtx ctx, const float* __restrict__ b1_in,
+                                                             float* __restrict__ b1_state_out) {
     using M = ModelT<MODEL, FAST>;
     __shared__ float s_min[BLOCK / WAVE];
+    // [4*R] mean groups, [4*R] zeros (samples that do not inherit the mean), then [T*KROW] step rows
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+    // One extra block (the last) when the PREVIOUS solve left its state sequence pending (option "lazy_state_seq"): the
+    // batch-1 rollout of that solution (mppi.py:448-449) from the inputs finalize_kernel left in b1_in — T dependent steps
+    // of one wave, hidden behind this launch's N-sample rollout instead of extending the previous solve's tail.
+    if (b1_state_out != nullptr && blockIdx.x == gridDim.x - 1) {
+        for (int i = threadIdx.x; i < d.row + M::DS; i += BLOCK) s_dyn[i] = b1_in[i];
+        __syncthreads();
+        batch1_rollout<MODEL, FAST>(ctx, s_dyn + d.row, s_dyn, d.T, b1_state_out);
+        return;
+    }
+#ifdef MPPI_AB_VGPR_FLOOR  // (A/B knob of scripts/build_variant.sh: same code at the occupancy of an 85-VGPR build)
+    asm volatile("; vgpr floor" ::: "v84");
+#endif
     // the state this solve starts from outlives the caller's buffer (mppi_bind_state is zero-copy): later
     // re-rolls of this solve's samples (get_top_samples, _state_seq_batch) read the snapshot
     if (blockIdx.x == 0 && threadIdx.x < M::DS) x0_used[threadIdx.x] = x0[threadIdx.x];
-    // [4*R] mean groups, [4*R] zeros (samples that do not inherit the mean), then [T*KROW] step rows
-    extern __shared__ __attribute__((aligned(16))) float s_dyn[];
     float4* s_mean4 = reinterpret_cast<float4*>(s_dyn);
     float* s_ktab = s_dyn + 8 * d.R;
     for (int f = threadIdx.x; f < 4 * d.R; f += BLOCK) {
@@ -294,19 +357,7 @@ __global__ __launch_bounds__(BLOCK) MPPI_ROLLOUT_ATTR void rollout_cost_kernel(c
         const float4* np = noise + tile * d.R * 64 + lane;
         bool bad = false;
         const float4* mp = inherit ? s_mean4 : s_mean4 + d.R;
-        // (racing, fast math: the unit wheel base of the reference is a launch-uniform branch around two copies of the loop)
-        if (MODEL == MPPI_MODEL_RACING && FAST != 0 && ctx.unit_L)
-            total = trajectory_cost<MODEL, FAST, GEN, UC, true>(np, gi, gen, mp, s_ktab, x0, d, ctx, bad);
-        else
-            total = trajectory_cost<MODEL, FAST, GEN, UC>(np, gi, gen, mp, s_ktab, x0, d, ctx, bad);
-#ifndef MPPI_AB_NO_REDO  // (A/B knob: bounds what the cold redo path costs the hot loop in registers / code layout)
-        if (FAST) {
-            if (bad) {  // a fast path left its validity range: redo this lane with the library math
-                bool ignore = false;
-                total = trajectory_cost<MODEL, 0, GEN, false>(np, gi, gen, mp, s_ktab, x0, d, ctx, ignore);
-            }
-        }
-#endif
+        total = lane_cost<MODEL, FAST, GEN, UC>(np, gi, gen, mp, s_ktab, x0, d, ctx);
         if (i < d.N) costs[i] = total;
         else total = INFINITY;
     }
@@ -702,13 +753,29 @@ __device__ __forceinline__ bool rollout_states(const float* __restrict__ x0, int
     float s[DS];
 #pragma unroll
     for (int j = 0; j < DS; ++j) s[j] = x0[j];
-    if (FAST) M::check_state(ctx, s, bad);
-    for (int t = 0; t < T; ++t) {
-        float u[DC], sn[DS], ss[DS];
-        getu(t, u);
-        M::step(ctx, s, u, sn, ss, bad);
+    if constexpr (FAST != 0 && EntryGeneral<M>::value) {
+        // any finite start (see Model::enter_any): the heading is wrapped once by the reference's own operation and every
+        // later one is a fixed point of the wrap; row 0 keeps the caller's state as given (mppi.py:280-283: S[:, 0] = x0)
+        const float raw_heading = s[2];
+        M::enter_any(s);
+        for (int t = 0; t < T; ++t) {
+            float u[DC], sn[DS], ss[DS];
+            getu(t, u);
+            M::step(ctx, s, u, sn, ss, bad, false, true);
+            if (t == 0) ss[2] = raw_heading;
 #pragma unroll
-        for (int j = 0; j < DS; ++j) { out[t * DS + j] = ss[j]; s[j] = sn[j]; }
+            for (int j = 0; j < DS; ++j) { out[t * DS + j] = ss[j]; s[j] = sn[j]; }
+        }
+        if (T == 0) s[2] = raw_heading;
+    } else {
+        if (FAST) M::check_state(ctx, s, bad);
+        for (int t = 0; t < T; ++t) {
+            float u[DC], sn[DS], ss[DS];
+            getu(t, u);
+            M::step(ctx, s, u, sn, ss, bad);
+#pragma unroll
+            for (int j = 0; j < DS; ++j) { out[t * DS + j] = ss[j]; s[j] = sn[j]; }
+        }
     }
 #pragma unroll
     for (int j = 0; j < DS; ++j) out[T * DS + j] = s[j];
@@ -718,7 +785,7 @@ template <int MODEL, int FAST, class GETU>
 __device__ __forceinline__ void rollout_states_checked(const float* __restrict__ x0, int T, const ModelCtx& ctx,
                                                        float* __restrict__ out, GETU getu) {
     const bool bad = rollout_states<MODEL, FAST>(x0, T, ctx, out, getu);
-    if (FAST) {
+    if constexpr (FAST != 0 && !EntryGeneral<ModelT<MODEL, FAST>>::value) {  // (EntryGeneral models cannot leave a fast path)
         if (bad) (void)rollout_states<MODEL, 0>(x0, T, ctx, out, getu);
     }
 }
@@ -761,6 +828,43 @@ __global__ __launch_bounds__(BLOCK) void p2p_collect_kernel(P2pCtx x, int len, f
     p2p_collect<BLOCK>(x, len, out, len);
 }
 
+// Step 8 (mppi.py:448-449,508-524): the batch-1 rollout of the solution `s_act` [T][dc] from `s_x0`, by the calling
+// block's first wave (racing / fast math: spread over the wave, see Model::rollout_wave; else lane 0 walks the T steps).
+// Shared by finalize_tail (in the solve's last kernel), state_seq_kernel and the extra block of rollout_cost_kernel (the same
+// rollout completed lazily): one code path, so all of them produce the same bits.
+template <int MODEL, int FAST>
+__device__ __forceinline__ void batch1_rollout(const ModelCtx& ctx, const float* s_x0, const float* s_act, int T,
+                                               float* __restrict__ state_out) {
+    constexpr int DC = ModelT<MODEL, FAST>::DC;
+    const auto getu = [&](int t, float* u) {
+#pragma unroll
+        for (int k = 0; k < DC; ++k) u[k] = s_act[t * DC + k];
+    };
+    if constexpr (MODEL == MPPI_MODEL_RACING && FAST) {
+        if (T <= 63) {  // the serial part of the batch-1 rollout shrinks to the heading/speed recurrences
+            if (threadIdx.x >= WAVE) return;
+            ModelT<MODEL, FAST>::rollout_wave(ctx, s_x0, s_act, T, state_out);  // (any finite start: no library-math redo)
+            return;
+        }
+    }
+    if (threadIdx.x == 0) rollout_states_checked<MODEL, FAST>(s_x0, T, ctx, state_out, getu);
+}
+
+// The same rollout as its own one-wave kernel: `b1_in` = [row] action sequence, then [ds] start state, left behind by
+// finalize_kernel (its `b1_out`) under option "lazy_state_seq".  The 50 dependent steps are not needed by anything on the
+// solve's critical path (the next solve samples around the mean, env.step applies a[0]): they normally ride in an extra
+// block of the NEXT rollout launch (rollout_cost_kernel), and this kernel runs only when somebody reads the state
+// sequence before that (mppi_join_state_seq).
+template <int MODEL, int FAST>
+__global__ __launch_bounds__(WAVE) void state_seq_kernel(const float* __restrict__ b1_in, int row, int T,
+                                                         float* __restrict__ state_out, ModelCtx ctx) {
+    constexpr int DS = ModelT<MODEL, FAST>::DS;
+    extern __shared__ __attribute__((aligned(16))) float s_b1[];  // [row] action, [DS] start state
+    for (int i = threadIdx.x; i < row + DS; i += WAVE) s_b1[i] = b1_in[i];
+    __syncthreads();
+    batch1_rollout<MODEL, FAST>(ctx, s_b1 + row, s_b1, T, state_out);
+}
+
 constexpr int FIN_BLOCK = 1024;
 // The tail of a solve once the shard summaries are at hand (block-wide, FIN_BLOCK threads): combine the shards, normalise,
 // Savitzky-Golay step, warm start, outputs, batch-1 rollout.  Shared by finalize_kernel and solve_fused_kernel.
@@ -770,8 +874,8 @@ __device__ __forceinline__ void finalize_tail(const float* summaries, int num_sh
                                               const float* s_x0, float* s_act, float* s_yp,
                                               float* __restrict__ mean_store, float* __restrict__ action_out,
                                               float* __restrict__ state_out, float* __restrict__ stats_out,
-                                              float* __restrict__ stats_keep, const SgFilter& sg, const ModelCtx& ctx) {
-    constexpr int DC = ModelT<MODEL, FAST>::DC;
+                                              float* __restrict__ stats_keep, const SgFilter& sg, const ModelCtx& ctx,
+                                              float* __restrict__ b1_out = nullptr) {
     const int stride = MPPI_SUMMARY_HEAD + row;
     float xmax = -INFINITY, cmin = INFINITY;
     for (int g = 0; g < num_shards; ++g) {
@@ -843,22 +947,12 @@ __device__ __forceinline__ void finalize_tail(const float* summaries, int num_sh
         if (threadIdx.x < dcn && T >= 2) sg.history[(T - 2) * dcn + threadIdx.x] = s_act[threadIdx.x];
         __syncthreads();
     }
-    if (!state_out) return;
-    const auto getu = [&](int t, float* u) {
-#pragma unroll
-        for (int k = 0; k < DC; ++k) u[k] = s_act[t * DC + k];
-    };
-    if constexpr (MODEL == MPPI_MODEL_RACING && FAST) {
-        if (T <= 63) {  // the serial part of the batch-1 rollout shrinks to the heading/speed recurrences
-            if (threadIdx.x >= WAVE) return;
-            bool bad = false;
-            ModelT<MODEL, FAST>::rollout_wave(ctx, s_x0, s_act, T, state_out, bad);
-            if (__ballot(bad) != 0ull && threadIdx.x == 0)  // left a fast-path validity range: library math
-                (void)rollout_states<MODEL, 0>(s_x0, T, ctx, state_out, getu);
-            return;
-        }
+    if (b1_out) {  // the batch-1 rollout is deferred to state_seq_kernel: leave its inputs behind (final action, start state)
+        for (int cidx = threadIdx.x; cidx < row; cidx += FIN_BLOCK) b1_out[cidx] = s_act[cidx];
+        if (threadIdx.x < ModelT<MODEL, FAST>::DS) b1_out[row + threadIdx.x] = s_x0[threadIdx.x];
     }
-    if (threadIdx.x == 0) rollout_states_checked<MODEL, FAST>(s_x0, T, ctx, state_out, getu);
+    if (!state_out) return;
+    batch1_rollout<MODEL, FAST>(ctx, s_x0, s_act, T, state_out);
 }
 
 // Combine shard summaries, normalise, store the warm start, roll the result out with batch 1
@@ -885,8 +979,7 @@ __global__ __launch_bounds__(FIN_BLOCK) void finalize_kernel(const float* __rest
                                                              float* __restrict__ state_out,
                                                              float* __restrict__ stats_out,
                                                              float* __restrict__ stats_keep, SgFilter sg,
-                                                             P2pCtx p2p, ModelCtx ctx) {
-    constexpr int DC = ModelT<MODEL, FAST>::DC;
+                                                             P2pCtx p2p, ModelCtx ctx, float* __restrict__ b1_out) {
     const float lambda = lambda_dev ? *lambda_dev : lambda_arg;
     // issued before the first barrier so that their latency hides behind the fold: the shard minimum and the start
     // state of the batch-1 rollout (both would otherwise be dependent loads at the end of the chain)
@@ -960,7 +1053,7 @@ __global__ __launch_bounds__(FIN_BLOCK) void finalize_kernel(const float* __rest
         num_shards = 1;
     }
     finalize_tail<MODEL, FAST>(summaries, num_shards, lambda, row, T, s_x0, s_act, s_yp, mean_store, action_out, state_out,
-                               stats_out, stats_keep, sg, ctx);
+                               stats_out, stats_keep, sg, ctx, b1_out);
 }
 
 // Softmax statistics of the cost vector for one temperature — the device half of the auto-lambda
@@ -1580,18 +1673,8 @@ __global__ __launch_bounds__(FUSED_BLOCK) void solve_fused_kernel(FusedArgs A, D
     if (mine) {
         const uint64_t gi = (uint64_t)(d.sample_offset + i);
         const bool inherit = (d.sample_offset + i) < d.inherit_count;
-        bool bad = false;
         const float4* mp = inherit ? s_mean4 : s_mean4 + d.R;
-        if (MODEL == MPPI_MODEL_RACING && FAST != 0 && ctx.unit_L)
-            total = trajectory_cost<MODEL, FAST, true, UC, true>(nullptr, gi, gen, mp, s_ktab, s_x0, d, ctx, bad);
-        else
-            total = trajectory_cost<MODEL, FAST, true, UC>(nullptr, gi, gen, mp, s_ktab, s_x0, d, ctx, bad);
-        if (FAST) {
-            if (bad) {
-                bool ignore = false;
-                total = trajectory_cost<MODEL, 0, true, false>(nullptr, gi, gen, mp, s_ktab, s_x0, d, ctx, ignore);
-            }
-        }
+        total = lane_cost<MODEL, FAST, true, UC>(nullptr, gi, gen, mp, s_ktab, s_x0, d, ctx);
         A.costs[i] = total;
     }
     FX_TRACE(1);

@@ -82,11 +82,14 @@ MPPI_HD float clampf(float x, float lo, float hi) {
 // The order of torch.sum is not part of the reference's contract (a vectorised cascade on the CPU that depends on the
 // ISA, a tree on a GPU), and softmax(-c / lambda) amplifies the last bits of c by |c| / lambda: the reference's own
 // action sequence moves by 2e-5 .. 7e-5 (nav2d, goal zone at lambda = 1) when its costs are re-summed in another valid
-// fp32 order (tests/golden/make_golden.py: the recorded bands).  EXACT = true adds the fp32 stage costs in double
-// and rounds once: the value every fp32 order approximates, so the distance to ANY build of the reference is its
-// own rounding error only.  EXACT = false is the plain sequential fp32 sum (one v_add_f32 per step instead of a
-// conversion + a double add): kept for racing, whose costs / lambda are far from that regime (arg-min at lambda = 1,
-// 1e4-scale obstacle costs over lambda >= 100 in the dense cases: bands <= 6e-6) and whose kernel is VALU-issue bound.
+// fp32 order (tests/golden/make_golden.py: the recorded bands).  EXACT = true adds the fp32 stage costs in DOUBLE and
+// rounds once: the value every fp32 order approximates, so the distance to ANY build of the reference is that build's own
+// rounding error only (the sequential fp32 sum of rounds 1-3 sat at the edge of the reference's spread: 2.7e-5 against a
+// band of 2.7e-5 on nav2d).  EXACT = false is the plain sequential fp32 sum, kept for racing: its costs / lambda are
+// far from that regime (an arg-min at lambda = 1, 1e4-scale obstacle costs over lambda >= 100 in the dense cases: the
+// reference's own spread is <= 6e-6 and the kernel's distance to it <= 2e-6), and in its VALU-issue-bound kernel the
+// conversion + half-rate add + register-pair moves are 6 of 209 instructions per two steps: 125.1 against 121.7 us
+// (profiles/r04_experiments.md).
 template <bool EXACT>
 struct CostSum {
     float a = 0.0f;
@@ -161,4 +164,11 @@ struct ModelSel<MODEL, 2> { using type = fused_hw::Model<MODEL, true>; };
 #endif
 template <int MODEL, int MATH>
 using ModelT = typename ModelSel<MODEL, MATH>::type;
+
+// Models whose fast-math cost loop takes ANY finite initial state (Model::enter_any / start_in_box / cost(..., general)):
+// no lane of theirs can leave a fast path's validity range, so their cost kernels carry no library-math redo.
+template <class M, class = void>
+struct EntryGeneral { static constexpr bool value = false; };
+template <class M>
+struct EntryGeneral<M, decltype((void)M::ENTRY_GENERAL)> { static constexpr bool value = M::ENTRY_GENERAL; };
 }  // namespace mppi

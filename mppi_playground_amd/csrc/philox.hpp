@@ -19,8 +19,13 @@ struct u32x4 {
     uint32_t x, y, z, w;
 };
 
+// k0v / k1v / k0w: the key again — (k0, k1) for round 0, k0 + 0x9E3779B9 for round 1.  With a wave-uniform group and solve
+// index (c2, c3: every caller's) round 0 XORs two uniform words per output, and so does the first output of round 1 (its
+// c1 is the low half of the uniform product of round 0); a VALU instruction reads ONE scalar register, so one of the two
+// needs a vector copy.  A caller with a hot loop hands in copies it pinned in VGPRs once (trajectory_cost); everybody
+// else passes nothing and the compiler makes the copies where it needs them.
 __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
-                                               uint32_t k1) {
+                                               uint32_t k1, uint32_t k0v, uint32_t k1v, uint32_t k0w) {
 #pragma unroll
     for (int r = 0; r < MPPI_PHILOX_ROUNDS; ++r) {
         // one 32x32->64 multiply each (v_mad_u64_u32): integer multiplies are quarter rate on CDNA
@@ -29,12 +34,16 @@ __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_
         const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
         const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         // three-input XOR in one v_bitop3_b32 (truth table 0x96)
-        const uint32_t n0 = __builtin_amdgcn_bitop3_b32(hi1, c1, k0, 0x96);
-        const uint32_t n2 = __builtin_amdgcn_bitop3_b32(hi0, c3, k1, 0x96);
+        const uint32_t n0 = __builtin_amdgcn_bitop3_b32(hi1, c1, r == 0 ? k0v : r == 1 ? k0w : k0, 0x96);
+        const uint32_t n2 = __builtin_amdgcn_bitop3_b32(hi0, c3, r == 0 ? k1v : k1, 0x96);
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
     return {c0, c1, c2, c3};
+}
+__device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                               uint32_t k1) {
+    return philox4x32_10(c0, c1, c2, c3, k0, k1, k0, k1, k0 + 0x9E3779B9u);
 }
 
 // Box-Muller on (a, b): u1 = ((a>>8)+1) * 2^-24 in (0,1], u2 = (b>>8) * 2^-24 in [0,1).

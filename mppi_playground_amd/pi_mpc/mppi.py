@@ -31,6 +31,42 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+class _DeferredStateSeq(torch.Tensor):
+    """`state_seq` of a solve whose batch-1 rollout (src/pi_mpc/mppi.py:448-449) is completed lazily
+    (MPPI(..., lazy_state_seq=True); mppi_set_option("lazy_state_seq")): a plain float32 tensor [1, T+1, ds] whose FIRST
+    use through torch (indexing, .cpu(), arithmetic, printing, ...) completes it on the consumer's current stream if the
+    next solve has not done so already (mppi_join_state_seq: at most one small kernel launch, no host synchronisation).
+    The T dependent steps are off the solve's critical path: in a control loop they ride in one extra block of the NEXT
+    solve's rollout launch.  Results of operations on it are ordinary tensors.  Consumers that bypass torch (a raw
+    data_ptr() handed to another library) must call `solver.join_state_seq()` first."""
+
+    @staticmethod
+    def wrap(t: torch.Tensor, join) -> "_DeferredStateSeq":
+        r = torch.Tensor._make_subclass(_DeferredStateSeq, t)
+        r.__dict__["_mppi_join"] = join
+        return r
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        def join(a):
+            if isinstance(a, _DeferredStateSeq):
+                j = a.__dict__.get("_mppi_join")
+                if j is not None:
+                    a.__dict__["_mppi_join"] = None
+                    j(a)
+            elif isinstance(a, (list, tuple)):  # torch.cat([...]), torch.stack((...))
+                for b in a:
+                    join(b)
+
+        for a in args:
+            join(a)
+        if kwargs:
+            for a in kwargs.values():
+                join(a)
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*args, **(kwargs or {}))
+
+
 class MPPI(nn.Module):
     """Model Predictive Path Integral control (Williams et al., T-RO 2017) — MI355X-native."""
 
@@ -77,6 +113,7 @@ class MPPI(nn.Module):
         lbps_search: str = "device",
         sg_filter: str = "device",
         graph_callables: bool = False,
+        lazy_state_seq: Optional[bool] = None,
         _force_exchange: bool = False,
     ) -> None:
         """Arguments up to `seed` are the reference's (src/pi_mpc/mppi.py:24-47).
@@ -109,6 +146,12 @@ class MPPI(nn.Module):
                 data-dependent shapes (boolean-mask assignment is not capturable), and an `info` dict used as the
                 reference documents it (tensor views + the integer `t`).  If the capture fails the solver says so once
                 and stays on the eager loops.
+            lazy_state_seq: native models on the multi-kernel path.  True: the batch-1 rollout of the solution
+                (`state_seq`, mppi.py:448-449: T dependent steps of one wave, 5.8 us of a 146 us racing solve) leaves the
+                solve's last kernel; it rides in one extra block of the NEXT solve's rollout launch, or is launched on the
+                spot when `state_seq` is used first (_DeferredStateSeq) — same code, same bits.  None (default): on when
+                this rank holds more than 16 384 samples (below that the solve is a single launch that rolls out itself,
+                or short enough for callers that look at `state_seq` every tick to lose more than they gain).  False: off.
             shard_samples: treat `num_samples` as the GLOBAL sample count and let this rank own the
                 contiguous block rank*N/W .. (rank+1)*N/W of it (torch.distributed must be
                 initialised); the 4+T*dc-float shard summaries are exchanged once per solve with one RCCL
@@ -313,6 +356,11 @@ class MPPI(nn.Module):
                           and not (self._world > 1 and lambda_ in ("MPO", "LBPS", "ESSPS"))
                           and not (use_sg_filter and not self._sg_on_device)
                           and (self._auto_lambda is None or self._rule_on_device is not None))
+        # the batch-1 rollout of the solution completed lazily (see `lazy_state_seq` above)
+        want = lazy_state_seq if lazy_state_seq is not None else self._local_samples > 16384
+        self._lazy_state = bool(want and self._model is not None and not (use_sg_filter and not self._sg_on_device))
+        if self._lazy_state:
+            self._h.call("mppi_set_option", b"lazy_state_seq", 1)
         self._last_lambda = None
         self._fused_error_seen = False
         self._injected = None
@@ -576,7 +624,12 @@ class MPPI(nn.Module):
         self._h.call("mppi_get_timing", out)
         names = ("sample", "rollout_cost", "weights_reduce", "finalize")
         # a stage that launched nothing (e.g. `sample` when the noise is regenerated in registers) is 0
-        return {n: max(float(out[i]), 0.0) for i, n in enumerate(names)} | {"calls": float(out[4 + 1])}
+        res = {n: max(float(out[i]), 0.0) for i, n in enumerate(names)} | {"calls": float(out[4 + 1])}
+        if self._lazy_state:  # stand-alone completions of a pending state sequence (not part of `finalize`)
+            o2 = (C.c_float * 2)()
+            self._h.call("mppi_get_state_seq_timing", o2)
+            res["state_seq_standalone"], res["state_seq_standalone_launches"] = max(float(o2[0]), 0.0), float(o2[1])
+        return res
 
     def set_option(self, key: str, value: int) -> None:
         self._h.call("mppi_set_option", key.encode(), int(value))
@@ -608,6 +661,24 @@ class MPPI(nn.Module):
                          hist.ctypes.data_as(C.c_void_p))
         else:
             self._sg_history_host = hist
+
+    # ------------------------------------------------------------------ lazily completed state sequence
+    def _returned_state_seq(self):
+        """What forward() returns as `state_seq`: the tensor itself, or — rollout pending — its completing wrapper."""
+        if not self._lazy_state:
+            return self._state_out
+        serial, pending = C.c_uint32(0), C.c_int(0)
+        self._h.call("mppi_state_seq_serial", C.byref(serial), C.byref(pending))
+        if not pending.value:  # (this solve ran as a single launch: nothing left to do)
+            return self._state_out
+        n = int(serial.value)
+        return _DeferredStateSeq.wrap(self._state_out, lambda _t: self._h.call("mppi_join_state_seq", n, self._stream()))
+
+    def join_state_seq(self) -> None:
+        """Complete the newest `state_seq` on torch's current stream if it is still pending (for consumers that read it
+        outside torch)."""
+        if self._lazy_state:
+            self._h.call("mppi_join_state_seq", 0, self._stream())
 
     # ------------------------------------------------------------------ forward
     def forward(self, state: torch.Tensor, info: Dict = {}) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -741,7 +812,7 @@ class MPPI(nn.Module):
                 self._state_out = self._states_prediction(self._x0_tensor, self._action_out.repeat(1, 1, 1))
         self._lambda_override = None
         self._previous_action_seq = self._action_out
-        return self._action_out, self._state_out
+        return self._action_out, (self._returned_state_seq() if native and not use_sg else self._state_out)
 
     def _forward_one_call(self, state, h, st):
         """forward() through mppi_solve: the same kernel sequence as the step-by-step path below in one library call
@@ -773,12 +844,16 @@ class MPPI(nn.Module):
         else:  # the configured rule runs on the device; the temperature is fetched when somebody asks for it
             lam = _capi.LAMBDA_DEVICE
             self._lambda_pending, self._lambda_stream, self._used_known = True, st, False
+        # (the previous solve's state tensor stays alive across this launch: with a lazily completed state sequence this
+        # solve's rollout launch may still write it)
+        prev_state_keep = self._state_out
         self._action_out = torch.empty(self._horizon, self._dim_control, device=self._device, dtype=self._dtype)
         self._state_out = torch.empty(1, self._horizon + 1, self._dim_state, device=self._device, dtype=self._dtype)
         h.call("mppi_solve", x0p, self._solve_idx, lam, _ptr(self._action_out), _ptr(self._state_out), _ptr(self._stats), st)
+        del prev_state_keep
         self._solve_idx += 1
         self._previous_action_seq = self._action_out
-        return self._action_out, self._state_out
+        return self._action_out, self._returned_state_seq()
 
     # ------------------------------------------------------------------ generic (opaque callables) path
     def _generic_rollout_costs(self, state, info: Dict) -> None:

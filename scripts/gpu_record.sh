@@ -30,6 +30,7 @@ timeout 200 python scripts/host_overhead.py 2>&1 | grep -v amdgpu.ids > gpurun_o
 [ -f mppi_playground_amd/csrc/variants/lib_trace.so ] && MPPI_HIP_LIB=mppi_playground_amd/csrc/variants/lib_trace.so timeout 300 python scripts/fused_trace.py 2>&1 | grep -v amdgpu.ids > gpurun_out/fused_trace.txt
 scripts/ubench/icache_cold > gpurun_out/ubench_cold_code.txt 2>&1; scripts/ubench/clock_cost > gpurun_out/ubench_clock_cost.txt 2>&1
 cd /tmp
+mkdir -p $P; python -c "import sys; sys.path.insert(0, '$R'); from mppi_playground_amd import _build; print(_build.source_digest())" > $P/csrc_sha256.txt
 B="python $R/bench.py --no-cpu-baseline --no-extras"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $P -o kt -- $B --steps 30 --warmup 5 > $R/gpurun_out/rocprof_kt.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $P -o kt_tiles -- $B --steps 30 --warmup 5 --noise-regen 0 > /dev/null 2>&1

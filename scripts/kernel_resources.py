@@ -18,6 +18,8 @@ for line in text.splitlines():
     if m and cur is not None:
         cur[m.group(1).strip()] = int(m.group(2))
 names = {r["name"] for r in rows}
+if not names:
+    sys.exit("no kernel-resource-usage remarks in the input (did the build fail?)")
 dem = dict(zip(sorted(names), subprocess.run(["c++filt"] + sorted(names), capture_output=True,
                                              text=True).stdout.splitlines()))
 print(f"{'kernel':90s} VGPR AGPR SGPRsp VGPRsp scratch occ  LDS")

