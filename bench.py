@@ -140,17 +140,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed_run(mode):
+    def timed_run(mode, n_total=None, force_exchange=False):
         """One complete measurement: a solver on transport `mode` (None at one GPU), SETUP_SOLVES un-timed solves to leave
         the idle power state, the contract's W warm-up steps, then EXACTLY K timed steps between barrier + synchronise on
-        both sides, MAX over ranks.  Returns {exchange, dt, stages, exchange_ms, ctrl} or {exchange, error}."""
+        both sides, MAX over ranks.  `n_total`: the global sample count (default: weak scaling, N_local per rank).
+        `force_exchange`: one rank, but through the sharded code path (summary -> exchange -> combine).
+        Returns {exchange, dt, stages, exchange_ms, ctrl, ...} or {exchange, error}."""
         from mppi_playground_amd import _capi
 
+        n_total = N_total if n_total is None else n_total
         if mode is not None:
             os.environ["MPPI_EXCHANGE"] = mode
         try:
             dkw = {} if args.lazy_state_seq < 0 else {"lazy_state_seq": bool(args.lazy_state_seq)}
-            ctrl = racing_controller(env, horizon=T, num_samples=N_total, lambda_=1.0, shard_samples=world > 1, **dkw)
+            if force_exchange:
+                dkw["_force_exchange"] = True
+            ctrl = racing_controller(env, horizon=T, num_samples=n_total, lambda_=1.0,
+                                     shard_samples=world > 1 or force_exchange, **dkw)
         except (_capi.MppiError, RuntimeError) as e:  # the transport's set-up / self-test failed on every rank alike
             return {"exchange": mode, "error": str(e)[:300]}
         ctrl.set_cost_map(env._obstacle_map, env._lane_map)
@@ -201,9 +207,29 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         finite = bool(torch.isfinite(a).all() and torch.isfinite(s).all())
-        used = "none" if world == 1 else ("p2p" if solver._p2p else "rccl" if solver._comm else "nccl")
+        sharded = world > 1 or force_exchange
+        used = "none" if not sharded else ("p2p" if solver._p2p else "rccl" if solver._comm else "nccl")
+        # every rank's own stage times (a straggler shows here, not in the MAX-over-ranks wall clock) and what RCCL itself
+        # reports for the communicator that carried the exchange
+        rank_stages, rccl_ranks = [stages], None
+        if world > 1:
+            rank_stages = [None] * world
+            dist.all_gather_object(rank_stages, {k: round(v, 6) for k, v in stages.items()})
+        if sharded:
+            if solver._comm:
+                import ctypes as C
+
+                cnt, rk = C.c_int(-1), C.c_int(-1)
+                try:
+                    solver._h.call("mppi_comm_info", C.byref(cnt), C.byref(rk))
+                    rccl_ranks = {"ncclCommCount": cnt.value, "ncclCommUserRank_of_rank0": rk.value, "communicator": "library"}
+                except _capi.MppiError as e:
+                    rccl_ranks = {"error": str(e)[:200]}
+            else:
+                rccl_ranks = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                              "communicator": "torch.distributed process group"}
         return {"exchange": used, "requested": mode, "dt": dt, "stages": stages, "exchange_ms": t_exchange_ms, "finite": finite,
-                "ctrl": ctrl}
+                "ctrl": ctrl, "n_total": n_total, "rank_stages": rank_stages, "rccl_ranks": rccl_ranks}
 
     def compose(best, runs):
         """The contract's JSON line from the best complete run (rank 0)."""
@@ -300,13 +326,17 @@ def main():
             out["transports"] = [
                 {"exchange": r["exchange"], "requested": r.get("requested"), "error": r["error"]} if "error" in r else
                 {"exchange": r["exchange"], "requested": r.get("requested"), "ms_per_step": r["dt"] / args.steps * 1e3,
-                 "value": N_total * T * args.steps / r["dt"], "finite": r["finite"],
-                 "exchange_us": None if r["exchange_ms"] is None else r["exchange_ms"] * 1e3} for r in runs]
+                 "value": r["n_total"] * T * args.steps / r["dt"], "finite": r["finite"],
+                 "exchange_us": None if r["exchange_ms"] is None else r["exchange_ms"] * 1e3,
+                 "rccl_ranks": r["rccl_ranks"], "per_rank_stages_ms": r["rank_stages"]} for r in runs]
+            out["rccl_ranks"] = best["rccl_ranks"]
         if valu is not None:
             out["valu_roofline"] = valu
+        out.update(extras)
         return out
 
     printed = {"done": False}
+    extras = {}  # entries added to the line once they exist (strong-scaling leg)
 
     def emit(out):
         if not printed["done"]:
@@ -323,6 +353,7 @@ def main():
         out = compose(runs[0], runs)
         ctrl = runs[0]["ctrl"]
         if not args.no_extras:
+            out["sharded_one_rank"] = sharded_one_rank(torch, dist, timed_run, runs[0], args, N_total, T)
             out["closed_loop"] = closed_loop(torch, env, ctrl, T, N_total)
             out["example_loop"] = example_loop(torch)
             out["other_configs"] = other_configs(torch, np)
@@ -353,18 +384,61 @@ def main():
     timer = None
     for mode in order:
         runs.append(timed_run(mode))
-        if timer is None and best_of(runs) is not None and len(order) > 1:
+        if timer is None and best_of(runs) is not None:
             timer = threading.Timer(args.alt_budget_s, watchdog)
             timer.daemon = True
             timer.start()
-    if timer is not None:
-        timer.cancel()
     best = best_of(runs)
     assert best is not None, [r.get("error", "non-finite outputs") for r in runs]
+    # strong-scaling leg (BASELINE's metric also reads "racing N = 1M ... at 1/2/4/8 GPUs"): the SAME 2^20 samples split
+    # over the ranks, on the transport that won the weak leg, behind the same watchdog.  Reported next to the weak-scaling
+    # `value` (which stays the contract's line: fixed work per GPU), never instead of it.
+    sr = timed_run(best["requested"], n_total=N_local)
+    if "error" in sr or not sr["finite"]:
+        extras["strong"] = {"error": sr.get("error", "non-finite outputs")}
+    else:
+        extras["strong"] = {"scaling": "strong", "num_samples_total": N_local, "num_samples_per_gpu": N_local // world,
+                            "exchange": sr["exchange"], "ms_per_step": sr["dt"] / args.steps * 1e3,
+                            "solves_per_sec": args.steps / sr["dt"], "value": N_local * T * args.steps / sr["dt"],
+                            "unit": "sample-steps/s", "exchange_us": None if sr["exchange_ms"] is None else sr["exchange_ms"] * 1e3,
+                            "per_rank_stages_ms": sr["rank_stages"]}
+    sr["ctrl"] = None
+    if timer is not None:
+        timer.cancel()
     if rank == 0:
         emit(compose(best, runs))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def sharded_one_rank(torch, dist, timed_run, plain, args, N, T):
+    """The N-GPU code path with ONE rank (shard_samples=True + the solver's private one-rank exchange hook: summary ->
+    exchange over the real RCCL backend -> combine), timed like the headline: a multi-GPU run at N = 1 and this bench's
+    single-GPU line must be the same number, so the first point of a scaling curve is not an artefact of the sharded
+    path's fixed cost.  Reports both transports and whether each is within 3 % of the unsharded `value`."""
+    import tempfile
+
+    out = {}
+    try:
+        store = dist.FileStore(os.path.join(tempfile.mkdtemp(prefix="mppi_bench_"), "store"), 1)
+        dist.init_process_group("nccl", store=store, rank=0, world_size=1, device_id=torch.device("cuda", torch.cuda.current_device()))
+    except Exception as e:  # noqa: BLE001
+        return {"error": f"one-rank nccl process group: {type(e).__name__}: {str(e)[:200]}"}
+    try:
+        for mode in ("rccl", "nccl"):
+            r = timed_run(mode, n_total=N, force_exchange=True)
+            if "error" in r:
+                out[mode] = {"error": r["error"]}
+                continue
+            ratio = plain["dt"] / r["dt"]
+            out[mode] = {"ms_per_step": r["dt"] / args.steps * 1e3, "value": N * T * args.steps / r["dt"],
+                         "value_over_unsharded": ratio, "within_3pct": bool(abs(ratio - 1.0) <= 0.03), "finite": r["finite"],
+                         "exchange": r["exchange"], "rccl_ranks": r["rccl_ranks"]}
+            r["ctrl"] = None
+    finally:
+        os.environ.pop("MPPI_EXCHANGE", None)
+        dist.destroy_process_group()
+    return out
 
 
 def closed_loop(torch, env, ctrl, T, N):

@@ -274,9 +274,12 @@ int mppi_get_state_seq_timing(mppi_handle_t h, float* out2_host);
  * multi-kernel path; temperature, action and state sequences equal to rounding (another summation partition).
  * "fused_solve" = 0 keeps the multi-kernel path, = 2 takes the single launch whenever every block can be resident at once
  * (num_samples <= 512 x #CUs = 131 072; measured on par or slower than the multi-kernel path beyond the defaults above:
- * a cell round trip costs what a kernel boundary costs).  A poll that cannot complete within ~2 s (the device is shared
- * with another cooperative kernel and a block never became resident) voids that solve's outputs (NaN), raises the flag
- * below and returns the handle to the multi-kernel path — it never hangs. */
+ * a cell round trip costs what a kernel boundary costs).  Co-residency of the blocks is checked against the kernel's own
+ * occupancy before every launch configuration is used (hipOccupancyMaxActiveBlocksPerMultiprocessor x #CUs; a grid that
+ * does not fit takes the multi-kernel path in the same call); what other work holds of the device at run time cannot be
+ * known at launch, so a poll that cannot complete within 20 ms gives up: that solve returns the PREVIOUS plan (the warm
+ * start it sampled around, unchanged, and its rollout from the current state — never NaN, never a partial combine),
+ * statistics NaN, the flag below is raised and the handle stays on the multi-kernel path from then on.  It never hangs. */
 int mppi_fused_error(mppi_handle_t h);
 /* Step 7 inside mppi_finalize (mppi.py:423-443,598-620): Savitzky-Golay smoothing of [history(T-1); a(T)] per control
  * dimension (symmetric-flip padding, valid cross-correlation, keep the last T), applied whenever mppi_finalize is

@@ -47,6 +47,8 @@ struct MppiSolver {
     int* fused_error = nullptr;        // mapped pinned
     int* fused_error_dev = nullptr;
     unsigned fused_seq = 0;
+    uint64_t fused_occ_key = 0;        // (math level, LDS bytes) the cached occupancy below belongs to
+    int fused_occ_blocks = 0;          // resident blocks of solve_fused_kernel per CU (hipOccupancyMaxActiveBlocksPerMultiprocessor)
     int fused_mode = 1;                // option "fused_solve": 0 = never, 1 = small problems (default), 2 = whenever resident
     int cu_count = 0;
     double* grid0_dev = nullptr;       // [STATS_L] round-0 grid of the fused LBPS search (ESSPS: essps_dev->grid0)
@@ -1151,7 +1153,9 @@ static int essps_prepare(mppi_handle_t h, double lam_min, double lam_max) {
     return MPPI_OK;
 }
 
-static int solve_fused(mppi_handle_t h, float lambda, float* action_out, float* state_out, float* stats_out, hipStream_t s) {
+static int solve_fused(mppi_handle_t h, float lambda, float* action_out, float* state_out, float* stats_out, hipStream_t s,
+                       bool* declined) {
+    *declined = false;
     if (!h->fused_cells) {  // first use: set-up path (blocking)
         const size_t bytes = sizeof(unsigned long long) * FX_PHASES * FUSED_MAX_BLOCKS * FX_CELLS;
         HIP_TRY(h, hipMalloc(&h->fused_cells, bytes));
@@ -1211,10 +1215,25 @@ static int solve_fused(mppi_handle_t h, float lambda, float* action_out, float* 
     do {                                                                                              \
         const size_t shmem = sizeof(float) * ((size_t)8 * h->d.R + (size_t)h->d.T * ModelT<MODEL, FASTV>::KROW + 2 * (size_t)h->d.row + \
                                               MPPI_SUMMARY_HEAD + (sg.window ? (size_t)(2 * h->d.T - 1 + 2 * (sg.window / 2)) * h->dc : 0)); \
+        /* the blocks synchronise through cells in HBM: every one of them must be resident at once.  Checked against the   \
+           kernel's own occupancy (cached per (math level, LDS size)); what OTHER work holds of the GPU at run time is what  \
+           the polls' time-out is for */                                                                                   \
+        const uint64_t okey = ((uint64_t)(FASTV + 1) << 48) | (uint64_t)shmem;                                             \
+        if (h->fused_occ_key != okey) {                                                                                    \
+            int nb = 0;                                                                                                    \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, solve_fused_kernel<MODEL, FASTV>, FUSED_BLOCK, shmem) != hipSuccess) nb = 0; \
+            h->fused_occ_key = okey; h->fused_occ_blocks = nb;                                                             \
+        }                                                                                                                  \
+        if ((int64_t)grid > (int64_t)h->fused_occ_blocks * h->cu_count) { *declined = true; break; }                       \
         hipLaunchKernelGGL((solve_fused_kernel<MODEL, FASTV>), dim3(grid), dim3(FUSED_BLOCK), shmem, s, A, h->d, h->gen, h->ctx, sg, fx); \
     } while (0)
     MPPI_DISPATCH(h, CALL_FUSED);
 #undef CALL_FUSED
+    if (*declined) {  // (undo the bookkeeping of a solve that did not start: the multi-kernel path takes it from here)
+        h->min_slot ^= 1;
+        --h->fused_seq;
+        return MPPI_OK;
+    }
     HIP_TRY(h, hipGetLastError());
     if (rule != FUSED_RULE_NONE) h->lambda_dev_valid = true;
     // (the single launch rolls the solution out itself; a state sequence still pending from an earlier multi-kernel solve
@@ -1247,9 +1266,12 @@ int mppi_solve(mppi_handle_t h, const float* x0_dev, uint32_t solve_idx, float l
     if (int rc = mppi_sample(h, solve_idx, stream)) return rc;
     if (fused_applies(h, lambda)) {
         if (int rc = flush_state_seq(h, (hipStream_t)stream)) return rc;  // (pending from an earlier multi-kernel solve)
-        if (int rc = solve_fused(h, lambda, action_out_dev, state_seq_out_dev, stats_out_dev, (hipStream_t)stream)) return rc;
-        if (h->auto_rule == MPPI_AUTO_MPO) return mppi_mpo_step_device(h, stream);
-        return MPPI_OK;
+        bool declined = false;
+        if (int rc = solve_fused(h, lambda, action_out_dev, state_seq_out_dev, stats_out_dev, (hipStream_t)stream, &declined)) return rc;
+        if (!declined) {
+            if (h->auto_rule == MPPI_AUTO_MPO) return mppi_mpo_step_device(h, stream);
+            return MPPI_OK;
+        }
     }
     if (int rc = mppi_rollout_cost(h, stream)) return rc;
     if (dev && h->auto_rule == MPPI_AUTO_ESSPS) {

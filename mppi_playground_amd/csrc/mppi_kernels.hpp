@@ -1467,6 +1467,10 @@ constexpr int FUSED_SMALL_BLOCKS = 32;       // up to this many blocks no hop is
 constexpr int FX_CELLS = FUSED_MAX_ROW + 8;  // per (phase, block): >= 4 + row, >= 97
 enum { FX_MIN = 0, FX_STATS = 1 /* +2*round */, FX_BCAST = 2 /* +2*round */, FX_ROW = 7, FX_PHASES = 8 };
 enum { FUSED_RULE_NONE = 0, FUSED_RULE_ESSPS = 1, FUSED_RULE_LBPS = 2 };
+// A poll that cannot complete within this long gives up (100 MHz wall clock: 20 ms — three orders of magnitude above the
+// ~30 us a healthy single-launch solve takes, short enough for a control loop to notice within a tick or two): a block
+// of this launch is not resident, i.e. something else holds the GPU's CUs.
+constexpr long long FUSED_TIMEOUT_TICKS = 2000000ll;
 struct FusedCtx {
     unsigned long long* cells;  // [FX_PHASES][FUSED_MAX_BLOCKS][FX_CELLS]
     int* error;                 // mapped host flag
@@ -1483,7 +1487,7 @@ __device__ __forceinline__ float fx_wait(const FusedCtx& x, const unsigned long 
                                          bool& timed_out) {
     unsigned spins = 0;
     while ((unsigned)(cell >> 32) != x.seq) {
-        if ((++spins & 255u) == 0u && wall_clock64() - t0 > 200000000ll) { timed_out = true; break; }  // 100 MHz: 2 s
+        if ((++spins & 255u) == 0u && wall_clock64() - t0 > FUSED_TIMEOUT_TICKS) { timed_out = true; break; }
         __builtin_amdgcn_s_sleep(2);
         cell = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -1969,12 +1973,19 @@ __global__ __launch_bounds__(FUSED_BLOCK) void solve_fused_kernel(FusedArgs A, D
     FX_TRACE(8);
     if (timed_out) s_flag = 1;
     __syncthreads();
-    if (s_flag) {  // a block is missing: no partial answer leaves this kernel
-        const float nanv = __uint_as_float(0x7fc00000u);
-        for (int c = tid; c < d.row; c += FUSED_BLOCK) if (A.action_out) A.action_out[c] = nanv;
-        for (int c = tid; c < (d.T + 1) * M::DS; c += FUSED_BLOCK) if (A.state_out) A.state_out[c] = nanv;
-        if (tid < 4 && A.stats_out) A.stats_out[tid] = nanv;
+    if (s_flag) {
+        // A block is missing: no partial answer leaves this kernel — but no NaN reaches an actuator either.  The outputs
+        // become the PREVIOUS plan (the warm start this solve sampled around, which stays the warm start: nothing is stored)
+        // and its rollout from the current state; the statistics are NaN and the error flag is raised (mapped host memory:
+        // mppi_fused_error; the handle returns to the multi-kernel path for good).
+        for (int c = tid; c < d.row; c += FUSED_BLOCK) {
+            s_act[c] = A.mean[c];
+            if (A.action_out) A.action_out[c] = s_act[c];
+        }
+        if (tid < 4 && A.stats_out) A.stats_out[tid] = __uint_as_float(0x7fc00000u);
         if (tid == 0) *fx.error = 1;
+        __syncthreads();
+        if (A.state_out) batch1_rollout<MODEL, FAST>(ctx, s_x0, s_act, d.T, A.state_out);
         return;
     }
     finalize_tail<MODEL, FAST>(s_sum, 1, lambda, d.row, d.T, s_x0, s_act, s_yp, A.mean_store, A.action_out, A.state_out,

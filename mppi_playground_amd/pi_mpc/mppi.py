@@ -309,15 +309,14 @@ class MPPI(nn.Module):
         self._search_in_library = auto_lambda_stats == "device" and self._world == 1
         # which rule runs as kernels with the temperature resident in HBM (no host wait): mppi_set_auto_lambda
         self._rule_on_device = None
+        self._auto_params_sent = None  # (rule parameter, lambda_min, lambda_max) the handle was last given
         if self._search_in_library:
             if self._auto_lambda == "ESSPS" and essps_search == "device":
                 self._rule_on_device = "ESSPS"
-                self._h.call("mppi_set_auto_lambda", _capi.AUTO_RULES["ESSPS"], float(self._essps_target_ess),
-                             float(lambda_min), float(lambda_max))
+                self._push_auto_lambda()
             elif self._auto_lambda == "LBPS" and lbps_search == "device":
                 self._rule_on_device = "LBPS"
-                self._h.call("mppi_set_auto_lambda", _capi.AUTO_RULES["LBPS"], float(lbps_delta), float(lambda_min),
-                             float(lambda_max))
+                self._push_auto_lambda()
             elif self._auto_lambda == "MPO":
                 self._rule_on_device = "MPO"
                 self._h.call("mppi_mpo_reset", 1.0, 0.1, 0.2)  # mppi.py:191-200
@@ -368,6 +367,16 @@ class MPPI(nn.Module):
         self._state_seq_batch_buf = None
         self._perturbed_action_seqs_buf = None
         self._x0_tensor = None
+
+    def _push_auto_lambda(self) -> None:
+        """The device-resident ESSPS / LBPS rule reads its parameters from the handle (mppi_set_auto_lambda), the reference
+        reads `_essps_target_ess` / `_lbps_delta` / `_lambda_min` / `_lambda_max` on every solve (mppi.py:341-370): hand them
+        over again whenever a caller changed one of these attributes (a tuple compare per solve)."""
+        p = (float(self._essps_target_ess if self._rule_on_device == "ESSPS" else self._lbps_delta), float(self._lambda_min),
+             float(self._lambda_max))
+        if p != self._auto_params_sent:
+            self._h.call("mppi_set_auto_lambda", _capi.AUTO_RULES[self._rule_on_device], *p)
+            self._auto_params_sent = p
 
     # ------------------------------------------------------------------ temperature (lazily fetched)
     def _fetch_lambda(self) -> None:
@@ -831,8 +840,9 @@ class MPPI(nn.Module):
         self._refresh_model_inputs()
         if not self._fused_error_seen and h.lib.mppi_fused_error(h.h):
             self._fused_error_seen = True  # (from now on the library stays on the multi-kernel path)
-            raise _capi.MppiError("a single-launch solve timed out waiting for one of its blocks (is the GPU shared with another "
-                                  "cooperative kernel?): its outputs are void; later solves use the multi-kernel path")
+            raise _capi.MppiError("a single-launch solve gave up waiting for one of its blocks after 20 ms (is the GPU shared with "
+                                  "other work?): that solve returned the previous plan instead of a new one; later solves use "
+                                  "the multi-kernel path")
         self._mean_of_last_solve = self._previous_action_seq
         if self._auto_lambda is None:
             lam = float(self._lambda_value)
@@ -842,6 +852,8 @@ class MPPI(nn.Module):
             self._lambda_pending, self._lambda_stream, self._used_known = True, st, True
             self._lambda_override = None
         else:  # the configured rule runs on the device; the temperature is fetched when somebody asks for it
+            if self._rule_on_device != "MPO":
+                self._push_auto_lambda()
             lam = _capi.LAMBDA_DEVICE
             self._lambda_pending, self._lambda_stream, self._used_known = True, st, False
         # (the previous solve's state tensor stays alive across this launch: with a lazily completed state sequence this
@@ -964,8 +976,7 @@ class MPPI(nn.Module):
             self._graph_state = "replay"
             # what the caller's dict held besides the solver's own four keys when the loops were captured: a replay cannot
             # see later changes of it (see _check_replay_info)
-            self._graph_info_keys = {k: id(v) for k, v in info.items()
-                                     if k not in ("prev_state", "prev_action", "initial_state", "t")}
+            self._graph_info_keys = self._info_signature(info)
             g.replay()
         except Exception as e:  # not capturable (host sync, data-dependent shapes, ...): stay eager
             self._graph, self._graph_state = None, "failed"
@@ -974,11 +985,29 @@ class MPPI(nn.Module):
                           f"{str(e).splitlines()[0] if str(e) else ''}); staying on the eager loops")
             self._callable_loops(info)
 
+    @staticmethod
+    def _info_signature(info: Dict) -> Dict:
+        """What a captured graph saw of the CALLER's entries of `info`, by value: a tensor is its storage (address, shape,
+        in-place version counter: a replay reads that storage, so an equal-valued NEW tensor is a change and an in-place
+        update of the captured one is not — but bumps the version, which is allowed), a Python scalar / string / None is
+        its value (a caller may rebuild an equal dict every tick), anything else its identity."""
+        sig = {}
+        for k, v in info.items():
+            if k in ("prev_state", "prev_action", "initial_state", "t"):
+                continue
+            if torch.is_tensor(v):
+                sig[k] = ("tensor", v.data_ptr(), tuple(v.shape), v.dtype)
+            elif isinstance(v, (bool, int, float, str, bytes, type(None))):
+                sig[k] = ("value", v)
+            else:
+                sig[k] = ("object", id(v))
+        return sig
+
     def _check_replay_info(self, info: Dict) -> None:
         """A replayed graph ignores the `info` dict it is handed: the solver's own keys are views of the static buffers
         (filled in below like the eager loop leaves them), but entries the CALLER put there were read at capture time.  If
         those changed identity since, the replay would silently use the old objects: refuse instead."""
-        now = {k: id(v) for k, v in info.items() if k not in ("prev_state", "prev_action", "initial_state", "t")}
+        now = self._info_signature(info)
         if now != self._graph_info_keys:
             raise RuntimeError("graph_callables: the caller's entries of `info` changed since the loops were captured "
                                f"({sorted(set(now) ^ set(self._graph_info_keys)) or sorted(now)}); update tensors in place "
