@@ -464,8 +464,11 @@ __global__ __launch_bounds__(BLOCK) void rollout_cost_wave_kernel(const float* _
 // partials layout: [gridDim.x][colsp] with colsp = gridDim.y * NW * GPW * 4; heads: [gridDim.x][4].
 constexpr int REDUCE_MAX_BLOCKS = 2048;
 // WIDE: per-column clamp bounds from `coltab` (see gen_noise4) staged in LDS next to the mean; tiles only (GEN = false).
+#ifndef MPPI_REDUCE_ATTR
+#define MPPI_REDUCE_ATTR  // (A/B knob of scripts/build_variant.sh, e.g. __attribute__((amdgpu_waves_per_eu(2,3))))
+#endif
 template <int GPW, bool GEN, bool WIDE = false>  // GPW: float4 groups per wave and column chunk (8 or 32)
-__global__ __launch_bounds__(BLOCK) void weights_reduce_kernel(const float4* __restrict__ noise,
+__global__ __launch_bounds__(BLOCK) MPPI_REDUCE_ATTR void weights_reduce_kernel(const float4* __restrict__ noise,
                                                                const float* __restrict__ mean,
                                                                const float* __restrict__ costs,
                                                                const unsigned* __restrict__ min_key,
@@ -551,27 +554,44 @@ __global__ __launch_bounds__(BLOCK) void weights_reduce_kernel(const float4* __r
                 const float4* mp = reinterpret_cast<const float4*>(&s_mean[0][0]) + moff;
                 int nrl = d.R - r0 - wid;               // groups r0 + wid + NW*m with NW*m < nrl exist
                 asm volatile("" : "+s"(nrl));           // opaque: keeps the group predicates out of SGPRs
+                const auto accumulate = [&](int m, const float4& n4) {
+                    const float4 m4 = mp[NW * m];
+                    const float nv[4] = {n4.x, n4.y, n4.z, n4.w};
+                    const float mv[4] = {m4.x, m4.y, m4.z, m4.w};
+                    // (columns past the row length accumulate unused values; the fold drops them)
 #pragma unroll
-                for (int m = 0; m < GPW; ++m) {
-                    if (NW * m < nrl) {
-                        const float4 n4 = noise_group<GEN>(np, r0 + wid + NW * m, gi, gen, d);
-                        const float4 m4 = mp[NW * m];
-                        const float nv[4] = {n4.x, n4.y, n4.z, n4.w};
-                        const float mv[4] = {m4.x, m4.y, m4.z, m4.w};
-                        // (columns past the row length accumulate unused values; the fold drops them)
+                    for (int j = 0; j < 4; ++j) {
+                        float u;
+                        if (WIDE) {
+                            const int cj = 4 * (wid + NW * m) + j;  // column inside this chunk
+                            u = clampf(mv[j] + nv[j], s_bnd[0][cj], s_bnd[1][cj]);
+                        } else {
+                            const int k = ctrl_index(j, d.dc);
+                            u = clampf(mv[j] + nv[j], d.u_min[k], d.u_max[k]);
+                        }
+                        acc[4 * m + j] = fmaf(e, u, acc[4 * m + j]);
+                    }
+                };
+                if constexpr (GEN) {
+                    // Regenerated noise: the wave's groups are predicated FOUR AT A TIME, so that four independent
+                    // Philox + Box-Muller chains (10 dependent 64-bit multiplies each) sit in one basic block and
+                    // overlap — a per-group branch serialised them, and with two waves per SIMD the dense reduction
+                    // ran at 0.39 of the VALU issue peak.  A group past the row length (the chunk holds CHG = 32
+                    // slots, racing's row 25) costs arithmetic only: its accumulators are columns the fold drops.
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            float u;
-                            if (WIDE) {
-                                const int cj = 4 * (wid + NW * m) + j;  // column inside this chunk
-                                u = clampf(mv[j] + nv[j], s_bnd[0][cj], s_bnd[1][cj]);
-                            } else {
-                                const int k = ctrl_index(j, d.dc);
-                                u = clampf(mv[j] + nv[j], d.u_min[k], d.u_max[k]);
-                            }
-                            acc[4 * m + j] = fmaf(e, u, acc[4 * m + j]);
+                    for (int m0 = 0; m0 < GPW; m0 += 4) {
+                        if (NW * m0 < nrl) {
+                            float4 n4[4];
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) n4[k] = noise_group<true>(np, r0 + wid + NW * (m0 + k), gi, gen, d);
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) accumulate(m0 + k, n4[k]);
                         }
                     }
+                } else {
+#pragma unroll
+                    for (int m = 0; m < GPW; ++m)
+                        if (NW * m < nrl) accumulate(m, noise_group<false>(np, r0 + wid + NW * m, gi, gen, d));
                 }
             }
         }

@@ -46,15 +46,16 @@ __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_
     return philox4x32_10(c0, c1, c2, c3, k0, k1, k0, k1, k0 + 0x9E3779B9u);
 }
 
-// Box-Muller on (a, b): u1 = ((a>>8)+1) * 2^-24 in (0,1], u2 = (b>>8) * 2^-24 in [0,1).
-// Hardware transcendentals: v_log_f32 (log2), v_sqrt_f32, v_sin_f32 / v_cos_f32 (argument in
-// revolutions, so 2*pi*u2 needs no multiply).
+// Box-Muller on (a, b): u1 = ((a>>8)+1) * 2^-24 in (0,1], u2 = (b>>9) * 2^-23 in [0,1).
+// Hardware transcendentals: v_log_f32 (log2), v_sqrt_f32, v_sin_f32 / v_cos_f32.  The latter take their argument in
+// REVOLUTIONS and are periodic in 1, so the angle needs neither the 2*pi multiply nor a conversion: the 23 bits of u2 are
+// the mantissa of a float in [1, 2) (one shift + one OR), and cos(2 pi (1 + u2)) = cos(2 pi u2).
 __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& z0, float& z1) {
     const float u1 = (float)((a >> 8) + 1u) * (1.0f / 16777216.0f);
-    const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);
+    const float rev = __uint_as_float(0x3f800000u | (b >> 9));  // 1 + u2
     const float rad = __builtin_amdgcn_sqrtf(-1.38629436112f * __builtin_amdgcn_logf(u1));  // -2 ln2 log2(u1)
-    z0 = rad * __builtin_amdgcn_cosf(u2);
-    z1 = rad * __builtin_amdgcn_sinf(u2);
+    z0 = rad * __builtin_amdgcn_cosf(rev);
+    z1 = rad * __builtin_amdgcn_sinf(rev);
 }
 
 }  // namespace mppi

@@ -367,6 +367,8 @@ class MPPI(nn.Module):
         self._state_seq_batch_buf = None
         self._perturbed_action_seqs_buf = None
         self._x0_tensor = None
+        self._costs_host = None
+        self._pick_strategy()
 
     def _push_auto_lambda(self) -> None:
         """The device-resident ESSPS / LBPS rule reads its parameters from the handle (mppi_set_auto_lambda), the reference
@@ -691,24 +693,67 @@ class MPPI(nn.Module):
 
     # ------------------------------------------------------------------ forward
     def forward(self, state: torch.Tensor, info: Dict = {}) -> Tuple[torch.Tensor, torch.Tensor]:
-        """Solve one MPPI step (src/pi_mpc/mppi.py:223-460)."""
+        """Solve one MPPI step (src/pi_mpc/mppi.py:223-460).
+
+        One of three strategies, resolved once in __init__ (`_solve`, see _pick_strategy):
+          _solve_one_call   native model and nothing needs the host between the steps: ONE library call (mppi_solve);
+          _solve_by_steps   native model through the individual entry points, with host work in between (torch-CPU noise,
+                            a host-side temperature rule, the exchange through torch.distributed, the host SG filter);
+          _solve_generic    opaque `dynamics` / `cost_func` callables around the library's sampler / softmax / reduction.
+        Injected noise (parity hook) sends a one-call solver through the entry points for that one solve."""
         assert state.shape == (self._dim_state,)
-        h, st = self._h, self._stream()
-        if self._one_call and self._injected is None:
-            return self._forward_one_call(state, h, st)
+        if self._injected is not None and self._one_call:
+            return self._solve_by_steps(state, info)
+        return self._solve(state, info)
+
+    def _pick_strategy(self) -> None:
+        """Resolve every per-solve mode decision ONCE (called at the end of __init__): the solve strategy and the step that
+        produces this solve's temperature (src/pi_mpc/mppi.py:341-370; MPO: the temperature the previous solve left)."""
+        if self._model is None:
+            self._solve = self._solve_generic
+        elif self._one_call:
+            self._solve = self._solve_one_call
+        else:
+            self._solve = self._solve_by_steps
+        on_dev = self._auto_lambda_stats == "device"
+        rule = self._auto_lambda
+        if rule is None:
+            step = self._lam_fixed
+        elif self._rule_on_device == "LBPS":
+            step = self._lam_lbps_device
+        elif self._rule_on_device == "MPO":
+            step = self._lam_mpo_device
+        elif self._rule_on_device == "ESSPS":
+            step = self._lam_essps_device
+        elif rule == "LBPS":
+            step = self._lam_lbps_library if self._search_in_library else self._lam_lbps_host
+        elif rule == "ESSPS":
+            step = (self._lam_essps_library if (on_dev and self._essps_search == "grid" and self._world == 1)
+                    else self._lam_essps_host)
+        else:  # MPO with the dual on the host: nothing before the weights (the dual steps after them)
+            step = self._lam_fixed
+        self._temperature_step = step
+        self._stats_on_device = on_dev
+        self._sharded = self._world > 1 or self._force_exchange
+        self._host_sg = self._use_sg_filter and not self._sg_on_device  # host round trip only for sg_filter="host"
+
+    # ---- stages shared by the step-by-step strategies
+    def _bind_state(self, state, st) -> None:
         if torch.is_tensor(state) and state.is_cuda:
             # zero-copy: this solve's kernels read the caller's tensor (kept alive until the next solve); the rollout
             # kernel snapshots it, so later re-rolls (get_top_samples, _state_seq_batch) do not depend on it
             self._x0_keep = state.detach().to(self._device, self._dtype).contiguous()
-            h.call("mppi_bind_state", _ptr(self._x0_keep))
+            self._h.call("mppi_bind_state", _ptr(self._x0_keep))
         else:
             x0h = np.ascontiguousarray(state.detach().cpu().numpy() if torch.is_tensor(state) else state,
                                        dtype=np.float32)
-            h.call("mppi_set_state", x0h.ctypes.data_as(C.c_void_p), 0, st)
+            self._h.call("mppi_set_state", x0h.ctypes.data_as(C.c_void_p), 0, st)
         self._refresh_model_inputs()
         self._mean_of_last_solve = self._previous_action_seq  # the mean this solve samples around
 
-        # Step 1: noise (src/pi_mpc/mppi.py:261-263)
+    def _draw_noise(self, st) -> None:
+        """Step 1 (src/pi_mpc/mppi.py:261-263): injected, the reference's CPU stream, or the device Philox stream."""
+        h = self._h
         if self._injected is not None:
             h.call("mppi_inject_noise", _ptr(self._injected), st)
             self._injected = None
@@ -721,111 +766,153 @@ class MPPI(nn.Module):
             h.call("mppi_sample", self._solve_idx, st)
         self._solve_idx += 1
 
-        # Steps 1b-3: clamp, rollout, costs (src/pi_mpc/mppi.py:266-336)
-        if self._model is not None:
-            h.call("mppi_rollout_cost", st)
-        else:
-            self._generic_rollout_costs(state, info)
+    # ---- Step 4, one method per way of getting this solve's temperature (picked once: _pick_strategy)
+    def _lam_fixed(self, st) -> None:
+        pass
 
-        # Step 4: temperature (host; src/pi_mpc/mppi.py:341-370)
-        costs_host = None
-        on_dev = self._auto_lambda_stats == "device"
-        if self._auto_lambda is not None and not on_dev:
-            costs_host = self._gather_costs_host()
-        if self._rule_on_device == "LBPS":  # three grid rounds as kernels: nothing is read back
-            h.call("mppi_lbps_lambda_device", float(self._lbps_delta), float(self._lambda_min), float(self._lambda_max), st)
-            self._lambda_pending, self._lambda_stream = True, st
-        elif self._rule_on_device == "MPO":  # this solve uses the temperature the dual left in HBM (or the caller's)
-            self._lambda_pending, self._lambda_stream = self._lambda_override is None, st
-        elif self._auto_lambda == "LBPS" and self._search_in_library:
-            lam_out = C.c_double(0.0)  # bounded Brent inside the library (same algorithm as scipy's, host C++)
-            h.call("mppi_lbps_lambda", float(self._lbps_delta), float(self._lambda_min), float(self._lambda_max),
-                   C.byref(lam_out), st)
-            self._lambda = lam_out.value
-        elif self._auto_lambda == "LBPS":
-            self._lambda = (_host.lbps_lambda_stats(self._softmax_stats, self._lbps_delta, self._lambda_min,
-                                                    self._lambda_max) if on_dev else
-                            _host.lbps_lambda(costs_host, self._lbps_delta, self._lambda_min, self._lambda_max))
-        elif self._auto_lambda == "ESSPS" and on_dev and self._essps_search == "device" and self._world == 1:
-            # the whole search as kernels on this stream: nothing is read back, the temperature stays in HBM
-            h.call("mppi_essps_lambda_device", float(self._essps_target_ess), float(self._lambda_min),
-                   float(self._lambda_max), st)
-            self._lambda_pending, self._lambda_stream = True, st
-        elif self._auto_lambda == "ESSPS" and on_dev and self._essps_search == "grid" and self._world == 1:
-            lam_out = C.c_double(0.0)  # the search as a host loop inside the library (same algorithm, one read-back per grid)
-            h.call("mppi_essps_lambda", float(self._essps_target_ess), float(self._lambda_min),
-                   float(self._lambda_max), C.byref(lam_out), st)
-            self._lambda = lam_out.value
-        elif self._auto_lambda == "ESSPS":
-            self._lambda = ((_host.essps_lambda_grid(self._ess_grid, self._essps_target_ess, self._lambda_min,
-                                                     self._lambda_max, lam_prev=self._essps_prev)
-                             if self._essps_search != "brentq" else
-                             _host.essps_lambda_stats(self._softmax_stats, self._essps_target_ess, self._lambda_min,
-                                                      self._lambda_max)) if on_dev else
-                            _host.essps_lambda(costs_host, self._essps_target_ess, self._lambda_min,
-                                               self._lambda_max))
-            self._essps_prev = float(self._lambda)  # the next grid search starts around it (one exchange instead of two)
+    def _lam_lbps_device(self, st) -> None:  # grid rounds as kernels: nothing is read back
+        self._h.call("mppi_lbps_lambda_device", float(self._lbps_delta), float(self._lambda_min), float(self._lambda_max), st)
+        self._lambda_pending, self._lambda_stream = True, st
+
+    def _lam_mpo_device(self, st) -> None:  # this solve uses the temperature the dual left in HBM (or the caller's)
+        self._lambda_pending, self._lambda_stream = self._lambda_override is None, st
+
+    def _lam_essps_device(self, st) -> None:  # the whole search as kernels on this stream; the temperature stays in HBM
+        self._h.call("mppi_essps_lambda_device", float(self._essps_target_ess), float(self._lambda_min),
+                     float(self._lambda_max), st)
+        self._lambda_pending, self._lambda_stream = True, st
+
+    def _lam_lbps_library(self, st) -> None:  # bounded Brent inside the library (same algorithm as scipy's, host C++)
+        lam_out = C.c_double(0.0)
+        self._h.call("mppi_lbps_lambda", float(self._lbps_delta), float(self._lambda_min), float(self._lambda_max),
+                     C.byref(lam_out), st)
+        self._lambda = lam_out.value
+
+    def _lam_lbps_host(self, st) -> None:  # scipy's bounded Brent over device statistics or over the costs on the host
+        self._lambda = (_host.lbps_lambda_stats(self._softmax_stats, self._lbps_delta, self._lambda_min, self._lambda_max)
+                        if self._stats_on_device else
+                        _host.lbps_lambda(self._costs_host, self._lbps_delta, self._lambda_min, self._lambda_max))
+
+    def _lam_essps_library(self, st) -> None:  # the grid search as a host loop inside the library (one read-back per grid)
+        lam_out = C.c_double(0.0)
+        self._h.call("mppi_essps_lambda", float(self._essps_target_ess), float(self._lambda_min), float(self._lambda_max),
+                     C.byref(lam_out), st)
+        self._lambda = lam_out.value
+
+    def _lam_essps_host(self, st) -> None:
+        if not self._stats_on_device:  # the reference's own calls on the costs (mppi.py:351-370)
+            self._lambda = _host.essps_lambda(self._costs_host, self._essps_target_ess, self._lambda_min, self._lambda_max)
+        elif self._essps_search == "brentq":
+            self._lambda = _host.essps_lambda_stats(self._softmax_stats, self._essps_target_ess, self._lambda_min,
+                                                    self._lambda_max)
+        else:
+            self._lambda = _host.essps_lambda_grid(self._ess_grid, self._essps_target_ess, self._lambda_min,
+                                                   self._lambda_max, lam_prev=self._essps_prev)
+        self._essps_prev = float(self._lambda)  # the next grid search starts around it (one exchange instead of two)
+
+    def _temperature(self, st) -> float:
+        """Run the rule's step and return what the reduce / finalize entry points are given: a value, or the marker for
+        "read it from device memory"."""
+        self._costs_host = None
+        if self._auto_lambda is not None and not self._stats_on_device:
+            self._costs_host = self._gather_costs_host()
+        self._temperature_step(st)
         if self._lambda_pending:
-            lam = _capi.LAMBDA_DEVICE  # weights_reduce / finalize read the temperature from device memory
             self._used_known = False
-        else:
-            lam = float(self._lambda_override if self._lambda_override is not None else self._lambda)
-            self._last_lambda = lam
-            self._used_known = True
+            return _capi.LAMBDA_DEVICE  # weights_reduce / finalize read the temperature from device memory
+        lam = float(self._lambda_override if self._lambda_override is not None else self._lambda)
+        self._last_lambda = lam
+        self._used_known = True
+        return lam
 
-        # Steps 5-6: weights + weighted mean (src/pi_mpc/mppi.py:376-385)
-        sharded = self._world > 1 or self._force_exchange
-        summaries, nsh = None, 1
+    def _reduce_and_exchange(self, lam, st):
+        """Steps 5-6 (src/pi_mpc/mppi.py:376-385): weights + weighted mean of this shard and, when sharded, the solve's only
+        exchange.  Returns (gathered summaries or None, number of shards)."""
+        h = self._h
         if self._p2p or self._comm:  # the library exchanges the shard summaries itself (buffers / its own all_gather)
             if self._p2p and h.lib.mppi_p2p_error(h.h):
                 raise _capi.MppiError("peer-to-peer exchange timed out on an earlier solve (a rank is missing or stalled)")
             h.call("mppi_weights_reduce", lam, None, st)
-            nsh = self._world
-        else:
-            h.call("mppi_weights_reduce", lam, _ptr(self._summary) if sharded else None, st)
-            if sharded:  # the only exchange of the solve: 4+T*dc floats per rank over RCCL/xGMI
-                if self._gathered is None:
-                    self._gathered = torch.empty(self._world, self._summary.numel(), device=self._device, dtype=self._dtype)
-                summaries, nsh = all_gather_summaries(self._summary, self._pg, out=self._gathered), self._world
+            return None, self._world
+        h.call("mppi_weights_reduce", lam, _ptr(self._summary) if self._sharded else None, st)
+        if not self._sharded:
+            return None, 1
+        if self._gathered is None:  # 4+T*dc floats per rank over RCCL/xGMI
+            self._gathered = torch.empty(self._world, self._summary.numel(), device=self._device, dtype=self._dtype)
+        return all_gather_summaries(self._summary, self._pg, out=self._gathered), self._world
 
-        # Steps 6-8: normalise, warm start, batch-1 rollout (src/pi_mpc/mppi.py:381-385,448-452)
-        use_sg = self._use_sg_filter and not self._sg_on_device  # host round trip only for sg_filter="host"
-        # fresh output tensors every solve (the kernel writes straight into what is returned)
+    def _finalize(self, summaries, nsh, lam, st, native: bool) -> None:
+        """Steps 6-8 (src/pi_mpc/mppi.py:381-385,448-452): normalise, warm start, batch-1 rollout — into fresh output tensors
+        (the kernel writes straight into what is returned)."""
         self._action_out = torch.empty(self._horizon, self._dim_control, device=self._device, dtype=self._dtype)
         self._state_out = torch.empty(1, self._horizon + 1, self._dim_state, device=self._device, dtype=self._dtype)
-        native = self._model is not None
-        h.call("mppi_finalize", _ptr(summaries), nsh, lam, 0 if use_sg else 1, _ptr(self._action_out),
-               _ptr(self._state_out) if (native and not use_sg) else None, _ptr(self._stats), st)
+        self._h.call("mppi_finalize", _ptr(summaries), nsh, lam, 0 if self._host_sg else 1, _ptr(self._action_out),
+                     _ptr(self._state_out) if (native and not self._host_sg) else None, _ptr(self._stats), st)
 
-        if self._auto_lambda == "MPO":  # after the weights, affects the next solve (mppi.py:387-398)
-            if self._rule_on_device == "MPO":
-                h.call("mppi_mpo_step_device", st)  # dual, moments and the next temperature stay in HBM
-                self._lambda_pending, self._lambda_stream = True, st
-            else:
-                self._lambda = (self._mpo.step_from_stats(self._softmax_stats(self._mpo.temperature())) if on_dev
-                                else self._mpo.step(costs_host))
+    def _mpo_after_weights(self, st) -> None:
+        """MPO steps its dual AFTER the weights; the result is the next solve's temperature (mppi.py:387-398)."""
+        if self._auto_lambda != "MPO":
+            return
+        if self._rule_on_device == "MPO":
+            self._h.call("mppi_mpo_step_device", st)  # dual, moments and the next temperature stay in HBM
+            self._lambda_pending, self._lambda_stream = True, st
+        else:
+            self._lambda = (self._mpo.step_from_stats(self._softmax_stats(self._mpo.temperature())) if self._stats_on_device
+                            else self._mpo.step(self._costs_host))
 
-        if use_sg:  # Step 7 on the host (src/pi_mpc/mppi.py:423-443)
-            a = self._action_out.cpu().numpy()
-            a = _host.sg_filter_sequence(self._actions_history_for_sg, a, self._coeffs)
-            self._action_out.copy_(torch.from_numpy(a))
-            h.call("mppi_set_mean", _ptr(self._action_out), 1, st)
-            if native:
-                h.call("mppi_rollout_actions", _ptr(self._action_out), 1, None, _ptr(self._state_out), st)
-            first = a[0]
-            self._actions_history_for_sg = np.concatenate([self._actions_history_for_sg[1:], first[None, :]])
-        if not native:  # Step 8 with the user's dynamics (src/pi_mpc/mppi.py:448-449,508-524)
-            if self._graph_state == "replay":
-                self._state_out = self._states_prediction_graphed()
-            else:
-                self._state_out = self._states_prediction(self._x0_tensor, self._action_out.repeat(1, 1, 1))
+    def _host_sg_step(self, st, native: bool) -> None:
+        """Step 7 on the host (sg_filter="host"; src/pi_mpc/mppi.py:423-443)."""
+        a = self._action_out.cpu().numpy()
+        a = _host.sg_filter_sequence(self._actions_history_for_sg, a, self._coeffs)
+        self._action_out.copy_(torch.from_numpy(a))
+        self._h.call("mppi_set_mean", _ptr(self._action_out), 1, st)
+        if native:
+            self._h.call("mppi_rollout_actions", _ptr(self._action_out), 1, None, _ptr(self._state_out), st)
+        self._actions_history_for_sg = np.concatenate([self._actions_history_for_sg[1:], a[0][None, :]])
+
+    # ---- the strategies
+    def _solve_by_steps(self, state, info):
+        """A native model through the individual entry points (same kernels as mppi_solve)."""
+        st = self._stream()
+        self._bind_state(state, st)
+        self._draw_noise(st)
+        self._h.call("mppi_rollout_cost", st)  # Steps 1b-3: clamp, rollout, costs (src/pi_mpc/mppi.py:266-336)
+        lam = self._temperature(st)
+        summaries, nsh = self._reduce_and_exchange(lam, st)
+        self._finalize(summaries, nsh, lam, st, native=True)
+        self._mpo_after_weights(st)
+        if self._host_sg:
+            self._host_sg_step(st, native=True)
         self._lambda_override = None
         self._previous_action_seq = self._action_out
-        return self._action_out, (self._returned_state_seq() if native and not use_sg else self._state_out)
+        return self._action_out, (self._state_out if self._host_sg else self._returned_state_seq())
 
-    def _forward_one_call(self, state, h, st):
-        """forward() through mppi_solve: the same kernel sequence as the step-by-step path below in one library call
-        (native model, device noise, fixed lambda or the device-resident ESSPS search, one GPU)."""
+    def _solve_generic(self, state, info):
+        """Opaque callables: the reference's two T-step loops over the user's torch `dynamics` / `cost_func` on GPU tensors
+        (or their captured hipGraph) between the library's sampler and its softmax / reduction / warm start."""
+        st = self._stream()
+        self._bind_state(state, st)
+        self._draw_noise(st)
+        self._generic_rollout_costs(state, info)  # Steps 1b-3 with the callables; the summed costs go back to the library
+        lam = self._temperature(st)
+        summaries, nsh = self._reduce_and_exchange(lam, st)
+        self._finalize(summaries, nsh, lam, st, native=False)
+        self._mpo_after_weights(st)
+        if self._host_sg:
+            self._host_sg_step(st, native=False)
+        # Step 8 with the user's dynamics (src/pi_mpc/mppi.py:448-449,508-524)
+        if self._graph_state == "replay":
+            self._state_out = self._states_prediction_graphed()
+        else:
+            self._state_out = self._states_prediction(self._x0_tensor, self._action_out.repeat(1, 1, 1))
+        self._lambda_override = None
+        self._previous_action_seq = self._action_out
+        return self._action_out, self._state_out
+
+    def _solve_one_call(self, state, info=None):
+        """forward() through mppi_solve: the same kernel sequence as _solve_by_steps in one library call (native model,
+        device noise, a fixed temperature or a device-resident rule, one GPU or an in-library exchange)."""
+        h, st = self._h, self._stream()
         if torch.is_tensor(state) and state.is_cuda:
             if state.dtype is self._dtype and state.device == self._device and state.is_contiguous():
                 self._x0_keep = state  # zero-copy as it is (kept alive until the next solve)

@@ -3,7 +3,7 @@
 # rocprofv3 kernel trace + separate PMC passes for C3 (regen / tiles) and for the dense-weight configs C2 / C5.
 # Usage: bash scripts/gpu_record.sh [tag]   (writes gpurun_out/prof_<tag>/, default tag r2)
 set -u
-TAG=${1:-r3}
+TAG=${1:-r4}
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -34,13 +34,14 @@ mkdir -p $P; python -c "import sys; sys.path.insert(0, '$R'); from mppi_playgrou
 B="python $R/bench.py --no-cpu-baseline --no-extras"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $P -o kt -- $B --steps 30 --warmup 5 > $R/gpurun_out/rocprof_kt.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $P -o kt_tiles -- $B --steps 30 --warmup 5 --noise-regen 0 > /dev/null 2>&1
-for wl in c2 c5; do
+for wl in c2 c5 c3_dense; do
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $P -o kt_$wl -- $B --workload $wl --steps 200 --warmup 20 > $R/gpurun_out/rocprof_kt_$wl.log 2>&1
 done
-for mode in regen tiles c2 c5; do
+for mode in regen tiles c2 c5 c3_dense; do
   case $mode in
     regen) extra="--steps 6 --warmup 2";;
     tiles) extra="--steps 6 --warmup 2 --noise-regen 0";;
+    c3_dense) extra="--workload $mode --steps 8 --warmup 2";;
     *) extra="--workload $mode --steps 40 --warmup 10";;
   esac
   for pass in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU" "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE"; do

@@ -9,12 +9,12 @@ text = open(sys.argv[1]).read() if len(sys.argv) > 1 else sys.stdin.read()
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
 cur, rows = None, []
 for line in text.splitlines():
-    m = re.search(r"remark: Function Name: (\S+)", line)
+    m = re.search(r"Function Name: (\S+)", line)
     if m:
         cur = {"name": m.group(1)}
         rows.append(cur)
         continue
-    m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[bytes/lane\]| \[bytes/workgroup\]| \[waves/SIMD\])?: (\d+)", line)
+    m = re.search(r"(?:remark:|:0:)\s+([A-Za-z][A-Za-z ]*?)(?: \[bytes/lane\]| \[bytes/workgroup\]| \[bytes/block\]| \[waves/SIMD\])?: (\d+) \[-Rpass", line)
     if m and cur is not None:
         cur[m.group(1).strip()] = int(m.group(2))
 names = {r["name"] for r in rows}

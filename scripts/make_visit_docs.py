@@ -9,13 +9,15 @@ import subprocess
 import sys
 
 tag, name = sys.argv[1], sys.argv[2]
+rnd = name.split("_")[0]  # "r04" of "r04_visitB"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(root, "gpurun_out", f"prof_{tag}")
 out = lambda f: os.path.join(root, "profiles", f)  # noqa: E731
 run = lambda *a: subprocess.run([sys.executable, *a], capture_output=True, text=True, check=True, cwd=root).stdout  # noqa: E731
 d = json.loads([l for l in open(os.path.join(root, "gpurun_out", "bench.log")) if l.startswith("{")][-1])
 c3 = run("scripts/pmc_summary.py", P)
-dense = run("scripts/dense_profile_md.py", P)
+dense = run("scripts/dense_profile_md.py", P, "c2", "c5")
+c3_dense = run("scripts/dense_profile_md.py", P, "c3_dense")
 open(out("pmc_constants.json"), "w").write(run("scripts/pmc_constants.py", P, f"profiles/{name}_c3_kernel_stats_pmc.md"))
 rl, vr = d["roofline"], d["valu_roofline"]
 hdr = f"""# {name}: kernel stats and PMC passes, C3 racing
@@ -32,6 +34,21 @@ Same build and box as `{name}_c3_kernel_stats_pmc.md`.  These sizes (65 536 / 26
 
 """
 open(out(f"{name}_c2_c5_dense_path.md"), "w").write(hdr2 + dense)
+oc = d.get("other_configs", {})
+if c3_dense.strip():
+    hdr3 = f"""# {name}: the metric's workload with a DENSE softmax — C3 racing N = 2^20, T = 50, lambda = 5000
+
+At lambda = 1 (BASELINE configs[2], the headline) the racing softmax is an arg-min: `weights_reduce_kernel` finds one or two of the
+16 384 tiles alive and skips the rest.  This is the same problem at lambda = 5000 (ESS of a few 10^5): every tile's noise is
+regenerated a second time and accumulated — what a non-degenerate 1 M-sample solve costs.  Same build and box as
+`{name}_c3_kernel_stats_pmc.md`; `python bench.py --no-cpu-baseline --no-extras --workload c3_dense --steps 200 --warmup 20` under
+`rocprofv3 --kernel-trace --stats`, `--steps 8 --warmup 2` under `rocprofv3 --pmc <group> --kernel-trace` (one group per run).
+Un-profiled (`bench.py` `other_configs`): c3_dense {oc.get('c3_dense', {}).get('ms_per_solve', float('nan'))*1e3:.1f} us per solve (stages
+{oc.get('c3_dense', {}).get('stages_ms')}), c3_essps {oc.get('c3_essps', {}).get('ms_per_solve', float('nan'))*1e3:.1f} us (lambda
+{oc.get('c3_essps', {}).get('lambda')}, ESS {oc.get('c3_essps', {}).get('ess')}).
+
+"""
+    open(out(f"{name}_c3_dense_path.md"), "w").write(hdr3 + c3_dense)
 for src, dst in (("fused_timing.txt", "fused_timing.txt"), ("essps_passes.txt", "essps_passes.txt"), ("nccl_single_rank.txt", "exchange_single_rank.txt"),
                  ("pytest_gpu.log", "pytest_gpu.log"), ("top_samples_breakdown.txt", "top_samples.txt"), ("fused_crossover.txt", "fused_crossover.txt"),
                  ("host_overhead.txt", "host_overhead.txt")):
@@ -45,5 +62,5 @@ with open(out(f"{name}_multirank_dry_runs.jsonl"), "w") as fo:
             lines = [l for l in open(p) if l.startswith("{")]
             if lines:
                 fo.write(lines[-1])
-shutil.copy(os.path.join(root, "gpurun_out", "parity_report.json"), out("r03_parity_report.json"))
+shutil.copy(os.path.join(root, "gpurun_out", "parity_report.json"), out(f"{rnd}_parity_report.json"))
 print("wrote", name)
