@@ -316,16 +316,17 @@ int mppi_essps_lambda(mppi_handle_t h, double target_ess, double lam_min, double
  * (synchronises the stream).  Identical arithmetic to mppi_essps_lambda (both call csrc/host_search.hpp). */
 #define MPPI_LAMBDA_DEVICE (-1.0f)
 int mppi_essps_lambda_device(mppi_handle_t h, double target_ess, double lam_min, double lam_max, void* stream);
-/* Passes over the costs the last device-resident search took (ESSPS: 1 or 2; LBPS: 3); 0 = none yet.  Synchronises. */
+/* Passes over the costs the last device-resident search took (ESSPS: 1 or 2; LBPS: 2); 0 = none yet.  Synchronises. */
 int mppi_search_passes(mppi_handle_t h, void* stream);
 /* The temperature a device-resident rule left in HBM, and (lambda_used_out_host != NULL) the one the last solve's weights
  * used — the same value for ESSPS / LBPS, the previous one for MPO (mppi.py:387-398 updates it AFTER the weights).
  * Synchronises `stream` (pass the stream the solve was enqueued on). */
 int mppi_get_lambda(mppi_handle_t h, double* lambda_out_host, double* lambda_used_out_host, void* stream);
-/* LBPS (mppi.py:341-349,534-557) with NO host synchronisation: the reference's ~25 dependent Brent probes become three
- * 32-temperature grids (one pass over the costs each; the grid minimum is bracketed by the next, finer grid) and a
- * parabola through the last three points in log(lambda) — within 1e-3 relative of the Brent minimiser wherever the
- * objective is not flat to fp32 rounding.  The temperature stays in HBM (MPPI_LAMBDA_DEVICE). */
+/* LBPS (mppi.py:341-349,534-557) with NO host synchronisation: the reference's ~25 dependent Brent probes become two
+ * 32-temperature grids (one pass over the costs each; the grid minimum is bracketed by the second, finer grid) and the
+ * minimiser of the quartic through the five grid points around the minimum in log(lambda) — the float64 minimiser to 3e-7
+ * on exact statistics; against the reference's own Brent (which stops 6e-5 .. 5e-3 away from it) within 1e-3 relative
+ * wherever the objective is not flat to fp32 rounding.  The temperature stays in HBM (MPPI_LAMBDA_DEVICE). */
 int mppi_lbps_lambda_device(mppi_handle_t h, double delta, double lam_min, double lam_max, void* stream);
 /* LBPS (mppi.py:341-349,534-557): argmin over [lam_min, lam_max] of -(E_w[-c] - (max c - min c) * sqrt((1-delta)/delta)
  * / sqrt(ESS)), searched on the host with Brent's bounded minimiser (scipy minimize_scalar(method="bounded"): xatol

@@ -302,11 +302,17 @@ bool essps_lambda(G&& ess_grid, double target_ess, double lam_min, double lam_ma
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// LBPS, device-resident variant.  The same minimisation as a grid search (device-resident variant: one pass over the costs per grid of P temperatures
+// LBPS, device-resident variant.  The same minimisation as a grid search (one pass over the costs per grid of P temperatures
 // instead of one per probe).  One step: obj[j] = objective at grid[j] (geometric grid).  Not the last round: [lo, hi] =
 // the two grid intervals around the first grid minimum (the next round's geometric grid spans them).  Last round:
-// lam = the vertex of the parabola through the three points around the minimum in (log lambda, objective), kept
-// inside them; the grid point itself when the minimum sits at an end of the grid or the three points are not convex.
+// lam = the minimiser of the QUARTIC that interpolates the five grid points around the minimum in (log lambda,
+// objective) (uniform spacing h; Newton on its derivative from the parabola's vertex), kept inside the two neighbouring
+// intervals; within two points of an end of the grid the parabola through three points; the grid point itself when the
+// minimum sits at an end of the grid or the points are not convex.  Two rounds (spacing 25 % -> 1.4 % of lambda over
+// [0.01, 10]) + the quartic land within 3e-7 of the float64 minimiser on exact statistics — what three rounds + a
+// parabola did (2e-7; two rounds + a parabola: 1e-4) — and on the device's fp32-summed statistics every variant is
+// noise-limited alike (~1e-3 on nav2d's flat objective), so the third round bought nothing but two launches.
+constexpr int LBPS_GRID_ROUNDS = 2;
 template <int P>
 MPPI_SEARCH_HD void lbps_grid_step(const double* grid, const double* obj, bool last, double& lo, double& hi, double& lam) {
     int i = 0;
@@ -321,6 +327,25 @@ MPPI_SEARCH_HD void lbps_grid_step(const double* grid, const double* obj, bool l
         if (curv > 0.0) {
             const double xv = 0.5 * (x0 + x1) - 0.5 * d01 / curv;
             if (xv > x0 && xv < x2) lam = exp(xv);
+            if (i >= 2 && i <= P - 3) {  // five points: p(t) = y2 + a1 t + a2 t^2 + a3 t^3 + a4 t^4, t = (x - x1) / h
+                const double* y = obj + (i - 2);
+                const double h = (log(grid[i + 2]) - log(grid[i - 2])) * 0.25;
+                const double a1 = (y[0] - 8.0 * y[1] + 8.0 * y[3] - y[4]) / 12.0;
+                const double a2 = (-y[0] + 16.0 * y[1] - 30.0 * y[2] + 16.0 * y[3] - y[4]) / 24.0;
+                const double a3 = (-y[0] + 2.0 * y[1] - 2.0 * y[3] + y[4]) / 12.0;
+                const double a4 = (y[0] - 4.0 * y[1] + 6.0 * y[2] - 4.0 * y[3] + y[4]) / 24.0;
+                if (a2 > 0.0) {
+                    double t = -a1 / (2.0 * a2);
+                    bool ok = true;
+                    for (int it = 0; it < 4 && ok; ++it) {
+                        const double dp = a1 + t * (2.0 * a2 + t * (3.0 * a3 + t * 4.0 * a4));
+                        const double ddp = 2.0 * a2 + t * (6.0 * a3 + t * 12.0 * a4);
+                        ok = ddp > 0.0;
+                        if (ok) t -= dp / ddp;
+                    }
+                    if (ok && t > -1.0 && t < 1.0) lam = exp(x1 + t * h);
+                }
+            }
         }
     }
 }

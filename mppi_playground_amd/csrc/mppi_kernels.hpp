@@ -1361,11 +1361,12 @@ __global__ __launch_bounds__(1024) void essps_select_kernel(const float* __restr
 // LBPS without leaving the device (mppi.py:341-349,534-557).  The reference minimises the lower-bound objective with
 // scipy's bounded Brent search, ~25 dependent probes; here every round evaluates the objective on a 32-temperature
 // geometric grid in ONE pass over the costs (stats_multi_kernel), one block picks the grid minimum and writes the next
-// grid over the two intervals around it; after LBPS_ROUNDS grids (spacing 25 % -> 1.4 % -> 0.09 % of lambda over
-// [0.01, 10]) the last round fits a parabola in log(lambda) through the three points around the minimum
-// (host_search.hpp: lbps_grid_step — the same code the CPU tests run against scipy).  The temperature stays in
+// grid over the two intervals around it; after LBPS_ROUNDS grids (spacing 25 % -> 1.4 % of lambda over [0.01, 10]) the
+// last round minimises the quartic through the five points around the minimum in log(lambda)
+// (host_search.hpp: lbps_grid_step — the same code the CPU tests run against scipy; round 4: two rounds instead of
+// three + a parabola: same accuracy, two launches fewer).  The temperature stays in
 // `lambda_out` (device) + mapped host memory; the host never waits.
-constexpr int LBPS_ROUNDS = 3;
+constexpr int LBPS_ROUNDS = mppi::host::LBPS_GRID_ROUNDS;
 struct LbpsDev {
     double grid0[STATS_L];  // round-0 temperatures: geometric over [lam_min, lam_max], written once by the host
     double grid[STATS_L];   // temperatures of the round in flight (`lams` holds their fp32 casts)

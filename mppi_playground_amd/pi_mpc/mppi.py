@@ -134,8 +134,13 @@ class MPPI(nn.Module):
                 call.  All return the same root (to ~1e-6 relative).  Sharded solvers combine the shards'
                 statistics on the host ("device" behaves like "grid" there).
             lbps_search: with device statistics on one GPU, "device" (default) replaces the reference's ~25 dependent Brent
-                probes by three 32-temperature grids + a parabola, all as kernels (no host wait; within 1e-3 relative of
-                the Brent minimiser), "brent" runs scipy's bounded Brent inside the library, one read-back per probe.
+                probes by two 32-temperature grids + the minimiser of the quartic through the five grid points around the
+                minimum, all as kernels (no host wait).  On exact statistics that is the float64 minimiser to 3e-7; the
+                REFERENCE's own Brent stops 6e-5..5e-3 away from it (xatol = 1e-5 absolute, short of a bound it never
+                evaluates, on an objective that is flat to fp32 noise for nav2d: its temperature moves by up to 1e-2 under
+                1-ulp changes of its costs — the `band_rule` entries of tests/golden/), so the two agree to max(1e-3, that
+                measured spread), not to ESSPS's 1e-5.  "brent" runs scipy's bounded Brent inside the library, one read-back
+                per probe (the reference's algorithm on the device's statistics).
                 The MPO dual always steps on the device when the statistics are the device's own.
             sg_filter: "device" (default) runs the Savitzky-Golay step inside the finalize kernel
                 (bit-identical to the host statement), "host" keeps the reference's numpy-style round trip.

@@ -35,7 +35,7 @@ int search_lbps(const float* costs, int n, double delta, double lo, double hi, d
 int search_lbps_grid(const float* costs, int n, double delta, double lo, double hi, double* lam_out) {
     float cmin = INFINITY, cmax = -INFINITY;
     for (int i = 0; i < n; ++i) { cmin = std::fmin(cmin, costs[i]); cmax = std::fmax(cmax, costs[i]); }
-    return lbps_lambda_grid<32, 3>(
+    return lbps_lambda_grid<32, LBPS_GRID_ROUNDS>(
                [&](const double* grid, double* obj) {
                    for (int j = 0; j < 32; ++j) {
                        const float inv_lam = 1.0f / (float)grid[j];
