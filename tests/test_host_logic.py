@@ -407,3 +407,59 @@ def test_essps_warm_start_lands_on_the_same_root():
                 one_pass += passes == 1
                 assert passes in (1, 2) and (passes == 2 or lam in (0.01, 10.0) or 1 / 1.5 < f < 1.5), (name, k, f, passes)
     assert one_pass > 20  # (a sharp ESS curve — few samples — may fail the convergence check and take the second grid)
+
+
+def test_deferred_state_seq_wrapper_completes_on_first_use_only():
+    """`_DeferredStateSeq` (what forward() returns as state_seq while its batch-1 rollout is still pending): a tensor whose
+    FIRST use through torch — directly, nested in a list, or as a keyword argument — calls the completion hook once;
+    results are plain tensors; an untouched wrapper never calls it."""
+    from pi_mpc.mppi import _DeferredStateSeq
+
+    calls = []
+    base = torch.arange(24.0).reshape(1, 4, 6)
+    w = _DeferredStateSeq.wrap(base, lambda t: calls.append("a"))
+    assert isinstance(w, torch.Tensor) and calls == []
+    row = w[0, 1]
+    assert calls == ["a"] and type(row) is torch.Tensor and torch.equal(row, base[0, 1])
+    assert type(w + 1) is torch.Tensor and bool(torch.isfinite(w).all()) and calls == ["a"]  # joined once
+    w2 = _DeferredStateSeq.wrap(base, lambda t: calls.append("b"))
+    assert type(torch.cat([w2, base])) is torch.Tensor and calls == ["a", "b"]
+    w3 = _DeferredStateSeq.wrap(base, lambda t: calls.append("c"))
+    assert torch.equal(torch.sum(input=w3, dim=1), base.sum(1)) and calls == ["a", "b", "c"]
+    w4 = _DeferredStateSeq.wrap(base, lambda t: calls.append("d"))
+    del w4
+    assert calls == ["a", "b", "c"]
+    assert np.array_equal(w.numpy(), base.numpy())  # (CPU tensors only: what a caller does after .cpu())
+
+
+def test_graph_replay_compares_the_callers_info_by_value():
+    """graph_callables: a replayed graph cannot see changes of the caller's `info` entries; the check compares tensors by
+    storage (an equal-valued NEW tensor is a change, an in-place update is not) and Python scalars by value (a caller may
+    rebuild an equal dict every tick)."""
+    from pi_mpc.mppi import MPPI
+
+    t = torch.zeros(3)
+    a = MPPI._info_signature({"w": 2.0, "ref": t, "mode": "x", "prev_state": object(), "t": 5})
+    assert a == MPPI._info_signature({"w": 2.0, "ref": t, "mode": "x", "t": 7})       # rebuilt dict, the solver's own keys ignored
+    t.add_(1.0)
+    assert a == MPPI._info_signature({"w": 2.0, "ref": t, "mode": "x"})                # in-place update: same storage
+    assert a != MPPI._info_signature({"w": 3.0, "ref": t, "mode": "x"})                # a scalar changed value
+    assert a != MPPI._info_signature({"w": 2.0, "ref": t.clone(), "mode": "x"})        # another tensor object / storage
+    assert a != MPPI._info_signature({"w": 2.0, "ref": t})                             # an entry disappeared
+
+
+def test_fixture_bands_are_complete():
+    """Every solve fixture carries the reference's own measured spread (tests/golden/make_golden.py): 24 probes per solve
+    at the reference's temperature, with its rule re-run where it has one, and per closed loop; racing at lambda = 1 is an
+    arg-min (no spread at all), the ill-conditioned cases show the 1e-5 of the north star is below the reference's own
+    rounding noise."""
+    for name, cfg in CASES.items():
+        g = load(name)
+        K = int(g["K"])
+        assert g["band_closed_loop"].shape == (K, 24, 4)
+        for k in range(K):
+            assert g[f"band_fixed_{k}"].shape == (24, 2) and np.isfinite(g[f"band_fixed_{k}"]).all()
+            assert (f"band_rule_{k}" in g.files) == isinstance(cfg["lambda_"], str)
+    assert load("racing_T50_N512_fixed")["band_closed_loop"].max() == 0.0
+    assert load("nav2d_T30_N256_fixed_explore")["band_fixed_1"][:, 0].max() > 1e-5
+    assert load("nav2d_T30_N512_lbps")["band_rule_0"][:, 2].max() > 1e-3  # the reference's own LBPS temperature under 1-ulp changes
