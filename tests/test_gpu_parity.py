@@ -613,8 +613,10 @@ def _sharded_worker(rank, world, port, q, exchange="nccl"):
     try:
         import mppi_playground_amd  # noqa: F401
 
-        solver, ctrl = make_solver("racing", 50, 8192, lambda_=5000.0, shard_samples=True)
-        assert solver._p2p == (exchange == "p2p")
+        # (lazy_state_seq forced on: the sharded finalize — gathered summaries, or the peer-to-peer poll — with the batch-1
+        # rollout completed by the next rollout launch / on first use, like a rank of a large sharded solve)
+        solver, ctrl = make_solver("racing", 50, 8192, lambda_=5000.0, shard_samples=True, lazy_state_seq=True)
+        assert solver._p2p == (exchange == "p2p") and solver._lazy_state
         env = _envs["racing"]
         x0 = env._robot_state.clone()
         ref, _ = ctrl.calc_ref_trajectory(x0, env.racing_center_path, 0, 50, DL=0.1, lookahead_distance=3,
