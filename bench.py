@@ -528,6 +528,38 @@ def _time_solver(torch, solver, x0, n=50, warm=10, repeats=3):
     return best
 
 
+def _other_solvers(torch, np, which=None):
+    """The other BASELINE configs: (key, label, N*T, B_alg per solve, solver factory, x0)."""
+    from envs import classic_control as cc
+    from envs.navigation_2d import Navigation2DEnv
+    from pi_mpc.mppi import MPPI
+
+    nav = Navigation2DEnv()
+    t = torch.tensor
+    rows = [
+        ("c1", "C1 pendulum T=50 N=1000 ESSPS", 1000 * 50, 3 * 4 * 1 * 1000 * 50 + 8 * 1000,
+         lambda: MPPI(50, 1000, 2, 1, cc.pendulum_dynamics, cc.pendulum_cost, t([-2.0]), t([2.0]), t([1.0]), "ESSPS"),
+         t([np.pi, 0.0], device="cuda", dtype=torch.float32)),
+        ("c2", "C2 nav2d T=50 N=65536 lambda=1", 65536 * 50, 3 * 4 * 2 * 65536 * 50 + 8 * 65536,
+         lambda: MPPI(50, 65536, 3, 2, nav.dynamics, nav.cost_function, nav.u_min, nav.u_max, t([0.5, 0.5]), 1.0),
+         nav.reset().clone()),
+        ("c2_essps", "C2 nav2d T=50 N=65536 ESSPS", 65536 * 50, 3 * 4 * 2 * 65536 * 50 + 8 * 65536,
+         lambda: MPPI(50, 65536, 3, 2, nav.dynamics, nav.cost_function, nav.u_min, nav.u_max, t([0.5, 0.5]), "ESSPS"),
+         nav.reset().clone()),
+        ("c2_lbps", "C2 nav2d T=50 N=65536 LBPS (device-resident grid search)", 65536 * 50, 3 * 4 * 2 * 65536 * 50 + 8 * 65536,
+         lambda: MPPI(50, 65536, 3, 2, nav.dynamics, nav.cost_function, nav.u_min, nav.u_max, t([0.5, 0.5]), "LBPS"),
+         nav.reset().clone()),
+        ("c2_mpo", "C2 nav2d T=50 N=65536 MPO (dual on the device)", 65536 * 50, 3 * 4 * 2 * 65536 * 50 + 8 * 65536,
+         lambda: MPPI(50, 65536, 3, 2, nav.dynamics, nav.cost_function, nav.u_min, nav.u_max, t([0.5, 0.5]), "MPO"),
+         nav.reset().clone()),
+        ("c5", "C5 cartpole T=64 N=262144 ESSPS + Savitzky-Golay", 262144 * 64, 3 * 4 * 1 * 262144 * 64 + 8 * 262144,
+         lambda: MPPI(64, 262144, 4, 1, cc.cartpole_dynamics, cc.cartpole_cost, t([-3.0]), t([3.0]), t([1.0]), "ESSPS",
+                      use_sg_filter=True),
+         t([0.01, 0.0, 0.02, 0.0], device="cuda")),
+    ]
+    return [r for r in rows if which is None or r[0] in which]
+
+
 def _stage_times(torch, solver, x0, n=30):
     """Per-stage device times (HIP events around each stage's launches) from a separate instrumented pass."""
     solver.set_option("timing", 1)

@@ -409,7 +409,11 @@ int mppi_create(const MppiConfig* cfg, mppi_handle_t* out) {
         d.u_min[k] = cfg->u_min[k]; d.u_max[k] = cfg->u_max[k]; d.sigma[k] = cfg->sigmas[k];
     }
     h->wide = cfg->model == MPPI_MODEL_GENERIC && md.dc != 1 && md.dc != 2 && md.dc != 4;
-    h->GPW = d.R <= 32 ? 8 : 32;
+    // Every wave owns 8 float4 groups of a 32-group column chunk; longer rows (T*dim_control > 128) take more chunks
+    // (grid.y), each regenerating / reading only its own groups.  (Rounds 1-3 gave such rows 32 groups per wave: 128
+    // accumulators per lane, 163-231 VGPRs and 15-66 SGPR spills; the chunked form computes the same sums — a column is
+    // owned by one wave either way and accumulates its tiles in the same order — without that kernel.)
+    h->GPW = 8;
     const int chg = h->GPW * (BLOCK / WAVE);  // float4 groups per column chunk
     h->nchunks = (d.R + chg - 1) / chg;
     h->colsp = h->nchunks * chg * 4;
@@ -1000,9 +1004,9 @@ int mppi_weights_reduce(mppi_handle_t h, float lambda, float* summary_out_dev, v
 #define CALL_REDUCE(GPWV, GENV, WIDEV)                                                                \
     hipLaunchKernelGGL((weights_reduce_kernel<GPWV, GENV, WIDEV>), grid, dim3(BLOCK), 0, s, h->noise, h->mean, h->costs, mk, \
                        h->partials, h->heads, h->d, h->gen, lambda, lam_dev, (const float*)h->coltab)
-    if (h->wide) { if (h->GPW == 8) CALL_REDUCE(8, false, true); else CALL_REDUCE(32, false, true); }
-    else if (h->GPW == 8) { if (gen) CALL_REDUCE(8, true, false); else CALL_REDUCE(8, false, false); }
-    else { if (gen) CALL_REDUCE(32, true, false); else CALL_REDUCE(32, false, false); }
+    if (h->wide) CALL_REDUCE(8, false, true);
+    else if (gen) CALL_REDUCE(8, true, false);
+    else CALL_REDUCE(8, false, false);
 #undef CALL_REDUCE
     HIP_TRY(h, hipGetLastError());
     // Fold the published partial rows into the shard summary.  Sharded use needs the summary before the

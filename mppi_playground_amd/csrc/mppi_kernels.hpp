@@ -467,7 +467,7 @@ constexpr int REDUCE_MAX_BLOCKS = 2048;
 #ifndef MPPI_REDUCE_ATTR
 #define MPPI_REDUCE_ATTR  // (A/B knob of scripts/build_variant.sh, e.g. __attribute__((amdgpu_waves_per_eu(2,3))))
 #endif
-template <int GPW, bool GEN, bool WIDE = false>  // GPW: float4 groups per wave and column chunk (8 or 32)
+template <int GPW, bool GEN, bool WIDE = false>  // GPW: float4 groups per wave and column chunk (8: the host launches ceil(R / 32) chunks)
 __global__ __launch_bounds__(BLOCK) MPPI_REDUCE_ATTR void weights_reduce_kernel(const float4* __restrict__ noise,
                                                                const float* __restrict__ mean,
                                                                const float* __restrict__ costs,

@@ -463,3 +463,34 @@ def test_fixture_bands_are_complete():
     assert load("racing_T50_N512_fixed")["band_closed_loop"].max() == 0.0
     assert load("nav2d_T30_N256_fixed_explore")["band_fixed_1"][:, 0].max() > 1e-5
     assert load("nav2d_T30_N512_lbps")["band_rule_0"][:, 2].max() > 1e-3  # the reference's own LBPS temperature under 1-ulp changes
+
+
+def _undefined_globals(path):
+    """Names a module's functions read that are neither local, nor defined at module level, nor builtins (a poor man's
+    pyflakes: the GPU-only scripts cannot be exercised by the CPU suite, but a deleted helper must not survive a commit)."""
+    import ast
+    import builtins
+
+    tree = ast.parse(open(path).read())
+    module_names = set(dir(builtins)) | {"__file__", "__name__", "__doc__"}
+    for node in ast.walk(tree):
+        if isinstance(node, (ast.FunctionDef, ast.AsyncFunctionDef, ast.ClassDef)):
+            module_names.add(node.name)
+        elif isinstance(node, (ast.Import, ast.ImportFrom)):
+            for a in node.names:
+                module_names.add((a.asname or a.name).split(".")[0])
+        elif isinstance(node, ast.Name) and isinstance(node.ctx, (ast.Store, ast.Del)):
+            module_names.add(node.id)
+        elif isinstance(node, ast.arg):
+            module_names.add(node.arg)
+        elif isinstance(node, ast.ExceptHandler) and node.name:
+            module_names.add(node.name)
+    loads = {n.id for n in ast.walk(tree) if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Load)}
+    return sorted(loads - module_names)
+
+
+@pytest.mark.parametrize("rel", ["bench.py", "__graft_entry__.py", "mppi_playground_amd/pi_mpc/mppi.py",
+                                 "mppi_playground_amd/_capi.py", "mppi_playground_amd/envs/racing_controller.py",
+                                 "scripts/make_visit_docs.py", "scripts/pmc_constants.py", "tests/golden/make_golden.py"])
+def test_no_function_reads_an_undefined_name(rel):
+    assert _undefined_globals(os.path.join(ROOT, rel)) == []
