@@ -32,8 +32,10 @@ scripts/ubench/icache_cold > gpurun_out/ubench_cold_code.txt 2>&1; scripts/ubenc
 cd /tmp
 mkdir -p $P; python -c "import sys; sys.path.insert(0, '$R'); from mppi_playground_amd import _build; print(_build.source_digest())" > $P/csrc_sha256.txt
 B="python $R/bench.py --no-cpu-baseline --no-extras"
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $P -o kt -- $B --steps 30 --warmup 5 > $R/gpurun_out/rocprof_kt.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $P -o kt_tiles -- $B --steps 30 --warmup 5 --noise-regen 0 > /dev/null 2>&1
+# (1 000 timed steps: the ~50 launches a box needs to reach its clocks — 136-140 us each instead of 121-124 — would
+# otherwise be a fifth of the 265 launches --stats averages over, and the summary would disagree with the live HIP-event time)
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $P -o kt -- $B --steps 1000 --warmup 50 > $R/gpurun_out/rocprof_kt.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $P -o kt_tiles -- $B --steps 300 --warmup 20 --noise-regen 0 > /dev/null 2>&1
 for wl in c2 c5 c3_dense; do
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $P -o kt_$wl -- $B --workload $wl --steps 200 --warmup 20 > $R/gpurun_out/rocprof_kt_$wl.log 2>&1
 done

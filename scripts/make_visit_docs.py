@@ -22,7 +22,7 @@ open(out("pmc_constants.json"), "w").write(run("scripts/pmc_constants.py", P, f"
 rl, vr = d["roofline"], d["valu_roofline"]
 hdr = f"""# {name}: kernel stats and PMC passes, C3 racing
 
-Command per pass: `python bench.py --no-cpu-baseline --no-extras --steps 30 --warmup 5` under `rocprofv3 --kernel-trace --stats` (kt*), `--steps 6 --warmup 2` under `rocprofv3 --pmc <group> --kernel-trace` (one counter group per run; FETCH_SIZE / WRITE_SIZE in KB, FETCH to be doubled for wide reads on gfx950).  Recipe: scripts/gpu_record.sh {tag}; this file: scripts/make_visit_docs.py.  bench.py's `roofline.traffic` / `valu_roofline` constants (profiles/pmc_constants.json) are generated from these CSVs by scripts/pmc_constants.py.
+Command per pass: `python bench.py --no-cpu-baseline --no-extras --steps 1000 --warmup 50` (tiles: 300 / 20) under `rocprofv3 --kernel-trace --stats` (kt*; 1 250 launches, so that the ~50 launches a box needs to reach its clocks do not dominate the average), `--steps 6 --warmup 2` under `rocprofv3 --pmc <group> --kernel-trace` (one counter group per run; FETCH_SIZE / WRITE_SIZE in KB, FETCH to be doubled for wide reads on gfx950).  Recipe: scripts/gpu_record.sh {tag}; this file: scripts/make_visit_docs.py.  bench.py's `roofline.traffic` / `valu_roofline` constants (profiles/pmc_constants.json) are generated from these CSVs by scripts/pmc_constants.py.
 
 Un-profiled `python bench.py` of the same visit: {d['ms_per_step']:.4f} ms/solve, {d['solves_per_sec']:.0f} solves/s, {d['value']:.4g} sample-steps/s; stages (HIP events) rollout {d['stages_ms']['rollout_cost']*1e3:.1f} / weights+reduce {d['stages_ms']['weights_reduce']*1e3:.1f} / finalize {d['stages_ms']['finalize']*1e3:.1f} us; `roofline`: {rl['achieved']:.0f} GB/s-equivalent of the algorithmic {rl['algorithmic_bytes_per_launch']} B per launch = **{rl['frac']:.3f}** of 8 TB/s (bound: {rl['bound']}; PMC traffic {rl['traffic']} B); `valu_roofline`: {vr['valu_insts_per_launch']:.4g} VALU wave-instructions per launch = {vr['achieved_Ginst_per_s']:.0f} G/s = {vr['frac']:.3f} of the issue peak; closed loop {d['closed_loop']['ms_per_tick']:.4f} ms/tick (host enqueue {', '.join(f'{k}: {v*1e3:.1f} us' for k, v in d['closed_loop']['host_enqueue_ms_per_tick'].items())}); other configs (us per solve): {', '.join(f"{k} {v['ms_per_solve']*1e3:.1f}" for k, v in d['other_configs'].items())}; cpu_baseline {d['cpu_baseline']['value']:.3g} sample-steps/s on {d['cpu_baseline']['cores']} threads ({d['cpu_baseline']['sample']}).
 
