@@ -36,7 +36,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured copy
-SETUP_SOLVES = 200     # un-timed solves before the contract's warm-up: leave the idle power state (see main)
+SETUP_SOLVES = int(os.environ.get("MPPI_BENCH_SETUP_SOLVES", "200"))  # un-timed solves before the contract's warm-up: leave the idle power state (see main)
 
 
 def launch_ranks(args) -> int:
