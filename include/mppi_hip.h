@@ -343,6 +343,9 @@ int mppi_mpo_step(mppi_handle_t h, double* lambda_out_host, void* stream);
  * stay in device memory; the NEXT solve's weights read it through MPPI_LAMBDA_DEVICE.  Call it after mppi_finalize. */
 int mppi_mpo_step_device(mppi_handle_t h, void* stream);
 int mppi_mpo_state(mppi_handle_t h, double* out4_host);
+/* Device address of the dual's log T (fp32; read-only for the caller — valid until mppi_destroy): the reference keeps it as an
+ * nn.Parameter (mppi.py:194-199); a binding can wrap this address instead of copying the value after every solve. */
+int mppi_mpo_log_temperature_ptr(mppi_handle_t h, float** out_dev);
 
 /* `_weights` (mppi.py:376) for this shard given the GLOBAL {min c, sum e}: w_out_dev[N]. */
 int mppi_weights(mppi_handle_t h, float lambda, float cmin_global, float sum_e_global, float* w_out_dev,

@@ -35,7 +35,7 @@ SYMBOLS = [
     "mppi_set_center_path", "mppi_ref_window", "mppi_set_path_index", "mppi_get_path_index", "mppi_get_reference",
     "mppi_model_step", "mppi_comm_unique_id", "mppi_comm_init", "mppi_comm_exchange", "mppi_comm_destroy",
     "mppi_set_auto_lambda", "mppi_lbps_lambda_device", "mppi_mpo_step_device", "mppi_fused_error",
-    "mppi_search_passes", "mppi_grid_lookup", "mppi_join_state_seq", "mppi_state_seq_serial", "mppi_get_state_seq_timing", "mppi_comm_info",
+    "mppi_search_passes", "mppi_grid_lookup", "mppi_mpo_log_temperature_ptr", "mppi_join_state_seq", "mppi_state_seq_serial", "mppi_get_state_seq_timing", "mppi_comm_info",
 ]
 
 
@@ -109,6 +109,7 @@ def load():
     lib.mppi_mpo_reset.argtypes = [vp, C.c_double, C.c_double, C.c_double]
     lib.mppi_mpo_step.argtypes = [vp, vp, vp]
     lib.mppi_mpo_state.argtypes = [vp, vp]
+    lib.mppi_mpo_log_temperature_ptr.argtypes = [vp, vp]
     lib.mppi_set_control_limits.argtypes = [vp, vp, vp, vp, i32]
     lib.mppi_sample_posterior.argtypes = [vp, u32, vp, i32, vp, vp]
     lib.mppi_set_reference.argtypes = [vp, vp, i32, vp]

@@ -1560,6 +1560,15 @@ int mppi_mpo_state(mppi_handle_t h, double* out4_host) {
     return MPPI_OK;
 }
 
+// Device address of the dual's log T (one fp32, first field of the state mppi_mpo_step_device updates): lets a caller
+// expose it without a copy (this build's MPPI makes it the storage of its `log_temperature` nn.Parameter, mppi.py:194-199).
+// Read-only for the caller: the library derives the temperatures it uses when the dual steps.
+int mppi_mpo_log_temperature_ptr(mppi_handle_t h, float** out_dev) {
+    if (!h || !out_dev || !h->mpo_dev) return fail(h, MPPI_E_INVALID, "null");
+    *out_dev = &h->mpo_dev->log_temperature;
+    return MPPI_OK;
+}
+
 // get_samples_from_posterior, the sampling half (mppi.py:489-503): k unclamped action sequences
 // loc + eps, eps ~ N(0, diag(sigma^2)) from the Philox stream of the RESERVED solve index `solve_idx` (callers advance
 // their solve counter: the draw consumes the stream like the reference's global generator).  Roll them out with

@@ -67,6 +67,41 @@ class _DeferredStateSeq(torch.Tensor):
             return func(*args, **(kwargs or {}))
 
 
+class _LazyInfoTensor(torch.Tensor):
+    """An entry the reference leaves in the CALLER's `info` dict after a solve (src/pi_mpc/mppi.py:299-306,318-322:
+    `prev_state` = S[:, T-1], `prev_action` = U[:, T-2]) whose value the native path never holds — the N state trajectories
+    are not materialised, the clamped actions are regenerated in registers.  It stands in the dict as a tensor that is
+    built from the solve's noise (a re-roll / an export launch) the first time a torch function touches it; nobody pays
+    for it otherwise.  Like the reference's views it describes the LAST solve: build it before the next one."""
+
+    @staticmethod
+    def make(thunk) -> "_LazyInfoTensor":
+        r = torch.Tensor._make_subclass(_LazyInfoTensor, torch.empty(0))
+        r.__dict__["_mppi_thunk"], r.__dict__["_mppi_value"] = thunk, None
+        return r
+
+    def materialize(self) -> torch.Tensor:
+        d = self.__dict__
+        if d["_mppi_value"] is None:
+            d["_mppi_value"], d["_mppi_thunk"] = d["_mppi_thunk"](), None
+        return d["_mppi_value"]
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        def real(a):
+            if isinstance(a, _LazyInfoTensor):
+                return a.materialize()
+            if isinstance(a, (list, tuple)):
+                return type(a)(real(b) for b in a)
+            return a
+
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*[real(a) for a in args], **{k: real(v) for k, v in (kwargs or {}).items()})
+
+
+_NO_INFO: Dict = {}  # forward()'s default `info` (the reference's shared mutable default, mppi.py:224): nobody can read it back
+
+
 class MPPI(nn.Module):
     """Model Predictive Path Integral control (Williams et al., T-RO 2017) — MI355X-native."""
 
@@ -326,6 +361,7 @@ class MPPI(nn.Module):
                 self._rule_on_device = "MPO"
                 self._h.call("mppi_mpo_reset", 1.0, 0.1, 0.2)  # mppi.py:191-200
                 self._h.call("mppi_set_auto_lambda", _capi.AUTO_RULES["MPO"], 0.0, 0.0, 0.0)
+                self._bind_log_temperature()
         if self._sg_on_device:  # step 7 runs inside mppi_finalize (taps computed above, history zero)
             self._h.call("mppi_set_sg_filter", self._coeffs.ctypes.data_as(C.c_void_p), int(len(self._coeffs)), None)
         self._uploaded = {}  # slot -> (id(cells), version)
@@ -375,6 +411,25 @@ class MPPI(nn.Module):
         self._costs_host = None
         self._pick_strategy()
 
+    def _bind_log_temperature(self) -> None:
+        """`log_temperature` of the reference (an nn.Parameter, mppi.py:194-199) as a registered Parameter whose storage IS
+        the dual the library steps on the device (zero-copy view through __cuda_array_interface__): always current on the
+        solve's stream, listed by parameters() / state_dict(), never copied.  Read-only in effect — the library derives the
+        temperatures it uses when the dual steps; assigning `_lambda` is how a caller overrides a solve's temperature."""
+        ptr = C.c_void_p(0)
+        self._h.call("mppi_mpo_log_temperature_ptr", C.byref(ptr))
+
+        class _View:  # (one fp32 at a device address owned by the handle, which this module keeps alive)
+            __cuda_array_interface__ = {"shape": (1,), "typestr": "<f4", "data": (int(ptr.value), False), "version": 2}
+
+        self._log_temperature_is_view = True
+        try:
+            t = torch.as_tensor(_View(), device=self._device)
+        except Exception:  # noqa: BLE001  (a torch build without the interface: a copy, refreshed whenever the temperature is fetched)
+            t = torch.zeros(1, device=self._device, dtype=torch.float32)
+            self._log_temperature_is_view = False
+        self.log_temperature = nn.Parameter(t, requires_grad=False)
+
     def _push_auto_lambda(self) -> None:
         """The device-resident ESSPS / LBPS rule reads its parameters from the handle (mppi_set_auto_lambda), the reference
         reads `_essps_target_ess` / `_lbps_delta` / `_lambda_min` / `_lambda_max` on every solve (mppi.py:341-370): hand them
@@ -395,6 +450,8 @@ class MPPI(nn.Module):
         if not self._used_known:  # (an explicitly given temperature is already on record)
             self._last_lambda_value = used.value
         self._lambda_pending = False
+        if self.__dict__.get("_log_temperature_is_view") is False:  # MPO: lambda = exp(log T) (mppi.py:398)
+            self.log_temperature.data.fill_(float(np.log(nxt.value)))
 
     @property
     def _lambda(self):
@@ -697,7 +754,7 @@ class MPPI(nn.Module):
             self._h.call("mppi_join_state_seq", 0, self._stream())
 
     # ------------------------------------------------------------------ forward
-    def forward(self, state: torch.Tensor, info: Dict = {}) -> Tuple[torch.Tensor, torch.Tensor]:
+    def forward(self, state: torch.Tensor, info: Dict = _NO_INFO) -> Tuple[torch.Tensor, torch.Tensor]:
         """Solve one MPPI step (src/pi_mpc/mppi.py:223-460).
 
         One of three strategies, resolved once in __init__ (`_solve`, see _pick_strategy):
@@ -708,8 +765,25 @@ class MPPI(nn.Module):
         Injected noise (parity hook) sends a one-call solver through the entry points for that one solve."""
         assert state.shape == (self._dim_state,)
         if self._injected is not None and self._one_call:
-            return self._solve_by_steps(state, info)
-        return self._solve(state, info)
+            out = self._solve_by_steps(state, info)
+        else:
+            out = self._solve(state, info)
+        if info is not _NO_INFO and self._model is not None:
+            self._leave_info(info, state)
+        return out
+
+    def _leave_info(self, info: Dict, state) -> None:
+        """What the reference's cost loop leaves in the caller's dict (mppi.py:299-306,318-322) — the native path has no
+        such loop: `t` = T-1, `initial_state` = the start state seen by every sample (an expanded view), and `prev_state` =
+        S[:, T-1] / `prev_action` = U[:, max(T-2, 0)] as tensors that are built on first use (_LazyInfoTensor).  Only for a
+        dict the caller passed: the default one cannot be read back."""
+        N, T = self._local_samples, self._horizon
+        info["t"] = T - 1
+        x0 = state if (torch.is_tensor(state) and state.is_cuda) else torch.as_tensor(
+            np.asarray(state.detach().cpu() if torch.is_tensor(state) else state, dtype=np.float32)).to(self._device)
+        info["initial_state"] = x0.detach().to(self._dtype).reshape(1, -1).expand(N, -1)
+        info["prev_state"] = _LazyInfoTensor.make(lambda: self._state_seq_batch[:, T - 1, :])
+        info["prev_action"] = _LazyInfoTensor.make(lambda: self._perturbed_action_seqs[:, max(T - 2, 0), :])
 
     def _pick_strategy(self) -> None:
         """Resolve every per-solve mode decision ONCE (called at the end of __init__): the solve strategy and the step that

@@ -1260,6 +1260,46 @@ def test_lazy_state_seq_same_bits_read_early_late_or_never(model, T, N, kw):
     assert st["state_seq_standalone_launches"] == 5.0, st
 
 
+def test_info_dict_and_log_temperature_like_the_reference():
+    """Side effects the reference's forward() has besides its return values (src/pi_mpc/mppi.py:299-306,318-322,194-199):
+    the CALLER's `info` dict ends with t = T-1, initial_state = S[:, 0], prev_state = S[:, T-1], prev_action = U[:, T-2]
+    (here: built on first use from the solve's noise — checked against the materialised buffers), and with lambda_="MPO"
+    the solver carries `log_temperature` as a registered nn.Parameter (here: a view of the dual on the device)."""
+    from pi_mpc.mppi import _LazyInfoTensor
+
+    solver, _ = make_solver("nav2d", 20, 512, lambda_=5.0)
+    x0 = torch.tensor([-9.0, -9.0, 0.785], device="cuda")
+    info = {"mine": 1}
+    a, s = solver.forward(x0, info)
+    assert info["t"] == 19 and info["mine"] == 1
+    assert type(info["prev_state"]) is _LazyInfoTensor and info["prev_state"].__dict__["_mppi_value"] is None  # not built yet
+    S, U = solver._state_seq_batch, solver._perturbed_action_seqs
+    assert torch.equal(info["initial_state"], S[:, 0, :]) and info["initial_state"].shape == (512, 3)
+    assert torch.equal(info["prev_state"] + 0.0, S[:, 19, :])
+    assert torch.equal(torch.stack([info["prev_action"], info["prev_action"]])[1], U[:, 18, :])
+    assert info["prev_action"].shape == (512, 2)
+    solver.forward(x0)  # the default dict: nothing to leave anywhere
+    # opaque callables fill the dict in their own loop, like the reference
+    from envs import classic_control as cc
+    from pi_mpc.mppi import MPPI
+
+    g = MPPI(15, 64, 2, 1, lambda s_, a_: cc.pendulum_dynamics(s_, a_), lambda s_, a_, i_: cc.pendulum_cost(s_, a_, i_),
+             torch.tensor([-2.0]), torch.tensor([2.0]), torch.tensor([1.0]), 1.0)
+    gi = {}
+    g.forward(torch.tensor([3.0, 0.0]), gi)
+    assert gi["t"] == 14 and gi["prev_state"].shape == (64, 2) and gi["prev_action"].shape == (64, 1)
+    # MPO: the dual as a Parameter
+    m, _ = make_solver("nav2d", 20, 512, lambda_="MPO")
+    assert isinstance(m.log_temperature, torch.nn.Parameter) and "log_temperature" in dict(m.named_parameters())
+    assert float(m.log_temperature) == 0.0  # log(1.0), mppi.py:194-199
+    m.forward(x0)
+    lam = float(m._lambda)  # (fetching the temperature waits for the solve's stream)
+    assert abs(float(torch.exp(m.log_temperature)) - lam) <= 1e-6 * lam  # lambda = exp(log T), mppi.py:398
+    m.forward(x0)
+    lam2 = float(m._lambda)
+    assert lam2 != lam and abs(float(torch.exp(m.log_temperature)) - lam2) <= 1e-6 * lam2
+
+
 def test_device_sg_filter_equals_the_host_statement():
     """Step 7 inside finalize_kernel (sg_filter="device", default) against the host numpy statement of the reference's
     filter (sg_filter="host"): same taps, same accumulation order -> identical actions, states and history, over a

@@ -494,3 +494,22 @@ def _undefined_globals(path):
                                  "scripts/make_visit_docs.py", "scripts/pmc_constants.py", "tests/golden/make_golden.py"])
 def test_no_function_reads_an_undefined_name(rel):
     assert _undefined_globals(os.path.join(ROOT, rel)) == []
+
+
+def test_lazy_info_tensor_is_built_on_first_use():
+    """`_LazyInfoTensor` (the reference's `info["prev_state"]` / `info["prev_action"]` on the native path): nothing is
+    computed until a torch function touches it; then it behaves like the tensor its thunk returns, built once."""
+    from pi_mpc.mppi import _LazyInfoTensor
+
+    built = []
+
+    def thunk():
+        built.append(1)
+        return torch.arange(6.0).reshape(3, 2)
+
+    t = _LazyInfoTensor.make(thunk)
+    assert isinstance(t, torch.Tensor) and built == []
+    assert t.shape == (3, 2) and built == [1]
+    assert torch.equal(t * 2, torch.arange(6.0).reshape(3, 2) * 2) and float(t.sum()) == 15.0
+    assert torch.equal(torch.cat([t, t]), torch.arange(6.0).reshape(3, 2).repeat(2, 1)) and built == [1]
+    assert type(t[0]) is torch.Tensor and t[:, 1].tolist() == [1.0, 3.0, 5.0]
