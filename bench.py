@@ -39,6 +39,26 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/
 SETUP_SOLVES = int(os.environ.get("MPPI_BENCH_SETUP_SOLVES", "200"))  # un-timed solves before the contract's warm-up: leave the idle power state (see main)
 
 
+_LINE_FD = None
+
+
+def own_stdout():
+    """stdout carries ONE thing, the JSON line.  Libraries that print from C get stderr instead: RCCL writes a version
+    banner at the first communicator of a process, into a stdio buffer that is flushed at exit — i.e. AFTER the line."""
+    global _LINE_FD
+    if _LINE_FD is None:
+        sys.stdout.flush()
+        _LINE_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def print_line(text: str) -> None:
+    data = (text + "\n").encode()
+    fd = 1 if _LINE_FD is None else _LINE_FD
+    while data:
+        data = data[os.write(fd, data):]
+
+
 def launch_ranks(args) -> int:
     """`python bench.py --gpus N` without a launcher: re-run this script under torch.distributed.run, one rank per
     GPU of this node, rendezvous on 127.0.0.1; the ranks' output (rank 0's JSON line) passes through."""
@@ -90,6 +110,7 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))
+    own_stdout()
 
     import numpy as np
     import torch
@@ -342,7 +363,7 @@ def main():
     def emit(out):
         if not printed["done"]:
             printed["done"] = True
-            print(json.dumps(out), flush=True)
+            print_line(json.dumps(out))
 
     def best_of(runs):
         ok = [r for r in runs if "error" not in r and r["finite"]]
@@ -621,15 +642,15 @@ def other_workload(args, torch, np):
     if args.workload == "c3_dense":
         ctrl, x0 = _racing_c3(torch, 5000.0)
         dt = _time_solver(torch, ctrl.solver, x0, n=args.steps, warm=args.warmup)
-        print(json.dumps({"workload": "C3 racing T=50 N=1048576 lambda=5000 (dense softmax)", "ms_per_solve": dt * 1e3,
-                          "steps": args.steps, "lambda": ctrl.solver._last_lambda, "ess": ctrl.solver.last_stats()["ess"]}), flush=True)
+        print_line(json.dumps({"workload": "C3 racing T=50 N=1048576 lambda=5000 (dense softmax)", "ms_per_solve": dt * 1e3,
+                          "steps": args.steps, "lambda": ctrl.solver._last_lambda, "ess": ctrl.solver.last_stats()["ess"]}))
         return
     which = {"c2": ("c2_essps",), "c5": ("c5",)}[args.workload]
     for key, label, work, b_alg, make, x0 in _other_solvers(torch, np, which):
         s = make()
         dt = _time_solver(torch, s, x0, n=args.steps, warm=args.warmup)
-        print(json.dumps({"workload": label, "ms_per_solve": dt * 1e3, "steps": args.steps,
-                          "algorithmic_bytes_per_solve": b_alg, "lambda": s._last_lambda}), flush=True)
+        print_line(json.dumps({"workload": label, "ms_per_solve": dt * 1e3, "steps": args.steps,
+                          "algorithmic_bytes_per_solve": b_alg, "lambda": s._last_lambda}))
 
 
 def cpu_baseline(np, T, ref, x0):

@@ -107,6 +107,10 @@ struct MppiSolver {
     float* heads = nullptr;
     float* summary = nullptr;
     float* stats_part = nullptr;     // [STATS_BLOCKS][max(4, STATS_L*3)]
+    unsigned long long* round1_cells = nullptr;  // [STATS_BLOCKS][STATS_L*3] {value, launch number}: essps_round1_kernel
+    unsigned round1_seq = 0;
+    bool essps_merge0 = false;  // round 0 as one launch too (option "essps_merge0": measured on par at 65 536 samples and
+                                // 3.8 us SLOWER at 262 144 — profiles/r04_experiments.md; round 1 is merged for its skip case)
     double* stats_host_dev = nullptr;  // the device's view of stats_host
     double* stats_host = nullptr;    // mapped pinned [8 + STATS_L*3 + 3]: single-lambda stats, grid stats, device-searched lambda (next, used), its passes
     float* lams_dev = nullptr;       // [3][STATS_L]: caller's grid, ESSPS round-0 grid (preset), ESSPS round-1 grid (device-written)
@@ -449,6 +453,8 @@ int mppi_create(const MppiConfig* cfg, mppi_handle_t* out) {
     HIP_TRY(h, hipMalloc(&h->heads, sizeof(float) * (size_t)max_blocks * 4));
     HIP_TRY(h, hipMalloc(&h->summary, sizeof(float) * (size_t)(MPPI_SUMMARY_HEAD + d.row)));
     HIP_TRY(h, hipMalloc(&h->stats_part, sizeof(float) * STATS_L * 3 * STATS_BLOCKS));
+    HIP_TRY(h, hipMalloc(&h->round1_cells, sizeof(unsigned long long) * STATS_L * 3 * STATS_BLOCKS));
+    HIP_TRY(h, hipMemset(h->round1_cells, 0, sizeof(unsigned long long) * STATS_L * 3 * STATS_BLOCKS));
     HIP_TRY(h, hipHostMalloc((void**)&h->stats_host, sizeof(double) * (8 + STATS_L * 3 + 3), hipHostMallocMapped));
     HIP_TRY(h, hipHostGetDevicePointer((void**)&h->stats_host_dev, h->stats_host, 0));  // (looked up once: an API call per solve otherwise)
     HIP_TRY(h, hipMalloc(&h->mpo_dev, sizeof(mppi::host::MpoState)));
@@ -513,7 +519,7 @@ int mppi_destroy(mppi_handle_t h) {
     (void)hipFree(h->ref); (void)hipFree(h->partials); (void)hipFree(h->heads);
     (void)hipFree(h->center8); (void)hipFree(h->win_dind); (void)hipFree(h->path_index);
     (void)hipFree(h->summary); (void)hipFree(h->map_cells[0]); (void)hipFree(h->map_cells[1]);
-    (void)hipFree(h->map_pad); (void)hipFree(h->stats_part); (void)hipFree(h->noise_std);
+    (void)hipFree(h->map_pad); (void)hipFree(h->stats_part); (void)hipFree(h->round1_cells); (void)hipFree(h->noise_std);
     if (h->stats_host) (void)hipHostFree(h->stats_host);
     if (h->live_hint) (void)hipHostFree(h->live_hint);
     (void)hipFree(h->fused_cells); (void)hipFree(h->grid0_dev);
@@ -1353,7 +1359,7 @@ int mppi_softmax_stats_multi(mppi_handle_t h, const float* lambdas_host, int cou
     const unsigned* mk = h->min_key + h->min_slot;
     const int blocks = stats_blocks(h);
     hipLaunchKernelGGL(stats_multi_kernel, dim3(blocks), dim3(STATS_THREADS), 0, s, h->costs, h->d.N, mk,
-                       (const float*)h->lams_dev, h->stats_part, (const int32_t*)nullptr, (float*)nullptr);
+                       (const float*)h->lams_dev, h->stats_part, (float*)nullptr);
     HIP_TRY(h, hipGetLastError());
     double* dev_out = nullptr;
     dev_out = h->stats_host_dev;
@@ -1380,14 +1386,22 @@ int mppi_essps_lambda_device(mppi_handle_t h, double target_ess, double lam_min,
     host_lam += 8 + STATS_L * 3;
     float* lams0 = h->lams_dev + STATS_L;
     float* lams1 = h->lams_dev + 2 * STATS_L;
-    hipLaunchKernelGGL(stats_multi_kernel, dim3(blocks), dim3(STATS_THREADS), 0, s, h->costs, h->d.N, mk, (const float*)lams0,
-                       h->stats_part, (const int32_t*)nullptr, (float*)nullptr);
-    hipLaunchKernelGGL(essps_select_kernel<0>, dim3(1), dim3(1024), 0, s, (const float*)h->stats_part, blocks, target_ess,
-                       h->essps_range, h->essps_dev, lams1, lams0, h->lambda_dev, host_lam);
-    hipLaunchKernelGGL(stats_multi_kernel, dim3(blocks), dim3(STATS_THREADS), 0, s, h->costs, h->d.N, mk, (const float*)lams1,
-                       h->stats_part, (const int32_t*)&h->essps_dev->done, (float*)nullptr);
-    hipLaunchKernelGGL(essps_select_kernel<1>, dim3(1), dim3(1024), 0, s, (const float*)h->stats_part, blocks, target_ess,
-                       h->essps_range, h->essps_dev, lams1, lams0, h->lambda_dev, host_lam);
+    for (int r = 0; r < 2; ++r) {
+        if (++h->round1_seq == 0u) h->round1_seq = 1u;  // (the cells start out zeroed: 0 tags nothing)
+        if (r == 0 && h->essps_merge0)
+            hipLaunchKernelGGL(essps_round_kernel<0>, dim3(blocks), dim3(STATS_THREADS), 0, s, h->costs, h->d.N, mk, target_ess,
+                               h->essps_range, h->essps_dev, lams1, lams0, h->lambda_dev, host_lam, h->round1_cells,
+                               h->round1_seq);
+        else if (r == 0) {
+            hipLaunchKernelGGL(stats_multi_kernel, dim3(blocks), dim3(STATS_THREADS), 0, s, h->costs, h->d.N, mk,
+                               (const float*)lams0, h->stats_part, (float*)nullptr);
+            hipLaunchKernelGGL(essps_select_kernel, dim3(1), dim3(1024), 0, s, (const float*)h->stats_part, blocks, target_ess,
+                               h->essps_range, h->essps_dev, lams1, lams0, h->lambda_dev, host_lam);
+        } else
+            hipLaunchKernelGGL(essps_round_kernel<1>, dim3(blocks), dim3(STATS_THREADS), 0, s, h->costs, h->d.N, mk, target_ess,
+                               h->essps_range, h->essps_dev, lams1, lams0, h->lambda_dev, host_lam, h->round1_cells,
+                               h->round1_seq);
+    }
     HIP_TRY(h, hipGetLastError());
     h->lambda_dev_valid = true;
     return MPPI_OK;
@@ -1443,7 +1457,7 @@ int mppi_lbps_lambda_device(mppi_handle_t h, double delta, double lam_min, doubl
     host_lam += 8 + STATS_L * 3;
     for (int r = 0; r < LBPS_ROUNDS; ++r) {
         hipLaunchKernelGGL(stats_multi_kernel, dim3(blocks), dim3(STATS_THREADS), 0, s, h->costs, h->d.N, mk,
-                           (const float*)(r == 0 ? lams0 : lams1), h->stats_part, (const int32_t*)nullptr, h->stats_max);
+                           (const float*)(r == 0 ? lams0 : lams1), h->stats_part, h->stats_max);
         if (r == 0)
             hipLaunchKernelGGL((lbps_select_kernel<false, true>), dim3(1), dim3(1024), 0, s, (const float*)h->stats_part,
                                (const float*)h->stats_max, blocks, mk, delta, h->lbps_dev, lams1, h->lambda_dev, host_lam);
@@ -1898,6 +1912,7 @@ int mppi_set_option(mppi_handle_t h, const char* key, int64_t value) {
         h->lazy_state = value ? 1 : 0;
         return MPPI_OK;
     }
+    if (k == "essps_merge0") { h->essps_merge0 = value != 0; return MPPI_OK; }  // A/B: round 0 of the ESSPS chain as one launch
     if (k == "fold_path") { h->fold_mode = (value >= 0 && value <= 2) ? (int)value : 0; return MPPI_OK; }
     if (k == "exchange_p2p") {  // sharded solves: summaries travel through the peer-to-peer buffer, no collective
         if (value && !h->p2p_connected) return fail(h, MPPI_E_STATE, "exchange_p2p: call mppi_p2p_alloc / mppi_p2p_connect first");

@@ -1144,19 +1144,20 @@ __global__ __launch_bounds__(WAVE) void stats_combine_kernel(const float* __rest
 // grid are produced on the device (essps_select_kernel) and never visit the host.
 constexpr int STATS_L = 32;
 constexpr int STATS_THREADS = 1024;
-__global__ __launch_bounds__(STATS_THREADS) void stats_multi_kernel(const float* __restrict__ costs, int64_t N,
-                                                                    const unsigned* __restrict__ min_key,
-                                                                    const float* __restrict__ lams,
-                                                                    float* __restrict__ part,
-                                                                    const int32_t* __restrict__ skip /* nullable */,
-                                                                    float* __restrict__ part_max /* nullable: [blocks] max c */) {
+// One block's share: thread j < 96 returns the block's partial sum of column j (0 elsewhere); part_max as the kernel's.
+struct StatsLds {
+    float c[STATS_THREADS];
+    float p[STATS_THREADS / WAVE][STATS_L][3];
+    float mx[STATS_THREADS / WAVE];
+};
+__device__ __forceinline__ float stats_multi_block(const float* __restrict__ costs, int64_t N, float cmin,
+                                                   const float* __restrict__ lams, float* __restrict__ part_max,
+                                                   StatsLds& lds) {
     constexpr int NWV = STATS_THREADS / WAVE;
-    if (skip && *skip) return;  // second pass of a search that an end-point rule already decided
-    __shared__ float s_c[STATS_THREADS];
-    __shared__ float s_p[NWV][STATS_L][3];
-    __shared__ float s_mx[NWV];
+    float (&s_c)[STATS_THREADS] = lds.c;
+    float (&s_p)[NWV][STATS_L][3] = lds.p;
+    float (&s_mx)[NWV] = lds.mx;
     float cmaxv = -INFINITY;
-    const float cmin = key_to_float(*min_key);
     const int l = threadIdx.x & (STATS_L - 1), chunk = threadIdx.x >> 5;
     const float inv_lam = 1.0f / lams[l];
     float se = 0.0f, se2 = 0.0f, sec = 0.0f;
@@ -1195,12 +1196,21 @@ __global__ __launch_bounds__(STATS_THREADS) void stats_multi_kernel(const float*
         for (int w = 1; w < NWV; ++w) v = fmaxf(v, s_mx[w]);
         part_max[blockIdx.x] = v;
     }
+    float v = 0.0f;
     if (threadIdx.x < STATS_L * 3) {
-        float v = 0.0f;
 #pragma unroll
         for (int w = 0; w < NWV; ++w) v += (&s_p[w][0][0])[threadIdx.x];
-        part[(int64_t)blockIdx.x * STATS_L * 3 + threadIdx.x] = v;
     }
+    return v;
+}
+__global__ __launch_bounds__(STATS_THREADS) void stats_multi_kernel(const float* __restrict__ costs, int64_t N,
+                                                                    const unsigned* __restrict__ min_key,
+                                                                    const float* __restrict__ lams,
+                                                                    float* __restrict__ part,
+                                                                    float* __restrict__ part_max /* nullable: [blocks] max c */) {
+    __shared__ StatsLds lds;
+    const float v = stats_multi_block(costs, N, key_to_float(*min_key), lams, part_max, lds);
+    if (threadIdx.x < STATS_L * 3) part[(int64_t)blockIdx.x * STATS_L * 3 + threadIdx.x] = v;
 }
 // Block-wide (960 of 1024 threads = 24 column quads x 40 row groups): column sums of part[nblocks][96] in double, fixed
 // order -> out[96] (LDS or global).  The partial rows were written by other XCDs a moment ago, so every load is a
@@ -1208,23 +1218,67 @@ __global__ __launch_bounds__(STATS_THREADS) void stats_multi_kernel(const float*
 // for up to 320 rows (a thread per (row group, column) with two loads in flight needed 13).  Ends with a barrier.
 constexpr int STATS_COMB_THREADS = 960;
 constexpr int STATS_COMB_GROUPS = 40;
-__device__ __forceinline__ void stats_combine_columns(const float* __restrict__ part, int nblocks,
+// Where the partial rows come from: the array a statistics kernel wrote before this one started ...
+struct PartRows {
+    const float* __restrict__ part;
+    static constexpr int K = 8;  // rows in flight per thread: 8 x 40 groups = one round of latency for up to 320 rows
+    struct Raw { float4 v; };
+    __device__ __forceinline__ void issue(int bb, int quad, Raw& r) const {
+        r.v = *reinterpret_cast<const float4*>(part + (int64_t)bb * (STATS_L * 3) + 4 * quad);
+    }
+    __device__ __forceinline__ float4 finish(int, int, const Raw& r) const { return r.v; }
+};
+// ... or 8-byte {value, launch number} cells the blocks of THIS launch are still writing (relaxed agent-scope stores: data
+// and readiness in one store, no fence — the hand-off of the single-launch solve): polled until the tag is this launch's.
+struct CellRows {
+    const unsigned long long* cells;  // [blocks][96]
+    unsigned seq;
+    static constexpr int K = 7;  // 7 x 40 >= STATS_BLOCKS: still one round (8 spills under the kernel's 128-VGPR cap)
+    struct Raw { unsigned long long c[4]; };
+    __device__ __forceinline__ const unsigned long long* at(int bb, int quad) const {
+        return cells + (int64_t)bb * (STATS_L * 3) + 4 * quad;
+    }
+    __device__ __forceinline__ void issue(int bb, int quad, Raw& r) const {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) r.c[c] = __hip_atomic_load(at(bb, quad) + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __device__ __forceinline__ float4 finish(int bb, int quad, const Raw& r) const {
+        float o[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            unsigned long long cell = r.c[c];
+            // (no time-out: the writers wait for nothing, every one of them gets its turn on the device)
+            while ((unsigned)(cell >> 32) != seq) {
+                __builtin_amdgcn_s_sleep(2);
+                cell = __hip_atomic_load(at(bb, quad) + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            o[c] = __uint_as_float((unsigned)cell);
+        }
+        return make_float4(o[0], o[1], o[2], o[3]);
+    }
+};
+template <class Rows>
+__device__ __forceinline__ void stats_combine_columns(const Rows rows, int nblocks,
                                                       double* s_acc /*[STATS_COMB_GROUPS][96]*/, double* out /*[96]*/) {
     constexpr int COLS = STATS_L * 3, QUADS = COLS / 4, GROUPS = STATS_COMB_GROUPS;
     static_assert(QUADS * GROUPS == STATS_COMB_THREADS, "thread layout");
     const int quad = threadIdx.x % QUADS, g = threadIdx.x / QUADS;
     if (g < GROUPS) {
         double v[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int b0 = g; b0 < nblocks; b0 += 8 * GROUPS) {
-            float4 r[8];
+        constexpr int K = Rows::K;
+        for (int b0 = g; b0 < nblocks; b0 += K * GROUPS) {
+            typename Rows::Raw raw[K];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
+            for (int q = 0; q < K; ++q) {
                 const int bb = b0 + q * GROUPS;
-                r[q] = bb < nblocks ? *reinterpret_cast<const float4*>(part + (int64_t)bb * COLS + 4 * quad)
-                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (bb < nblocks) rows.issue(bb, quad, raw[q]);
             }
 #pragma unroll
-            for (int q = 0; q < 8; ++q) { v[0] += r[q].x; v[1] += r[q].y; v[2] += r[q].z; v[3] += r[q].w; }
+            for (int q = 0; q < K; ++q) {
+                const int bb = b0 + q * GROUPS;
+                const float4 r = bb < nblocks ? rows.finish(bb, quad, raw[q]) : make_float4(0.f, 0.f, 0.f, 0.f);
+                v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+            }
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) s_acc[g * COLS + 4 * quad + c] = v[c];
@@ -1236,6 +1290,10 @@ __device__ __forceinline__ void stats_combine_columns(const float* __restrict__ 
         out[threadIdx.x] = v;
     }
     __syncthreads();
+}
+__device__ __forceinline__ void stats_combine_columns(const float* __restrict__ part, int nblocks, double* s_acc,
+                                                      double* out) {
+    stats_combine_columns(PartRows{part}, nblocks, s_acc, out);
 }
 __global__ __launch_bounds__(1024) void stats_multi_combine_kernel(const float* __restrict__ part, int nblocks,
                                                                    double* __restrict__ out /*[STATS_L][3] mapped*/) {
@@ -1313,19 +1371,13 @@ struct EsspsDev {
     double lam;                              // result
     int32_t done, pad;                       // round 0 already finished the search
 };
+// The scalar step after the sums of round ROUND are in s_sum (call with one full wave; j = lane).
 template <int ROUND>
-__global__ __launch_bounds__(1024) void essps_select_kernel(const float* __restrict__ part, int nblocks, double target_ess,
-                                                            mppi::host::EsspsRange range, EsspsDev* __restrict__ st,
-                                                            float* __restrict__ lams, float* __restrict__ lams0,
-                                                            float* __restrict__ lambda_out,
-                                                            double* __restrict__ lambda_host) {
-    __shared__ double s_acc[STATS_COMB_GROUPS * STATS_L * 3];
-    __shared__ double s_sum[STATS_L * 3];
-    __shared__ double s_ess[STATS_L], s_grid[STATS_L], s_lgrid[STATS_L];
-    stats_combine_columns(part, nblocks, s_acc, s_sum);
-    if (threadIdx.x >= WAVE) return;  // the scalar step: one wave, lane j owns temperature j where that helps
-    if (ROUND == 1 && st->done) return;
-    const int j = threadIdx.x;
+__device__ __forceinline__ void essps_select_step(const double* s_sum, double* s_ess, double* s_grid, double* s_lgrid,
+                                                  double target_ess, const mppi::host::EsspsRange& range,
+                                                  EsspsDev* __restrict__ st, float* __restrict__ lams,
+                                                  float* __restrict__ lams0, float* __restrict__ lambda_out,
+                                                  double* __restrict__ lambda_host, int j) {
     if (j < STATS_L) {
         s_ess[j] = s_sum[3 * j] * s_sum[3 * j] / s_sum[3 * j + 1];  // 32 double divisions, one per lane
         s_grid[j] = ROUND == 0 ? st->grid0[j] : st->grid1[j];
@@ -1357,6 +1409,54 @@ __global__ __launch_bounds__(1024) void essps_select_kernel(const float* __restr
             lams[j] = (float)g;
         }
     }
+}
+__global__ __launch_bounds__(1024) void essps_select_kernel(const float* __restrict__ part, int nblocks, double target_ess,
+                                                            mppi::host::EsspsRange range, EsspsDev* __restrict__ st,
+                                                            float* __restrict__ lams, float* __restrict__ lams0,
+                                                            float* __restrict__ lambda_out,
+                                                            double* __restrict__ lambda_host) {
+    __shared__ double s_acc[STATS_COMB_GROUPS * STATS_L * 3];
+    __shared__ double s_sum[STATS_L * 3];
+    __shared__ double s_ess[STATS_L], s_grid[STATS_L], s_lgrid[STATS_L];
+    stats_combine_columns(part, nblocks, s_acc, s_sum);
+    if (threadIdx.x >= WAVE) return;  // the scalar step: one wave, lane j owns temperature j where that helps
+    essps_select_step<0>(s_sum, s_ess, s_grid, s_lgrid, target_ess, range, st, lams, lams0, lambda_out, lambda_host,
+                         (int)threadIdx.x);
+}
+// Round 1 — statistics over the refined grid AND its select step — as ONE launch that costs its launch floor when round 0
+// already finished the search (the warm-started first grid usually does: every block returns at once; as two kernels the
+// skipped pair cost two floors, and the select kernel combined stale partial rows before it looked at `done`).  When the
+// round runs, block 0 gathers the other blocks' 96 partial sums through tagged cells (CellRows) in the order and with the
+// arithmetic of the two-kernel chain: the same temperature to the bit.  No `done` is written here, so reading it at the
+// top does not race with block 0's step.
+template <int ROUND>
+__global__ __launch_bounds__(STATS_THREADS) void essps_round_kernel(const float* __restrict__ costs, int64_t N,
+                                                                    const unsigned* __restrict__ min_key, double target_ess,
+                                                                    mppi::host::EsspsRange range, EsspsDev* __restrict__ st,
+                                                                    float* __restrict__ lams, float* __restrict__ lams0,
+                                                                    float* __restrict__ lambda_out,
+                                                                    double* __restrict__ lambda_host,
+                                                                    unsigned long long* __restrict__ cells, unsigned seq) {
+    if (ROUND == 1 && st->done) return;
+    __shared__ union {
+        StatsLds stats;
+        double acc[STATS_COMB_GROUPS * STATS_L * 3];
+    } u;
+    __shared__ double s_sum[STATS_L * 3];
+    __shared__ double s_ess[STATS_L], s_grid[STATS_L], s_lgrid[STATS_L];
+    // (block 0's step rewrites lams0 — the NEXT search's first grid — only after every block published its sums, i.e.
+    // after the last read of this round's temperatures)
+    const float v = stats_multi_block(costs, N, key_to_float(*min_key), ROUND == 0 ? lams0 : lams, nullptr, u.stats);
+    if (threadIdx.x < STATS_L * 3)
+        __hip_atomic_store(cells + (int64_t)blockIdx.x * STATS_L * 3 + threadIdx.x,
+                           ((unsigned long long)seq << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    if (blockIdx.x != 0) return;
+    __syncthreads();  // u.stats is dead from here on
+    stats_combine_columns(CellRows{cells, seq}, (int)gridDim.x, u.acc, s_sum);
+    if (threadIdx.x >= WAVE) return;
+    essps_select_step<ROUND>(s_sum, s_ess, s_grid, s_lgrid, target_ess, range, st, lams, lams0, lambda_out, lambda_host,
+                             (int)threadIdx.x);
 }
 
 // LBPS without leaving the device (mppi.py:341-349,534-557).  The reference minimises the lower-bound objective with

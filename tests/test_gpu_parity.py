@@ -1904,6 +1904,42 @@ def test_essps_warm_start_in_a_closed_loop(fused):
     assert h.lib.mppi_search_passes(h.h, None) == 2
 
 
+@pytest.mark.parametrize("N", [65536, 262144 + 1000])
+def test_essps_rounds_as_one_launch_same_temperature_to_the_bit(N):
+    """Round 1 of the device-resident ESSPS chain is ONE launch (statistics pass + select step: block 0 gathers the other
+    blocks' partial sums through tagged cells; every block returns at once when round 0 finished the search), and option
+    "essps_merge0" makes round 0 one as well.  Same sums in the same order as a statistics kernel followed by a one-block
+    select kernel: the temperatures, the number of passes and the actions are bit-equal over a loop with cold (two-pass)
+    and warm searches, and every temperature is the root brentq finds on a float64 evaluation of the same costs."""
+    _need_gpu()
+    from scipy.optimize import brentq
+
+    a_s, _ = make_solver("nav2d", 30, N, lambda_="ESSPS")
+    b_s, _ = make_solver("nav2d", 30, N, lambda_="ESSPS")
+    a_s.set_option("fused_solve", 0)
+    b_s.set_option("fused_solve", 0)
+    b_s.set_option("essps_merge0", 1)
+    x = torch.tensor([-9.0, -9.0, 0.785]).cuda()
+    passes = []
+    for k in range(10):
+        if k in (4, 5):
+            a_s.set_option("essps_cold", 1)
+            b_s.set_option("essps_cold", 1)
+        a, st = a_s.forward(x)
+        b, sb = b_s.forward(x)
+        pa = a_s._h.lib.mppi_search_passes(a_s._h.h, None)
+        assert pa == b_s._h.lib.mppi_search_passes(b_s._h.h, None)
+        passes.append(pa)
+        assert a_s._last_lambda == b_s._last_lambda, (k, a_s._last_lambda, b_s._last_lambda)
+        assert torch.equal(a, b) and torch.equal(torch.as_tensor(st), torch.as_tensor(sb))
+        c = a_s._costs.cpu().numpy().astype(np.float64)
+        ess = lambda l: (lambda e: e.sum() ** 2 / (e * e).sum())(np.exp(-(c - c.min()) / l))  # noqa: E731
+        want = brentq(lambda l: ess(l) - 0.1 * N, 0.01, 10.0, xtol=1e-13)
+        assert abs(a_s._last_lambda - want) <= 1e-5 * want, (k, a_s._last_lambda, want)
+        x = sb[0, 1].clone()
+    assert passes[0] == 2 and passes[4] == 2 and passes[5] == 2 and 1 in passes, passes
+
+
 # ------------------------------------------------------------------------------ device-resident racing tick
 def _device_window(solver, ctrl, env, T, state, cind):
     """calc_ref_trajectory through the library: (reference_path [T+1,4], path index)."""

@@ -513,3 +513,24 @@ def test_lazy_info_tensor_is_built_on_first_use():
     assert torch.equal(t * 2, torch.arange(6.0).reshape(3, 2) * 2) and float(t.sum()) == 15.0
     assert torch.equal(torch.cat([t, t]), torch.arange(6.0).reshape(3, 2).repeat(2, 1)) and built == [1]
     assert type(t[0]) is torch.Tensor and t[:, 1].tolist() == [1.0, 3.0, 5.0]
+
+
+def test_bench_stdout_carries_only_its_line():
+    """bench.py: whatever a library prints from C (RCCL's version banner, flushed at exit) lands on stderr; stdout is the
+    JSON line and nothing else."""
+    import subprocess
+    import sys
+    code = (
+        "import ctypes, os, sys\n"
+        f"sys.path.insert(0, {str(ROOT)!r})\n"
+        "import bench\n"
+        "bench.own_stdout()\n"
+        "libc = ctypes.CDLL(None)\n"
+        "libc.printf(b'banner from C\\n')\n"      # stays in the stdio buffer until exit, like RCCL's
+        "print('python chatter')\n"
+        "bench.print_line('{\"metric\": 1}')\n"
+    )
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == '{"metric": 1}\n'
+    assert "banner from C" in r.stderr and "python chatter" in r.stderr
