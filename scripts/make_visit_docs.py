@@ -30,7 +30,7 @@ Un-profiled `python bench.py` of the same visit: {d['ms_per_step']:.4f} ms/solve
 open(out(f"{name}_c3_kernel_stats_pmc.md"), "w").write(hdr + c3)
 hdr2 = f"""# {name}: the dense-weight path — C2 (nav2d, ESSPS) and C5 (cartpole, ESSPS + Savitzky-Golay)
 
-Same build and box as `{name}_c3_kernel_stats_pmc.md`.  These sizes (65 536 / 262 144 samples) stay on the multi-kernel path.  Commands: `python bench.py --no-cpu-baseline --no-extras --workload c2|c5 --steps 200 --warmup 20` under `rocprofv3 --kernel-trace --stats`; `--steps 40 --warmup 10` under `rocprofv3 --pmc <group> --kernel-trace`, one counter group per run (scripts/gpu_record.sh; table: scripts/dense_profile_md.py).  The ESSPS search is warm-started: in these open loops every search after the first ends after one pass over the costs, the second `stats_multi_kernel` / `essps_select_kernel<1>` pair returns at once (under the profiler, which serialises dispatches, each still shows its ~4-5 us launch floor; un-profiled a solve takes {d['other_configs']['c2_essps']['ms_per_solve']*1e3:.1f} us at C2 and {d['other_configs']['c5']['ms_per_solve']*1e3:.1f} us at C5).
+Same build and box as `{name}_c3_kernel_stats_pmc.md`.  These sizes (65 536 / 262 144 samples) stay on the multi-kernel path.  Commands: `python bench.py --no-cpu-baseline --no-extras --workload c2|c5 --steps 200 --warmup 20` under `rocprofv3 --kernel-trace --stats`; `--steps 40 --warmup 10` under `rocprofv3 --pmc <group> --kernel-trace`, one counter group per run (scripts/gpu_record.sh; table: scripts/dense_profile_md.py).  The ESSPS search is warm-started: in these open loops every search after the first ends after one pass over the costs, the second round (`essps_round_kernel<1>`: statistics pass + select step as one conditional launch) returns at once (under the profiler, which serialises dispatches, it still shows a launch floor of a few us; un-profiled a solve takes {d['other_configs']['c2_essps']['ms_per_solve']*1e3:.1f} us at C2 and {d['other_configs']['c5']['ms_per_solve']*1e3:.1f} us at C5).
 
 """
 open(out(f"{name}_c2_c5_dense_path.md"), "w").write(hdr2 + dense)
