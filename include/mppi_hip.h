@@ -431,7 +431,9 @@ int mppi_p2p_error(mppi_handle_t h);
  * the north star's literal wavefront-per-trajectory rollout (comparison only, ~20x slower); "reduce_blocks" grid of the weighted
  * reduction; "fold_path" who sums the reduction's partial rows: 0 = by the live-row count of earlier solves (default),
  * 1 = inside mppi_finalize whenever the rows fit its LDS, 2 = always the separate summarize kernel (both use the same
- * summation tree: results are bit-identical); "timing" (see mppi_get_timing). */
+ * summation tree: results are bit-identical); "essps_merge0" 1 = round 0 of mppi_essps_lambda_device as one launch too
+ * (statistics pass + select step; round 1 always is: it returns at once when round 0 finished the search) — same
+ * temperature to the bit, measured no faster (default 0); "timing" (see mppi_get_timing). */
 int mppi_set_option(mppi_handle_t h, const char* key, int64_t value);
 /* Device time per stage from HIP event pairs recorded on the caller's stream around every stage call
  * since the last drain (no host synchronisation while recording): out[0..3] = mean ms of
