@@ -42,5 +42,7 @@ for N, T, rule in ((1000, 30, "ESSPS"), (3000, 30, "ESSPS"), (4096, 50, 1.0), (7
     d = float((a1 - a2).abs().max() / (a2.abs().max() + 1e-12))
     total += per
     print(f"N={N} T={T} lambda={rule}: {per} solves, fused error flag {err}, non-finite checks {bad}, last action vs multi-kernel {d:.1e}", flush=True)
-    assert err == 0 and bad == 0 and d < 1e-4
+    # (LBPS: the two paths sum the statistics over different partitions and the objective is flat around its minimum — the
+    # temperatures agree to ~1e-3, tests/test_gpu_parity.py LBPS_TOL, and the actions follow)
+    assert err == 0 and bad == 0 and d < (1e-3 if rule == "LBPS" else 1e-4)
 print(f"{total} solves in {time.perf_counter() - t0:.1f} s: ok")
