@@ -59,9 +59,106 @@ def print_line(text: str) -> None:
         data = data[os.write(fd, data):]
 
 
+def null_line(args, world, reason, transports=()):
+    """A contract-shaped line for a multi-GPU run that produced NO complete measurement (`value` null): the keys the driver
+    reads, the reason, and what every transport that was tried reported — so that a hang in a communicator's set-up or first
+    collective costs one run, not the evidence of what happened."""
+    return {"metric": "sample_steps_per_sec", "value": None, "unit": "sample-steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "racing kinematic-bicycle MPPI solve (BASELINE configs[2]; configs[3] when n_gpus = 8)",
+                       "num_samples_per_gpu": args.samples, "horizon": args.horizon, "lambda": 1.0},
+            "error": reason,
+            "transports": [{"exchange": r.get("exchange"), "requested": r.get("requested", r.get("exchange")),
+                            "error": r.get("error", None if r.get("finite", True) else "non-finite outputs"),
+                            "ms_per_step": None if "dt" not in r else r["dt"] / args.steps * 1e3} for r in transports]}
+
+
+class Watchdog:
+    """Wall-clock guard of the multi-GPU legs.  arm(seconds, phase) (re)starts the clock for one phase — process-group
+    set-up, each transport's set-up + self-test + timed run, the strong-scaling leg; when a phase outlives its budget
+    `on_expiry(phase)` runs on the timer thread (rank 0 prints the best complete run so far, or a null line) and the
+    process ends through `exit_fn` — a rank blocked inside a collective cannot be unwound any other way."""
+
+    def __init__(self, on_expiry, exit_fn=os._exit):
+        import threading
+
+        self._threading, self._on_expiry, self._exit, self._timer, self.phase = threading, on_expiry, exit_fn, None, None
+
+    def arm(self, seconds, phase):
+        self.cancel()
+        self.phase = phase
+        self._timer = self._threading.Timer(seconds, self._fire, args=(phase, seconds))
+        self._timer.daemon = True
+        self._timer.start()
+
+    def _fire(self, phase, seconds):
+        code = 1
+        try:
+            code = self._on_expiry(phase, seconds)
+        finally:
+            self._exit(code)
+
+    def cancel(self):
+        if self._timer is not None:
+            self._timer.cancel()
+            self._timer = None
+
+
+def best_of(runs):
+    ok = [r for r in runs if "error" not in r and r["finite"]]
+    return min(ok, key=lambda r: r["dt"]) if ok else None
+
+
+def run_transports(order, timed_run, dog, first_budget_s, alt_budget_s, runs):
+    """Time every transport in `order` (appending to `runs`), each under its own watchdog phase: the first one — nothing has
+    completed yet — with `first_budget_s`, the later ones with `alt_budget_s`."""
+    for i, mode in enumerate(order):
+        dog.arm(first_budget_s if i == 0 else alt_budget_s, f"transport {mode}")
+        runs.append(timed_run(mode))
+    dog.cancel()
+    return runs
+
+
+def run_with_deadline(cmd, env, timeout_s, on_timeout_line):
+    """Run the launcher with a wall-clock limit; the ranks' stdout (rank 0's JSON line) passes through.  On expiry the whole
+    process group is killed and, if no line came out, `on_timeout_line()` is printed instead — the driver's own limit would
+    otherwise end the run with nothing on stdout."""
+    import signal
+    import threading
+
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, start_new_session=True)
+    seen = {"line": False}
+
+    def pump():
+        for raw in proc.stdout:
+            text = raw.decode(errors="replace").rstrip("\n")
+            if text.startswith("{"):
+                seen["line"] = True
+            print_line(text)
+
+    t = threading.Thread(target=pump, daemon=True)
+    t.start()
+    try:
+        rc = proc.wait(timeout=timeout_s)
+        t.join(timeout=10)
+        return rc
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        proc.wait()
+        t.join(timeout=10)
+        if not seen["line"]:
+            print_line(json.dumps(on_timeout_line()))
+        return 124
+
+
 def launch_ranks(args) -> int:
     """`python bench.py --gpus N` without a launcher: re-run this script under torch.distributed.run, one rank per
-    GPU of this node, rendezvous on 127.0.0.1; the ranks' output (rank 0's JSON line) passes through."""
+    GPU of this node, rendezvous on 127.0.0.1; the ranks' output (rank 0's JSON line) passes through.  The launcher gets a
+    wall-clock limit (--launch-timeout-s) below the driver's."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -71,7 +168,9 @@ def launch_ranks(args) -> int:
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "8")
-    return subprocess.call(cmd, env=env)
+    return run_with_deadline(cmd, env, args.launch_timeout_s,
+                             lambda: null_line(args, args.gpus, f"the {args.gpus} ranks did not finish within "
+                                               f"--launch-timeout-s = {args.launch_timeout_s:.0f} s (killed)"))
 
 
 def main():
@@ -83,21 +182,31 @@ def main():
     ap.add_argument("--horizon", type=int, default=50)
     ap.add_argument("--exchange", choices=("all", "nccl", "rccl", "p2p", "auto"), default="all",
                     help="per-solve exchange of the shard summaries at N > 1: all (default) = time EVERY transport with the "
-                         "full K steps — one all_gather through torch.distributed (nccl) first, then the library's own RCCL "
-                         "communicator (rccl: ncclAllGather on the solve's stream), then its peer-to-peer buffers (p2p) — and "
-                         "report the best complete run as `value` (all of them under `transports`); nccl / rccl / p2p / auto "
-                         "(rccl when its self-test passes on every rank, else nccl) time only that one")
+                         "full K steps — the library's own RCCL communicator first (rccl: ncclAllGather on the solve's stream, "
+                         "the cheapest at one rank: +3 us), then one all_gather through torch.distributed (nccl), then the "
+                         "peer-to-peer buffers (p2p) — and report the best complete run as `value` (all of them under "
+                         "`transports`); nccl / rccl / p2p / auto (rccl when its self-test passes on every rank, else nccl) "
+                         "time only that one")
     ap.add_argument("--alt-budget-s", type=float, default=150.0,
-                    help="wall-clock guard of the transports after the first complete one (a watchdog prints the best run "
-                         "so far and ends every rank if a later transport hangs)")
+                    help="wall-clock guard of every transport after the first (a watchdog prints the best run so far — or a "
+                         "line with value null and every transport's error — and ends every rank if one hangs)")
+    ap.add_argument("--first-budget-s", type=float, default=300.0,
+                    help="wall-clock guard of the process-group set-up and of the FIRST transport (armed before either starts)")
+    ap.add_argument("--launch-timeout-s", type=float, default=1500.0,
+                    help="wall-clock limit of the ranks `python bench.py --gpus N` launches itself (below the driver's)")
+    ap.add_argument("--preflight", action="store_true",
+                    help="N > 1: process-group set-up, every transport's own self-test and ONE sharded solve per transport on a "
+                         "small problem, under the watchdog; prints one JSON line of statuses (< 60 s) instead of the bench line")
     ap.add_argument("--math", type=int, default=2, help="2 = fast-path math with hardware sin/cos of the wrapped heading "
                     "(default), 1 = fast-path math with polynomial sin/cos, 0 = library math")
     ap.add_argument("--noise-regen", type=int, default=1,
                     help="1 = regenerate the Philox noise in registers (default), 0 = materialise the noise tiles")
     ap.add_argument("--mapping", type=int, default=0, help="0 = lane per trajectory (default), 1 = the literal "
                     "wavefront-per-trajectory rollout (comparison only)")
-    ap.add_argument("--lazy-state-seq", type=int, default=-1, help="the batch-1 rollout of the solution completed lazily (in an "
-                    "extra block of the next solve's rollout launch): 1 = on, 0 = off, -1 = the solver's default")
+    ap.add_argument("--lazy-state-seq", type=int, default=1, help="the batch-1 rollout of the solution completed lazily (in an "
+                    "extra block of the next solve's rollout launch; every state sequence is still completed inside the "
+                    "timed region): 1 = on (default here; the solver's own default is off since round 5), 0 = off.  The line "
+                    "reports the other setting next to the headline (`eager_state_seq`)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip both CPU baselines")
     ap.add_argument("--no-extras", action="store_true", help="skip closed_loop and other_configs")
     ap.add_argument("--workload", choices=("c3", "c2", "c5", "c3_dense"), default="c3",
@@ -125,6 +234,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     one_device = bool(os.environ.get("MPPI_BENCH_ONE_DEVICE"))
     backend = "none"
+    printed = {"done": False}
+
+    def emit(out):
+        if not printed["done"]:
+            printed["done"] = True
+            print_line(json.dumps(out))
+
+    # what the watchdog can report when a phase of the multi-GPU run outlives its budget: the runs completed so far and,
+    # once it exists, the function that turns the best of them into the contract's line
+    mg = {"runs": [], "compose": None}
+    dog = None
     if world > 1 or args.gpus > 1:
         if world != args.gpus:
             sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
@@ -133,6 +253,22 @@ def main():
         if ndev < world and not one_device:
             sys.exit(f"bench.py: {world} ranks but {ndev} visible GPU(s).  For a dry run of the multi-rank path on one "
                      "GPU set MPPI_BENCH_ONE_DEVICE=1 MPPI_BENCH_BACKEND=gloo (RCCL needs one device per rank)")
+
+        def on_expiry(phase, seconds):
+            why = f"{phase} exceeded its {seconds:.0f} s budget"
+            runs = mg["runs"] + [{"exchange": phase, "error": why}]
+            best = best_of(mg["runs"])
+            if rank == 0:
+                if best is not None and mg["compose"] is not None:
+                    emit(mg["compose"](best, runs))
+                else:
+                    emit(null_line(args, world, why + "; no transport had completed", runs))
+            return 0 if best is not None else 1
+
+        # armed BEFORE the process group exists: a hang in its set-up or in the first transport's first collective must
+        # still leave a line on stdout
+        dog = Watchdog(on_expiry)
+        dog.arm(args.first_budget_s, "process-group set-up")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.exchange != "all":
             os.environ["MPPI_EXCHANGE"] = args.exchange
@@ -144,6 +280,7 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
         else:
             dist.init_process_group(backend)
+        dog.cancel()
     else:
         torch.cuda.set_device(0)
 
@@ -162,7 +299,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed_run(mode, n_total=None, force_exchange=False):
+    def timed_run(mode, n_total=None, force_exchange=False, lazy=None):
         """One complete measurement: a solver on transport `mode` (None at one GPU), SETUP_SOLVES un-timed solves to leave
         the idle power state, the contract's W warm-up steps, then EXACTLY K timed steps between barrier + synchronise on
         both sides, MAX over ranks.  `n_total`: the global sample count (default: weak scaling, N_local per rank).
@@ -174,7 +311,7 @@ def main():
         if mode is not None:
             os.environ["MPPI_EXCHANGE"] = mode
         try:
-            dkw = {} if args.lazy_state_seq < 0 else {"lazy_state_seq": bool(args.lazy_state_seq)}
+            dkw = {"lazy_state_seq": bool(args.lazy_state_seq) if lazy is None else lazy}
             if force_exchange:
                 dkw["_force_exchange"] = True
             ctrl = racing_controller(env, horizon=T, num_samples=n_total, lambda_=1.0,
@@ -357,17 +494,8 @@ def main():
         out.update(extras)
         return out
 
-    printed = {"done": False}
     extras = {}  # entries added to the line once they exist (strong-scaling leg)
-
-    def emit(out):
-        if not printed["done"]:
-            printed["done"] = True
-            print_line(json.dumps(out))
-
-    def best_of(runs):
-        ok = [r for r in runs if "error" not in r and r["finite"]]
-        return min(ok, key=lambda r: r["dt"]) if ok else None
+    mg["compose"] = compose
 
     if world == 1:
         runs = [timed_run(None)]
@@ -375,6 +503,13 @@ def main():
         out = compose(runs[0], runs)
         ctrl = runs[0]["ctrl"]
         if not args.no_extras:
+            # the solver's own default since round 5: state_seq rolled out inside the solve's last kernel
+            er = timed_run(None, lazy=not bool(args.lazy_state_seq))
+            out["eager_state_seq" if args.lazy_state_seq else "lazy_state_seq"] = {
+                "ms_per_step": er["dt"] / args.steps * 1e3, "value": N_total * T * args.steps / er["dt"],
+                "stages_ms": {k: er["stages"][k] for k in ("rollout_cost", "weights_reduce", "finalize")},
+                "note": "the same run with the other state_seq setting (MPPI's default: completed inside finalize_kernel)"}
+            er["ctrl"] = None
             out["sharded_one_rank"] = sharded_one_rank(torch, dist, timed_run, runs[0], args, N_total, T)
             out["closed_loop"] = closed_loop(torch, env, ctrl, T, N_total)
             out["example_loop"] = example_loop(torch)
@@ -388,34 +523,29 @@ def main():
         emit(out)
         return
 
-    # N > 1: time EVERY transport of the per-solve exchange with the full K steps — the known one first — and report the
-    # best complete run as `value`, all of them under `transports`.  No transport had crossed a device boundary before
-    # the first multi-GPU run, so from the second transport on a watchdog guards the wall clock: if one hangs, every rank
-    # ends after rank 0 printed the line of the best run completed so far.
-    import threading
-
-    order = {"all": ["nccl", "rccl", "p2p"]}.get(args.exchange, [args.exchange])
-    runs = []
-
-    def watchdog():
-        best = best_of(runs)
-        if rank == 0 and best is not None:
-            emit(compose(best, runs + [{"exchange": "?", "error": f"a later transport exceeded {args.alt_budget_s:.0f} s"}]))
-        os._exit(0 if best is not None else 1)
-
-    timer = None
-    for mode in order:
-        runs.append(timed_run(mode))
-        if timer is None and best_of(runs) is not None:
-            timer = threading.Timer(args.alt_budget_s, watchdog)
-            timer.daemon = True
-            timer.start()
+    # N > 1: time EVERY transport of the per-solve exchange with the full K steps and report the best complete run as
+    # `value`, all of them under `transports`.  No transport had crossed a device boundary before the first multi-GPU run,
+    # so EVERY phase runs under the watchdog (armed before the process group was set up): the cheapest transport first
+    # (the in-library communicator: +3 us per solve at one rank), so that a good number exists before the riskier ones; a
+    # phase that outlives its budget ends every rank after rank 0 printed the best run completed so far — or, if none, a
+    # contract-shaped line with `value: null` and every transport's error.
+    order = {"all": ["rccl", "nccl", "p2p"]}.get(args.exchange, [args.exchange])
+    if args.preflight:
+        return preflight(args, torch, dist, env, order, dog, emit, world, rank)
+    runs = run_transports(order, timed_run, dog, args.first_budget_s, args.alt_budget_s, mg["runs"])
     best = best_of(runs)
-    assert best is not None, [r.get("error", "non-finite outputs") for r in runs]
+    if best is None:
+        if rank == 0:
+            emit(null_line(args, world, "no transport completed a finite run", runs))
+        dist.barrier()
+        dist.destroy_process_group()
+        sys.exit(1)
     # strong-scaling leg (BASELINE's metric also reads "racing N = 1M ... at 1/2/4/8 GPUs"): the SAME 2^20 samples split
     # over the ranks, on the transport that won the weak leg, behind the same watchdog.  Reported next to the weak-scaling
     # `value` (which stays the contract's line: fixed work per GPU), never instead of it.
+    dog.arm(args.alt_budget_s, "strong-scaling leg")
     sr = timed_run(best["requested"], n_total=N_local)
+    dog.cancel()
     if "error" in sr or not sr["finite"]:
         extras["strong"] = {"error": sr.get("error", "non-finite outputs")}
     else:
@@ -425,12 +555,59 @@ def main():
                             "unit": "sample-steps/s", "exchange_us": None if sr["exchange_ms"] is None else sr["exchange_ms"] * 1e3,
                             "per_rank_stages_ms": sr["rank_stages"]}
     sr["ctrl"] = None
-    if timer is not None:
-        timer.cancel()
     if rank == 0:
         emit(compose(best, runs))
+    dog.arm(60.0, "process-group tear-down")
     dist.barrier()
     dist.destroy_process_group()
+    dog.cancel()
+
+
+def preflight(args, torch, dist, env, order, dog, emit, world, rank):
+    """--preflight: what a multi-GPU run needs before its first timed step, on a small problem and in under a minute — the
+    process group (already up when this runs), every transport's own set-up and self-test (three pattern exchanges checked
+    on every rank: `MPPI(shard_samples=True)`), and ONE sharded solve per transport whose outputs every rank checks to be
+    finite and identical to rank 0's.  One JSON line of statuses; exit code 0 only if at least one transport passed."""
+    from envs.racing_controller import racing_controller
+    from mppi_playground_amd import _capi
+
+    t_all = time.perf_counter()
+    status = []
+    N, T = 65536 * world, args.horizon
+    state = env.reset()
+    for mode in order:
+        dog.arm(60.0, f"preflight {mode}")
+        t0 = time.perf_counter()
+        os.environ["MPPI_EXCHANGE"] = mode
+        try:
+            ctrl = racing_controller(env, horizon=T, num_samples=N, lambda_=1.0, shard_samples=True)
+            ctrl.set_cost_map(env._obstacle_map, env._lane_map)
+            ref, _ = ctrl.calc_ref_trajectory(state, env.racing_center_path, 0, T, DL=0.1, lookahead_distance=3,
+                                              reference_path_interval=0.85)
+            ctrl.set_reference(ref)
+            a, s = ctrl.solver.forward(state)
+            torch.cuda.synchronize()
+            a0 = a.clone()
+            dist.broadcast(a0, src=0)
+            ok = bool(torch.isfinite(a).all() and torch.isfinite(s).all() and torch.equal(a0, a))
+            flag = torch.tensor([1.0 if ok else 0.0], device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            used = "p2p" if ctrl.solver._p2p else "rccl" if ctrl.solver._comm else "nccl"
+            status.append({"requested": mode, "exchange": used, "ok": bool(flag.item() == 1.0),
+                           "seconds": round(time.perf_counter() - t0, 3)})
+            del ctrl
+        except (_capi.MppiError, RuntimeError) as e:
+            status.append({"requested": mode, "ok": False, "error": str(e)[:300], "seconds": round(time.perf_counter() - t0, 3)})
+    dog.cancel()
+    ok_any = any(x["ok"] and x.get("exchange") == x["requested"] for x in status)
+    if rank == 0:
+        emit({"preflight": status, "n_gpus": world, "backend": dist.get_backend(), "num_samples_total": N, "horizon": T,
+              "seconds": round(time.perf_counter() - t_all, 3), "ok": ok_any})
+    dog.arm(60.0, "process-group tear-down")
+    dist.barrier()
+    dist.destroy_process_group()
+    dog.cancel()
+    sys.exit(0 if ok_any else 1)
 
 
 def sharded_one_rank(torch, dist, timed_run, plain, args, N, T):
@@ -557,25 +734,32 @@ def _other_solvers(torch, np, which=None):
 
     nav = Navigation2DEnv()
     t = torch.tensor
+    LZ = dict(lazy_state_seq=True)  # what MPPI defaulted to above 16 384 samples until round 4; opt-in since
     rows = [
         ("c1", "C1 pendulum T=50 N=1000 ESSPS", 1000 * 50, 3 * 4 * 1 * 1000 * 50 + 8 * 1000,
          lambda: MPPI(50, 1000, 2, 1, cc.pendulum_dynamics, cc.pendulum_cost, t([-2.0]), t([2.0]), t([1.0]), "ESSPS"),
          t([np.pi, 0.0], device="cuda", dtype=torch.float32)),
         ("c2", "C2 nav2d T=50 N=65536 lambda=1", 65536 * 50, 3 * 4 * 2 * 65536 * 50 + 8 * 65536,
-         lambda: MPPI(50, 65536, 3, 2, nav.dynamics, nav.cost_function, nav.u_min, nav.u_max, t([0.5, 0.5]), 1.0),
+         lambda: MPPI(50, 65536, 3, 2, nav.dynamics, nav.cost_function, nav.u_min, nav.u_max, t([0.5, 0.5]), 1.0, **LZ),
          nav.reset().clone()),
         ("c2_essps", "C2 nav2d T=50 N=65536 ESSPS", 65536 * 50, 3 * 4 * 2 * 65536 * 50 + 8 * 65536,
-         lambda: MPPI(50, 65536, 3, 2, nav.dynamics, nav.cost_function, nav.u_min, nav.u_max, t([0.5, 0.5]), "ESSPS"),
+         lambda: MPPI(50, 65536, 3, 2, nav.dynamics, nav.cost_function, nav.u_min, nav.u_max, t([0.5, 0.5]), "ESSPS", **LZ),
          nav.reset().clone()),
-        ("c2_lbps", "C2 nav2d T=50 N=65536 LBPS (device-resident grid search)", 65536 * 50, 3 * 4 * 2 * 65536 * 50 + 8 * 65536,
-         lambda: MPPI(50, 65536, 3, 2, nav.dynamics, nav.cost_function, nav.u_min, nav.u_max, t([0.5, 0.5]), "LBPS"),
+        ("c2_lbps", "C2 nav2d T=50 N=65536 LBPS (lbps_search='device': grid search as kernels, the opt-in fast path)", 65536 * 50,
+         3 * 4 * 2 * 65536 * 50 + 8 * 65536,
+         lambda: MPPI(50, 65536, 3, 2, nav.dynamics, nav.cost_function, nav.u_min, nav.u_max, t([0.5, 0.5]), "LBPS",
+                      lbps_search="device", **LZ),
+         nav.reset().clone()),
+        ("c2_lbps_brent", "C2 nav2d T=50 N=65536 LBPS (the default since round 5: scipy's bounded Brent inside the library, "
+         "one read-back of the device statistics per probe)", 65536 * 50, 3 * 4 * 2 * 65536 * 50 + 8 * 65536,
+         lambda: MPPI(50, 65536, 3, 2, nav.dynamics, nav.cost_function, nav.u_min, nav.u_max, t([0.5, 0.5]), "LBPS", **LZ),
          nav.reset().clone()),
         ("c2_mpo", "C2 nav2d T=50 N=65536 MPO (dual on the device)", 65536 * 50, 3 * 4 * 2 * 65536 * 50 + 8 * 65536,
-         lambda: MPPI(50, 65536, 3, 2, nav.dynamics, nav.cost_function, nav.u_min, nav.u_max, t([0.5, 0.5]), "MPO"),
+         lambda: MPPI(50, 65536, 3, 2, nav.dynamics, nav.cost_function, nav.u_min, nav.u_max, t([0.5, 0.5]), "MPO", **LZ),
          nav.reset().clone()),
         ("c5", "C5 cartpole T=64 N=262144 ESSPS + Savitzky-Golay", 262144 * 64, 3 * 4 * 1 * 262144 * 64 + 8 * 262144,
          lambda: MPPI(64, 262144, 4, 1, cc.cartpole_dynamics, cc.cartpole_cost, t([-3.0]), t([3.0]), t([1.0]), "ESSPS",
-                      use_sg_filter=True),
+                      use_sg_filter=True, **LZ),
          t([0.01, 0.0, 0.02, 0.0], device="cuda")),
     ]
     return [r for r in rows if which is None or r[0] in which]
@@ -630,6 +814,7 @@ def _racing_c3(torch, lam, **kw):
 
     env = RacingEnv()
     x0 = env.reset().clone()
+    kw.setdefault("lazy_state_seq", True)
     ctrl = racing_controller(env, horizon=50, num_samples=1 << 20, lambda_=lam, **kw)
     ctrl.set_cost_map(env._obstacle_map, env._lane_map)
     ref, _ = ctrl.calc_ref_trajectory(x0, env.racing_center_path, 0, 50, DL=0.1, lookahead_distance=3, reference_path_interval=0.85)

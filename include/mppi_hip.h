@@ -277,9 +277,11 @@ int mppi_get_state_seq_timing(mppi_handle_t h, float* out2_host);
  * a cell round trip costs what a kernel boundary costs).  Co-residency of the blocks is checked against the kernel's own
  * occupancy before every launch configuration is used (hipOccupancyMaxActiveBlocksPerMultiprocessor x #CUs; a grid that
  * does not fit takes the multi-kernel path in the same call); what other work holds of the device at run time cannot be
- * known at launch, so a poll that cannot complete within 20 ms gives up: that solve returns the PREVIOUS plan (the warm
- * start it sampled around, unchanged, and its rollout from the current state — never NaN, never a partial combine),
- * statistics NaN, the flag below is raised and the handle stays on the multi-kernel path from then on.  It never hangs. */
+ * known at launch, so a poll that cannot complete within 20 ms (option "fused_timeout_us": 100 us .. 60 s, for a GPU that is
+ * shared or preempted for longer) gives up: that solve returns the PREVIOUS plan (the warm start it sampled around,
+ * unchanged, and its rollout from the current state — never NaN, never a partial combine), the statistics of THAT solve
+ * are NaN (the `stats_out` of that call: the stale plan is visible in the solve it happened in), the flag below is
+ * raised and the handle stays on the multi-kernel path until mppi_set_option("fused_rearm", 1).  It never hangs. */
 int mppi_fused_error(mppi_handle_t h);
 /* Step 7 inside mppi_finalize (mppi.py:423-443,598-620): Savitzky-Golay smoothing of [history(T-1); a(T)] per control
  * dimension (symmetric-flip padding, valid cross-correlation, keep the last T), applied whenever mppi_finalize is
@@ -425,7 +427,8 @@ int mppi_p2p_exchange(mppi_handle_t h, const float* data_dev, float* gathered_ou
 int mppi_p2p_error(mppi_handle_t h);
 
 /* Tuning knobs (not in the reference): "math" 0 = library sin/cos/tan/fmod/div, 1 = range-checked polynomial
- * fast paths, 2 = 1 + the hardware sin/cos for model-bounded arguments (default); "fused_solve" (see mppi_fused_error);
+ * fast paths, 2 = 1 + the hardware sin/cos for model-bounded arguments (default); "fused_solve", "fused_timeout_us", "fused_rearm" (see mppi_fused_error);
+ * "lazy_state_seq" (see mppi_join_state_seq; off by default);
  * "essps_cold" (any value): the next ESSPS search of this handle starts from the geometric grid instead of the one
  * clustered around its last root; "noise_regen" (see mppi_sample); "mapping" 0 = lane per trajectory (default), 1 =
  * the north star's literal wavefront-per-trajectory rollout (comparison only, ~20x slower); "reduce_blocks" grid of the weighted

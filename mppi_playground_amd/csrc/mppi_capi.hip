@@ -50,6 +50,7 @@ struct MppiSolver {
     uint64_t fused_occ_key = 0;        // (math level, LDS bytes) the cached occupancy below belongs to
     int fused_occ_blocks = 0;          // resident blocks of solve_fused_kernel per CU (hipOccupancyMaxActiveBlocksPerMultiprocessor)
     int fused_mode = 1;                // option "fused_solve": 0 = never, 1 = small problems (default), 2 = whenever resident
+    long long fused_timeout_ticks = mppi::FUSED_TIMEOUT_TICKS;  // option "fused_timeout_us" (100 MHz ticks)
     int cu_count = 0;
     double* grid0_dev = nullptr;       // [STATS_L] round-0 grid of the fused LBPS search (ESSPS: essps_dev->grid0)
     double grid0_lo = 0.0, grid0_hi = 0.0;
@@ -129,6 +130,7 @@ struct MppiSolver {
     // options
     int math_fast = 2;
     int reduce_blocks = 512;
+    int reduce_chains = 0;             // option "reduce_chains": 0 = by the grid size, 2 / 4 = pinned (A/B)
     int timing = 0;
     std::vector<hipEvent_t> ev_pool[5];  // per stage (4 = the deferred state sequence): start0, stop0, start1, stop1, ...
     size_t ev_used[5] = {0, 0, 0, 0, 0};
@@ -144,6 +146,8 @@ struct MppiSolver {
     float* b1 = nullptr;                    // [row + MPPI_MAX_DIM_STATE]
     float* pending_state_out = nullptr;     // where the not-yet-rolled-out state sequence of the last solve goes (or null)
     uint32_t pending_serial = 0;            // which solve that is (mppi_join_state_seq)
+    hipStream_t pending_stream = nullptr;   // the stream its finalize ran on: a completion on ANOTHER stream waits for it
+    hipEvent_t lazy_ev = nullptr;           // (created on first use: orders such a completion behind finalize's write of b1)
     uint32_t finalize_serial = 0;
     std::string err;
 };
@@ -368,6 +372,8 @@ P2pCtx p2p_ctx(mppi_handle_t h) {
 
 static int mpo_upload(mppi_handle_t h, double lambda0, double epsilon, double lr, bool lambda_too);
 static int flush_state_seq(mppi_handle_t h, hipStream_t s);
+static int settle_state_seq(mppi_handle_t h);
+static int order_behind_pending(mppi_handle_t h, hipStream_t s);
 
 extern "C" {
 
@@ -534,6 +540,7 @@ int mppi_destroy(mppi_handle_t h) {
         if (h->stage_ev[i]) (void)hipEventDestroy(h->stage_ev[i]);
     }
     for (auto& pool : h->ev_pool) for (auto& e : pool) if (e) (void)hipEventDestroy(e);
+    if (h->lazy_ev) (void)hipEventDestroy(h->lazy_ev);
     (void)hipFree(h->b1);
     delete h;
     return MPPI_OK;
@@ -544,10 +551,7 @@ int mppi_set_model_params(mppi_handle_t h, const float* p, int n) {
     const int need = h->cfg.model == MPPI_MODEL_RACING ? MPPI_RP_COUNT : h->cfg.model == MPPI_MODEL_NAV2D ? MPPI_NP_COUNT
                      : h->cfg.model == MPPI_MODEL_GOALZONE ? MPPI_GP_COUNT : 0;
     if (n != need) return fail(h, MPPI_E_INVALID, "parameter count does not match the model");
-    if (h->pending_state_out) {  // a lazily completed state sequence belongs to the OLD constants: roll it out first (set-up path)
-        HIP_TRY(h, hipDeviceSynchronize());
-        if (int rc = flush_state_seq(h, nullptr)) return rc;
-    }
+    if (int rc = settle_state_seq(h)) return rc;  // a lazily completed state sequence belongs to the OLD constants: roll it out first
     for (int i = 0; i < n; ++i) h->ctx.P[i] = p[i];
     const float* um = h->cfg.u_min; const float* uM = h->cfg.u_max;
     if (h->cfg.model == MPPI_MODEL_GOALZONE) {
@@ -586,6 +590,7 @@ int mppi_upload_map(mppi_handle_t h, int slot, const uint8_t* cells, int nx, int
     const size_t n = (size_t)(nx > 0 ? nx : 0) * (ny > 0 ? ny : 0);
     for (size_t i = 0; i < n; ++i)
         if (cells[i] > 1) return fail(h, MPPI_E_INVALID, "map cells must be 0/1 occupancy");
+    if (int rc = settle_state_seq(h)) return rc;  // (a pending state sequence keeps the kernel variant of ITS solve)
     if (int rc = prepare_map(h, slot, nx, ny, cell, ox, oy)) return rc;
     HIP_TRY(h, hipMemcpy(h->map_cells[slot], cells, n, hipMemcpyHostToDevice));
     refresh_pad(h, nullptr);
@@ -599,6 +604,7 @@ int mppi_build_obstacle_map(mppi_handle_t h, int slot, int nx, int ny, float cel
         return fail(h, MPPI_E_INVALID, "bad obstacle list");
     for (int c = 0; c < n_circles; ++c)
         if (circles[3 * c + 2] < 0) return fail(h, MPPI_E_INVALID, "circle radius must be >= 0 cells");
+    if (int rc = settle_state_seq(h)) return rc;  // (a pending state sequence keeps the kernel variant of ITS solve)
     if (int rc = prepare_map(h, slot, nx, ny, cell, ox, oy)) return rc;
     hipStream_t s = (hipStream_t)stream;
     int32_t *dc = nullptr, *dr = nullptr;
@@ -618,6 +624,7 @@ int mppi_build_obstacle_map(mppi_handle_t h, int slot, int nx, int ny, float cel
 int mppi_build_lane_map(mppi_handle_t h, int slot, int nx, int ny, float cell, float ox, float oy,
                         const int32_t* seeds, int n_seeds, int64_t max_d2, void* stream) {
     if (!h || n_seeds < 1 || !seeds || max_d2 < 0) return fail(h, MPPI_E_INVALID, "bad lane seeds");
+    if (int rc = settle_state_seq(h)) return rc;  // (a pending state sequence keeps the kernel variant of ITS solve)
     if (int rc = prepare_map(h, slot, nx, ny, cell, ox, oy)) return rc;
     hipStream_t s = (hipStream_t)stream;
     int32_t* ds = nullptr;
@@ -934,7 +941,7 @@ int mppi_rollout_cost(mppi_handle_t h, void* stream) {
     // a state sequence still pending from the previous solve (option "lazy_state_seq") rides in one extra block of this
     // launch: its T dependent steps hide behind the N-sample rollout instead of extending the previous solve's tail
     float* ride = h->pending_state_out;
-    h->pending_state_out = nullptr;
+    if (ride) { if (int rc = order_behind_pending(h, s)) return rc; }
     const unsigned grid = (unsigned)((h->d.tiles + 3) / 4) + (ride ? 1u : 0u);
 #define CALL_ROLLOUT(MODEL, FASTV)                                                                    \
     do {                                                                                              \
@@ -953,6 +960,7 @@ int mppi_rollout_cost(mppi_handle_t h, void* stream) {
     MPPI_DISPATCH(h, CALL_ROLLOUT);
 #undef CALL_ROLLOUT
     HIP_TRY(h, hipGetLastError());
+    if (ride) h->pending_state_out = nullptr;  // (cleared only once the launch that carries it went through)
     return MPPI_OK;
 }
 
@@ -1007,12 +1015,15 @@ int mppi_weights_reduce(mppi_handle_t h, float lambda, float* summary_out_dev, v
     const bool gen = h->noise_regen && !h->injected && !h->wide;
     if (!gen && !h->tiles_valid) return fail(h, MPPI_E_STATE, "no noise: call mppi_sample or mppi_inject_noise first");
     const unsigned* mk = h->min_key + h->min_slot;
-#define CALL_REDUCE(GPWV, GENV, WIDEV)                                                                \
-    hipLaunchKernelGGL((weights_reduce_kernel<GPWV, GENV, WIDEV>), grid, dim3(BLOCK), 0, s, h->noise, h->mean, h->costs, mk, \
+#define CALL_REDUCE(GPWV, GENV, WIDEV, CHAINSV)                                                       \
+    hipLaunchKernelGGL((weights_reduce_kernel<GPWV, GENV, WIDEV, CHAINSV>), grid, dim3(BLOCK), 0, s, h->noise, h->mean, h->costs, mk, \
                        h->partials, h->heads, h->d, h->gen, lambda, lam_dev, (const float*)h->coltab)
-    if (h->wide) CALL_REDUCE(8, false, true);
-    else if (gen) CALL_REDUCE(8, true, false);
-    else CALL_REDUCE(8, false, false);
+    // regenerated noise: four chains per basic block while a SIMD holds one or two reduction waves, two beyond (see the kernel)
+    const bool chains4 = h->reduce_chains == 4 || (h->reduce_chains == 0 && blocks * (int64_t)h->nchunks <= 2 * (int64_t)h->cu_count);
+    if (h->wide) CALL_REDUCE(8, false, true, 2);
+    else if (gen && chains4) CALL_REDUCE(8, true, false, 4);
+    else if (gen) CALL_REDUCE(8, true, false, 2);
+    else CALL_REDUCE(8, false, false, 2);
 #undef CALL_REDUCE
     HIP_TRY(h, hipGetLastError());
     // Fold the published partial rows into the shard summary.  Sharded use needs the summary before the
@@ -1082,21 +1093,32 @@ int mppi_finalize(mppi_handle_t h, const float* summaries_dev, int num_shards, f
                        h->partials, h->heads, mk, h->last_reduce_blocks, h->colsp, h->summary, h->live_hint_dev,  \
                        lambda, lam_dev, h->d.row, h->d.T, h->x0_cur, store_mean ? h->mean : (float*)nullptr, action_out,  \
                        defer ? (float*)nullptr : state_out, stats_out, h->solve_stats, sg, p2p, h->ctx,          \
-                       defer ? h->b1 : (float*)nullptr)
+                       defer ? h->b1 : (float*)nullptr, defer ? state_out : (float*)nullptr)
         MPPI_DISPATCH(h, CALL_FINALIZE);
 #undef CALL_FINALIZE
     }
     HIP_TRY(h, hipGetLastError());
     ++h->finalize_serial;
-    if (defer) { h->pending_state_out = state_out; h->pending_serial = h->finalize_serial; }
+    if (defer) { h->pending_state_out = state_out; h->pending_serial = h->finalize_serial; h->pending_stream = s; }
     return MPPI_OK;
 }
 
-// The pending batch-1 rollout as its own one-wave kernel on `s` (same code and bits as the in-kernel rollout).
+// A pending state sequence is about to be completed on `s`: if that is not the stream its finalize_kernel ran on, order `s`
+// behind everything enqueued there so far (an event recorded NOW on the producing stream sits after finalize's write of b1).
+static int order_behind_pending(mppi_handle_t h, hipStream_t s) {
+    if (s == h->pending_stream) return MPPI_OK;
+    if (!h->lazy_ev) HIP_TRY(h, hipEventCreateWithFlags(&h->lazy_ev, hipEventDisableTiming));
+    HIP_TRY(h, hipEventRecord(h->lazy_ev, h->pending_stream));
+    HIP_TRY(h, hipStreamWaitEvent(s, h->lazy_ev, 0));
+    return MPPI_OK;
+}
+
+// The pending batch-1 rollout as its own one-wave kernel on `s` (same code and bits as the in-kernel rollout).  The pending
+// mark is cleared only once the launch went through.
 static int flush_state_seq(mppi_handle_t h, hipStream_t s) {
     if (!h->pending_state_out) return MPPI_OK;
     float* out = h->pending_state_out;
-    h->pending_state_out = nullptr;
+    if (int rc = order_behind_pending(h, s)) return rc;
     const size_t sh1 = sizeof(float) * ((size_t)h->d.row + MPPI_MAX_DIM_STATE);
     StageTimer tm(h, 4, s);
 #define CALL_STATE_SEQ(MODEL, FASTV)                                                                  \
@@ -1105,8 +1127,13 @@ static int flush_state_seq(mppi_handle_t h, hipStream_t s) {
     MPPI_DISPATCH(h, CALL_STATE_SEQ);
 #undef CALL_STATE_SEQ
     HIP_TRY(h, hipGetLastError());
+    h->pending_state_out = nullptr;
     return MPPI_OK;
 }
+// Before anything that changes which kernel variant MPPI_DISPATCH picks or what the model context holds (math level,
+// mapping, maps, model parameters): complete a pending state sequence with the settings of the solve it belongs to, on the
+// stream that solve ran on.
+static int settle_state_seq(mppi_handle_t h) { return h->pending_state_out ? flush_state_seq(h, h->pending_stream) : MPPI_OK; }
 
 // Complete the state sequence of the last mppi_finalize / mppi_solve on `stream` if its rollout is still pending (option
 // "lazy_state_seq"); a no-op otherwise.  `serial` = 0, or the value mppi_state_seq_serial returned right after that solve:
@@ -1190,7 +1217,6 @@ static int solve_fused(mppi_handle_t h, float lambda, float* action_out, float* 
         h->grid0_lo = h->auto_lo; h->grid0_hi = h->auto_hi;
     }
     if (!dev && !(lambda > 0.0f)) return fail(h, MPPI_E_INVALID, "lambda must be > 0");
-    StageTimer tm(h, 1, s);
     h->min_slot ^= 1;
     ++h->fused_seq;
     if (h->fused_seq == 0) h->fused_seq = 1;
@@ -1210,7 +1236,7 @@ static int solve_fused(mppi_handle_t h, float lambda, float* action_out, float* 
     A.mean_store = h->mean; A.action_out = action_out; A.state_out = state_out; A.stats_out = stats_out;
     A.stats_keep = h->solve_stats; A.summary_out = h->summary;
     const SgFilter sg{h->sg_coeffs, h->sg_history, h->sg_window};
-    const FusedCtx fx{h->fused_cells, h->fused_error_dev, h->fused_seq};
+    const FusedCtx fx{h->fused_cells, h->fused_error_dev, h->fused_seq, h->fused_timeout_ticks};
     // G = min(#CUs, ceil(N / 64)) blocks, each owning spb (a multiple of 64, <= 1024) consecutive trajectories: ONE wave
     // of rollouts per block as long as there are CUs left (the rest of its 1024 threads share the block's reductions and
     // the regeneration of its weighted noise rows, which a block of 256 trajectories spends ~5 us on)
@@ -1235,6 +1261,7 @@ static int solve_fused(mppi_handle_t h, float lambda, float* action_out, float* 
             h->fused_occ_key = okey; h->fused_occ_blocks = nb;                                                             \
         }                                                                                                                  \
         if ((int64_t)grid > (int64_t)h->fused_occ_blocks * h->cu_count) { *declined = true; break; }                       \
+        StageTimer tm(h, 1, s);  /* (after the occupancy check: a declined launch leaves no empty event pair behind) */    \
         hipLaunchKernelGGL((solve_fused_kernel<MODEL, FASTV>), dim3(grid), dim3(FUSED_BLOCK), shmem, s, A, h->d, h->gen, h->ctx, sg, fx); \
     } while (0)
     MPPI_DISPATCH(h, CALL_FUSED);
@@ -1897,6 +1924,7 @@ int mppi_p2p_error(mppi_handle_t h) { return (h && h->p2p_error) ? *(volatile in
 int mppi_set_option(mppi_handle_t h, const char* key, int64_t value) {
     if (!h || !key) return MPPI_E_INVALID;
     const std::string k(key);
+    if (k == "math" || k == "mapping") { if (int rc = settle_state_seq(h)) return rc; }  // (a pending state sequence keeps ITS solve's variant)
     if (k == "math") { h->math_fast = value < 0 ? 0 : value > 2 ? 2 : (int)value; return MPPI_OK; }
     if (k == "reduce_blocks") { h->reduce_blocks = (int)std::max<int64_t>(1, std::min<int64_t>(value, 2048)); return MPPI_OK; }
     if (k == "timing") { h->timing = (int)value; return MPPI_OK; }
@@ -1906,7 +1934,17 @@ int mppi_set_option(mppi_handle_t h, const char* key, int64_t value) {
         h->essps_prev_host.warm = false;
         return MPPI_OK;
     }
+    if (k == "reduce_chains") { h->reduce_chains = value == 2 ? 2 : value == 4 ? 4 : 0; return MPPI_OK; }
     if (k == "fused_solve") { h->fused_mode = value < 0 ? 0 : value > 2 ? 2 : (int)value; return MPPI_OK; }
+    if (k == "fused_timeout_us") {  // poll budget of the single-launch solve (default 20 000 us; 100 MHz ticks inside)
+        if (value < 100 || value > 60000000) return fail(h, MPPI_E_INVALID, "fused_timeout_us: 100 us .. 60 s");
+        h->fused_timeout_ticks = (long long)value * 100;
+        return MPPI_OK;
+    }
+    if (k == "fused_rearm") {  // after a timed-out poll demoted the handle: allow the single launch again
+        if (h->fused_error) *(volatile int*)h->fused_error = 0;
+        return MPPI_OK;
+    }
     if (k == "lazy_state_seq") {  // see mppi_join_state_seq
         if (value && !h->b1) HIP_TRY(h, hipMalloc(&h->b1, sizeof(float) * ((size_t)h->d.row + MPPI_MAX_DIM_STATE)));
         h->lazy_state = value ? 1 : 0;

@@ -467,7 +467,10 @@ constexpr int REDUCE_MAX_BLOCKS = 2048;
 #ifndef MPPI_REDUCE_ATTR
 #define MPPI_REDUCE_ATTR  // (A/B knob of scripts/build_variant.sh, e.g. __attribute__((amdgpu_waves_per_eu(2,3))))
 #endif
-template <int GPW, bool GEN, bool WIDE = false>  // GPW: float4 groups per wave and column chunk (8: the host launches ceil(R / 32) chunks)
+// CHAINS: Philox + Box-Muller chains per basic block of the regenerating reduction.  4: a lone wave per SIMD (grids of a few
+// hundred blocks: C2) hides the chains' latencies inside its own instruction stream, 104 VGPRs; 2: 72 VGPRs = seven waves
+// per SIMD, the interleaving comes from the other waves (C3 / C5 sizes).  The host picks by the tile count.
+template <int GPW, bool GEN, bool WIDE = false, int CHAINS = 2>  // GPW: float4 groups per wave and column chunk (8: the host launches ceil(R / 32) chunks)
 __global__ __launch_bounds__(BLOCK) MPPI_REDUCE_ATTR void weights_reduce_kernel(const float4* __restrict__ noise,
                                                                const float* __restrict__ mean,
                                                                const float* __restrict__ costs,
@@ -483,7 +486,9 @@ __global__ __launch_bounds__(BLOCK) MPPI_REDUCE_ATTR void weights_reduce_kernel(
     constexpr int NW = BLOCK / WAVE;
     constexpr int CHG = NW * GPW;  // float4 groups per column chunk
     constexpr int TPW = 8;
-    __shared__ float s_red[NW][32][WAVE + 1];
+    constexpr int RP = 8;  // accumulators combined per pass of the cross-lane sum (round 5: 8, was 32 — 33 KB of LDS for a
+                           // tile used once after the loop held the kernel at three waves per SIMD)
+    __shared__ float s_red[NW][RP][WAVE + 1];
     __shared__ float s_e[NW][TPW][WAVE];
     __shared__ unsigned s_live[NW];
     __shared__ float s_head[NW][4];
@@ -573,20 +578,45 @@ __global__ __launch_bounds__(BLOCK) MPPI_REDUCE_ATTR void weights_reduce_kernel(
                     }
                 };
                 if constexpr (GEN) {
-                    // Regenerated noise: the wave's groups are predicated FOUR AT A TIME, so that four independent
-                    // Philox + Box-Muller chains (10 dependent 64-bit multiplies each) sit in one basic block and
-                    // overlap — a per-group branch serialised them, and with two waves per SIMD the dense reduction
-                    // ran at 0.39 of the VALU issue peak.  A group past the row length (the chunk holds CHG = 32
-                    // slots, racing's row 25) costs arithmetic only: its accumulators are columns the fold drops.
+                    // Regenerated noise: the wave's groups are taken FOUR AT A TIME while four exist, so that four
+                    // independent Philox + Box-Muller chains (10 dependent 64-bit multiplies each) sit in one basic block
+                    // and overlap — a per-group branch serialised them.  The tail of the row is a pair and / or a single
+                    // group (round 5): predicating whole quads generated 32 groups per tile for racing's / nav2d's
+                    // 25-group rows — 22 % of the second noise generation of a dense solve for columns the fold drops.
+                    const auto quad = [&](int m0) {
+                        float4 n4[4];
 #pragma unroll
-                    for (int m0 = 0; m0 < GPW; m0 += 4) {
-                        if (NW * m0 < nrl) {
-                            float4 n4[4];
+                        for (int k = 0; k < 4; ++k) n4[k] = noise_group<true>(np, r0 + wid + NW * (m0 + k), gi, gen, d);
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) n4[k] = noise_group<true>(np, r0 + wid + NW * (m0 + k), gi, gen, d);
+                        for (int k = 0; k < 4; ++k) accumulate(m0 + k, n4[k]);
+                    };
+                    const auto pair = [&](int m0) {
+                        float4 n4[2];
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) accumulate(m0 + k, n4[k]);
-                        }
+                        for (int k = 0; k < 2; ++k) n4[k] = noise_group<true>(np, r0 + wid + NW * (m0 + k), gi, gen, d);
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) accumulate(m0 + k, n4[k]);
+                    };
+                    const auto single = [&](int m) { accumulate(m, noise_group<true>(np, r0 + wid + NW * m, gi, gen, d)); };
+                    static_assert(GPW == 8, "the tail cases below are written for eight groups per wave");
+                    // live groups of this wave: m = 0 .. cnt-1 with cnt = ceil(nrl / NW) clamped to [0, GPW]
+                    if constexpr (CHAINS == 4) {
+                    if (NW * 7 < nrl) { quad(0); quad(4); }
+                    else if (NW * 3 < nrl) {
+                        quad(0);
+                        if (NW * 5 < nrl) { pair(4); if (NW * 6 < nrl) single(6); }
+                        else if (NW * 4 < nrl) single(4);
+                    } else {
+                        if (NW * 1 < nrl) { pair(0); if (NW * 2 < nrl) single(2); }
+                        else if (0 < nrl) single(0);
+                    }
+                    } else {
+                    (void)quad;
+#pragma unroll
+                    for (int m0 = 0; m0 < GPW; m0 += 2) {
+                        if (NW * (m0 + 1) < nrl) pair(m0);
+                        else if (NW * m0 < nrl) single(m0);
+                    }
                     }
                 } else {
 #pragma unroll
@@ -597,25 +627,25 @@ __global__ __launch_bounds__(BLOCK) MPPI_REDUCE_ATTR void weights_reduce_kernel(
         }
         __syncthreads();  // s_e / s_live are rewritten by the next round
     }
-    // cross-lane reduction, 32 accumulators per pass: every lane stores its 32 values as a column of
-    // s_red[wid][j][lane]; lane l then sums row j = l & 31 over lanes [32*(l>>5), +32) (row stride 65
-    // floats: conflict-free), and the two halves are added with one shuffle.  Accumulator 4*m + j of wave
+    // cross-lane reduction, RP = 8 accumulators per pass: every lane stores its 8 values as a column of
+    // s_red[wid][j][lane]; lane l then sums row j = l & 7 over the 8 lanes [8*(l>>3), +8) (row stride 65 floats:
+    // conflict-free), and the eight segments are added with three shuffles.  Accumulator 4*m + j of wave
     // w is column 4*(r0 + w + NW*m) + j of the row.
     const int colsp = gridDim.y * CHG * 4;
     if (block_live) {
 #pragma unroll
-        for (int p = 0; p < NACC / 32; ++p) {
+        for (int p = 0; p < NACC / RP; ++p) {
 #pragma unroll
-            for (int j = 0; j < 32; ++j) s_red[wid][j][lane] = acc[p * 32 + j];
+            for (int j = 0; j < RP; ++j) s_red[wid][j][lane] = acc[p * RP + j];
             __builtin_amdgcn_wave_barrier();
-            const float* rowp = &s_red[wid][lane & 31][(lane >> 5) * 32];
-            float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f;
-#pragma unroll
-            for (int k = 0; k < 32; k += 4) { v0 += rowp[k]; v1 += rowp[k + 1]; v2 += rowp[k + 2]; v3 += rowp[k + 3]; }
+            const float* rowp = &s_red[wid][lane & (RP - 1)][(lane >> 3) * 8];
+            float v0 = rowp[0] + rowp[1], v1 = rowp[2] + rowp[3], v2 = rowp[4] + rowp[5], v3 = rowp[6] + rowp[7];
             float v = (v0 + v1) + (v2 + v3);
+            v += __shfl_xor(v, 8);
+            v += __shfl_xor(v, 16);
             v += __shfl_xor(v, 32);
-            if (lane < 32) {
-                const int a = p * 32 + lane;
+            if (lane < RP) {
+                const int a = p * RP + lane;
                 const int col = 4 * (r0 + wid + NW * (a >> 2)) + (a & 3);
                 partials[(int64_t)blockIdx.x * colsp + col] = v;
             }
@@ -895,7 +925,7 @@ __device__ __forceinline__ void finalize_tail(const float* summaries, int num_sh
                                               float* __restrict__ mean_store, float* __restrict__ action_out,
                                               float* __restrict__ state_out, float* __restrict__ stats_out,
                                               float* __restrict__ stats_keep, const SgFilter& sg, const ModelCtx& ctx,
-                                              float* __restrict__ b1_out = nullptr) {
+                                              float* __restrict__ b1_out = nullptr, float* __restrict__ poison_out = nullptr) {
     const int stride = MPPI_SUMMARY_HEAD + row;
     float xmax = -INFINITY, cmin = INFINITY;
     for (int g = 0; g < num_shards; ++g) {
@@ -970,6 +1000,10 @@ __device__ __forceinline__ void finalize_tail(const float* summaries, int num_sh
     if (b1_out) {  // the batch-1 rollout is deferred to state_seq_kernel: leave its inputs behind (final action, start state)
         for (int cidx = threadIdx.x; cidx < row; cidx += FIN_BLOCK) b1_out[cidx] = s_act[cidx];
         if (threadIdx.x < ModelT<MODEL, FAST>::DS) b1_out[row + threadIdx.x] = s_x0[threadIdx.x];
+        // ... and void the caller's buffer until the rollout lands in it: a reader that bypasses the join (a raw pointer
+        // handed to another library, a different stream) sees NaN, not the previous solve's states or uninitialised memory
+        if (poison_out)
+            for (int c = threadIdx.x; c < (T + 1) * ModelT<MODEL, FAST>::DS; c += FIN_BLOCK) poison_out[c] = __uint_as_float(0x7fc00000u);
     }
     if (!state_out) return;
     batch1_rollout<MODEL, FAST>(ctx, s_x0, s_act, T, state_out);
@@ -999,7 +1033,8 @@ __global__ __launch_bounds__(FIN_BLOCK) void finalize_kernel(const float* __rest
                                                              float* __restrict__ state_out,
                                                              float* __restrict__ stats_out,
                                                              float* __restrict__ stats_keep, SgFilter sg,
-                                                             P2pCtx p2p, ModelCtx ctx, float* __restrict__ b1_out) {
+                                                             P2pCtx p2p, ModelCtx ctx, float* __restrict__ b1_out,
+                                                             float* __restrict__ poison_out) {
     const float lambda = lambda_dev ? *lambda_dev : lambda_arg;
     // issued before the first barrier so that their latency hides behind the fold: the shard minimum and the start
     // state of the batch-1 rollout (both would otherwise be dependent loads at the end of the chain)
@@ -1023,6 +1058,7 @@ __global__ __launch_bounds__(FIN_BLOCK) void finalize_kernel(const float* __rest
             for (int c = threadIdx.x; c < row; c += FIN_BLOCK) if (action_out) action_out[c] = nanv;
             for (int c = threadIdx.x; c < (T + 1) * DSN; c += FIN_BLOCK) if (state_out) state_out[c] = nanv;
             for (int c = threadIdx.x; c < row + DSN; c += FIN_BLOCK) if (b1_out) b1_out[c] = nanv;  // (a lazily completed state sequence is void too)
+            for (int c = threadIdx.x; c < (T + 1) * DSN; c += FIN_BLOCK) if (poison_out) poison_out[c] = nanv;
             if (threadIdx.x < 4 && stats_out) stats_out[threadIdx.x] = nanv;
             return;
         }
@@ -1074,7 +1110,7 @@ __global__ __launch_bounds__(FIN_BLOCK) void finalize_kernel(const float* __rest
         num_shards = 1;
     }
     finalize_tail<MODEL, FAST>(summaries, num_shards, lambda, row, T, s_x0, s_act, s_yp, mean_store, action_out, state_out,
-                               stats_out, stats_keep, sg, ctx, b1_out);
+                               stats_out, stats_keep, sg, ctx, b1_out, poison_out);
 }
 
 // Softmax statistics of the cost vector for one temperature — the device half of the auto-lambda
@@ -1589,14 +1625,16 @@ constexpr int FUSED_SMALL_BLOCKS = 32;       // up to this many blocks no hop is
 constexpr int FX_CELLS = FUSED_MAX_ROW + 8;  // per (phase, block): >= 4 + row, >= 97
 enum { FX_MIN = 0, FX_STATS = 1 /* +2*round */, FX_BCAST = 2 /* +2*round */, FX_ROW = 7, FX_PHASES = 8 };
 enum { FUSED_RULE_NONE = 0, FUSED_RULE_ESSPS = 1, FUSED_RULE_LBPS = 2 };
-// A poll that cannot complete within this long gives up (100 MHz wall clock: 20 ms — three orders of magnitude above the
-// ~30 us a healthy single-launch solve takes, short enough for a control loop to notice within a tick or two): a block
-// of this launch is not resident, i.e. something else holds the GPU's CUs.
+// A poll that cannot complete within `timeout_ticks` gives up (100 MHz wall clock; default 20 ms — three orders of magnitude
+// above the ~30 us a healthy single-launch solve takes, short enough for a control loop to notice within a tick or two;
+// option "fused_timeout_us" for a GPU that is shared or preempted for longer): a block of this launch is not resident, i.e.
+// something else holds the GPU's CUs.
 constexpr long long FUSED_TIMEOUT_TICKS = 2000000ll;
 struct FusedCtx {
     unsigned long long* cells;  // [FX_PHASES][FUSED_MAX_BLOCKS][FX_CELLS]
     int* error;                 // mapped host flag
     unsigned seq;               // this solve's number (never 0)
+    long long timeout_ticks;    // poll budget
 };
 __device__ __forceinline__ unsigned long long* fx_cell(const FusedCtx& x, int phase, int b, int j) {
     return x.cells + ((size_t)phase * FUSED_MAX_BLOCKS + b) * FX_CELLS + j;
@@ -1609,7 +1647,7 @@ __device__ __forceinline__ float fx_wait(const FusedCtx& x, const unsigned long 
                                          bool& timed_out) {
     unsigned spins = 0;
     while ((unsigned)(cell >> 32) != x.seq) {
-        if ((++spins & 255u) == 0u && wall_clock64() - t0 > FUSED_TIMEOUT_TICKS) { timed_out = true; break; }
+        if ((++spins & 255u) == 0u && wall_clock64() - t0 > x.timeout_ticks) { timed_out = true; break; }
         __builtin_amdgcn_s_sleep(2);
         cell = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }

@@ -145,7 +145,7 @@ class MPPI(nn.Module):
         process_group=None,
         auto_lambda_stats: str = "device",
         essps_search: str = "device",
-        lbps_search: str = "device",
+        lbps_search: str = "brent",
         sg_filter: str = "device",
         graph_callables: bool = False,
         lazy_state_seq: Optional[bool] = None,
@@ -168,14 +168,17 @@ class MPPI(nn.Module):
                 statistics back after each pass; "brentq" probes one lambda at a time like the reference's scipy
                 call.  All return the same root (to ~1e-6 relative).  Sharded solvers combine the shards'
                 statistics on the host ("device" behaves like "grid" there).
-            lbps_search: with device statistics on one GPU, "device" (default) replaces the reference's ~25 dependent Brent
-                probes by two 32-temperature grids + the minimiser of the quartic through the five grid points around the
-                minimum, all as kernels (no host wait).  On exact statistics that is the float64 minimiser to 3e-7; the
-                REFERENCE's own Brent stops 6e-5..5e-3 away from it (xatol = 1e-5 absolute, short of a bound it never
-                evaluates, on an objective that is flat to fp32 noise for nav2d: its temperature moves by up to 1e-2 under
-                1-ulp changes of its costs — the `band_rule` entries of tests/golden/), so the two agree to max(1e-3, that
-                measured spread), not to ESSPS's 1e-5.  "brent" runs scipy's bounded Brent inside the library, one read-back
-                per probe (the reference's algorithm on the device's statistics).
+            lbps_search: with device statistics on one GPU.  "brent" (default since round 5) is the reference's own
+                algorithm (mppi.py:341-349: scipy's bounded Brent, ported step for step in csrc/host_search.hpp) inside
+                the library, one read-back of the device's softmax statistics per probe — the north star's split (auto-lambda
+                on the host) and the rule that lands where the reference lands: within its own measured spread on every
+                LBPS fixture (2.7e-5 .. 2.8e-3 against bands of 5.8e-5 .. 1.4e-2).  "device" is the opt-in fast path:
+                two 32-temperature grids + the minimiser of the quartic through the five grid points around the minimum,
+                all as kernels (no host wait; C2: 64 us per solve instead of ~1 ms).  On exact statistics it returns the
+                float64 minimiser to 3e-7 — the REFERENCE's Brent stops 6e-5..5e-3 away from that (xatol = 1e-5 absolute,
+                short of a bound it never evaluates, on an objective that is flat to fp32 noise for nav2d: its temperature
+                moves by up to 1e-2 under 1-ulp changes of its costs — the `band_rule` entries of tests/golden/), so
+                "device" agrees with the reference to that spread only.
                 The MPO dual always steps on the device when the statistics are the device's own.
             sg_filter: "device" (default) runs the Savitzky-Golay step inside the finalize kernel
                 (bit-identical to the host statement), "host" keeps the reference's numpy-style round trip.
@@ -186,12 +189,14 @@ class MPPI(nn.Module):
                 data-dependent shapes (boolean-mask assignment is not capturable), and an `info` dict used as the
                 reference documents it (tensor views + the integer `t`).  If the capture fails the solver says so once
                 and stays on the eager loops.
-            lazy_state_seq: native models on the multi-kernel path.  True: the batch-1 rollout of the solution
-                (`state_seq`, mppi.py:448-449: T dependent steps of one wave, 5.8 us of a 146 us racing solve) leaves the
-                solve's last kernel; it rides in one extra block of the NEXT solve's rollout launch, or is launched on the
-                spot when `state_seq` is used first (_DeferredStateSeq) — same code, same bits.  None (default): on when
-                this rank holds more than 16 384 samples (below that the solve is a single launch that rolls out itself,
-                or short enough for callers that look at `state_seq` every tick to lose more than they gain).  False: off.
+            lazy_state_seq: native models on the multi-kernel path; OPT-IN (default None / False: forward() returns a
+                completed plain tensor, like the reference).  True: the batch-1 rollout of the solution (`state_seq`,
+                mppi.py:448-449: T dependent steps of one wave, 5.8 us of a 146 us racing solve) leaves the solve's last
+                kernel; it rides in one extra block of the NEXT solve's rollout launch, or is launched on the spot when
+                `state_seq` is used first through torch (_DeferredStateSeq) — same code, same bits.  Until then the
+                returned buffer holds NaN (a reader that bypasses torch — a raw data_ptr(), another library — must call
+                `join_state_seq()` first; a completion on another stream is ordered behind the solve's stream).  For
+                control loops that do not look at `state_seq` every tick (bench.py passes True and says so in its line).
             shard_samples: treat `num_samples` as the GLOBAL sample count and let this rank own the
                 contiguous block rank*N/W .. (rank+1)*N/W of it (torch.distributed must be
                 initialised); the 4+T*dc-float shard summaries are exchanged once per solve with one RCCL
@@ -397,8 +402,7 @@ class MPPI(nn.Module):
                           and not (use_sg_filter and not self._sg_on_device)
                           and (self._auto_lambda is None or self._rule_on_device is not None))
         # the batch-1 rollout of the solution completed lazily (see `lazy_state_seq` above)
-        want = lazy_state_seq if lazy_state_seq is not None else self._local_samples > 16384
-        self._lazy_state = bool(want and self._model is not None and not (use_sg_filter and not self._sg_on_device))
+        self._lazy_state = bool(lazy_state_seq and self._model is not None and not (use_sg_filter and not self._sg_on_device))
         if self._lazy_state:
             self._h.call("mppi_set_option", b"lazy_state_seq", 1)
         self._last_lambda = None
@@ -429,6 +433,31 @@ class MPPI(nn.Module):
             t = torch.zeros(1, device=self._device, dtype=torch.float32)
             self._log_temperature_is_view = False
         self.log_temperature = nn.Parameter(t, requires_grad=False)
+        if not self.__dict__.get("_log_temperature_hooked"):
+            self._log_temperature_hooked = True
+            self.register_load_state_dict_post_hook(MPPI._after_load_state_dict)
+
+    @staticmethod
+    def _after_load_state_dict(module, incompatible_keys) -> None:
+        """load_state_dict() copied a value into `log_temperature` — i.e. straight into the library's dual.  The temperature
+        the next solve uses and the Adam moments are derived state the library keeps next to it: restart the dual from the
+        loaded value (mppi_mpo_reset: lambda = exp(log T), moments zero, like a freshly constructed reference solver whose
+        parameter was loaded before its optimizer state) instead of leaving them stale."""
+        if module.__dict__.get("_auto_lambda") == "MPO" and module._rule_on_device == "MPO":
+            v = float(module.log_temperature.detach().cpu()[0])
+            module._h.call("mppi_mpo_reset", float(np.exp(v)), 0.1, 0.2)
+            module._lambda_value = float(np.exp(v))
+            module._bind_log_temperature()
+
+    def _apply(self, fn, *args, **kwargs):
+        """module.to() / .float() / .cpu() replace every Parameter by a converted COPY — for `log_temperature` that would be a
+        detached value going stale while the library keeps stepping its own dual.  The solver is bound to its device and
+        dtype (the reference's constructor arguments, mppi.py:45-46), so after the conversion the parameter is re-bound to
+        the library's dual."""
+        out = super()._apply(fn, *args, **kwargs)
+        if self.__dict__.get("_log_temperature_is_view") is not None and "log_temperature" in self._parameters:
+            self._bind_log_temperature()
+        return out
 
     def _push_auto_lambda(self) -> None:
         """The device-resident ESSPS / LBPS rule reads its parameters from the handle (mppi_set_auto_lambda), the reference
@@ -706,6 +735,8 @@ class MPPI(nn.Module):
 
     def set_option(self, key: str, value: int) -> None:
         self._h.call("mppi_set_option", key.encode(), int(value))
+        if key == "fused_rearm":
+            self._fused_error_seen = False
 
     def reset(self):
         """Reset the previous action sequence (src/pi_mpc/mppi.py:212-221)."""
@@ -1006,9 +1037,11 @@ class MPPI(nn.Module):
         self._refresh_model_inputs()
         if not self._fused_error_seen and h.lib.mppi_fused_error(h.h):
             self._fused_error_seen = True  # (from now on the library stays on the multi-kernel path)
-            raise _capi.MppiError("a single-launch solve gave up waiting for one of its blocks after 20 ms (is the GPU shared with "
-                                  "other work?): that solve returned the previous plan instead of a new one; later solves use "
-                                  "the multi-kernel path")
+            raise _capi.MppiError("a single-launch solve gave up waiting for one of its blocks (default budget 20 ms; is the GPU "
+                                  "shared with other work?): that solve returned the previous plan instead of a new one and NaN "
+                                  "statistics (last_stats()); later solves use the multi-kernel path.  "
+                                  "set_option('fused_timeout_us', ...) widens the budget, set_option('fused_rearm', 1) allows "
+                                  "the single launch again")
         self._mean_of_last_solve = self._previous_action_seq
         if self._auto_lambda is None:
             lam = float(self._lambda_value)

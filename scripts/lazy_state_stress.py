@@ -32,7 +32,7 @@ cases = (
                                                           use_sg_filter=True, **k), lambda: t([0.01, 0.0, 0.02, 0.0]).cuda()),
 )
 for name, make, start in cases:
-    lazy, eager = make(), make(lazy_state_seq=False)
+    lazy, eager = make(lazy_state_seq=True), make()
     assert lazy._lazy_state and not eager._lazy_state
     x = start()
     per = n_solves // len(cases)

@@ -7,10 +7,16 @@ inputs/outputs of ``pi_mpc.mppi.MPPI.forward`` for the five shipped models into 
 bytecode) is written into the fixtures: they hold arrays only.
 
 Usage (container only; the GPU box has no /root/reference):
-    python tests/golden/make_golden.py            # everything
+    python tests/golden/make_golden.py            # every small case (N <= 4096) + env artefacts + RNG stream + model pins
     python tests/golden/make_golden.py round2     # only the cases added in round 2 (dense softmax at N = 4096,
                                                   # racing / nav2d with SG, exploration, LBPS, MPO, ESSPS end point,
                                                   # get_samples_from_posterior between two solves)
+    python tests/golden/make_golden.py round5     # only the cases added in round 5 (LBPS / MPO at N = 4096 on nav2d and
+                                                  # racing, ESSPS clamped at lambda_min and at lambda_max; noise by seed)
+    python tests/golden/make_golden.py fullsize [c2|c5|c3 ...]
+                                                  # BASELINE.json's configs at FULL size through the real reference,
+                                                  # seed 42, two closed-loop solves; outputs and summaries only (< 100 KB)
+    python tests/golden/make_golden.py only <substring> [...]   # the small cases whose name contains a substring
 
 Recipe follows SURVEY.md Appendix C: stub the UI-only imports (moviepy, fire,
 gymnasium), run with cwd=/root/reference (racing_env.py:47-49 opens a relative CSV),
@@ -118,17 +124,24 @@ def torch_zeros_like(t):
 # north star asks of action_seq / state_seq is a statement about the costs to ~1e-5 * lambda — below one fp32 ulp of the
 # cost for nav2d / goal zone at lambda = 1.  Instead of deriving a tolerance analytically, every fixture records how far
 # the reference's own outputs move when its total costs are replaced by equally valid fp32 evaluations of the same
-# sums.  VARIANTS (index = column of every band array):
-#   0-15  every total cost moved to the next fp32 value up or down (seeded random signs): a 1-ulp change
-#   16     the T stage costs + terminal re-summed in float64, rounded once to fp32 (the exactly rounded sum — what the
-#          HIP kernels compute for every model but racing, mppi_models.hpp: CostSum)
-#   17     the same terms summed sequentially in fp32, t = 0..T-1 then the terminal (another valid fp32 order — the
-#          racing kernel's; torch.sum's own order is a vectorised cascade that depends on the CPU's ISA)
-#   18-23  every stage cost and the terminal moved by one fp32 ulp (seeded signs), then summed by the reference's own
-#          torch.sum(dim=1) + terminal: what a different-but-valid fp32 evaluation of each stage cost would do
-# A band is the maximum over the variants: a sample of the reference's spread under rounding-level changes of its costs
-# (24 probes), against which the tests hold the HIP path's distance to the reference: err <= max(1e-5, band).
-BAND_VARIANTS = tuple(f"ulp_{i}" for i in range(16)) + ("f64sum", "seqsum") + tuple(f"stage_ulp_{i}" for i in range(6))
+# sums.
+# VARIANTS (index = row of every band array; round 5: 256 probes instead of 24, so that a band is a measurement — the tests
+# hold the HIP path to 1.0 x the sample maximum and the report also gives the 99th percentile):
+#   ulp_0..159        every total cost moved to the next fp32 value up or down (seeded random signs): a 1-ulp change
+#   f64sum            the T stage costs + terminal re-summed in float64, rounded once to fp32 (the exactly rounded sum —
+#                     what the HIP kernels compute for every model but racing, mppi_models.hpp: CostSum)
+#   seqsum / revsum   the same terms summed sequentially in fp32, t = 0..T-1 then the terminal (the racing kernel's
+#                     order) / terminal first, then t = T-1..0
+#   pairsum           the same terms summed as a balanced pairwise tree in fp32 (torch.sum's own order is a vectorised
+#                     cascade that depends on the CPU's ISA: all of these are valid fp32 evaluations of the same sum)
+#   stage_ulp_0..91   every stage cost and the terminal moved by one fp32 ulp (seeded signs), then summed by the
+#                     reference's own torch.sum(dim=1) + terminal: a different-but-valid fp32 evaluation of each term
+# A band is the maximum over the variants: a sample of the reference's spread under rounding-level changes of its costs,
+# against which the tests hold the HIP path's distance to the reference: err <= max(1e-5, band).
+N_ULP, N_STAGE_ULP = 160, 92
+BAND_VARIANTS = (tuple(f"ulp_{i}" for i in range(N_ULP)) + ("f64sum", "seqsum", "revsum", "pairsum")
+                 + tuple(f"stage_ulp_{i}" for i in range(N_STAGE_ULP)))
+assert len(BAND_VARIANTS) == 256
 
 
 def _variant_costs(v: int, costs, stage, terminal):
@@ -146,10 +159,37 @@ def _variant_costs(v: int, costs, stage, terminal):
         for t in range(stage.shape[1]):
             acc = acc + stage[:, t]
         return acc + terminal
+    if name == "revsum":
+        acc = terminal.clone()
+        for t in reversed(range(stage.shape[1])):
+            acc = acc + stage[:, t]
+        return acc
+    if name == "pairsum":
+        terms = [stage[:, t] for t in range(stage.shape[1])] + [terminal]
+        while len(terms) > 1:
+            terms = [terms[i] + terms[i + 1] if i + 1 < len(terms) else terms[i] for i in range(0, len(terms), 2)]
+        return terms[0]
     sign = torch.from_numpy(rng.choice(np.float32([-1.0, 1.0]), size=tuple(stage.shape)))
     st = torch.nextafter(stage, stage + sign * float("inf"))
     sign_t = torch.from_numpy(rng.choice(np.float32([-1.0, 1.0]), size=terminal.shape[0]))
     return torch.sum(st, dim=1) + torch.nextafter(terminal, terminal + sign_t * float("inf"))
+
+
+class FeedDynamics:
+    """Wraps the dynamics callable of a recorded solver.  While the Recorder feeds prescribed total costs, the N-sample
+    rollout (mppi.py:280-336) cannot influence anything the probes measure — steps 4-8 read the costs, the clamped
+    actions and, for state_seq, the batch-1 rollout only — so the N-row calls return their input untouched and the 256
+    probes per solve cost a softmax each instead of a rollout each.  Batch-1 calls (the solution's rollout,
+    mppi.py:448-449,508-524) always run the real dynamics.  run_case() asserts that a fed solve with the recorded costs
+    reproduces the recorded solve bit for bit THROUGH this wrapper."""
+
+    def __init__(self, fn, rec, num_samples):
+        self.fn, self.rec, self.n = fn, rec, num_samples
+
+    def __call__(self, state, action):
+        if self.rec.feed is not None and self.n > 1 and state.shape[0] == self.n:
+            return state
+        return self.fn(state, action)
 
 
 def _snapshot(solver):
@@ -195,25 +235,48 @@ def _feed_solve(solver, rec, state, costs):
     return a.detach().numpy().copy(), s.detach().numpy().copy()
 
 
-ONLY_ROUND2 = len(sys.argv) > 1 and sys.argv[1] == "round2"
+MODE = sys.argv[1] if len(sys.argv) > 1 else "all"
+assert MODE in ("all", "round2", "round5", "fullsize", "only"), MODE
+ONLY_ROUND2 = MODE == "round2"
+PARTIAL = MODE != "all"  # env artefacts, RNG stream and model pins are rewritten by the full run only
 ROUND2 = set()  # names registered with round2=True
 
 
-def run_case(name, make_solver, x0, K, next_state, keep_S, before_solve=None, round2=False, posterior_after=None):
+def _selected(name, round2=False, round5=False):
+    if MODE == "all":
+        return True
+    if MODE == "round2":
+        return round2
+    if MODE == "round5":
+        return round5
+    if MODE == "only":
+        return any(sub in name for sub in sys.argv[2:])
+    return False  # fullsize: handled by run_case_full
+
+
+def run_case(name, make_solver, x0, K, next_state, keep_S, before_solve=None, round2=False, posterior_after=None,
+             round5=False, eps_by_seed=False):
     """Run K closed-loop solves and dump everything the parity tests need.  posterior_after = (k, n): call
     get_samples_from_posterior(action_seq_k, state, n) right after solve k (mppi.py:489-506) and record it — the draw
-    comes from the same global generator, so the noise of solve k+1 pins the stream position."""
+    comes from the same global generator, so the noise of solve k+1 pins the stream position.
+    eps_by_seed: the [N,T,dc] noise blocks are NOT stored (they are torch's CPU stream from seed 42, which
+    oracle/mppi_oracle.c restates and torch_cpu_randn.npz pins: tests/helpers.py regenerates them); a float64 checksum and
+    the first / last rows are kept to verify the regenerated blocks."""
     import torch
 
     if round2:
         ROUND2.add(name)
-    if ONLY_ROUND2 and not round2:
+    if not _selected(name, round2, round5):
         return
 
     solver, rec, extra = make_solver()
     N, T = solver._num_samples, solver._horizon
     d = dict(extra)
-    d["ctor_eps"] = solver._action_noises.numpy().copy()  # Q2: ctor consumes one draw
+    if eps_by_seed:
+        d["eps_by_seed"] = np.int64(42)
+        d["sigmas"] = solver._sigmas.numpy().copy() if hasattr(solver, "_sigmas") else np.zeros(0, np.float32)
+    else:
+        d["ctor_eps"] = solver._action_noises.numpy().copy()  # Q2: ctor consumes one draw
     state = torch.as_tensor(np.asarray(x0), dtype=torch.float32)
     auto = solver._auto_lambda
     for k in range(K):
@@ -233,7 +296,12 @@ def run_case(name, make_solver, x0, K, next_state, keep_S, before_solve=None, ro
         d[f"x0_{k}"] = state.numpy().copy()
         d[f"mean_in_{k}"] = mean_in
         d[f"sg_hist_in_{k}"] = hist_in
-        d[f"eps_{k}"] = solver._action_noises.numpy().copy()
+        if eps_by_seed:
+            e = solver._action_noises.numpy()
+            d[f"eps_sum64_{k}"] = np.float64(e.astype(np.float64).sum())
+            d[f"eps_head_{k}"], d[f"eps_tail_{k}"] = e[:2].copy(), e[-1:].copy()
+        else:
+            d[f"eps_{k}"] = solver._action_noises.numpy().copy()
         d[f"costs_{k}"] = costs.numpy().copy()
         d[f"stage_costs_{k}"] = stage.numpy().copy() if keep_S else np.zeros(0, np.float32)
         d[f"lambda_{k}"] = np.float64(solver._lambda)
@@ -309,6 +377,153 @@ def run_case(name, make_solver, x0, K, next_state, keep_S, before_solve=None, ro
     print(f"wrote {path}  ({os.path.getsize(path)/1024:.0f} KiB)")
 
 
+def run_case_full(name, make_solver, x0, K, next_state, before_solve=None, nv_fixed=256, nv_closed=32):
+    """BASELINE.json's configurations at FULL size through the real reference, seed 42 (its constructor default,
+    mppi.py:46,93), K closed-loop solves.  Only outputs and summaries are kept (the noise is torch's CPU stream from the
+    seed; the product draws the same stream with noise_source="torch_cpu" and the oracle restates it): per solve the start
+    state, temperature, action_seq, state_seq, warm start / SG history going in, min / max / float64 sum / ESS / a 64-bin
+    histogram of the N total costs, the 32 smallest (index, cost, weight) triples with their noise rows (pins the stream
+    position and the arg-min), checksums of the whole noise block, and the bands (nv_fixed probes per solve, nv_closed
+    whole-loop probes: a full-size closed-loop probe is a full rollout per solve)."""
+    import time
+
+    import torch
+
+    t0 = time.time()
+    solver, rec, extra = make_solver()
+    N, T = solver._num_samples, solver._horizon
+    d = dict(extra)
+    d["N"], d["T"], d["K"], d["seed"] = np.int64(N), np.int64(T), np.int64(K), np.int64(42)
+    e0 = solver._action_noises.numpy()
+    d["ctor_eps_sum64"] = np.float64(e0.astype(np.float64).sum())
+    state = torch.as_tensor(np.asarray(x0), dtype=torch.float32)
+    auto = solver._auto_lambda
+    vsel_fixed = _spread(nv_fixed)
+    vsel_closed = _spread(nv_closed)
+    d["band_variants_fixed"], d["band_variants_closed"] = np.int64(vsel_fixed), np.int64(vsel_closed)
+    for k in range(K):
+        if before_solve is not None:
+            for kk, vv in before_solve(state, k).items():
+                d[f"{kk}_{k}"] = vv
+        rec.calls.clear()
+        d[f"mean_in_{k}"] = solver._previous_action_seq.detach().clone().numpy()
+        d[f"sg_hist_in_{k}"] = solver._actions_history_for_sg.detach().clone().numpy()
+        pre = _snapshot(solver)
+        a, s = solver.forward(state=state.clone())
+        calls = list(rec.calls)
+        rec.calls.clear()
+        stage = torch.stack(calls[:T], dim=1)
+        terminal = calls[T]
+        del calls
+        costs = torch.sum(stage, dim=1) + terminal  # exactly mppi.py:333-334
+        c = costs.numpy()
+        w = solver._weights.detach().numpy()
+        eps = solver._action_noises.numpy()
+        order = np.lexsort((np.arange(N), c))[:32]  # ascending cost, then index
+        d[f"x0_{k}"] = state.numpy().copy()
+        d[f"lambda_{k}"] = np.float64(solver._lambda)
+        d[f"action_seq_{k}"] = a.detach().numpy().copy()
+        d[f"state_seq_{k}"] = s.detach().numpy().copy()
+        d[f"cmin_{k}"], d[f"cmax_{k}"] = np.float32(c.min()), np.float32(c.max())
+        d[f"costs_sum64_{k}"] = np.float64(c.astype(np.float64).sum())
+        w64 = w.astype(np.float64)
+        d[f"ess_{k}"] = np.float64(1.0 / np.sum(w64 * w64))
+        d[f"wsum64_{k}"] = np.float64(w64.sum())
+        d[f"wmax_{k}"] = np.float32(w.max())
+        edges = np.linspace(float(c.min()), float(c.max()), 65)
+        d[f"hist_edges_{k}"] = edges
+        d[f"hist_{k}"] = np.histogram(c.astype(np.float64), bins=edges)[0].astype(np.int64)
+        # quantiles of the cost distribution at sample ranks (robust against single bin-edge flips)
+        qs = np.array([0.001, 0.01, 0.1, 0.25, 0.5, 0.75, 0.9, 0.99])
+        d[f"quantile_ranks_{k}"] = (qs * (N - 1)).astype(np.int64)
+        d[f"quantiles_{k}"] = np.sort(c)[d[f"quantile_ranks_{k}"]]
+        d[f"top32_idx_{k}"] = order.astype(np.int64)
+        d[f"top32_cost_{k}"] = c[order].copy()
+        d[f"top32_weight_{k}"] = w[order].copy()
+        d[f"top32_eps_{k}"] = eps[order].copy()
+        d[f"top32_stage_{k}"] = stage.numpy()[order].copy()
+        d[f"top32_terminal_{k}"] = terminal.numpy()[order].copy()
+        e64 = eps.astype(np.float64)
+        d[f"eps_sum64_{k}"], d[f"eps_sumsq64_{k}"] = np.float64(e64.sum()), np.float64((e64 * e64).sum())
+        d[f"eps_head_{k}"], d[f"eps_tail_{k}"] = eps[:2].copy(), eps[-1:].copy()
+        del e64
+        # ---- per-solve bands (the reference's steps 4-8 on prescribed costs; see run_case)
+        post = _snapshot(solver)
+        lam_used = pre["lam"] if auto == "MPO" else solver._lambda
+        a_np, s_np = a.detach().numpy(), s.detach().numpy()
+        _restore(solver, pre)
+        a_chk, s_chk = _feed_solve(solver, rec, state, costs)
+        assert np.array_equal(a_chk, a_np) and np.array_equal(s_chk, s_np) and solver._lambda == post["lam"], name
+        if k == 0:  # the dim-0 reductions of steps 4-6 under another thread count: same bits?
+            nt = torch.get_num_threads()
+            torch.set_num_threads(1)
+            _restore(solver, pre)
+            a1, s1 = _feed_solve(solver, rec, state, costs)
+            d["one_thread_same_bits"] = np.bool_(np.array_equal(a1, a_np) and np.array_equal(s1, s_np)
+                                                 and solver._lambda == post["lam"])
+            d["one_thread_action_rel"] = np.float64(_rel(a1, a_np))
+            torch.set_num_threads(nt)
+        fixed = np.zeros((len(vsel_fixed), 2))
+        ruled = np.zeros((len(vsel_fixed), 3))
+        for j, v in enumerate(vsel_fixed):
+            cv = _variant_costs(v, costs, stage, terminal)
+            _restore(solver, pre)
+            solver._auto_lambda, solver._lambda = None, float(lam_used)
+            av, sv = _feed_solve(solver, rec, state, cv)
+            fixed[j] = _rel(av, a_np), _rel(sv, s_np)
+            if auto is not None:
+                _restore(solver, pre)
+                av, sv = _feed_solve(solver, rec, state, cv)
+                ruled[j] = _rel(av, a_np), _rel(sv, s_np), abs(solver._lambda - post["lam"]) / post["lam"]
+        _restore(solver, post)
+        d[f"band_fixed_{k}"] = fixed
+        if auto is not None:
+            d[f"band_rule_{k}"] = ruled
+        print(f"  {name}: solve {k} done at {time.time() - t0:.0f} s, lambda {solver._lambda:.6g}, ess {d[f'ess_{k}']:.4g}, "
+              f"band action {fixed[:, 0].max():.2e}", flush=True)
+        del stage, terminal, costs
+        state = next_state(state, a, s)
+    # ---- closed-loop bands
+    cl = np.zeros((K, len(vsel_closed), 4))
+    for j, v in enumerate(vsel_closed):
+        solver2, rec2, _ = make_solver()
+        st2 = torch.as_tensor(np.asarray(x0), dtype=torch.float32)
+        for k in range(K):
+            if before_solve is not None:
+                before_solve(st2, k)
+            rec2.calls.clear()
+            pre = _snapshot(solver2)
+            solver2.forward(state=st2.clone())
+            calls = list(rec2.calls)
+            rec2.calls.clear()
+            stage2, term2 = torch.stack(calls[:T], dim=1), calls[T]
+            del calls
+            costs2 = torch.sum(stage2, dim=1) + term2
+            _restore(solver2, pre)
+            av, sv = _feed_solve(solver2, rec2, st2, _variant_costs(v, costs2, stage2, term2))
+            lam_ref = float(d[f"lambda_{k}"])
+            cl[k, j] = (_rel(st2.numpy(), d[f"x0_{k}"]), _rel(av, d[f"action_seq_{k}"]), _rel(sv, d[f"state_seq_{k}"]),
+                        abs(float(solver2._lambda) - lam_ref) / lam_ref)
+            a2, s2 = torch.from_numpy(av), torch.from_numpy(sv)
+            st2 = next_state(st2, a2, s2)
+        del solver2, rec2
+        print(f"  {name}: closed-loop probe {j + 1}/{len(vsel_closed)} at {time.time() - t0:.0f} s", flush=True)
+    d["band_closed_loop"] = cl
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **d)
+    print(f"wrote {path}  ({os.path.getsize(path)/1024:.0f} KiB) in {time.time() - t0:.0f} s")
+
+
+def _spread(n):
+    """n of the 256 variant indices, every class represented: the four re-summations always, the rest evenly."""
+    n = min(n, len(BAND_VARIANTS))
+    special = [N_ULP, N_ULP + 1, N_ULP + 2, N_ULP + 3]
+    rest = [v for v in range(len(BAND_VARIANTS)) if v not in special]
+    take = max(n - len(special), 0)
+    idx = sorted(set(special + [rest[int(i * len(rest) / max(take, 1))] for i in range(take)]))
+    return idx
+
+
 def main():
     _import_reference()
     import torch
@@ -328,7 +543,7 @@ def main():
 
         def make():
             rec = Recorder(fns[cost_name])
-            solver = MPPI(dynamics=fns[dyn_name], cost_func=rec, device=cpu, **kw)
+            solver = MPPI(dynamics=FeedDynamics(fns[dyn_name], rec, kw["num_samples"]), cost_func=rec, device=cpu, **kw)
             return solver, rec, {}
 
         return make
@@ -384,13 +599,14 @@ def main():
                             np.array(gz._danger_zone.center) - gz._pos]).astype(np.float32)
     gz_extra = {"goal": np.asarray(gz._goal, np.float64), "center": np.asarray(gz._danger_zone.center, np.float64),
                 "radius": np.float64(gz._danger_zone.radius), "x0": gz_x0}
-    if not ONLY_ROUND2:
+    if not PARTIAL:
         np.savez_compressed(os.path.join(OUT, "goalzone_env.npz"), **gz_extra)
 
     def goalzone(**kw):
         def make():
             rec = Recorder(gz.parallel_cost)
-            solver = MPPI(dim_state=7, dim_control=2, dynamics=gz.parallel_step, cost_func=rec,
+            solver = MPPI(dim_state=7, dim_control=2, dynamics=FeedDynamics(gz.parallel_step, rec, kw["num_samples"]),
+                          cost_func=rec,
                           u_min=torch.tensor([-1.0, -1.0]), u_max=torch.tensor([1.0, 1.0]),
                           sigmas=torch.tensor([0.5, 0.5]), device=cpu, **kw)
             return solver, rec, {}
@@ -423,14 +639,15 @@ def main():
     def nav(**kw):
         def make():
             rec = Recorder(nav_env.cost_function)
-            solver = MPPI(dim_state=3, dim_control=2, dynamics=nav_env.dynamics, cost_func=rec,
+            solver = MPPI(dim_state=3, dim_control=2, dynamics=FeedDynamics(nav_env.dynamics, rec, kw["num_samples"]),
+                          cost_func=rec,
                           u_min=nav_env.u_min, u_max=nav_env.u_max,
                           sigmas=torch.tensor([0.5, 0.5]), device=cpu, **kw)
             return solver, rec, {}
 
         return make
 
-    if not ONLY_ROUND2:
+    if not PARTIAL:
         np.savez_compressed(os.path.join(OUT, "nav2d_env.npz"), **nav_extra)
 
     x0_nav = nav_env._robot_state.numpy().copy()
@@ -480,20 +697,19 @@ def main():
 
     cp64, _, _ = make_csv_paths("src/envs/circuit_generator/circuit.csv")
     racing_extra["center_path_f64"] = cp64
-    if not ONLY_ROUND2:
+    if not PARTIAL:
         np.savez_compressed(os.path.join(OUT, "racing_env.npz"), **racing_extra)
 
-    def racing_case(name, T, N, K, keep_S, lambda_=1.0, round2=False, **kw):
+    def racing_parts(T, N, lambda_=1.0, **kw):
+        """(make_solver, before_solve, next_state) of a racing closed loop (example/racing.py:221-266 minus rendering)."""
         ctrl_box = {}
-        if ONLY_ROUND2 and not round2:
-            return
 
         def make():
             ctrl = racing_example.racing_controller(env, debug=False, device=cpu)
             ctrl.set_cost_map(env._obstacle_map, env._lane_map)
             rec = Recorder(ctrl.cost_function)
             ctrl.solver = MPPI(horizon=T, num_samples=N, dim_state=4, dim_control=2,
-                               dynamics=env.dynamics, cost_func=rec, u_min=env.u_min,
+                               dynamics=FeedDynamics(env.dynamics, rec, N), cost_func=rec, u_min=env.u_min,
                                u_max=env.u_max, sigmas=torch.tensor([0.5, 0.1]), lambda_=lambda_,
                                device=cpu, **kw)
             ctrl_box["c"] = ctrl
@@ -514,7 +730,14 @@ def main():
             u = torch.clamp(a[0], env.u_min, env.u_max)
             return env.dynamics(state.unsqueeze(0), u.unsqueeze(0)).squeeze(0).detach().clone()
 
-        run_case(name, make, env._robot_state.numpy().copy(), K, nxt, keep_S, before_solve=before, round2=round2)
+        return make, before, nxt
+
+    def racing_case(name, T, N, K, keep_S, lambda_=1.0, round2=False, round5=False, eps_by_seed=False, **kw):
+        if not _selected(name, round2, round5):
+            return
+        make, before, nxt = racing_parts(T, N, lambda_, **kw)
+        run_case(name, make, env._robot_state.numpy().copy(), K, nxt, keep_S, before_solve=before, round2=round2,
+                 round5=round5, eps_by_seed=eps_by_seed)
 
     racing_case("racing_T50_N512_fixed", 50, 512, 3, keep_S=False)
     racing_case("racing_T25_N256_fixed", 25, 256, 3, keep_S=True)
@@ -524,8 +747,39 @@ def main():
                 exploration=0.25, use_sg_filter=True)
     racing_case("racing_T25_N1024_essps", 25, 1024, 2, keep_S=False, lambda_="ESSPS", round2=True)
 
-    if ONLY_ROUND2:
-        print("done (round-2 cases only):", sorted(ROUND2))
+    # round 5 (VERDICT r4 #2c): the other temperature rules at the examples' sample count on nav2d AND racing, and one
+    # ESSPS case per end-point rule (mppi.py:361-364).  Noise by seed (not stored).
+    run_case("nav2d_T30_N4096_lbps", nav(horizon=30, num_samples=4096, lambda_="LBPS"), x0_nav, 2, pred_next,
+             keep_S=False, round5=True, eps_by_seed=True)
+    run_case("nav2d_T30_N4096_mpo", nav(horizon=30, num_samples=4096, lambda_="MPO"), x0_nav, 3, pred_next,
+             keep_S=False, round5=True, eps_by_seed=True)
+    racing_case("racing_T25_N4096_lbps", 25, 4096, 2, keep_S=False, lambda_="LBPS", round5=True, eps_by_seed=True)
+    racing_case("racing_T25_N4096_mpo", 25, 4096, 3, keep_S=False, lambda_="MPO", round5=True, eps_by_seed=True)
+    run_case("nav2d_T30_N512_essps_at_min", nav(horizon=30, num_samples=512, lambda_="ESSPS", lambda_min=40.0,
+                                                lambda_max=100.0), x0_nav, 2, pred_next, keep_S=False, round5=True,
+             eps_by_seed=True)
+    run_case("nav2d_T30_N512_essps_at_max", nav(horizon=30, num_samples=512, lambda_="ESSPS", lambda_max=0.5),
+             x0_nav, 2, pred_next, keep_S=False, round5=True, eps_by_seed=True)
+
+    if MODE == "fullsize":
+        want = set(sys.argv[2:]) or {"c2", "c5", "c3"}
+        threads = int(os.environ.get("GOLDEN_THREADS", "8"))
+        torch.set_num_threads(threads)  # (elementwise ops and the reductions along dim 1 do not depend on the thread count;
+        #                                 the dim-0 reductions of steps 4-6 are checked below: same bits with 1 thread)
+        if "c2" in want:  # BASELINE configs[1]
+            run_case_full("full_c2_nav2d_T50_N65536_essps", nav(horizon=50, num_samples=65536, lambda_="ESSPS"), x0_nav, 2,
+                          pred_next, nv_fixed=256, nv_closed=64)
+        if "c5" in want:  # BASELINE configs[4]
+            run_case_full("full_c5_cartpole_T64_N262144_essps_sg",
+                          classic("cartpole", "dynamics", "stage_cost", horizon=64, num_samples=262144, lambda_="ESSPS",
+                                  use_sg_filter=True, **cart), x0_cart, 2, pred_next, nv_fixed=256, nv_closed=32)
+        if "c3" in want:  # BASELINE configs[2], the configuration the metric is quoted on
+            make, before, nxt = racing_parts(50, 1 << 20, 1.0)
+            run_case_full("full_c3_racing_T50_N1048576_lambda1", make, env._robot_state.numpy().copy(), 2, nxt,
+                          before_solve=before, nv_fixed=64, nv_closed=8)
+        return
+    if PARTIAL:
+        print(f"done ({MODE}):", sorted(ROUND2) if ONLY_ROUND2 else "")
         return
     # ------------------------------------------------------------ torch-CPU RNG stream
     rng = {}

@@ -29,9 +29,9 @@ def summary() -> dict:
     return out
 
 
-def write(path: str) -> dict:
+def write(path: str, **extra) -> dict:
     os.makedirs(os.path.dirname(path), exist_ok=True)
-    rep = dict(summary=summary(), entries=entries)
+    rep = dict(summary=summary(), **extra, entries=entries)
     with open(path, "w") as f:
         json.dump(rep, f, indent=1)
     return rep

@@ -9,9 +9,9 @@ Tolerances (fp32, north star: 1e-5 relative):
   * end-to-end against the reference fixtures (`check_end_to_end`): 1e-5, or — where softmax(-c / lambda) amplifies the
     last bits of the costs beyond that (nav2d, goal zone, pendulum at lambda ~ 1: |c| / lambda ~ 1e3) — the REFERENCE'S
     OWN measured spread: every fixture records how far the reference's action_seq / state_seq move when its total costs
-    are replaced by equally valid fp32 evaluations of the same sums (24 probes per solve: 1-ulp changes, other summation
-    orders; tests/golden/make_golden.py `band_fixed_k`, `band_rule_k`, `band_closed_loop`).  limit = max(1e-5, 1.5 x the
-    sample maximum of the probes, see BAND_MARGIN); nothing is derived analytically.  Where the softmax is an arg-min (racing at lambda = 1) the winning sample must be
+    are replaced by equally valid fp32 evaluations of the same sums (256 probes per solve since round 5: 1-ulp changes, other
+    summation orders; tests/golden/make_golden.py `band_fixed_k`, `band_rule_k`, `band_closed_loop`).  limit = max(1e-5,
+    1.0 x the sample maximum of the probes, see BAND_MARGIN); nothing is derived analytically.  Where the softmax is an arg-min (racing at lambda = 1) the winning sample must be
     the reference's and the action must equal its clamped action sequence to 1e-6; only a top-2 cost gap under 4 ulps
     lifts that.
   * automatic temperatures are compared with the reference's on their own terms; the end-to-end check of those
@@ -91,7 +91,7 @@ def used_lambda(g, cfg, k):
 
 def check_costs(c_gpu, r, max_flips=None):
     if max_flips is None:
-        max_flips = 3 + int(2e-4 * len(c_gpu))  # boundary samples only; see module docstring
+        max_flips = max(1, int(2e-5 * len(c_gpu)))  # boundary samples only (measured: 0 in every check of rounds 3-4); see module docstring
     scale = np.abs(r["costs"]).max()
     diff = np.abs(c_gpu - r["costs"])
     clear = r["margin"] > 1e-3
@@ -113,12 +113,10 @@ def check_rel(quantity, got, want, tol):
     return err
 
 
-# A fixture band is the MAXIMUM over 24 probes of the reference — a sample maximum, not a supremum: a 25th equally valid
-# evaluation of the same costs exceeds it with probability 1/25.  Measured: the host-lambda path (the reference's own
-# scipy calls on costs that differ from the reference's by fp32 rounding — literally one more probe) lands at 1.05x the
-# band once in ~300 banded checks.  The tests therefore allow 1.5x the sample maximum; the parity report counts the
-# checks beyond 1.0x.
-BAND_MARGIN = 1.5
+# A fixture band is the MAXIMUM over 256 probes of the reference (round 5; 24 until round 4, when the tests allowed 1.5x the
+# sample maximum): a measurement of the reference's own spread, held at 1.0x.  The parity report also counts the checks
+# beyond 1e-5 and gives each band's 99th percentile.
+BAND_MARGIN = 1.0
 
 
 def check_banded(quantity, got, want, band, floor=TOL):
@@ -126,8 +124,9 @@ def check_banded(quantity, got, want, band, floor=TOL):
     quantity (committed with the fixture); the report keeps the value, the band and whether the plain 1e-5 held."""
     err = rel_err(got, want)
     limit = max(floor, BAND_MARGIN * band)
-    parity_report.record(quantity, err, limit, reference_band=float(band), within_1e5=bool(err <= TOL),
-                         within_band=bool(err <= max(floor, band)))
+    parity_report.record(quantity, err, limit, reference_band=float(band), reference_band_p99=getattr(band, "p99", None),
+                         band_probes=getattr(band, "probes", None), within_1e5=bool(err <= TOL),
+                         within_band=bool(err <= max(floor, band)), above_band_itself=bool(err > band))
     assert err <= limit, f"{quantity}: {err:.2e} > max({floor:.0e}, {BAND_MARGIN} x reference band {band:.2e})"
     return err
 
@@ -161,9 +160,15 @@ def check_end_to_end(a, s, c_gpu, g, k, cfg, band_a, band_s, tag=""):
 # the library's own search tolerances (the reference-side spread of the temperature comes from the fixture bands):
 # ESSPS: grid + inverse interpolation, checked to 1e-5 against brentq (test_host_logic); LBPS: scipy's bounded Brent stops
 # within xatol = 1e-5 ABSOLUTE + sqrt(eps) of a minimum of the reference's fp32 objective, short of a bound it never
-# evaluates (pendulum: lambda_max = 10 -> 9.9994..9.9998), while the library returns the float64 minimiser to 1e-7
+# evaluates (pendulum: lambda_max = 10 -> 9.9994..9.9998), while the library's opt-in grid search (lbps_search="device")
+# returns the float64 minimiser to 1e-7: 1e-3 for that one; the default — the port of scipy's Brent — is held to 1e-4
 LBPS_TOL = 1e-3
+LBPS_TOL_BRENT = 1e-4
 LAMBDA_TOL = {"ESSPS": 1e-4}
+
+
+def lbps_floor(solver):
+    return LBPS_TOL if getattr(solver, "_rule_on_device", None) == "LBPS" else LBPS_TOL_BRENT
 
 
 # ------------------------------------------------------------------------------ whole solve vs oracle / golden
@@ -207,7 +212,7 @@ def test_forward_parity(name, math):
         lam_ref = used_lambda(g, cfg, k)
         if cfg["lambda_"] == "LBPS":
             # the reference's own temperature moves by band_rule (nav2d: up to 1e-2) under 1-ulp changes of its costs
-            lim = max(LBPS_TOL, BAND_MARGIN * band_rule_lambda(g, k))
+            lim = max(lbps_floor(solver), BAND_MARGIN * band_rule_lambda(g, k))
             parity_report.record("lambda_rel_err_LBPS", abs(lam - lam_ref) / lam_ref, lim, reference_band=band_rule_lambda(g, k))
             assert abs(lam - lam_ref) <= lim * lam_ref, (lam, lam_ref, lim)
             assert same_lbps_minimum(c_gpu, lam, lam_ref, tol=lim), (lam, lam_ref)  # ... and it is no worse a minimiser
@@ -261,7 +266,10 @@ def test_forward_parity(name, math):
                                   "pendulum_T50_N1000_essps", "cartpole_T64_N1024_essps_sg", "mjcartpole_T50_N256_fixed",
                                   "goalzone_T30_N256_fixed", "racing_T25_N4096_dense", "racing_T25_N512_explore_sg",
                                   "racing_T25_N1024_essps", "nav2d_T30_N4096_essps", "nav2d_T30_N512_lbps",
-                                  "nav2d_T30_N512_mpo", "nav2d_T30_N512_sg", "nav2d_T20_N256_posterior"])
+                                  "nav2d_T30_N512_mpo", "nav2d_T30_N512_sg", "nav2d_T20_N256_posterior",
+                                  "pendulum_T15_N256_lbps", "pendulum_T15_N256_mpo", "nav2d_T50_N512_essps",
+                                  "nav2d_T30_N4096_lbps", "nav2d_T30_N4096_mpo", "racing_T25_N4096_lbps",
+                                  "racing_T25_N4096_mpo", "nav2d_T30_N512_essps_at_min", "nav2d_T30_N512_essps_at_max"])
 def test_identical_seed_closed_loop_matches_reference(name):
     """`noise_source="torch_cpu"`, seed 42: the solver draws the reference's own CPU noise stream (the
     constructor consumes one draw, mppi.py:146-148) — nothing is injected.  The closed-loop solves must
@@ -271,19 +279,25 @@ def test_identical_seed_closed_loop_matches_reference(name):
     _identical_seed_closed_loop(name)
 
 
-@pytest.mark.parametrize("mode", ["host", "brent"])
+@pytest.mark.parametrize("mode", ["host", "brent", "device"])
 @pytest.mark.parametrize("name", ["pendulum_T50_N1000_essps", "cartpole_T64_N1024_essps_sg", "racing_T25_N1024_essps",
                                   "nav2d_T30_N4096_essps", "nav2d_T50_N512_essps", "pendulum_T15_N256_lbps",
-                                  "nav2d_T30_N512_lbps", "pendulum_T15_N256_mpo", "nav2d_T30_N512_mpo"])
+                                  "nav2d_T30_N512_lbps", "pendulum_T15_N256_mpo", "nav2d_T30_N512_mpo",
+                                  "nav2d_T30_N4096_lbps", "racing_T25_N4096_lbps", "nav2d_T30_N4096_mpo",
+                                  "racing_T25_N4096_mpo", "nav2d_T30_N512_essps_at_min", "nav2d_T30_N512_essps_at_max"])
 def test_identical_seed_closed_loop_with_the_temperature_on_the_host(name, mode):
     """The north star's literal split — auto-lambda on the HOST — through the same identical-seed closed loops:
     mode "host": `auto_lambda_stats="host"`: costs[N] copied to the CPU and searched with scipy's brentq / bounded Brent /
     the Adam step in numpy fp32, the reference's own calls (mppi.py:341-370,387-398; pi_mpc/_host.py);
     mode "brent": the same root-finders inside the library (csrc/host_search.hpp ports of brentq's bracket rule and of
-    scipy's bounded Brent) probing the device-side softmax statistics one temperature at a time."""
-    if mode == "brent" and CASES[name]["lambda_"] == "MPO":
+    scipy's bounded Brent) probing the device-side softmax statistics one temperature at a time (LBPS: the default);
+    mode "device": the searches as kernels, the temperature resident in HBM (ESSPS: the default; LBPS: the opt-in fast path)."""
+    if mode != "host" and CASES[name]["lambda_"] == "MPO":
         pytest.skip("MPO has no search: the device-statistics step is the default path")
-    kw = dict(auto_lambda_stats="host") if mode == "host" else dict(lbps_search="brent", essps_search="brentq")
+    if mode == "device" and CASES[name]["lambda_"] != "LBPS":
+        pytest.skip("the device-resident ESSPS search is the default: test_identical_seed_closed_loop_matches_reference")
+    kw = {"host": dict(auto_lambda_stats="host"), "brent": dict(lbps_search="brent", essps_search="brentq"),
+          "device": dict(lbps_search="device")}[mode]
     _identical_seed_closed_loop(name, tag="_" + mode, **kw)
 
 
@@ -312,7 +326,7 @@ def _identical_seed_closed_loop(name, tag="", **solver_kw):
         if cfg["lambda_"] in ("ESSPS", "LBPS", "MPO"):
             kk = k - 1 if cfg["lambda_"] == "MPO" else k  # (MPO: this solve's weights use the temperature solve k-1 left)
             lam_band = band_closed_loop(g, kk)["lam"] if kk >= 0 else 0.0
-            lim = max({"ESSPS": 1e-4, "LBPS": LBPS_TOL, "MPO": 1e-4}[cfg["lambda_"]], BAND_MARGIN * lam_band)
+            lim = max({"ESSPS": 1e-4, "LBPS": lbps_floor(solver), "MPO": 1e-4}[cfg["lambda_"]], BAND_MARGIN * lam_band)
             parity_report.record("closed_loop_lambda_rel_err_" + cfg["lambda_"] + tag, abs(lam - lam_ref) / lam_ref, lim,
                                  reference_band=lam_band)
             assert abs(lam - lam_ref) <= lim * lam_ref, (k, lam, lam_ref, lim)
@@ -325,6 +339,115 @@ def _identical_seed_closed_loop(name, tag="", **solver_kw):
             assert rel_err(pst.cpu().numpy(), g["posterior_states"]) <= max(TOL, BAND_MARGIN * max(band["action"], band["state"]))
             assert np.abs((ps - a[None]).cpu().numpy() - (g["posterior_samples"] - g[f"action_seq_{k}"][None])).max() < 1e-6
         if ctrl is not None:  # env.step of the reference loop (example/racing.py:233)
+            env = _envs["racing"]
+            u = torch.clamp(a[0], env.u_min, env.u_max)
+            state = env.dynamics(state.cuda().unsqueeze(0), u.unsqueeze(0)).squeeze(0)
+        else:
+            state = s[0, 1].clone()
+
+
+# BASELINE.json's configurations at FULL size against the reference ITSELF (round 5): tests/golden/make_golden.py fullsize
+# ran the real reference (seed 42, two closed-loop solves) and kept outputs and summaries only; the solver draws the same
+# torch-CPU stream (noise_source="torch_cpu") and must reproduce them.
+FULL_SIZE = {
+    "c2": ("full_c2_nav2d_T50_N65536_essps", "nav2d", dict(lambda_="ESSPS")),
+    "c5": ("full_c5_cartpole_T64_N262144_essps_sg", "cartpole", dict(lambda_="ESSPS", use_sg_filter=True)),
+    "c3": ("full_c3_racing_T50_N1048576_lambda1", "racing", dict(lambda_=1.0)),
+}
+
+
+def full_size_band(g, k):
+    """Reference spread of solve k: maximum over the per-solve probes (fixed temperature and rule re-run) and the
+    closed-loop probes."""
+    fx = g[f"band_fixed_{k}"].max(axis=0)
+    cl = g["band_closed_loop"][k].max(axis=0)
+    rl = g[f"band_rule_{k}"].max(axis=0) if f"band_rule_{k}" in g.files else np.zeros(3)
+    return dict(x0=float(cl[0]), action=float(max(fx[0], rl[0], cl[1])), state=float(max(fx[1], rl[1], cl[2])),
+                lam=float(max(rl[2], cl[3])))
+
+
+@pytest.mark.parametrize("which", ["c2", "c5", "c3"])
+def test_identical_seed_full_size_matches_reference(which):
+    """North star: "action_seq / state_seq match the PyTorch reference on identical RNG seeds within 1e-5" at the sizes the
+    metric is quoted on (/root/reference/src/pi_mpc/mppi.py:255-460 run in the build container, outputs only).  Checked per
+    solve: the noise block (float64 sum and sum of squares of all N*T*dc values, first / last rows, the rows of the
+    reference's 32 best samples: bit for bit), the N costs through their minimum, maximum, float64 sum, eight order
+    statistics, a 64-bin histogram and the 32 smallest (index, cost) pairs — the arg-min among 2^20 samples must be the
+    reference's — then temperature, ESS, action_seq and state_seq."""
+    name, model, kw = FULL_SIZE[which]
+    g = load(name)
+    N, T, K = int(g["N"]), int(g["T"]), int(g["K"])
+    solver, ctrl = make_solver(model, T, N, noise_source="torch_cpu", seed=int(g["seed"]), **kw)
+    state = torch.from_numpy(g["x0_0"])
+    mc = MODEL_CFG[model]
+    for k in range(K):
+        band = full_size_band(g, k)
+        assert rel_err(state.cpu().numpy(), g[f"x0_{k}"]) <= max(TOL, band["x0"])
+        if ctrl is not None:
+            env = _envs["racing"]
+            ref, ctrl.current_path_index = ctrl.calc_ref_trajectory(state, env.racing_center_path, ctrl.current_path_index,
+                                                                    T, DL=0.1, lookahead_distance=3,
+                                                                    reference_path_interval=0.85)
+            ctrl.set_reference(ref)
+            assert np.array_equal(ref.numpy(), g[f"ref_path_{k}"]) and ctrl.current_path_index == int(g[f"cind_out_{k}"])
+        a, s = solver.forward(state)
+        # ---- the noise: the reference's block, bit for bit
+        eps = solver._action_noises.cpu().numpy()
+        e64 = eps.astype(np.float64)
+        assert float(e64.sum()) == float(g[f"eps_sum64_{k}"]) and float((e64 * e64).sum()) == float(g[f"eps_sumsq64_{k}"])
+        del e64
+        assert np.array_equal(eps[:2], g[f"eps_head_{k}"]) and np.array_equal(eps[-1:], g[f"eps_tail_{k}"])
+        top_i = g[f"top32_idx_{k}"]
+        assert np.array_equal(eps[top_i], g[f"top32_eps_{k}"])
+        # ---- the costs
+        c = solver._costs.cpu().numpy()
+        c_ref_top = g[f"top32_cost_{k}"]
+        scale = float(g[f"cmax_{k}"])
+        tag = f"_full_{which}"
+        parity_report.record("cost_rel_err_reference_top32" + tag, np.abs(c[top_i] - c_ref_top).max() / scale, TOL)
+        assert np.abs(c[top_i] - c_ref_top).max() <= TOL * scale
+        assert abs(float(c.min()) - float(g[f"cmin_{k}"])) <= TOL * scale and abs(float(c.max()) - scale) <= TOL * scale
+        rel_sum = abs(float(c.astype(np.float64).sum()) - float(g[f"costs_sum64_{k}"])) / abs(float(g[f"costs_sum64_{k}"]))
+        parity_report.record("cost_sum_rel_err_vs_reference" + tag, rel_sum, 1e-6)
+        assert rel_sum <= 1e-6
+        q = np.sort(c)[g[f"quantile_ranks_{k}"]]
+        assert np.abs(q - g[f"quantiles_{k}"]).max() <= TOL * scale
+        hist = np.histogram(c.astype(np.float64), bins=g[f"hist_edges_{k}"])[0]
+        moved = int(np.abs(hist - g[f"hist_{k}"]).sum())
+        parity_report.record("cost_histogram_L1_vs_reference" + tag, moved / N, 2e-3)
+        assert moved <= 2e-3 * N, (moved, N)
+        # the 32 smallest (cost, index) pairs in the reference's order, up to the first pair of neighbours the
+        # reference itself separates by less than 4 ulps of the cost scale
+        order = np.lexsort((np.arange(N), c))[:32]
+        gaps = np.diff(c_ref_top.astype(np.float64))
+        amb = np.nonzero(gaps < 4 * EPS32 * float(np.abs(c_ref_top).max()))[0]
+        need = int(amb[0]) if len(amb) else 32
+        agree = int(np.argmin(np.append(order == top_i, False)))
+        parity_report.record("reference_top32_order_reproduced" + tag, need - min(agree, need), 0, agree=agree, needed=need)
+        assert agree >= need, (agree, need, order[:8], top_i[:8])
+        # ---- temperature and effective sample size
+        lam, lam_ref = solver._last_lambda, float(g[f"lambda_{k}"])
+        if isinstance(kw["lambda_"], str):
+            lim = max(LAMBDA_TOL[kw["lambda_"]], band["lam"])
+            parity_report.record("lambda_rel_err_" + kw["lambda_"] + tag, abs(lam - lam_ref) / lam_ref, lim,
+                                 reference_band=band["lam"])
+            assert abs(lam - lam_ref) <= lim * lam_ref, (lam, lam_ref)
+        else:
+            assert lam == lam_ref
+        ess, ess_ref = solver.last_stats()["ess"], float(g[f"ess_{k}"])
+        w64, _ = orc.softmax_weights(c, lam)
+        ess_own = 1.0 / float(np.sum(w64.astype(np.float64) ** 2))
+        assert abs(ess - ess_own) <= 1e-4 * ess_own  # the device's statistic against a float64 evaluation of its own costs
+        if isinstance(kw["lambda_"], str):
+            assert abs(ess - ess_ref) <= 1e-3 * ess_ref
+        # ---- action_seq / state_seq
+        if float(g[f"top32_weight_{k}"][0]) >= 1.0 - 1e-6 and need >= 1:  # arg-min regime: an exact statement exists
+            U = np.clip(g[f"mean_in_{k}"] + g[f"top32_eps_{k}"][0], np.float32(mc["u_min"]), np.float32(mc["u_max"]))
+            assert int(np.argmin(c)) == int(top_i[0])
+            assert np.abs(a.cpu().numpy() - U).max() <= 1e-6 * np.abs(U).max()
+        check_banded("action_seq_vs_reference_fixture" + tag, a.cpu().numpy(), g[f"action_seq_{k}"], band["action"])
+        check_banded("state_seq_vs_reference_fixture" + tag, s.cpu().numpy(), g[f"state_seq_{k}"], band["state"])
+        if ctrl is not None:
             env = _envs["racing"]
             u = torch.clamp(a[0], env.u_min, env.u_max)
             state = env.dynamics(state.cuda().unsqueeze(0), u.unsqueeze(0)).squeeze(0)
@@ -851,14 +974,15 @@ def test_device_softmax_stats_drive_the_same_temperature(lam_mode):
     assert rel_err(outs[0][1], outs[1][1]) < 20 * tol
     x0 = torch.tensor([-9.0, -9.0, 0.785])
     if lam_mode == "LBPS":
-        # the default runs the search as kernels (three 32-temperature grids + a parabola, no host wait); scipy's
-        # Brent inside the library (one read-back per probe) lands on the same minimum
-        assert outs[0][3]._rule_on_device == "LBPS" and outs[0][3]._one_call
-        sb, _ = make_solver("nav2d", T, N, lambda_="LBPS", lbps_search="brent")
-        ab, _ = sb.forward(x0)
-        assert sb._rule_on_device is None
+        # the default (round 5) is the reference's own algorithm — scipy's bounded Brent inside the library, one read-back
+        # per probe (north star: auto-lambda stays on the host); lbps_search="device" runs the search as kernels (two
+        # 32-temperature grids + a quartic, no host wait) and lands on the same minimum
+        sb = outs[0][3]
+        assert sb._rule_on_device is None and sb._lbps_search == "brent"
         c = sb._costs.cpu().numpy()
-        sd, _ = make_solver("nav2d", T, N, lambda_="LBPS")
+        sd, _ = make_solver("nav2d", T, N, lambda_="LBPS", lbps_search="device")
+        assert sd._rule_on_device == "LBPS" and sd._one_call
+        sd.forward(x0)
         ad, _ = sd.forward(x0)
         assert sd._lambda_pending
         assert same_lbps_minimum(c, sd._last_lambda, sb._last_lambda) and not sd._lambda_pending
@@ -1211,15 +1335,18 @@ def test_wave_parallel_batch1_rollout_is_bit_identical_to_the_serial_one():
                                           ("cartpole", 64, 32768, dict(lambda_="ESSPS", use_sg_filter=True)),
                                           ("pendulum", 15, 20000, dict(lambda_=2.0))])
 def test_lazy_state_seq_same_bits_read_early_late_or_never(model, T, N, kw):
-    """Above 16 384 samples the batch-1 rollout of the solution (mppi.py:448-449) leaves the solve's last kernel (option
-    "lazy_state_seq"): it rides in one extra block of the NEXT solve's rollout launch, or is launched on the spot when the
-    returned `state_seq` is used first.  Read at once, after later solves, or never: the same bits as a solver that rolls
-    out inside finalize_kernel (lazy_state_seq=False), the same actions, and nothing else changes."""
+    """Opt-in (`lazy_state_seq=True`; the default returns a completed plain tensor like the reference): the batch-1 rollout of
+    the solution (mppi.py:448-449) leaves the solve's last kernel: it rides in one extra block of the NEXT solve's rollout
+    launch, or is launched on the spot when the returned `state_seq` is used first.  Read at once, after later solves, or
+    never: the same bits as a solver that rolls out inside finalize_kernel (the default), the same actions, and nothing else
+    changes.  Until it is completed the buffer holds NaN (a reader that bypasses the join cannot mistake it for states), and
+    a completion requested from ANOTHER stream is ordered behind the solve's stream."""
     from pi_mpc.mppi import _DeferredStateSeq
 
+    kw = dict(kw)
     lam = kw.pop("lambda_", 1.0)
-    a_s, a_ctrl = make_solver(model, T, N, lambda_=lam, **kw)
-    b_s, b_ctrl = make_solver(model, T, N, lambda_=lam, lazy_state_seq=False, **kw)
+    a_s, a_ctrl = make_solver(model, T, N, lambda_=lam, lazy_state_seq=True, **kw)
+    b_s, b_ctrl = make_solver(model, T, N, lambda_=lam, **kw)
     assert a_s._lazy_state and not b_s._lazy_state
     a_s.set_option("timing", 1)
     if model == "racing":
@@ -1253,11 +1380,21 @@ def test_lazy_state_seq_same_bits_read_early_late_or_never(model, T, N, kw):
         assert torch.equal(s, sb)
     a, s = a_s.forward(x0)
     b, sb = b_s.forward(x0)
+    assert torch.isnan(a_s._state_out.clone()).all()  # a reader of the plain buffer (bypassing the join) sees NaN, never stale states
     a_s.join_state_seq()  # (what a reader outside torch calls before it uses the raw pointer)
     assert torch.equal(s, sb)
     st = a_s.stage_times_ms()
     # stand-alone launches: the four reads at once + the explicit join; every other state sequence rode in a rollout launch
     assert st["state_seq_standalone_launches"] == 5.0, st
+    # a consumer on ANOTHER stream: its join waits for the solve's stream (finalize's write of the rollout's inputs)
+    side = torch.cuda.Stream()
+    for _ in range(20):
+        a, s = a_s.forward(x0)
+        b, sb = b_s.forward(x0)
+        with torch.cuda.stream(side):
+            got = s.clone()
+        side.synchronize()
+        assert torch.equal(got, sb)
 
 
 def test_info_dict_and_log_temperature_like_the_reference():

@@ -332,14 +332,15 @@ def test_library_searches_match_reference_fixtures():
 
 def test_bench_launches_its_own_ranks(monkeypatch):
     """`python bench.py --gpus N` without a launcher re-runs itself under torch.distributed.run with one rank per GPU
-    on 127.0.0.1 (the driver's N=1 command shape must work for N>1 too)."""
+    on 127.0.0.1 (the driver's N=1 command shape must work for N>1 too), with a wall-clock limit on the launcher."""
     import importlib
-    import subprocess
     import sys
 
     bench = importlib.import_module("bench")
     seen = {}
-    monkeypatch.setattr(subprocess, "call", lambda cmd, env=None: seen.update(cmd=cmd, env=env) or 0)
+    monkeypatch.setattr(bench, "run_with_deadline",
+                        lambda cmd, env, timeout_s, on_timeout_line: seen.update(cmd=cmd, env=env, timeout=timeout_s,
+                                                                                 line=on_timeout_line()) or 0)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "50", "--warmup", "10"])
     monkeypatch.delenv("WORLD_SIZE", raising=False)
     with pytest.raises(SystemExit) as e:
@@ -350,6 +351,80 @@ def test_bench_launches_its_own_ranks(monkeypatch):
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     assert cmd[-6:] == ["--gpus", "8", "--steps", "50", "--warmup", "10"] and cmd[-7].endswith("bench.py")
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert 0 < seen["timeout"] < 1800  # below the driver's own limit
+    line = seen["line"]
+    assert line["value"] is None and line["n_gpus"] == 8 and line["metric"] == "sample_steps_per_sec" and "error" in line
+
+
+def test_bench_launcher_deadline_leaves_a_line():
+    """A launcher that never returns (a rank stuck in a communicator's set-up) is killed at the deadline and a
+    contract-shaped line with value null is printed; a launcher that printed its line keeps it."""
+    import json
+    import subprocess
+    import sys
+    code = (
+        "import sys, json\n"
+        f"sys.path.insert(0, {str(ROOT)!r})\n"
+        "import bench\n"
+        "bench.own_stdout()\n"
+        "child = [sys.executable, '-c', sys.argv[1]]\n"
+        "rc = bench.run_with_deadline(child, None, float(sys.argv[2]), lambda: {'value': None, 'error': 'deadline'})\n"
+        "sys.exit(0 if rc == int(sys.argv[3]) else 1)\n"
+    )
+    hang = "import time; print('chatter', flush=True); time.sleep(600)"
+    r = subprocess.run([sys.executable, "-c", code, hang, "1.0", "124"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0]) == {"value": None, "error": "deadline"}
+    good = "print('{\"value\": 1.0}', flush=True)"
+    r = subprocess.run([sys.executable, "-c", code, good, "30", "0"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")] == [{"value": 1.0}]
+
+
+@pytest.mark.parametrize("hang_at", [0, 1])
+def test_bench_watchdog_reports_when_a_transport_blocks_forever(hang_at):
+    """The multi-GPU leg of bench.py with a transport that never returns (monkey-patched: the first, then the second): the
+    watchdog — armed BEFORE the first transport — must leave a line: a null-value line carrying the phase that hung when
+    nothing had completed, the best complete run otherwise; and end the process through its exit hook."""
+    import argparse
+    import importlib
+    import threading
+
+    bench = importlib.import_module("bench")
+    args = argparse.Namespace(steps=20, warmup=5, samples=1 << 20, horizon=50)
+    out, release, runs = {}, threading.Event(), []
+
+    def timed_run(mode):
+        if ["rccl", "nccl", "p2p"].index(mode) == hang_at:
+            release.wait(30)  # "blocks forever": only the watchdog's exit hook ends it
+            return {"exchange": mode, "requested": mode, "error": "ended by the watchdog"}
+        return {"exchange": mode, "requested": mode, "dt": 0.01, "finite": True}
+
+    def on_expiry(phase, seconds):
+        best = bench.best_of(runs)
+        why = f"{phase} exceeded its {seconds:.1f} s budget"
+        out["line"] = ({"value": 1.0, "from": best["exchange"], "transports": runs + [{"exchange": phase, "error": why}]}
+                       if best is not None else bench.null_line(args, 8, why, runs + [{"exchange": phase, "error": why}]))
+        return 0 if best is not None else 1
+
+    def exit_fn(code):
+        out["code"] = code
+        release.set()
+
+    dog = bench.Watchdog(on_expiry, exit_fn=exit_fn)
+    t = threading.Thread(target=lambda: bench.run_transports(["rccl", "nccl", "p2p"], timed_run, dog, 0.3, 0.3, runs),
+                         daemon=True)
+    t.start()
+    t.join(20)
+    assert not t.is_alive() and "line" in out, "the watchdog did not fire"
+    line = out["line"]
+    if hang_at == 0:
+        assert out["code"] == 1 and line["value"] is None and line["n_gpus"] == 8 and line["steps"] == 20
+        assert "transport rccl exceeded" in line["error"] and line["transports"][-1]["error"].startswith("transport rccl")
+    else:
+        assert out["code"] == 0 and line["value"] == 1.0 and line["from"] == "rccl"
+        assert line["transports"][-1]["exchange"] == "transport nccl"
 
 
 def test_lbps_grid_search_finds_the_brent_minimum_on_random_costs():
@@ -449,16 +524,16 @@ def test_graph_replay_compares_the_callers_info_by_value():
 
 
 def test_fixture_bands_are_complete():
-    """Every solve fixture carries the reference's own measured spread (tests/golden/make_golden.py): 24 probes per solve
+    """Every solve fixture carries the reference's own measured spread (tests/golden/make_golden.py): 256 probes per solve
     at the reference's temperature, with its rule re-run where it has one, and per closed loop; racing at lambda = 1 is an
     arg-min (no spread at all), the ill-conditioned cases show the 1e-5 of the north star is below the reference's own
     rounding noise."""
     for name, cfg in CASES.items():
         g = load(name)
         K = int(g["K"])
-        assert g["band_closed_loop"].shape == (K, 24, 4)
+        assert g["band_closed_loop"].shape == (K, 256, 4)
         for k in range(K):
-            assert g[f"band_fixed_{k}"].shape == (24, 2) and np.isfinite(g[f"band_fixed_{k}"]).all()
+            assert g[f"band_fixed_{k}"].shape == (256, 2) and np.isfinite(g[f"band_fixed_{k}"]).all()
             assert (f"band_rule_{k}" in g.files) == isinstance(cfg["lambda_"], str)
     assert load("racing_T50_N512_fixed")["band_closed_loop"].max() == 0.0
     assert load("nav2d_T30_N256_fixed_explore")["band_fixed_1"][:, 0].max() > 1e-5

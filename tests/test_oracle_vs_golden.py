@@ -173,3 +173,61 @@ def test_torch_cpu_restatement_of_the_reference_loop(name):
             state = env.dynamics(state.unsqueeze(0), u.unsqueeze(0)).squeeze(0)
         else:
             state = s[0, 1].clone()
+
+
+FULL_SIZE = {
+    "c2": ("full_c2_nav2d_T50_N65536_essps", "nav2d", {}),
+    "c5": ("full_c5_cartpole_T64_N262144_essps_sg", "cartpole", dict(use_sg_filter=True)),
+    "c3": ("full_c3_racing_T50_N1048576_lambda1", "racing", {}),
+}
+
+
+@pytest.mark.parametrize("which", ["c2", "c5", "c3"])
+def test_oracle_at_full_size_against_the_reference(which):
+    """The oracle at BASELINE.json's sizes against the real reference (tests/golden/make_golden.py fullsize: outputs and
+    summaries only).  The noise is drawn again with torch's CPU generator from the fixture's seed — the reference's own
+    sampler — and verified bit for bit against the fixture's checksums before it is used."""
+    import os
+
+    import torch
+
+    from helpers import GOLDEN, MODEL_CFG
+
+    name, model, kw = FULL_SIZE[which]
+    if not os.path.exists(os.path.join(GOLDEN, name + ".npz")):
+        pytest.skip(f"{name}.npz not generated")
+    g = load(name)
+    N, T, K = int(g["N"]), int(g["T"]), int(g["K"])
+    sig = torch.tensor(MODEL_CFG[model]["sigmas"])
+    gen = torch.Generator(device="cpu").manual_seed(int(g["seed"]))
+    ctor = torch.randn(N, T, len(sig), generator=gen) * sig
+    assert float(ctor.numpy().astype(np.float64).sum()) == float(g["ctor_eps_sum64"])
+    del ctor
+    P = oracle_problem(model, N, T)
+    for k in range(K):
+        eps = (torch.randn(N, T, len(sig), generator=gen) * sig).numpy()
+        assert float(eps.astype(np.float64).sum()) == float(g[f"eps_sum64_{k}"])
+        top_i = g[f"top32_idx_{k}"]
+        assert np.array_equal(eps[top_i], g[f"top32_eps_{k}"])
+        if model == "racing":
+            P.set_ref_path(g[f"ref_path_{k}"])
+        r = P.rollout_cost(g[f"x0_{k}"], g[f"mean_in_{k}"], eps)
+        c = r["costs"]
+        scale = float(g[f"cmax_{k}"])
+        assert np.abs(c[top_i] - g[f"top32_cost_{k}"]).max() <= TOL * scale
+        assert abs(float(c.min()) - float(g[f"cmin_{k}"])) <= TOL * scale and abs(float(c.max()) - scale) <= TOL * scale
+        assert abs(float(c.astype(np.float64).sum()) - float(g[f"costs_sum64_{k}"])) <= 1e-6 * abs(float(g[f"costs_sum64_{k}"]))
+        assert np.abs(np.sort(c)[g[f"quantile_ranks_{k}"]] - g[f"quantiles_{k}"]).max() <= TOL * scale
+        assert int(np.argmin(c)) == int(top_i[0]) or float(np.diff(g[f"top32_cost_{k}"][:2])[0]) < 4e-7 * scale
+        # steps 5-8 at the reference's temperature; the limit is the reference's own spread where that exceeds 1e-5
+        band = max(float(g[f"band_fixed_{k}"][:, 0].max()), TOL)
+        w, st = orc.softmax_weights(c, float(g[f"lambda_{k}"]))
+        a = P.weighted_actions(w, g[f"mean_in_{k}"], eps)
+        if kw.get("use_sg_filter"):
+            from pi_mpc import _host
+
+            a = _host.sg_filter_sequence(g[f"sg_hist_in_{k}"], a, _host.savitzky_golay_coeffs(5, 3))
+        assert rel_err(a, g[f"action_seq_{k}"]) <= band, (rel_err(a, g[f"action_seq_{k}"]), band)
+        s = P.rollout_single(g[f"x0_{k}"], g[f"action_seq_{k}"])
+        assert rel_err(s, g[f"state_seq_{k}"][0]) < TOL
+        del eps
