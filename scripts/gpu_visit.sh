@@ -1,21 +1,25 @@
 #!/bin/bash
-# One GPU visit: GPU tests, micro-benchmark, parity probe and A/B of the library variants given as arguments
-# (names under mppi_playground_amd/csrc/variants/), then the full bench line.  Everything lands in gpurun_out/.
+# One GPU visit, parameterised (replaces the per-visit scripts of round 4):
+#   bash scripts/gpu_visit.sh <tag> [step ...]     steps: tests[:<pytest -k expr>] smoke bench bench_full reduce_ab[:cfgs] py:<script+args>
+# Everything lands under gpurun_out/<tag>_*.  Each step runs under its own `timeout`.
 set -u
+TAG=$1; shift
 mkdir -p gpurun_out
-V=mppi_playground_amd/csrc/variants
-timeout 1500 python -m pytest tests -m gpu -q -x -rfs -p no:cacheprovider 2>&1 | tail -60 > gpurun_out/pytest_gpu.log; tail -5 gpurun_out/pytest_gpu.log
-[ -x scripts/ubench/hw_sincos_acc ] && timeout 120 scripts/ubench/hw_sincos_acc 2>&1 | tee gpurun_out/hw_sincos_acc.txt
-for lib in "" "$@"; do
-  MPPI_HIP_LIB=${lib:+$PWD/$V/lib_$lib.so} timeout 300 python tests/parity_probe.py 2>&1 | tail -1
-done | tee gpurun_out/parity_probe.txt
-for rep in 1 2 3; do
-for lib in "" "$@"; do
-  MPPI_HIP_LIB=${lib:+$PWD/$V/lib_$lib.so} timeout 300 python bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-extras --timing 2 2>/dev/null | python -c "
-import sys,json
-for l in sys.stdin:
-    if l.startswith('{'):
-        d=json.loads(l); print('${lib:-default}', 'ms/step %.4f'%d['ms_per_step'], 'solves/s %.0f'%d['solves_per_sec'], 'rollout %.2f us'%(1e3*d['stages_ms']['rollout_cost']))
-"
-done; done 2>&1 | tee gpurun_out/ab.txt
-timeout 900 python bench.py > gpurun_out/bench.log 2>&1; tail -c 3000 gpurun_out/bench.log; echo
+export TMPDIR=/tmp
+for step in "$@"; do
+  name=${step%%:*}; arg=""; [ "$step" != "$name" ] && arg=${step#*:}
+  case $name in
+    tests)
+      if [ -n "$arg" ]; then timeout 1500 python -m pytest tests -m gpu -q -rfs -p no:cacheprovider -k "$arg" > gpurun_out/${TAG}_pytest_gpu.log 2>&1
+      else timeout 1500 python -m pytest tests -m gpu -q -rfs -p no:cacheprovider > gpurun_out/${TAG}_pytest_gpu.log 2>&1; fi
+      echo "tests rc=$?"; tail -15 gpurun_out/${TAG}_pytest_gpu.log;;
+    smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${TAG}_smoke.log 2>&1; echo "smoke rc=$?"; tail -1 gpurun_out/${TAG}_smoke.log;;
+    bench) timeout 600 python bench.py --no-cpu-baseline $arg > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; echo "bench rc=$?"
+      python scripts/bench_digest.py gpurun_out/${TAG}_bench.json;;
+    bench_full) timeout 900 python bench.py $arg > gpurun_out/${TAG}_bench_full.json 2> gpurun_out/${TAG}_bench_full.err; echo "bench_full rc=$?"
+      python scripts/bench_digest.py gpurun_out/${TAG}_bench_full.json;;
+    reduce_ab) timeout 600 python scripts/reduce_ab.py $arg 2>&1 | grep -v amdgpu.ids | tee gpurun_out/${TAG}_reduce_ab.txt;;
+    py) s=${arg%% *}; timeout 900 python scripts/$arg 2>&1 | grep -v amdgpu.ids | tee gpurun_out/${TAG}_$(basename $s .py).txt;;
+    *) echo "unknown step $step";;
+  esac
+done
