@@ -514,6 +514,16 @@ __global__ __launch_bounds__(BLOCK) MPPI_REDUCE_ATTR void weights_reduce_kernel(
     float acc[NACC];
 #pragma unroll
     for (int j = 0; j < NACC; ++j) acc[j] = 0.0f;
+    // Ownership of this chunk's `ng` float4 groups (round 5): wave w owns r0 + w + NW*m for m < full = ng / NW — the same
+    // count for every wave — and the rem = ng % NW groups left over are spread over the TILES: with one left over, the
+    // wave (tile % 4) takes it; with two, waves {0, 1} take them on even tiles and {2, 3} on odd ones; three stay with
+    // waves 0..2.  Either way a wave only ever sees ONE remainder group (gx), so it needs one more accumulator set
+    // (accx), and the waves that share a group add theirs up at the end.  With the old static split a 25-group row
+    // (racing, nav2d) gave wave 0 seven groups and the others six: every block waited for its wave 0 at the round
+    // barrier, and all wave 0s share a SIMD — 12 % of a dense reduction.
+    float accx[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    __shared__ float s_x[NW][4];
+    const int ng = min(CHG, d.R - r0);
     float se = 0.0f, se2 = 0.0f, sec = 0.0f;
     const int64_t nwaves = (int64_t)gridDim.x * NW;
     bool block_live = false;  // block-uniform
@@ -554,35 +564,36 @@ __global__ __launch_bounds__(BLOCK) MPPI_REDUCE_ATTR void weights_reduce_kernel(
                 const uint64_t gi = (uint64_t)(d.sample_offset + i);
                 const bool inherit = (d.sample_offset + i) < d.inherit_count;
                 const float4* np = noise + (tile * d.R) * 64 + lane;
-                int moff = (inherit ? 0 : CHG) + wid;  // float4 offset of this lane's first mean group
+                int moff = inherit ? 0 : CHG;           // float4 offset of this lane's copy of the mean groups
                 asm volatile("" : "+v"(moff));          // opaque: keeps the LDS reads inside the loop
                 const float4* mp = reinterpret_cast<const float4*>(&s_mean[0][0]) + moff;
-                int nrl = d.R - r0 - wid;               // groups r0 + wid + NW*m with NW*m < nrl exist
-                asm volatile("" : "+s"(nrl));           // opaque: keeps the group predicates out of SGPRs
-                const auto accumulate = [&](int m, const float4& n4) {
-                    const float4 m4 = mp[NW * m];
+                int full = ng / NW;                     // groups r0 + wid + NW*m, m < full, exist for every wave
+                asm volatile("" : "+s"(full));          // opaque: keeps the group predicates out of SGPRs
+                const int rem = ng - full * NW;
+                // one float4 group (index g inside the chunk) of this tile into four accumulators
+                const auto accumulate4 = [&](float* a4, int g, const float4& n4) {
+                    const float4 m4 = mp[g];
                     const float nv[4] = {n4.x, n4.y, n4.z, n4.w};
                     const float mv[4] = {m4.x, m4.y, m4.z, m4.w};
-                    // (columns past the row length accumulate unused values; the fold drops them)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         float u;
                         if (WIDE) {
-                            const int cj = 4 * (wid + NW * m) + j;  // column inside this chunk
+                            const int cj = 4 * g + j;  // column inside this chunk
                             u = clampf(mv[j] + nv[j], s_bnd[0][cj], s_bnd[1][cj]);
                         } else {
                             const int k = ctrl_index(j, d.dc);
                             u = clampf(mv[j] + nv[j], d.u_min[k], d.u_max[k]);
                         }
-                        acc[4 * m + j] = fmaf(e, u, acc[4 * m + j]);
+                        a4[j] = fmaf(e, u, a4[j]);
                     }
                 };
+                const auto accumulate = [&](int m, const float4& n4) { accumulate4(&acc[4 * m], wid + NW * m, n4); };
                 if constexpr (GEN) {
-                    // Regenerated noise: the wave's groups are taken FOUR AT A TIME while four exist, so that four
+                    // Regenerated noise: the wave's groups are taken CHAINS at a time while that many exist, so that
                     // independent Philox + Box-Muller chains (10 dependent 64-bit multiplies each) sit in one basic block
-                    // and overlap — a per-group branch serialised them.  The tail of the row is a pair and / or a single
-                    // group (round 5): predicating whole quads generated 32 groups per tile for racing's / nav2d's
-                    // 25-group rows — 22 % of the second noise generation of a dense solve for columns the fold drops.
+                    // and overlap — a per-group branch serialised them.  Only groups of the row are generated (round 5:
+                    // predicating whole quads generated 32 groups per tile for racing's / nav2d's 25-group rows).
                     const auto quad = [&](int m0) {
                         float4 n4[4];
 #pragma unroll
@@ -598,30 +609,35 @@ __global__ __launch_bounds__(BLOCK) MPPI_REDUCE_ATTR void weights_reduce_kernel(
                         for (int k = 0; k < 2; ++k) accumulate(m0 + k, n4[k]);
                     };
                     const auto single = [&](int m) { accumulate(m, noise_group<true>(np, r0 + wid + NW * m, gi, gen, d)); };
-                    static_assert(GPW == 8, "the tail cases below are written for eight groups per wave");
-                    // live groups of this wave: m = 0 .. cnt-1 with cnt = ceil(nrl / NW) clamped to [0, GPW]
+                    static_assert(GPW == 8, "the cases below are written for eight groups per wave");
                     if constexpr (CHAINS == 4) {
-                    if (NW * 7 < nrl) { quad(0); quad(4); }
-                    else if (NW * 3 < nrl) {
-                        quad(0);
-                        if (NW * 5 < nrl) { pair(4); if (NW * 6 < nrl) single(6); }
-                        else if (NW * 4 < nrl) single(4);
+                        if (full >= 8) { quad(0); quad(4); }
+                        else if (full >= 4) {
+                            quad(0);
+                            if (full >= 6) { pair(4); if (full >= 7) single(6); }
+                            else if (full >= 5) single(4);
+                        } else {
+                            if (full >= 2) { pair(0); if (full >= 3) single(2); }
+                            else if (full >= 1) single(0);
+                        }
                     } else {
-                        if (NW * 1 < nrl) { pair(0); if (NW * 2 < nrl) single(2); }
-                        else if (0 < nrl) single(0);
-                    }
-                    } else {
-                    (void)quad;
+                        (void)quad;
 #pragma unroll
-                    for (int m0 = 0; m0 < GPW; m0 += 2) {
-                        if (NW * (m0 + 1) < nrl) pair(m0);
-                        else if (NW * m0 < nrl) single(m0);
-                    }
+                        for (int m0 = 0; m0 < GPW; m0 += 2) {
+                            if (full >= m0 + 2) pair(m0);
+                            else if (full >= m0 + 1) single(m0);
+                        }
                     }
                 } else {
 #pragma unroll
                     for (int m = 0; m < GPW; ++m)
-                        if (NW * m < nrl) accumulate(m, noise_group<false>(np, r0 + wid + NW * m, gi, gen, d));
+                        if (m < full) accumulate(m, noise_group<false>(np, r0 + wid + NW * m, gi, gen, d));
+                }
+                // this wave's share of the remainder groups (see `accx` above)
+                const bool mine = rem == 1 ? ((int)tile & 3) == wid : rem == 2 ? ((int)tile & 1) == (wid >> 1) : wid < rem;
+                if (mine) {  // wave-uniform
+                    const int g = NW * full + (rem == 1 ? 0 : rem == 2 ? (wid & 1) : wid);
+                    accumulate4(accx, g, noise_group<GEN>(np, r0 + g, gi, gen, d));
                 }
             }
         }
@@ -630,26 +646,45 @@ __global__ __launch_bounds__(BLOCK) MPPI_REDUCE_ATTR void weights_reduce_kernel(
     // cross-lane reduction, RP = 8 accumulators per pass: every lane stores its 8 values as a column of
     // s_red[wid][j][lane]; lane l then sums row j = l & 7 over the 8 lanes [8*(l>>3), +8) (row stride 65 floats:
     // conflict-free), and the eight segments are added with three shuffles.  Accumulator 4*m + j of wave
-    // w is column 4*(r0 + w + NW*m) + j of the row.
+    // w is column 4*(r0 + w + NW*m) + j of the row (m < ng / NW); the remainder groups' accumulators are summed over the
+    // waves that took them (fixed order) and are columns 4*(r0 + NW*(ng/NW) + group) + j.
     const int colsp = gridDim.y * CHG * 4;
-    if (block_live) {
+    const auto lane_sum8 = [&](const float* a8) {  // lanes 0..7 return the sums over the wave of a8[0..7]
+#pragma unroll
+        for (int j = 0; j < RP; ++j) s_red[wid][j][lane] = a8[j];
+        __builtin_amdgcn_wave_barrier();
+        const float* rowp = &s_red[wid][lane & (RP - 1)][(lane >> 3) * 8];
+        float v0 = rowp[0] + rowp[1], v1 = rowp[2] + rowp[3], v2 = rowp[4] + rowp[5], v3 = rowp[6] + rowp[7];
+        float v = (v0 + v1) + (v2 + v3);
+        v += __shfl_xor(v, 8);
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        __builtin_amdgcn_wave_barrier();
+        return v;
+    };
+    if (block_live) {  // (block-uniform)
+        const int full = ng / NW, rem = ng - full * NW;
 #pragma unroll
         for (int p = 0; p < NACC / RP; ++p) {
+            const float v = lane_sum8(&acc[p * RP]);
+            const int a = p * RP + lane;
+            if (lane < RP && (a >> 2) < full) partials[(int64_t)blockIdx.x * colsp + 4 * (r0 + wid + NW * (a >> 2)) + (a & 3)] = v;
+        }
+        if (rem) {
+            float x8[RP];
 #pragma unroll
-            for (int j = 0; j < RP; ++j) s_red[wid][j][lane] = acc[p * RP + j];
-            __builtin_amdgcn_wave_barrier();
-            const float* rowp = &s_red[wid][lane & (RP - 1)][(lane >> 3) * 8];
-            float v0 = rowp[0] + rowp[1], v1 = rowp[2] + rowp[3], v2 = rowp[4] + rowp[5], v3 = rowp[6] + rowp[7];
-            float v = (v0 + v1) + (v2 + v3);
-            v += __shfl_xor(v, 8);
-            v += __shfl_xor(v, 16);
-            v += __shfl_xor(v, 32);
-            if (lane < RP) {
-                const int a = p * RP + lane;
-                const int col = 4 * (r0 + wid + NW * (a >> 2)) + (a & 3);
-                partials[(int64_t)blockIdx.x * colsp + col] = v;
+            for (int j = 0; j < RP; ++j) x8[j] = j < 4 ? accx[j & 3] : 0.0f;
+            const float v = lane_sum8(x8);
+            if (lane < 4) s_x[wid][lane] = v;
+            __syncthreads();
+            if (threadIdx.x < 4 * rem) {  // remainder group j = threadIdx.x >> 2: the waves that took it, in order
+                const int j = threadIdx.x >> 2, jj = threadIdx.x & 3;
+                float t = 0.0f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w)
+                    if (rem == 1 || (rem == 2 ? (w & 1) == j : w == j)) t += s_x[w][jj];
+                partials[(int64_t)blockIdx.x * colsp + 4 * (r0 + NW * full + j) + jj] = t;
             }
-            __builtin_amdgcn_wave_barrier();
         }
     }
     se = wave_sum(se);

@@ -117,21 +117,25 @@ def check_rel(quantity, got, want, tol):
 # sample maximum): a measurement of the reference's own spread, held at 1.0x.  The parity report also counts the checks
 # beyond 1e-5 and gives each band's 99th percentile.
 BAND_MARGIN = 1.0
+# ... except for the OPT-IN device-resident LBPS search (lbps_search="device"): it returns the float64 minimiser of the
+# objective, which is not where the reference's Brent stops (MPPI's docstring); end to end it is held to 1.5x the band
+BAND_MARGIN_FAST_LBPS = 1.5
 
 
-def check_banded(quantity, got, want, band, floor=TOL):
+def check_banded(quantity, got, want, band, floor=TOL, margin=None):
     """rel_err(got, want) <= max(floor, BAND_MARGIN * band) where `band` is the reference's own measured spread of that
     quantity (committed with the fixture); the report keeps the value, the band and whether the plain 1e-5 held."""
     err = rel_err(got, want)
-    limit = max(floor, BAND_MARGIN * band)
+    margin = BAND_MARGIN if margin is None else margin
+    limit = max(floor, margin * band)
     parity_report.record(quantity, err, limit, reference_band=float(band), reference_band_p99=getattr(band, "p99", None),
                          band_probes=getattr(band, "probes", None), within_1e5=bool(err <= TOL),
                          within_band=bool(err <= max(floor, band)), above_band_itself=bool(err > band))
-    assert err <= limit, f"{quantity}: {err:.2e} > max({floor:.0e}, {BAND_MARGIN} x reference band {band:.2e})"
+    assert err <= limit, f"{quantity}: {err:.2e} > max({floor:.0e}, {margin} x reference band {band:.2e})"
     return err
 
 
-def check_end_to_end(a, s, c_gpu, g, k, cfg, band_a, band_s, tag=""):
+def check_end_to_end(a, s, c_gpu, g, k, cfg, band_a, band_s, tag="", margin=None):
     """Action / state sequence of solve k against the reference fixture: 1e-5, or the reference's own measured spread
     under rounding-level changes of its costs where that is larger (see the module docstring)."""
     from pi_mpc import _host
@@ -153,8 +157,8 @@ def check_end_to_end(a, s, c_gpu, g, k, cfg, band_a, band_s, tag=""):
                 U = _host.sg_filter_sequence(g[f"sg_hist_in_{k}"], U, sg_coeffs(cfg))
             parity_report.record("argmin_action_vs_reference_sample", np.abs(a - U).max() / max(np.abs(U).max(), 1e-30), 1e-6 + BAND_MARGIN * band_a)
             assert np.abs(a - U).max() <= (1e-6 + BAND_MARGIN * band_a) * max(np.abs(U).max(), 1e-30), "action != U[argmin]"
-    check_banded("action_seq_vs_reference_fixture" + tag, a, a_ref, band_a)
-    check_banded("state_seq_vs_reference_fixture" + tag, s, s_ref, band_s)
+    check_banded("action_seq_vs_reference_fixture" + tag, a, a_ref, band_a, margin=margin)
+    check_banded("state_seq_vs_reference_fixture" + tag, s, s_ref, band_s, margin=margin)
 
 
 # the library's own search tolerances (the reference-side spread of the temperature comes from the fixture bands):
@@ -332,7 +336,8 @@ def _identical_seed_closed_loop(name, tag="", **solver_kw):
             assert abs(lam - lam_ref) <= lim * lam_ref, (k, lam, lam_ref, lim)
         else:
             assert lam == lam_ref
-        check_end_to_end(a.cpu().numpy(), s.cpu().numpy(), c, g, k, cfg, band["action"], band["state"], tag=tag)
+        check_end_to_end(a.cpu().numpy(), s.cpu().numpy(), c, g, k, cfg, band["action"], band["state"], tag=tag,
+                         margin=BAND_MARGIN_FAST_LBPS if solver._rule_on_device == "LBPS" else None)
         if "posterior_after" in g.files and int(g["posterior_after"]) == k:
             ps, pst = solver.get_samples_from_posterior(a, state, g["posterior_samples"].shape[0])
             assert rel_err(ps.cpu().numpy(), g["posterior_samples"]) <= max(TOL, BAND_MARGIN * band["action"])
@@ -2276,6 +2281,8 @@ def test_single_launch_solve_equals_the_multi_kernel_path(model, T, N, lam, kw):
     against the same solve as separate launches (option fused_solve = 0), closed loop over the warm start: costs,
     minimum and the searched temperature bit-identical, action and state sequences equal to the rounding of the two
     summation orders; the queries that read the solve's state afterwards (top samples, weights) agree as well."""
+    if lam == "LBPS":
+        kw = dict(kw, lbps_search="device")  # (the search as kernels; the default — Brent — reads statistics back per probe)
     fused, cf = make_solver(model, T, N, lambda_=lam, **kw)
     fused.set_option("fused_solve", 2)  # (1, the default, takes the single launch up to 4096 samples only)
     multi, cm = make_solver(model, T, N, lambda_=lam, **kw)
