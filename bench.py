@@ -457,7 +457,20 @@ def main():
             "roofline": {"bound": "valu", "kernel": "rollout_cost_kernel<racing>", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale,
-                         "algorithmic_bytes_per_launch": b_alg_rollout, "kernel_ms": stages["rollout_cost"]},
+                         "algorithmic_bytes_per_launch": b_alg_rollout, "kernel_ms": stages["rollout_cost"],
+                         # what the kernel really moves (PMC bytes / its time) and how much of the VALU issue peak it uses:
+                         # read `frac` next to these two
+                         "hbm_measured_GBps": None if traffic is None else traffic / t_roll / 1e9,
+                         "valu_frac": None if valu is None else valu["frac"],
+                         "note": "`achieved` / `frac` price the kernel's ALGORITHMIC bytes (SURVEY 8d: the noise it consumes + the "
+                                 "costs it writes) against the HBM peak as the metric asks; the kernel regenerates that noise in "
+                                 "registers, moves ~1 % of those bytes (`hbm_measured_GBps`) and is bound by VALU issue "
+                                 "(`valu_frac`; 0.69 is what its instruction mix allows).  Whole solve: SURVEY 8d's B_alg / "
+                                 "ms_per_step = %.2f x the HBM peak — not a bandwidth: two of B_alg's three noise-sized terms never "
+                                 "exist (no sampler pass, no second read) and at lambda = 1 the weighted reduction is an arg-min "
+                                 "over one or two of 16 384 tiles.  `other_configs.c3_dense` is the same workload with a dense "
+                                 "softmax (every tile regenerated a second time), with its own per-kernel roofline."
+                                 % (b_alg_solve / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS)},
             # the whole solve (every kernel of it): what it MOVES through HBM (PMC, all mppi:: kernels of a solve) and how
             # much of the VALU issue peak it uses over its device time.  SURVEY 8d's B_alg (three noise-sized terms + the
             # costs) is kept for reference only: two of its terms never touch HBM in this design (the noise is
@@ -503,6 +516,21 @@ def main():
         out = compose(runs[0], runs)
         ctrl = runs[0]["ctrl"]
         if not args.no_extras:
+            if args.steps < 200:
+                # the driver's --steps 20 carries the fixed cost of ONE timed region (~40 us: pipeline fill after the
+                # synchronise, the stand-alone completion of the last state sequence, the final wake-up) = 2 us per step;
+                # the same solver over 200 steps shows it
+                sv = ctrl.solver
+                sync()
+                t0 = time.perf_counter()
+                for _ in range(200):
+                    sv.forward(x0)
+                sv.join_state_seq()
+                sync()
+                dt200 = time.perf_counter() - t0
+                out["long_run"] = {"steps": 200, "ms_per_step": dt200 / 200 * 1e3, "value": N_total * T * 200 / dt200,
+                                   "note": "the contract's line above times --steps %d; one timed region has a fixed cost of "
+                                           "~40 us whatever K is" % args.steps}
             # the solver's own default since round 5: state_seq rolled out inside the solve's last kernel
             er = timed_run(None, lazy=not bool(args.lazy_state_seq))
             out["eager_state_seq" if args.lazy_state_seq else "lazy_state_seq"] = {
@@ -789,7 +817,8 @@ def other_configs(torch, np):
         dt = _time_solver(torch, s, x0)
         out[key] = {"config": label, "ms_per_solve": dt * 1e3, "solves_per_sec": 1 / dt,
                     "sample_steps_per_sec": work / dt, "algorithmic_bytes_per_solve": b_alg,
-                    "frac_of_8TBps": b_alg / dt / 1e9 / HBM_PEAK_GBS, "lambda": s._last_lambda}
+                    "frac_of_8TBps": b_alg / dt / 1e9 / HBM_PEAK_GBS, "lambda": s._last_lambda,
+                    "timing": "best of three 50-solve loops (min-of-3)"}
         del s
     n, T = 1 << 20, 50
     for key, lam, label in (("c3_dense", 5000.0, "C3 racing T=50 N=1048576 lambda=5000 (dense softmax)"),
@@ -801,9 +830,42 @@ def other_configs(torch, np):
         stages = _stage_times(torch, s, x0)
         out[key] = {"config": label, "ms_per_solve": dt * 1e3, "solves_per_sec": 1 / dt, "sample_steps_per_sec": n * T / dt,
                     "stages_ms": stages, "other_launches_ms": max(dt * 1e3 - sum(stages.values()), 0.0),
-                    "lambda": s._last_lambda, "ess": st["ess"]}
+                    "lambda": s._last_lambda, "ess": st["ess"], "timing": "best of three 50-solve loops (min-of-3)"}
+        if key == "c3_dense":
+            out[key]["roofline"] = _dense_roofline(stages)
         del s, ctrl
         torch.cuda.empty_cache()
+    return out
+
+
+def _dense_roofline(stages):
+    """Per-kernel roofline of the dense C3 solve: the two kernels that each consume all N*T*dc noise values (algorithmic
+    423.6 MB per launch) against the HBM peak, and — from profiles/pmc_constants.json (`dense_*`: rocprofv3 PMC of
+    `bench.py --workload c3_dense`, keyed on the source hash) — their share of the VALU issue peak and what they really move.
+    Stage times are live HIP events; the weights_reduce STAGE is the reduction kernel plus the fold of its partial rows
+    (summarize_kernel, ~6 us)."""
+    n, T, dc = 1 << 20, 50, 2
+    b_alg = 4 * dc * n * T + 4 * n
+    peak = 1024 * 2.4e9 / 2
+    pc, stale = {}, None
+    try:
+        from mppi_playground_amd import _build
+
+        pc = json.load(open(os.path.join(ROOT, "profiles", "pmc_constants.json")))
+        stale = pc.get("csrc_sha256") != _build.source_digest()
+    except Exception:
+        pass
+    out = {"bound": "valu", "unit": "GB/s", "peak": HBM_PEAK_GBS, "counters_stale": stale}
+    for stage, kname, key in (("rollout_cost", "rollout_cost_kernel<racing>", "dense_rollout"),
+                              ("weights_reduce", "weights_reduce_kernel (+ summarize_kernel)", "dense_reduce")):
+        t = stages[stage] * 1e-3
+        k = pc.get(key) or {}
+        moved = None if k.get("fetch_kb") is None else int((2 * k["fetch_kb"] + k["write_kb"]) * 1024)
+        out[stage] = {"kernel": kname, "kernel_ms": stages[stage], "algorithmic_bytes_per_launch": b_alg,
+                      "achieved": b_alg / t / 1e9, "frac": b_alg / t / 1e9 / HBM_PEAK_GBS,
+                      "valu_insts_per_launch": k.get("valu_insts"),
+                      "valu_frac": None if not k.get("valu_insts") else k["valu_insts"] / t / peak,
+                      "traffic": moved, "hbm_measured_GBps": None if moved is None else moved / t / 1e9}
     return out
 
 
