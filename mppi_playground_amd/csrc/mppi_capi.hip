@@ -22,11 +22,6 @@ using namespace mppi;
 // beyond it the multi-block summarize_kernel is cheaper than one block walking the rows.
 static constexpr int FOLD_IN_FINALIZE_MAX_ROWS = 64;
 
-// The rollout kernel's epilogue produces the first-grid ESSPS statistics while its grid has at most this many blocks (the
-// select step rescales (blocks x 96) partial sums in ONE block: 256 rows at C2, 1024 at C5; at C3's 4096 the rescale costs
-// what the saved launch bought — profiles/r04_experiments.md, r05_experiments.md).
-static constexpr int ROLL_STATS_MAX_BLOCKS = mppi::RollStats::MAX_BLOCKS;
-
 struct MppiSolver {
     MppiConfig cfg{};
     Dims d{};
@@ -113,11 +108,6 @@ struct MppiSolver {
     float* heads = nullptr;
     float* summary = nullptr;
     float* stats_part = nullptr;     // [STATS_BLOCKS][max(4, STATS_L*3)]
-    // first-grid ESSPS statistics produced by the rollout kernel's epilogue (round 5): rows relative to the blocks' minima
-    float* roll_part = nullptr;      // [ROLL_STATS_MAX_BLOCKS][STATS_L*3]  (inside the lams_dev allocation: RollStats)
-    float* roll_pmin = nullptr;      // [ROLL_STATS_MAX_BLOCKS]
-    int roll_stats_blocks = 0;       // rows the last rollout launch left for the grid now in lams0 (0: none / stale)
-    int roll_stats = 1;              // option "roll_stats": 0 = always the separate statistics pass
     unsigned long long* round1_cells = nullptr;  // [STATS_BLOCKS][STATS_L*3] {value, launch number}: essps_round1_kernel
     unsigned round1_seq = 0;
     bool essps_merge0 = false;  // round 0 as one launch too (option "essps_merge0": measured on par at 65 536 samples and
@@ -381,7 +371,6 @@ P2pCtx p2p_ctx(mppi_handle_t h) {
 }  // namespace
 
 static int mpo_upload(mppi_handle_t h, double lambda0, double epsilon, double lr, bool lambda_too);
-static int essps_prepare(mppi_handle_t h, double lam_min, double lam_max);
 static int flush_state_seq(mppi_handle_t h, hipStream_t s);
 static int settle_state_seq(mppi_handle_t h);
 static int order_behind_pending(mppi_handle_t h, hipStream_t s);
@@ -470,7 +459,6 @@ int mppi_create(const MppiConfig* cfg, mppi_handle_t* out) {
     HIP_TRY(h, hipMalloc(&h->heads, sizeof(float) * (size_t)max_blocks * 4));
     HIP_TRY(h, hipMalloc(&h->summary, sizeof(float) * (size_t)(MPPI_SUMMARY_HEAD + d.row)));
     HIP_TRY(h, hipMalloc(&h->stats_part, sizeof(float) * STATS_L * 3 * STATS_BLOCKS));
-
     HIP_TRY(h, hipMalloc(&h->round1_cells, sizeof(unsigned long long) * STATS_L * 3 * STATS_BLOCKS));
     HIP_TRY(h, hipMemset(h->round1_cells, 0, sizeof(unsigned long long) * STATS_L * 3 * STATS_BLOCKS));
     HIP_TRY(h, hipHostMalloc((void**)&h->stats_host, sizeof(double) * (8 + STATS_L * 3 + 3), hipHostMallocMapped));
@@ -479,11 +467,7 @@ int mppi_create(const MppiConfig* cfg, mppi_handle_t* out) {
     HIP_TRY(h, hipMalloc(&h->mpo_temp_dev, sizeof(float)));
     HIP_TRY(h, hipMalloc(&h->lbps_dev, sizeof(LbpsDev)));
     HIP_TRY(h, hipMalloc(&h->stats_max, sizeof(float) * STATS_BLOCKS));
-    // (RollStats layout: grids, the rollout epilogue's rows, the inputs of a pending batch-1 rollout)
-    HIP_TRY(h, hipMalloc(&h->lams_dev, sizeof(float) * ((size_t)RollStats::B1 + d.row + MPPI_MAX_DIM_STATE)));
-    h->roll_pmin = h->lams_dev + RollStats::PMIN;
-    h->roll_part = h->lams_dev + RollStats::PART;
-    h->b1 = h->lams_dev + RollStats::B1;
+    HIP_TRY(h, hipMalloc(&h->lams_dev, sizeof(float) * 3 * STATS_L));
     HIP_TRY(h, hipMalloc(&h->essps_dev, sizeof(EsspsDev)));
     HIP_TRY(h, hipMalloc(&h->lambda_dev, sizeof(float)));
     HIP_TRY(h, hipHostMalloc((void**)&h->live_hint, sizeof(int), hipHostMallocMapped));
@@ -557,6 +541,7 @@ int mppi_destroy(mppi_handle_t h) {
     }
     for (auto& pool : h->ev_pool) for (auto& e : pool) if (e) (void)hipEventDestroy(e);
     if (h->lazy_ev) (void)hipEventDestroy(h->lazy_ev);
+    (void)hipFree(h->b1);
     delete h;
     return MPPI_OK;
 }
@@ -957,35 +942,25 @@ int mppi_rollout_cost(mppi_handle_t h, void* stream) {
     // launch: its T dependent steps hide behind the N-sample rollout instead of extending the previous solve's tail
     float* ride = h->pending_state_out;
     if (ride) { if (int rc = order_behind_pending(h, s)) return rc; }
-    const unsigned cost_blocks = (unsigned)((h->d.tiles + 3) / 4);
-    const unsigned grid = cost_blocks + (ride ? 1u : 0u);
-    // first-grid statistics of a device-resident ESSPS search from this kernel's epilogue (see the kernel)
-    h->roll_stats_blocks = 0;
-    const bool roll = gen && h->roll_stats && h->auto_rule == MPPI_AUTO_ESSPS && cost_blocks <= (unsigned)ROLL_STATS_MAX_BLOCKS && !h->essps_merge0;
-    if (roll) { if (int rc = essps_prepare(h, h->auto_lo, h->auto_hi)) return rc; }  // (the grid in lams0: set-up path the first time)
+    const unsigned grid = (unsigned)((h->d.tiles + 3) / 4) + (ride ? 1u : 0u);
 #define CALL_ROLLOUT(MODEL, FASTV)                                                                    \
     do {                                                                                              \
         const size_t shmem = sizeof(float) * std::max((size_t)8 * h->d.R + (size_t)h->d.T * ModelT<MODEL, FASTV>::KROW, \
                                                       (size_t)h->d.row + MPPI_MAX_DIM_STATE);         \
         constexpr bool UCV = FASTV != 0;  /* the FAST kernels exist in the u_in_bounds form only (see use_fast) */ \
-        if (gen && roll)                                                                              \
-            hipLaunchKernelGGL((rollout_cost_kernel<MODEL, FASTV, true, UCV, true>), dim3(grid), dim3(BLOCK), shmem, s, \
-                               h->noise, h->mean, h->x0_cur, h->costs, mk, mk_next, h->mean_used, h->x0_used, h->d, h->gen, h->ctx, \
-                               h->lams_dev, ride);                                                    \
-        else if (gen)                                                                                 \
+        if (gen)                                                                                      \
             hipLaunchKernelGGL((rollout_cost_kernel<MODEL, FASTV, true, UCV>), dim3(grid), dim3(BLOCK), shmem, s, \
                                h->noise, h->mean, h->x0_cur, h->costs, mk, mk_next, h->mean_used, h->x0_used, h->d, h->gen, h->ctx, \
-                               h->lams_dev, ride);                                                    \
+                               (const float*)h->b1, ride);                                           \
         else                                                                                          \
             hipLaunchKernelGGL((rollout_cost_kernel<MODEL, FASTV, false, UCV>), dim3(grid), dim3(BLOCK), shmem, s, \
                                h->noise, h->mean, h->x0_cur, h->costs, mk, mk_next, h->mean_used, h->x0_used, h->d, h->gen, h->ctx, \
-                               h->lams_dev, ride);                                                    \
+                               (const float*)h->b1, ride);                                           \
     } while (0)
     MPPI_DISPATCH(h, CALL_ROLLOUT);
 #undef CALL_ROLLOUT
     HIP_TRY(h, hipGetLastError());
     if (ride) h->pending_state_out = nullptr;  // (cleared only once the launch that carries it went through)
-    if (roll) h->roll_stats_blocks = (int)cost_blocks;
     return MPPI_OK;
 }
 
@@ -1006,7 +981,6 @@ int mppi_set_costs(mppi_handle_t h, const float* src, int on_device, void* strea
     if (!h || !src) return fail(h, MPPI_E_INVALID, "null");
     hipStream_t s = (hipStream_t)stream;
     if (int rc = copy_small(h, h->costs, src, sizeof(float) * (size_t)h->d.N, true, on_device != 0, s)) return rc;
-    h->roll_stats_blocks = 0;  // (the rollout kernel's epilogue statistics belong to the costs it wrote)
     HIP_TRY(h, hipMemsetAsync(h->min_key + h->min_slot, 0xFF, sizeof(unsigned), s));
     const unsigned grid = (unsigned)std::min<int64_t>((h->d.N + BLOCK - 1) / BLOCK, 1024);
     hipLaunchKernelGGL(min_cost_kernel, dim3(grid), dim3(BLOCK), 0, s, h->costs, h->d.N, h->min_key + h->min_slot);
@@ -1202,7 +1176,6 @@ static bool fused_applies(mppi_handle_t h, float lambda) {
 // finished search leaves the first grid of the next one behind (host_search.hpp: essps_first_grid).  Set-up path, blocking.
 static int essps_prepare(mppi_handle_t h, double lam_min, double lam_max) {
     if (h->essps_lo == lam_min && h->essps_hi == lam_max) return MPPI_OK;
-    h->roll_stats_blocks = 0;  // (rows of another grid)
     EsspsDev st{};
     float lamf[STATS_L];
     h->essps_range = mppi::host::essps_range(lam_min, lam_max);
@@ -1440,24 +1413,17 @@ int mppi_essps_lambda_device(mppi_handle_t h, double target_ess, double lam_min,
     host_lam += 8 + STATS_L * 3;
     float* lams0 = h->lams_dev + STATS_L;
     float* lams1 = h->lams_dev + 2 * STATS_L;
-    // rows the rollout launch of THIS solve left for the grid in lams0 (essps_prepare above voids them when the range
-    // changed); every search rewrites lams0, so they serve one search
-    const int roll_rows = h->roll_stats_blocks;
-    h->roll_stats_blocks = 0;
     for (int r = 0; r < 2; ++r) {
         if (++h->round1_seq == 0u) h->round1_seq = 1u;  // (the cells start out zeroed: 0 tags nothing)
         if (r == 0 && h->essps_merge0)
             hipLaunchKernelGGL(essps_round_kernel<0>, dim3(blocks), dim3(STATS_THREADS), 0, s, h->costs, h->d.N, mk, target_ess,
                                h->essps_range, h->essps_dev, lams1, lams0, h->lambda_dev, host_lam, h->round1_cells,
                                h->round1_seq);
-        else if (r == 0 && roll_rows > 0)  // the rollout kernel's epilogue already summed this grid (rows relative to block minima)
-            hipLaunchKernelGGL(essps_select_kernel, dim3(1), dim3(1024), 0, s, (const float*)h->roll_part, roll_rows, target_ess,
-                               h->essps_range, h->essps_dev, lams1, lams0, h->lambda_dev, host_lam, (const float*)h->roll_pmin, mk);
         else if (r == 0) {
             hipLaunchKernelGGL(stats_multi_kernel, dim3(blocks), dim3(STATS_THREADS), 0, s, h->costs, h->d.N, mk,
                                (const float*)lams0, h->stats_part, (float*)nullptr);
             hipLaunchKernelGGL(essps_select_kernel, dim3(1), dim3(1024), 0, s, (const float*)h->stats_part, blocks, target_ess,
-                               h->essps_range, h->essps_dev, lams1, lams0, h->lambda_dev, host_lam, (const float*)nullptr, mk);
+                               h->essps_range, h->essps_dev, lams1, lams0, h->lambda_dev, host_lam);
         } else
             hipLaunchKernelGGL(essps_round_kernel<1>, dim3(blocks), dim3(STATS_THREADS), 0, s, h->costs, h->d.N, mk, target_ess,
                                h->essps_range, h->essps_dev, lams1, lams0, h->lambda_dev, host_lam, h->round1_cells,
@@ -1968,7 +1934,6 @@ int mppi_set_option(mppi_handle_t h, const char* key, int64_t value) {
         h->essps_prev_host.warm = false;
         return MPPI_OK;
     }
-    if (k == "roll_stats") { h->roll_stats = value ? 1 : 0; h->roll_stats_blocks = 0; return MPPI_OK; }
     if (k == "reduce_chains") { h->reduce_chains = value == 2 ? 2 : value == 4 ? 4 : 0; return MPPI_OK; }
     if (k == "fused_solve") { h->fused_mode = value < 0 ? 0 : value > 2 ? 2 : (int)value; return MPPI_OK; }
     if (k == "fused_timeout_us") {  // poll budget of the single-launch solve (default 20 000 us; 100 MHz ticks inside)
@@ -1981,6 +1946,7 @@ int mppi_set_option(mppi_handle_t h, const char* key, int64_t value) {
         return MPPI_OK;
     }
     if (k == "lazy_state_seq") {  // see mppi_join_state_seq
+        if (value && !h->b1) HIP_TRY(h, hipMalloc(&h->b1, sizeof(float) * ((size_t)h->d.row + MPPI_MAX_DIM_STATE)));
         h->lazy_state = value ? 1 : 0;
         return MPPI_OK;
     }

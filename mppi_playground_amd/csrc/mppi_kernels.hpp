@@ -17,16 +17,6 @@ namespace mppi {
 
 constexpr int WAVE = 64;
 constexpr int BLOCK = 256;  // 4 waves
-constexpr int STATS_L = 32;  // temperatures per statistics pass of the device-resident searches (see stats_multi_kernel)
-// One device allocation (floats): the three 32-temperature grids of the searches, what rollout_cost_kernel's epilogue
-// leaves for the ESSPS select step (every block's minimum and its [32][3] partial sums), and the inputs of a pending
-// batch-1 rollout.
-struct RollStats {
-    static constexpr int MAX_BLOCKS = 1024;
-    static constexpr int LAMS = 0, LAMS0 = STATS_L, LAMS1 = 2 * STATS_L;  // caller's grid, ESSPS round-0 grid, round-1 grid
-    static constexpr int PMIN = 3 * STATS_L, PART = PMIN + MAX_BLOCKS, B1 = PART + MAX_BLOCKS * STATS_L * 3;
-    // B1: [row + dim_state] inputs of a lazily completed batch-1 rollout (finalize_kernel -> state_seq_kernel / the ride block)
-};
 
 struct Dims {
     int64_t N;              // local samples
@@ -313,7 +303,7 @@ __device__ __forceinline__ void batch1_rollout(const ModelCtx& ctx, const float*
 #ifndef MPPI_ROLLOUT_ATTR
 #define MPPI_ROLLOUT_ATTR  // e.g. __attribute__((amdgpu_waves_per_eu(8))) for occupancy experiments
 #endif
-template <int MODEL, int FAST, bool GEN, bool UC, bool STATS = false>
+template <int MODEL, int FAST, bool GEN, bool UC>
 __global__ __launch_bounds__(BLOCK) MPPI_ROLLOUT_ATTR void rollout_cost_kernel(const float4* __restrict__ noise,
                                                              const float* __restrict__ mean,
                                                              const float* __restrict__ x0,
@@ -322,13 +312,9 @@ __global__ __launch_bounds__(BLOCK) MPPI_ROLLOUT_ATTR void rollout_cost_kernel(c
                                                              unsigned* __restrict__ next_min_key,
                                                              float* __restrict__ mean_used,
                                                              float* __restrict__ x0_used, Dims d, GenCtx gen,
-                                                             ModelCtx ctx, float* __restrict__ aux,
+                                                             ModelCtx ctx, const float* __restrict__ b1_in,
                                                              float* __restrict__ b1_state_out) {
     using M = ModelT<MODEL, FAST>;
-    // `aux`: the handle's RollStats block — the inputs of a pending batch-1 rollout (B1) and the statistics rows the epilogue
-    // writes.  STATS is a template parameter, not a run-time flag: with the epilogue compiled in, the racing kernel needs
-    // 102-106 SGPRs instead of 98 and loses its eighth wave per SIMD whether or not the epilogue runs (parking the
-    // arguments in LDS across the loop cost every model 1-2 VGPRs instead — both measured on the compiler's resource report).
     __shared__ float s_min[BLOCK / WAVE];
     // [4*R] mean groups, [4*R] zeros (samples that do not inherit the mean), then [T*KROW] step rows
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];
@@ -336,7 +322,6 @@ __global__ __launch_bounds__(BLOCK) MPPI_ROLLOUT_ATTR void rollout_cost_kernel(c
     // batch-1 rollout of that solution (mppi.py:448-449) from the inputs finalize_kernel left in b1_in — T dependent steps
     // of one wave, hidden behind this launch's N-sample rollout instead of extending the previous solve's tail.
     if (b1_state_out != nullptr && blockIdx.x == gridDim.x - 1) {
-        const float* b1_in = aux + RollStats::B1;
         for (int i = threadIdx.x; i < d.row + M::DS; i += BLOCK) s_dyn[i] = b1_in[i];
         __syncthreads();
         batch1_rollout<MODEL, FAST>(ctx, s_dyn + d.row, s_dyn, d.T, b1_state_out);
@@ -379,49 +364,11 @@ __global__ __launch_bounds__(BLOCK) MPPI_ROLLOUT_ATTR void rollout_cost_kernel(c
     const float wm = wave_min(total);
     if (lane == 0) s_min[wid] = wm;
     __syncthreads();
-    float m = s_min[0];
+    if (threadIdx.x == 0) {
+        float m = s_min[0];
 #pragma unroll
-    for (int w = 1; w < BLOCK / WAVE; ++w) m = fminf(m, s_min[w]);
-    if (threadIdx.x == 0 && m < INFINITY) atomicMin(min_key, float_to_key(m));
-    // Epilogue (round 5; launch-uniform): the statistics of the FIRST temperature grid of a device-resident ESSPS search,
-    // {sum e, sum e^2, sum e*c} for the 32 temperatures in `stats_lams`, over this block's 256 costs and relative to the
-    // block's OWN minimum (the global one is not known before the last block is done) -> stats_part[block][32][3],
-    // stats_pmin[block].  The select step rescales every row by exp((cmin - m_b) / lambda) (ScaledRows).  This replaces
-    // the separate 32-temperature pass over the costs (stats_multi_kernel: a launch of ~6 us on a 16 us rollout at C2) by
-    // ~300 instructions per thread here.  Same mapping as stats_multi_block: thread (l = tid & 31, chunk = tid >> 5) walks
-    // the 32 costs of its chunk for ITS temperature (LDS broadcast reads).
-    if constexpr (STATS) {
-        float* auxp = aux;
-        const float* stats_lams = auxp + RollStats::LAMS0;
-        float* stats_pmin = auxp + RollStats::PMIN;
-        float* stats_part = auxp + RollStats::PART;
-        __shared__ float s_sc[BLOCK];
-        __shared__ float s_sp[BLOCK / WAVE][STATS_L * 3];
-        s_sc[threadIdx.x] = total < INFINITY ? total : 3.0e38f;  // padding lanes: e = 0 and 0 * c = 0
-        __syncthreads();
-        const float bm = m < INFINITY ? m : 0.0f;
-        const int l = threadIdx.x & (STATS_L - 1), chunk = threadIdx.x >> 5;
-        const float inv_lam = 1.0f / stats_lams[l];
-        const float* cc = s_sc + chunk * 32;
-        float se = 0.0f, se2 = 0.0f, sec = 0.0f;
-#pragma unroll 8
-        for (int j = 0; j < 32; ++j) {
-            const float c = cc[j];
-            const float e = expf((bm - c) * inv_lam);
-            se += e;
-            se2 = fmaf(e, e, se2);
-            sec = fmaf(e, c, sec);
-        }
-        se += __shfl_xor(se, 32); se2 += __shfl_xor(se2, 32); sec += __shfl_xor(sec, 32);  // the wave's two chunks
-        if (lane < STATS_L) { s_sp[wid][3 * lane] = se; s_sp[wid][3 * lane + 1] = se2; s_sp[wid][3 * lane + 2] = sec; }
-        __syncthreads();
-        if (threadIdx.x < STATS_L * 3) {
-            float v = 0.0f;
-#pragma unroll
-            for (int w = 0; w < BLOCK / WAVE; ++w) v += s_sp[w][threadIdx.x];
-            stats_part[(int64_t)blockIdx.x * (STATS_L * 3) + threadIdx.x] = v;
-        }
-        if (threadIdx.x == STATS_L * 3) stats_pmin[blockIdx.x] = bm;
+        for (int w = 1; w < BLOCK / WAVE; ++w) m = fminf(m, s_min[w]);
+        if (m < INFINITY) atomicMin(min_key, float_to_key(m));
     }
 }
 
@@ -604,19 +551,13 @@ __global__ __launch_bounds__(BLOCK) MPPI_REDUCE_ATTR void weights_reduce_kernel(
         }
         if (lane == 0) s_live[wid] = live;
         __syncthreads();
-        // ---- phase B: the block's live tiles, this wave's groups.  ONE flat loop over the set bits of the block's 32-tile
-        // live mask (round 5: the two nested loops with their `continue` paths made the compiler rotate all 32
-        // accumulators through v_mov copies at every loop edge — 32 + moves per tile and wave, 6 % of the kernel)
-        unsigned lvall = 0;
-#pragma unroll
-        for (int w2 = 0; w2 < NW; ++w2) lvall |= (unsigned)__builtin_amdgcn_readfirstlane(s_live[w2]) << (TPW * w2);
-        static_assert(NW * TPW == 32, "the block's live mask is one 32-bit word");
-        if (lvall) block_live = true;
-        while (lvall) {
-            {
-                const int bit = __builtin_ctz(lvall);
-                lvall &= lvall - 1u;
-                const int w2 = bit / TPW, q = bit % TPW;
+        // ---- phase B: the block's live tiles, this wave's groups
+        for (int w2 = 0; w2 < NW; ++w2) {
+            const unsigned lv = __builtin_amdgcn_readfirstlane(s_live[w2]);
+            if (lv == 0u) continue;
+            block_live = true;
+            for (int q = 0; q < TPW; ++q) {
+                if (!((lv >> q) & 1u)) continue;
                 const int64_t tile = base0 + w2 + q * nwaves;
                 const int64_t i = tile * 64 + lane;
                 const float e = s_e[w2][q][lane];
@@ -1272,6 +1213,7 @@ __global__ __launch_bounds__(WAVE) void stats_combine_kernel(const float* __rest
 // all 32 temperatures (12.6 us -> launch-bound at N = 65 536, profiles/r02_visitA_c2_c5_dense_path.md).
 // `lams` is a DEVICE array [STATS_L] (entries past the caller's count hold 1): the temperatures of the second ESSPS
 // grid are produced on the device (essps_select_kernel) and never visit the host.
+constexpr int STATS_L = 32;
 constexpr int STATS_THREADS = 1024;
 // One block's share: thread j < 96 returns the block's partial sum of column j (0 elsewhere); part_max as the kernel's.
 struct StatsLds {
@@ -1382,32 +1324,6 @@ struct CellRows {
                 cell = __hip_atomic_load(at(bb, quad) + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             o[c] = __uint_as_float((unsigned)cell);
-        }
-        return make_float4(o[0], o[1], o[2], o[3]);
-    }
-};
-// ... or the rows the ROLLOUT kernel's epilogue left behind (round 5): sums relative to every block's own minimum m_b, rescaled
-// here to the global minimum: e-sums and e*c-sums by f = exp((cmin - m_b) / lambda_l), e^2-sums by f^2 (column = 3*l + k).
-struct ScaledRows {
-    const float* __restrict__ part;  // [blocks][96]
-    const float* __restrict__ pmin;  // [blocks]
-    const float* __restrict__ lams;  // [32]
-    float cmin;
-    static constexpr int K = 8;
-    struct Raw { float4 v; float m; };
-    __device__ __forceinline__ void issue(int bb, int quad, Raw& r) const {
-        r.v = *reinterpret_cast<const float4*>(part + (int64_t)bb * (STATS_L * 3) + 4 * quad);
-        r.m = pmin[bb];
-    }
-    __device__ __forceinline__ float4 finish(int, int quad, const Raw& r) const {
-        const float in[4] = {r.v.x, r.v.y, r.v.z, r.v.w};
-        float o[4];
-        const float dm = cmin - r.m;  // <= 0
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int col = 4 * quad + c, l = col / 3, k = col - 3 * l;
-            const float f = expf(dm / lams[l]);
-            o[c] = in[c] * (k == 1 ? f * f : f);
         }
         return make_float4(o[0], o[1], o[2], o[3]);
     }
@@ -1565,24 +1481,15 @@ __device__ __forceinline__ void essps_select_step(const double* s_sum, double* s
         }
     }
 }
-// `pmin` != nullptr: the rows come from the rollout kernel's epilogue (sums relative to the blocks' own minima: ScaledRows).
 __global__ __launch_bounds__(1024) void essps_select_kernel(const float* __restrict__ part, int nblocks, double target_ess,
                                                             mppi::host::EsspsRange range, EsspsDev* __restrict__ st,
                                                             float* __restrict__ lams, float* __restrict__ lams0,
                                                             float* __restrict__ lambda_out,
-                                                            double* __restrict__ lambda_host,
-                                                            const float* __restrict__ pmin,
-                                                            const unsigned* __restrict__ min_key) {
+                                                            double* __restrict__ lambda_host) {
     __shared__ double s_acc[STATS_COMB_GROUPS * STATS_L * 3];
     __shared__ double s_sum[STATS_L * 3];
     __shared__ double s_ess[STATS_L], s_grid[STATS_L], s_lgrid[STATS_L];
-    if (pmin) {  // (the step below rewrites lams0 only after the barrier that ends the combine)
-        __shared__ float s_l0[STATS_L];
-        if (threadIdx.x < STATS_L) s_l0[threadIdx.x] = lams0[threadIdx.x];
-        __syncthreads();
-        stats_combine_columns(ScaledRows{part, pmin, s_l0, key_to_float(*min_key)}, nblocks, s_acc, s_sum);
-    } else
-        stats_combine_columns(part, nblocks, s_acc, s_sum);
+    stats_combine_columns(part, nblocks, s_acc, s_sum);
     if (threadIdx.x >= WAVE) return;  // the scalar step: one wave, lane j owns temperature j where that helps
     essps_select_step<0>(s_sum, s_ess, s_grid, s_lgrid, target_ess, range, st, lams, lams0, lambda_out, lambda_host,
                          (int)threadIdx.x);

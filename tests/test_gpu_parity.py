@@ -957,14 +957,7 @@ def test_device_softmax_stats_drive_the_same_temperature(lam_mode):
         sd, _ = make_solver("nav2d", T, N, lambda_="ESSPS", essps_search="device")
         ad, _ = sd.forward(torch.tensor([-9.0, -9.0, 0.785]))
         assert sd._lambda_pending and outs[0][3]._essps_search == "device"
-        # (the first grid's statistics come from the rollout kernel's epilogue since round 5: sums relative to the blocks' own
-        # minima, rescaled in the select step — another rounding of the same sums; with option roll_stats = 0 both searches
-        # read the same statistics kernel and agree to 1e-12)
-        assert abs(sd._last_lambda - sg._last_lambda) <= 2e-6 * sg._last_lambda and not sd._lambda_pending
-        s0, _ = make_solver("nav2d", T, N, lambda_="ESSPS", essps_search="device")
-        s0.set_option("roll_stats", 0)
-        s0.forward(torch.tensor([-9.0, -9.0, 0.785]))
-        assert abs(s0._last_lambda - sg._last_lambda) <= 1e-12 * sg._last_lambda
+        assert abs(sd._last_lambda - sg._last_lambda) <= 1e-12 * sg._last_lambda and not sd._lambda_pending
         assert rel_err(ad.cpu().numpy(), outs[0][1]) == 0.0
         # end-point rules decided on the device (mppi.py:361-364): racing costs never reach ESS = N/10 below lambda_max
         sr, cr = make_solver("racing", 25, 4096, lambda_="ESSPS")
@@ -2067,28 +2060,15 @@ def test_essps_rounds_as_one_launch_same_temperature_to_the_bit(N):
     b_s, _ = make_solver("nav2d", 30, N, lambda_="ESSPS")
     a_s.set_option("fused_solve", 0)
     b_s.set_option("fused_solve", 0)
-    a_s.set_option("roll_stats", 0)  # (the first grid's statistics from the statistics kernel, like the merged launch computes them)
     b_s.set_option("essps_merge0", 1)
-    # ... and the default since round 5: the first grid's statistics from the rollout kernel's epilogue (rows relative to the
-    # blocks' own minima, rescaled in the select step; grids of up to 1024 rollout blocks): the same search on another
-    # rounding of the same sums — the same number of passes, the temperature to 2e-6, the action to 1e-5
-    c_s, _ = make_solver("nav2d", 30, N, lambda_="ESSPS")
-    c_s.set_option("fused_solve", 0)
     x = torch.tensor([-9.0, -9.0, 0.785]).cuda()
     passes = []
     for k in range(10):
         if k in (4, 5):
             a_s.set_option("essps_cold", 1)
             b_s.set_option("essps_cold", 1)
-            c_s.set_option("essps_cold", 1)
-        mean_in = a_s._previous_action_seq.cpu().numpy().copy()
         a, st = a_s.forward(x)
         b, sb = b_s.forward(x)
-        c_s.set_warm_start(mean_in)  # (the same inputs every tick: two closed loops would drift apart by their rounding)
-        ca, _ = c_s.forward(x)
-        assert c_s._h.lib.mppi_search_passes(c_s._h.h, None) == a_s._h.lib.mppi_search_passes(a_s._h.h, None)
-        assert abs(c_s._last_lambda - a_s._last_lambda) <= 2e-6 * a_s._last_lambda, (k, c_s._last_lambda, a_s._last_lambda)
-        assert torch.equal(c_s._costs, a_s._costs) and rel_err(ca.cpu().numpy(), a.cpu().numpy()) <= 1e-5
         pa = a_s._h.lib.mppi_search_passes(a_s._h.h, None)
         assert pa == b_s._h.lib.mppi_search_passes(b_s._h.h, None)
         passes.append(pa)
