@@ -464,7 +464,7 @@ def main():
                          "valu_frac": None if valu is None else valu["frac"],
                          "note": "`achieved` / `frac` price the kernel's ALGORITHMIC bytes (SURVEY 8d: the noise it consumes + the "
                                  "costs it writes) against the HBM peak as the metric asks; the kernel regenerates that noise in "
-                                 "registers, moves ~1 % of those bytes (`hbm_measured_GBps`) and is bound by VALU issue "
+                                 "registers, moves ~1 %% of those bytes (`hbm_measured_GBps`) and is bound by VALU issue "
                                  "(`valu_frac`; 0.69 is what its instruction mix allows).  Whole solve: SURVEY 8d's B_alg / "
                                  "ms_per_step = %.2f x the HBM peak — not a bandwidth: two of B_alg's three noise-sized terms never "
                                  "exist (no sampler pass, no second read) and at lambda = 1 the weighted reduction is an arg-min "
