@@ -1,0 +1,381 @@
+// mppi_topk.hpp — Queries after a solve: weights, re-rolls of given actions / samples, get_top_samples (mppi.py:462-487: radix select, sort, re-roll).
+// Part of the MPPI.forward() hot path for gfx950; see mppi_kernels.hpp for the map of the files.
+#pragma once
+#include "mppi_rollout.hpp"
+#include "mppi_finalize.hpp"
+
+namespace mppi {
+
+// `_weights` (mppi.py:376) given the global min cost and sum e.
+__global__ __launch_bounds__(BLOCK) void weights_kernel(const float* __restrict__ costs, int64_t N, float lambda,
+                                                        float cmin, float sum_e, float* __restrict__ w) {
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < N) w[i] = expf((-costs[i]) / lambda - (-cmin) / lambda) / sum_e;
+}
+
+// `_states_prediction` (mppi.py:508-524) for k action sequences in the reference layout.
+template <int MODEL, int FAST>
+__global__ __launch_bounds__(WAVE) void rollout_actions_kernel(const float* __restrict__ actions, int k, int T,
+                                                               const float* __restrict__ x0,
+                                                               float* __restrict__ states, ModelCtx ctx) {
+    constexpr int DS = ModelT<MODEL, FAST>::DS, DC = ModelT<MODEL, FAST>::DC;
+    const int q = blockIdx.x * WAVE + threadIdx.x;
+    if (q >= k) return;
+    const float* a = actions + (int64_t)q * T * DC;
+    float* out = states + (int64_t)q * (T + 1) * DS;
+    rollout_states_checked<MODEL, FAST>(x0, T, ctx, out, [&](int t, float* u) {
+#pragma unroll
+        for (int kk = 0; kk < DC; ++kk) u[kk] = a[t * DC + kk];
+    });
+}
+
+// `_state_seq_batch[idx]` (mppi.py:481) re-rolled from the resident noise.
+template <int MODEL, int FAST>
+__global__ __launch_bounds__(WAVE) void rollout_samples_kernel(const float4* __restrict__ noise,
+                                                               const float* __restrict__ mean,
+                                                               const int64_t* __restrict__ idx, int k,
+                                                               const float* __restrict__ x0,
+                                                               float* __restrict__ states, Dims d, ModelCtx ctx) {
+    constexpr int DS = ModelT<MODEL, FAST>::DS, DC = ModelT<MODEL, FAST>::DC;
+    const int q = blockIdx.x * WAVE + threadIdx.x;
+    if (q >= k) return;
+    const int64_t i = idx[q];
+    const bool inherit = (d.sample_offset + i) < d.inherit_count;
+    const float* np = reinterpret_cast<const float*>(noise + (i >> 6) * d.R * 64 + (i & 63));
+    float* out = states + (int64_t)q * (d.T + 1) * DS;
+    rollout_states_checked<MODEL, FAST>(x0, d.T, ctx, out, [&](int t, float* u) {
+#pragma unroll
+        for (int kk = 0; kk < DC; ++kk) {
+            const int f = t * DC + kk;
+            const float e = np[(int64_t)(f >> 2) * 256 + (f & 3)];
+            const float m = inherit ? mean[f] : 0.0f;
+            u[kk] = clampf(m + e, d.u_min[kk], d.u_max[kk]);
+        }
+    });
+}
+
+// ------------------------------------------------------------------------------------------
+// get_top_samples (mppi.py:462-487) on the device: the k largest weights are the k smallest costs.
+// Radix select on the order-preserving cost keys (11 + 11 + 10 bits): three histogram passes over costs[N]
+// (LDS histograms merged into a global one; passes 1 and 2 count only keys under the prefix chosen so far, which
+// every block re-derives from the previous histogram), a collect pass that gathers the keys below the k-th key
+// plus as many ties as are needed, and one block that sorts the k candidates by (key, index) — the order does
+// not depend on the atomics that gathered them — and re-rolls their trajectories from the regenerated (or
+// resident) noise around the mean the solve sampled.  State trajectories S[N,T+1,ds] are never materialised.
+constexpr int TOPK_BINS = 2048;
+constexpr int TOPK_MAX = 1024;
+struct TopkSel { unsigned prefix, krem; };  // high bits selected so far; how many keys to take under that prefix
+__device__ __forceinline__ constexpr int topk_shift(int pass) { return pass == 0 ? 21 : pass == 1 ? 10 : 0; }
+__device__ __forceinline__ constexpr int topk_bits(int pass) { return pass == 2 ? 10 : 11; }
+
+// Block-wide (NT threads): the bin whose cumulative count first reaches krem, and the count below that bin.
+template <int NT = BLOCK>
+__device__ __forceinline__ void topk_pick(const unsigned* __restrict__ hist, int nbins, unsigned krem,
+                                          unsigned* __restrict__ s_scan /*[NT + 2]*/, unsigned& bin,
+                                          unsigned& below) {
+    constexpr int BLOCK = NT;  // (shadows the global block size inside this function)
+    const int per = (nbins + BLOCK - 1) / BLOCK;
+    const int b0 = threadIdx.x * per;
+    unsigned loc = 0;
+    for (int b = b0; b < min(b0 + per, nbins); ++b) loc += hist[b];
+    s_scan[threadIdx.x] = loc;
+    __syncthreads();
+    if (threadIdx.x < WAVE) {  // exclusive scan of the BLOCK partial sums by one wave (BLOCK / WAVE each)
+        constexpr int PER = BLOCK / WAVE;
+        unsigned v[PER], sum = 0;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) { v[q] = s_scan[threadIdx.x * PER + q]; sum += v[q]; }
+        unsigned incl = sum;
+#pragma unroll
+        for (int m = 1; m < WAVE; m <<= 1) {
+            const unsigned o = __shfl_up(incl, m);
+            if ((int)threadIdx.x >= m) incl += o;
+        }
+        unsigned run = incl - sum;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) { s_scan[threadIdx.x * PER + q] = run; run += v[q]; }
+    }
+    __syncthreads();
+    const unsigned excl = s_scan[threadIdx.x];
+    __syncthreads();
+    if (excl < krem && krem <= excl + loc) {  // exactly one thread (loc > 0 there)
+        unsigned run = excl;
+        for (int b = b0; b < min(b0 + per, nbins); ++b) {
+            const unsigned hcount = hist[b];
+            if (krem <= run + hcount) { s_scan[BLOCK] = (unsigned)b; s_scan[BLOCK + 1] = run; break; }
+            run += hcount;
+        }
+    }
+    __syncthreads();
+    bin = s_scan[BLOCK];
+    below = s_scan[BLOCK + 1];
+}
+
+// prefix/krem entering pass PASS (derived from the histogram of pass PASS-1); block 0 records it in sel[PASS-1]
+template <int PASS>
+__device__ __forceinline__ TopkSel topk_enter(const unsigned* __restrict__ hist, TopkSel* __restrict__ sel, unsigned k,
+                                              unsigned* __restrict__ s_scan) {
+    TopkSel cur{0u, k};
+    if (PASS > 0) {
+        if (PASS > 1) cur = sel[PASS - 2];
+        unsigned bin, below;
+        topk_pick(hist + (PASS - 1) * TOPK_BINS, 1 << topk_bits(PASS - 1), cur.krem, s_scan, bin, below);
+        cur.prefix = (cur.prefix << topk_bits(PASS - 1)) | bin;
+        cur.krem -= below;
+        if (blockIdx.x == 0 && threadIdx.x == 0) sel[PASS - 1] = cur;
+    }
+    return cur;
+}
+
+template <int PASS>
+__global__ __launch_bounds__(BLOCK) void topk_hist_kernel(const float* __restrict__ costs, int64_t N, unsigned k,
+                                                          unsigned* __restrict__ hist, TopkSel* __restrict__ sel) {
+    __shared__ unsigned s_hist[TOPK_BINS];
+    __shared__ unsigned s_scan[BLOCK + 2];
+    constexpr int NB = 1 << topk_bits(PASS);
+    for (int b = threadIdx.x; b < NB; b += BLOCK) s_hist[b] = 0u;
+    const TopkSel cur = topk_enter<PASS>(hist, sel, k, s_scan);
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < N; i += (int64_t)gridDim.x * BLOCK) {
+        const unsigned key = float_to_key(costs[i]);
+        if (PASS == 0 || (key >> (topk_shift(PASS) + topk_bits(PASS))) == cur.prefix)
+            atomicAdd(&s_hist[(key >> topk_shift(PASS)) & (NB - 1)], 1u);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < NB; b += BLOCK)
+        if (s_hist[b]) atomicAdd(&hist[PASS * TOPK_BINS + b], s_hist[b]);
+}
+
+// cand[j] = (key << 32) | GLOBAL sample index for the k selected samples (unordered); counters = {#below, #ties taken}.
+// The key is the cost itself (order-preserving bijection), so a candidate is self-contained: any rank can weigh and
+// re-roll it without the owner's cost vector.
+__global__ __launch_bounds__(BLOCK) void topk_collect_kernel(const float* __restrict__ costs, int64_t N, unsigned k,
+                                                             int64_t sample_offset,
+                                                             const unsigned* __restrict__ hist,
+                                                             TopkSel* __restrict__ sel,
+                                                             unsigned long long* __restrict__ cand,
+                                                             unsigned* __restrict__ counters) {
+    __shared__ unsigned s_scan[BLOCK + 2];
+    const TopkSel cur = topk_enter<3>(hist, sel, k, s_scan);  // prefix = the k-th smallest key, krem = ties to take
+    const unsigned nbelow = k - cur.krem;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < N; i += (int64_t)gridDim.x * BLOCK) {
+        const unsigned key = float_to_key(costs[i]);
+        if (key < cur.prefix) {
+            const unsigned slot = atomicAdd(&counters[0], 1u);
+            cand[slot] = ((unsigned long long)key << 32) | (unsigned long long)(sample_offset + i);
+        } else if (key == cur.prefix) {
+            const unsigned t = atomicAdd(&counters[1], 1u);
+            if (t < cur.krem) cand[nbelow + t] = ((unsigned long long)key << 32) | (unsigned long long)(sample_offset + i);
+        }
+    }
+}
+
+// Ascending bitonic sort of one 64-bit word per thread across the block's 1024 threads, NV independent sorts in lockstep
+// (v[r] of thread t = element t of row r).  Strides below 64 are wave shuffles (no barrier); only the 10 stages with a
+// stride >= 64 go through LDS (s_x [NV][1024]) — a plain LDS bitonic sort pays a 1024-thread barrier for each of its 55
+// stages.  first_size = 2: full sort; = 1024: the final merge only (rows that are bitonic already).
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int m) {
+    const unsigned lo = __shfl_xor((unsigned)v, m), hi = __shfl_xor((unsigned)(v >> 32), m);
+    return ((unsigned long long)hi << 32) | lo;
+}
+template <int NV>
+__device__ __forceinline__ void block_bitonic_1024(unsigned long long (&v)[NV], unsigned long long* s_x, int tid, int first_size) {
+    for (int size = first_size; size <= TOPK_MAX; size <<= 1) {
+        const bool up = (tid & size) == 0;  // (size = 1024: every thread)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            unsigned long long o[NV];
+            if (stride >= WAVE) {
+#pragma unroll
+                for (int r = 0; r < NV; ++r) s_x[r * TOPK_MAX + tid] = v[r];
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < NV; ++r) o[r] = s_x[r * TOPK_MAX + (tid ^ stride)];
+                __syncthreads();
+            } else {
+#pragma unroll
+                for (int r = 0; r < NV; ++r) o[r] = shfl_xor_u64(v[r], stride);
+            }
+            const bool keep_min = ((tid & stride) == 0) == up;
+#pragma unroll
+            for (int r = 0; r < NV; ++r) v[r] = keep_min ? (v[r] < o[r] ? v[r] : o[r]) : (v[r] > o[r] ? v[r] : o[r]);
+        }
+    }
+}
+// SORTED = false: every block of the grid (ceil(k / 64) blocks of 1024 threads) selects and sorts the same k <= TOPK_MAX
+//   candidates itself and re-rolls 64 of them with ONE wave (the re-roll is a serial chain of T steps per lane, ~0.36 us per
+//   step: spread over CUs, not stacked on the SIMDs of one).  The candidates are the k words of `cand` (radix select by
+//   topk_hist_kernel / topk_collect_kernel, any N), or — `costs` != nullptr, n_direct <= TOPK_DIRECT_MAX samples: the sizes
+//   of the reference's examples, which call get_top_samples every tick — they are selected from the costs right here (one
+//   row: sorted directly; up to four rows: radix select inside the block): ONE launch instead of five;
+// SORTED = true: `cand` is already ascending (topk_sort_* below: any k) and the grid's threads take one candidate each.
+// lambda <= 0: the temperature the last solve's weights used (stats[4], left by finalize_tail) — no host read-back.
+constexpr int TOPK_DIRECT_MAX = 4096;
+template <int MODEL, int FAST, bool SORTED>
+__global__ __launch_bounds__(TOPK_MAX) void topk_rollout_kernel(const unsigned long long* __restrict__ cand, int k,
+                                                                const float* __restrict__ costs, int n_direct,
+                                                                const float4* __restrict__ noise, bool gen_noise,
+                                                                const float* __restrict__ mean,
+                                                                const float* __restrict__ x0,
+                                                                const float* __restrict__ stats, float lambda_arg,
+                                                                float* __restrict__ states,
+                                                                float* __restrict__ weights,
+                                                                unsigned* __restrict__ hist,
+                                                                unsigned* __restrict__ counters, Dims d, GenCtx gen,
+                                                                ModelCtx ctx) {
+    constexpr int DS = ModelT<MODEL, FAST>::DS, DC = ModelT<MODEL, FAST>::DC;
+    __shared__ unsigned long long s_key[SORTED ? 1 : TOPK_MAX];
+    if (hist && blockIdx.x == 0) {  // leave the select state clean for the next call
+        for (int b = threadIdx.x; b < 3 * TOPK_BINS; b += blockDim.x) hist[b] = 0u;
+        if (threadIdx.x < 2) counters[threadIdx.x] = 0u;
+    }
+    const float lambda = lambda_arg > 0.0f ? lambda_arg : stats[4];
+    int q = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long mine;
+    if (!SORTED) {
+        // row r of the words = samples r * 1024 + t (direct) / the k candidates (one row); padding = the largest word
+        const int tid = threadIdx.x;
+        const int rows = costs ? (n_direct + TOPK_MAX - 1) / TOPK_MAX : 1;
+        unsigned long long v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = r * TOPK_MAX + tid;
+            if (costs) v[r] = i < n_direct ? ((unsigned long long)float_to_key(costs[i]) << 32) | (unsigned long long)(d.sample_offset + i) : ~0ull;
+            else v[r] = (r == 0 && tid < k) ? cand[tid] : ~0ull;
+        }
+        if (rows <= 1) {
+            unsigned long long w1[1] = {v[0]};
+            block_bitonic_1024<1>(w1, s_key, tid, 2);
+            v[0] = w1[0];
+        } else {
+            // 2-4 rows: radix select of the k smallest keys INSIDE the block (three passes of 11 / 11 / 10 bits over the <= 4
+            // keys a thread holds, histogram in LDS: the scheme of topk_hist_kernel / topk_collect_kernel without their four
+            // launches), then one row to sort.  (Sorting all four rows and pruning was measured at ~25 us: 4x the work.)
+            __shared__ unsigned s_hist[TOPK_BINS];
+            __shared__ unsigned s_scan[TOPK_MAX + 2];
+            __shared__ unsigned s_cnt[2];
+            unsigned prefix = 0u, krem = (unsigned)k;
+#pragma unroll
+            for (int pass = 0; pass < 3; ++pass) {
+                const int nb = 1 << topk_bits(pass), shift = topk_shift(pass);
+                for (int b = tid; b < nb; b += TOPK_MAX) s_hist[b] = 0u;
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const unsigned key = (unsigned)(v[r] >> 32);
+                    const bool valid = r * TOPK_MAX + tid < n_direct;
+                    const unsigned bin = (key >> shift) & (nb - 1);
+                    if (pass == 0) {
+                        // the top 11 bits of costs of one solve fall into a handful of bins: one atomic per (wave, distinct bin)
+                        // instead of 64 serialised ones on the same LDS word
+                        unsigned long long todo = __ballot(valid);
+                        while (todo) {
+                            const int leader = __ffsll((long long)todo) - 1;
+                            const unsigned b = __shfl(bin, leader);
+                            const unsigned long long same = __ballot(valid && bin == b) & todo;
+                            if ((tid & 63) == leader) atomicAdd(&s_hist[b], (unsigned)__popcll(same));
+                            todo &= ~same;
+                        }
+                    } else if (valid && (key >> (shift + topk_bits(pass))) == prefix) {
+                        atomicAdd(&s_hist[bin], 1u);
+                    }
+                }
+                __syncthreads();
+                unsigned bin, below;
+                topk_pick<TOPK_MAX>(s_hist, nb, krem, s_scan, bin, below);
+                prefix = (prefix << topk_bits(pass)) | bin;
+                krem -= below;
+            }
+            // prefix = the k-th smallest key, krem = how many samples with exactly that key to take
+            if (tid < 2) s_cnt[tid] = 0u;
+            __syncthreads();
+            const unsigned nbelow = (unsigned)k - krem;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const unsigned key = (unsigned)(v[r] >> 32);
+                if (r * TOPK_MAX + tid < n_direct) {
+                    if (key < prefix) s_key[atomicAdd(&s_cnt[0], 1u)] = v[r];
+                    else if (key == prefix) { const unsigned t = atomicAdd(&s_cnt[1], 1u); if (t < krem) s_key[nbelow + t] = v[r]; }
+                }
+            }
+            __syncthreads();
+            unsigned long long w1[1] = {tid < k ? s_key[tid] : ~0ull};
+            __syncthreads();
+            block_bitonic_1024<1>(w1, s_key, tid, 2);
+            v[0] = w1[0];
+        }
+        // Every block of the grid has sorted the same words; block b re-rolls candidates 64 b .. 64 b + 63 with ONE wave.
+        // (The re-roll is a serial chain of T steps per lane, ~12 us for a lone wave; k = 300 candidates in the first five
+        // waves of one block put two of them on one SIMD: 25 us.  One wave per block = one CU each.)
+        s_key[tid] = v[0];
+        __syncthreads();
+        q = blockIdx.x * WAVE + tid;
+        if (tid >= WAVE || q >= k) return;
+        mine = s_key[q];
+    } else {
+        if (q >= k) return;
+        mine = cand[q];
+    }
+    const uint64_t gi = mine & 0xFFFFFFFFull;            // global sample index
+    const float c = key_to_float((unsigned)(mine >> 32));  // its cost
+    weights[q] = expf((-c) / lambda - (-stats[0]) / lambda) / stats[1];  // softmax(-c/lambda)_i (mppi.py:376)
+    const bool inherit = (int64_t)gi < d.inherit_count;
+    const int64_t i = (int64_t)gi - d.sample_offset;  // local index: only meaningful when the tiles are read
+    const float4* np = noise + ((i >> 6) * d.R) * 64 + (i & 63);
+    float* out = states + (int64_t)q * (d.T + 1) * DS;
+    int have = -1;
+    float grp[4] = {0.f, 0.f, 0.f, 0.f};
+    rollout_states_checked<MODEL, FAST>(x0, d.T, ctx, out, [&](int t, float* u) {
+#pragma unroll
+        for (int kk = 0; kk < DC; ++kk) {
+            const int f = t * DC + kk;
+            if ((f >> 2) != have) {
+                have = f >> 2;
+                const float4 n4 = gen_noise ? gen_noise4(gi, have, gen, d) : np[(int64_t)have * 64];
+                grp[0] = n4.x; grp[1] = n4.y; grp[2] = n4.z; grp[3] = n4.w;
+            }
+            const float m = inherit ? mean[f] : 0.0f;
+            const int c4 = f & 3;
+            const float e = c4 == 0 ? grp[0] : c4 == 1 ? grp[1] : c4 == 2 ? grp[2] : grp[3];
+            u[kk] = clampf(m + e, d.u_min[kk], d.u_max[kk]);
+        }
+    });
+}
+
+// Ascending sort of P = 2^m >= 2048 candidate words in global memory (k > TOPK_MAX; the tail past k holds ~0).  Bitonic:
+// topk_sort_local_kernel<true> sorts every 1024-word chunk completely in LDS (all stages up to 1024, direction by the
+// chunk's position), then for size = 2048, 4096, ... P the strides >= 1024 are one global compare-exchange pass each
+// (topk_sort_global_kernel) and the strides 512 ... 1 of that stage run in LDS again (topk_sort_local_kernel<false>).
+template <bool FULL>
+__global__ __launch_bounds__(TOPK_MAX) void topk_sort_local_kernel(unsigned long long* __restrict__ cand, int size_arg) {
+    __shared__ unsigned long long s_key[TOPK_MAX];
+    const int g = blockIdx.x * TOPK_MAX + threadIdx.x;
+    s_key[threadIdx.x] = cand[g];
+    __syncthreads();
+    for (int size = FULL ? 2 : size_arg; size <= (FULL ? TOPK_MAX : size_arg); size <<= 1) {
+        for (int stride = min(size >> 1, TOPK_MAX >> 1); stride > 0; stride >>= 1) {
+            const int j = threadIdx.x ^ stride;
+            if (j > (int)threadIdx.x) {
+                const unsigned long long a = s_key[threadIdx.x], b = s_key[j];
+                const bool up = (g & size) == 0;
+                if ((a > b) == up) { s_key[threadIdx.x] = b; s_key[j] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    cand[g] = s_key[threadIdx.x];
+}
+__global__ __launch_bounds__(BLOCK) void topk_sort_global_kernel(unsigned long long* __restrict__ cand, int P, int size,
+                                                                 int stride) {
+    const int t = blockIdx.x * BLOCK + threadIdx.x;  // one thread per pair
+    if (t >= P / 2) return;
+    const int i = ((t / stride) * 2 * stride) + (t % stride), j = i + stride;
+    const unsigned long long a = cand[i], b = cand[j];
+    const bool up = (i & size) == 0;
+    if ((a > b) == up) { cand[i] = b; cand[j] = a; }
+}
+__global__ __launch_bounds__(BLOCK) void topk_pad_kernel(unsigned long long* __restrict__ cand, int k, int P) {
+    const int t = k + blockIdx.x * BLOCK + threadIdx.x;
+    if (t < P) cand[t] = ~0ull;
+}
+
+}  // namespace mppi

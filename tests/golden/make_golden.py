@@ -13,7 +13,7 @@ Usage (container only; the GPU box has no /root/reference):
                                                   # get_samples_from_posterior between two solves)
     python tests/golden/make_golden.py round5     # only the cases added in round 5 (LBPS / MPO at N = 4096 on nav2d and
                                                   # racing, ESSPS clamped at lambda_min and at lambda_max; noise by seed)
-    python tests/golden/make_golden.py fullsize [c2|c5|c3 ...]
+    python tests/golden/make_golden.py fullsize [c2|c5|c3|c4 ...]
                                                   # BASELINE.json's configs at FULL size through the real reference,
                                                   # seed 42, two closed-loop solves; outputs and summaries only (< 100 KB)
     python tests/golden/make_golden.py only <substring> [...]   # the small cases whose name contains a substring
@@ -777,6 +777,11 @@ def main():
             make, before, nxt = racing_parts(50, 1 << 20, 1.0)
             run_case_full("full_c3_racing_T50_N1048576_lambda1", make, env._robot_state.numpy().copy(), 2, nxt,
                           before_solve=before, nv_fixed=64, nv_closed=8)
+        if "c4" in sys.argv[2:]:  # BASELINE configs[3]: the 8 x 2^20 samples of the sharded run, UNSHARDED through the reference
+            # (~35 GB of RSS, minutes per solve: only on request; the probes are few — the regime is C3's arg-min)
+            make, before, nxt = racing_parts(50, 1 << 23, 1.0)
+            run_case_full("full_c4_racing_T50_N8388608_lambda1", make, env._robot_state.numpy().copy(), 2, nxt,
+                          before_solve=before, nv_fixed=8, nv_closed=2)
         return
     if PARTIAL:
         print(f"done ({MODE}):", sorted(ROUND2) if ONLY_ROUND2 else "")
