@@ -27,82 +27,16 @@ from pi_mpc.native import resolve
 from pi_mpc.sharding import all_gather_summaries, shard_range
 
 
-def _ptr(t: Optional[torch.Tensor]):
-    return None if t is None else C.c_void_p(t.data_ptr())
-
-
-class _DeferredStateSeq(torch.Tensor):
-    """`state_seq` of a solve whose batch-1 rollout (src/pi_mpc/mppi.py:448-449) is completed lazily
-    (MPPI(..., lazy_state_seq=True); mppi_set_option("lazy_state_seq")): a plain float32 tensor [1, T+1, ds] whose FIRST
-    use through torch (indexing, .cpu(), arithmetic, printing, ...) completes it on the consumer's current stream if the
-    next solve has not done so already (mppi_join_state_seq: at most one small kernel launch, no host synchronisation).
-    The T dependent steps are off the solve's critical path: in a control loop they ride in one extra block of the NEXT
-    solve's rollout launch.  Results of operations on it are ordinary tensors.  Consumers that bypass torch (a raw
-    data_ptr() handed to another library) must call `solver.join_state_seq()` first."""
-
-    @staticmethod
-    def wrap(t: torch.Tensor, join) -> "_DeferredStateSeq":
-        r = torch.Tensor._make_subclass(_DeferredStateSeq, t)
-        r.__dict__["_mppi_join"] = join
-        return r
-
-    @classmethod
-    def __torch_function__(cls, func, types, args=(), kwargs=None):
-        def join(a):
-            if isinstance(a, _DeferredStateSeq):
-                j = a.__dict__.get("_mppi_join")
-                if j is not None:
-                    a.__dict__["_mppi_join"] = None
-                    j(a)
-            elif isinstance(a, (list, tuple)):  # torch.cat([...]), torch.stack((...))
-                for b in a:
-                    join(b)
-
-        for a in args:
-            join(a)
-        if kwargs:
-            for a in kwargs.values():
-                join(a)
-        with torch._C.DisableTorchFunctionSubclass():
-            return func(*args, **(kwargs or {}))
-
-
-class _LazyInfoTensor(torch.Tensor):
-    """An entry the reference leaves in the CALLER's `info` dict after a solve (src/pi_mpc/mppi.py:299-306,318-322:
-    `prev_state` = S[:, T-1], `prev_action` = U[:, T-2]) whose value the native path never holds — the N state trajectories
-    are not materialised, the clamped actions are regenerated in registers.  It stands in the dict as a tensor that is
-    built from the solve's noise (a re-roll / an export launch) the first time a torch function touches it; nobody pays
-    for it otherwise.  Like the reference's views it describes the LAST solve: build it before the next one."""
-
-    @staticmethod
-    def make(thunk) -> "_LazyInfoTensor":
-        r = torch.Tensor._make_subclass(_LazyInfoTensor, torch.empty(0))
-        r.__dict__["_mppi_thunk"], r.__dict__["_mppi_value"] = thunk, None
-        return r
-
-    def materialize(self) -> torch.Tensor:
-        d = self.__dict__
-        if d["_mppi_value"] is None:
-            d["_mppi_value"], d["_mppi_thunk"] = d["_mppi_thunk"](), None
-        return d["_mppi_value"]
-
-    @classmethod
-    def __torch_function__(cls, func, types, args=(), kwargs=None):
-        def real(a):
-            if isinstance(a, _LazyInfoTensor):
-                return a.materialize()
-            if isinstance(a, (list, tuple)):
-                return type(a)(real(b) for b in a)
-            return a
-
-        with torch._C.DisableTorchFunctionSubclass():
-            return func(*[real(a) for a in args], **{k: real(v) for k, v in (kwargs or {}).items()})
+from pi_mpc._exchange import ExchangeMixin
+from pi_mpc._generic import GenericPathMixin
+from pi_mpc._lazy import _DeferredStateSeq, _LazyInfoTensor, _ptr  # noqa: F401  (re-exported: tests, callers)
+from pi_mpc._queries import QueriesMixin
 
 
 _NO_INFO: Dict = {}  # forward()'s default `info` (the reference's shared mutable default, mppi.py:224): nobody can read it back
 
 
-class MPPI(nn.Module):
+class MPPI(ExchangeMixin, GenericPathMixin, QueriesMixin, nn.Module):
     """Model Predictive Path Integral control (Williams et al., T-RO 2017) — MI355X-native."""
 
     # Private state ("_name") never holds Parameters, sub-modules or buffers, so it skips nn.Module's attribute
@@ -571,101 +505,6 @@ class MPPI(nn.Module):
         self._h.call("mppi_download_map", slot, out.ctypes.data_as(C.c_void_p), None, None)
         return out
 
-    def _setup_exchange(self) -> None:
-        """Pick the per-solve exchange of a sharded solver (environment variable MPPI_EXCHANGE):
-          "nccl" (default)  one all_gather per solve through torch.distributed (RCCL on ProcessGroupNCCL's stream);
-          "rccl"            the library's own communicator (mppi_comm_*): ncclAllGather issued by mppi_weights_reduce on
-                            the solve's stream — no process-group stream, no events, the sharded solve is ONE library
-                            call like the unsharded one;
-          "p2p"             the library's peer-to-peer buffers (mppi_p2p_*: xGMI stores + polling, no collective launch);
-          "auto"            "rccl" when it passes its start-up self-test on every rank, else "nccl".
-        "rccl" / "p2p" raise when their set-up or self-test fails; every decision is agreed on by all ranks (all_reduce),
-        so the ranks always take the same path."""
-        import os
-
-        import torch.distributed as dist
-
-        mode = os.environ.get("MPPI_EXCHANGE", "nccl").lower()
-        if mode not in ("nccl", "rccl", "p2p", "auto"):
-            raise ValueError("MPPI_EXCHANGE must be nccl, rccl, p2p or auto")
-        if mode == "nccl":
-            return
-        W, r, length = self._world, self._rank, int(self._summary.numel())
-
-        def all_ok(ok: bool) -> bool:  # agreement point: every rank takes the same branch afterwards
-            if W == 1:
-                return ok
-            t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self._device)
-            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self._pg)
-            return bool(int(t.item()))
-
-        def pattern_ok(entry: str) -> bool:  # rank w sends 1000*w + j + round; everybody must see everybody's
-            base = torch.arange(length, device=self._device, dtype=torch.float32)
-            got = torch.empty(W, length, device=self._device, dtype=torch.float32)
-            ok = True
-            for rnd in range(3):
-                self._h.call(entry, _ptr(base + (1000.0 * r + rnd)), _ptr(got), self._stream())
-                want = base[None, :] + (1000.0 * torch.arange(W, device=self._device)[:, None] + rnd)
-                ok = ok and bool(torch.equal(got, want))
-            return ok
-
-        why = ""
-        if mode in ("rccl", "auto"):
-            ident = torch.zeros(128, dtype=torch.uint8, device=self._device)
-            ok = True
-            if r == 0:
-                buf = (C.c_ubyte * 128)()
-                ok = self._h.lib.mppi_comm_unique_id(buf) == 0
-                ident = torch.tensor(list(bytes(buf)), dtype=torch.uint8, device=self._device)
-                why = "" if ok else "librccl.so.1 is not loadable"
-            if all_ok(ok):
-                if W > 1:
-                    dist.broadcast(ident, src=dist.get_global_rank(self._pg, 0) if self._pg is not None else 0,
-                                   group=self._pg)
-                blob = (C.c_ubyte * 128)(*ident.cpu().tolist())
-                try:
-                    self._h.call("mppi_comm_init", W, r, blob)
-                    ok = pattern_ok("mppi_comm_exchange")
-                except _capi.MppiError as e:
-                    ok, why = False, str(e)
-                if all_ok(ok):
-                    self._h.call("mppi_set_option", b"exchange_comm", 1)
-                    self._comm = True
-                    return
-            if mode == "rccl":
-                raise _capi.MppiError("MPPI_EXCHANGE=rccl: the in-library collective is not usable here: "
-                                      + (why or "self-test mismatch"))
-            return  # auto: fall back to the torch.distributed all_gather, on every rank
-
-        handle = (C.c_ubyte * 64)()
-        ok = True
-        try:
-            self._h.call("mppi_p2p_alloc", W, r, handle)
-        except _capi.MppiError as e:
-            ok, why = False, str(e)
-        if all_ok(ok):
-            # 64 handle bytes + this rank's device ordinal
-            mine = torch.tensor(list(bytes(handle)) + [int(self._device.index)], dtype=torch.uint8, device=self._device)
-            allh = torch.empty(W * 65, dtype=torch.uint8, device=self._device)
-            dist.all_gather_into_tensor(allh, mine, group=self._pg)
-            rows = allh.cpu().numpy().reshape(W, 65)
-            blob = (C.c_ubyte * (64 * W)).from_buffer_copy(rows[:, :64].tobytes())
-            devs = (C.c_int32 * W)(*[int(v) for v in rows[:, 64]])
-            try:
-                self._h.call("mppi_p2p_connect", blob, devs)
-            except _capi.MppiError as e:
-                ok, why = False, str(e)
-            if all_ok(ok):
-                try:
-                    ok = pattern_ok("mppi_p2p_exchange")
-                except _capi.MppiError as e:
-                    ok, why = False, str(e)
-                if all_ok(ok):
-                    self._h.call("mppi_set_option", b"exchange_p2p", 1)
-                    self._p2p = True
-                    return
-        raise _capi.MppiError("MPPI_EXCHANGE=p2p: the peer-to-peer exchange is not usable here: " + (why or "self-test mismatch"))
-
     # ------------------------------------------------------------------ device-resident racing tick
     def set_center_path(self, path_xyyaw: np.ndarray, dind: np.ndarray, v_target: float) -> None:
         """Hand the racing centre line [n,3] and the window row offsets of calc_ref_trajectory (example/racing.py:
@@ -1065,379 +904,3 @@ class MPPI(nn.Module):
         self._solve_idx += 1
         self._previous_action_seq = self._action_out
         return self._action_out, self._returned_state_seq()
-
-    # ------------------------------------------------------------------ generic (opaque callables) path
-    def _generic_rollout_costs(self, state, info: Dict) -> None:
-        """Steps 2-3 of forward() with the user's torch callables on GPU tensors, same call sequence and
-        `info` protocol as the reference (src/pi_mpc/mppi.py:280-336); the summed costs go back to the
-        library with mppi_set_costs.  With graph_callables the two loops are one hipGraph replay."""
-        N, T = self._local_samples, self._horizon
-        x0 = torch.as_tensor(np.asarray(state) if not torch.is_tensor(state) else state)
-        x0 = x0.to(self._device, self._dtype)
-        if self._x0_tensor is None:
-            self._x0_tensor = torch.empty(self._dim_state, device=self._device, dtype=self._dtype)
-        self._x0_tensor.copy_(x0)  # static buffers: the same storage every solve (what a captured graph replays on)
-        # clamp(mean + eps) in the reference layout [N,T,dc]; the handle's warm start still holds the
-        # mean of this solve (it is replaced by mppi_finalize)
-        if self._state_seq_batch_buf is None:  # (the reference allocates `_state_seq_batch` once, too: mppi.py:168-174)
-            self._state_seq_batch_buf = torch.zeros(N, T + 1, self._dim_state, device=self._device, dtype=self._dtype)
-            self._generic_costs_keep = torch.empty(N, device=self._device, dtype=self._dtype)
-        if self._perturbed_action_seqs_buf is None or not self._graph_callables:
-            # a new `_perturbed_action_seqs` tensor every solve like the reference (mppi.py:266-275); a captured graph
-            # needs the same storage every solve instead
-            self._perturbed_action_seqs_buf = torch.empty(N, T, self._dim_control, device=self._device, dtype=self._dtype)
-        U = self._perturbed_action_seqs_buf
-        self._h.call("mppi_export_noise", None, _ptr(U), self._stream())
-        if self._graph_state == "replay":
-            self._check_replay_info(info)
-            self._graph.replay()
-        elif self._graph_state == "capture":
-            self._capture_callables(info)
-        else:
-            self._callable_loops(info)
-            if self._graph_state == "warmup":
-                self._graph_state = "capture"  # the next solve captures (this one warmed the allocator / kernels up)
-        self._h.call("mppi_set_costs", _ptr(self._generic_costs_keep), 1, self._stream())
-
-    def _callable_loops(self, info: Dict) -> None:
-        """src/pi_mpc/mppi.py:280-336 on the static buffers: S <- rollout of U from x0, total costs -> _generic_costs_keep."""
-        N, T = self._local_samples, self._horizon
-        U, S = self._perturbed_action_seqs_buf, self._state_seq_batch_buf
-        S[:, 0, :] = self._x0_tensor.repeat(N, 1)
-        for t in range(T):
-            S[:, t + 1, :] = self._dynamics(S[:, t, :], U[:, t, :])
-        costs = torch.zeros(N, T, device=self._device, dtype=self._dtype)
-        initial_state = S[:, 0, :]
-        for t in range(T):
-            p = t - 1 if t > 0 else 0
-            info["prev_state"] = S[:, p, :]
-            info["prev_action"] = U[:, p, :]
-            info["initial_state"] = initial_state
-            info["t"] = t
-            costs[:, t] = self._cost_func(S[:, t, :], U[:, t, :], info)
-        info["prev_state"] = S[:, -2, :]
-        zero_action = torch.zeros(N, self._dim_control, device=self._device, dtype=self._dtype)
-        terminal = self._cost_func(S[:, -1, :], zero_action, info)
-        self._generic_costs_keep.copy_(torch.sum(costs, dim=1) + terminal)
-
-    def _states_prediction_graphed(self) -> torch.Tensor:
-        """Step 8 (the batch-1 rollout of the solution through the user's dynamics, T launch-bound calls) as a second
-        captured graph on static buffers; returns a fresh tensor like the eager path.  A dynamics that cannot be captured
-        at batch 1 keeps the eager rollout (warned once), like the N-sample loops."""
-        import warnings
-
-        if self._graph_b1 is None:
-            self._b1_actions = torch.empty(1, self._horizon, self._dim_control, device=self._device, dtype=self._dtype)
-            self._b1_actions.copy_(self._action_out)
-            try:
-                side = torch.cuda.Stream(device=self._device)
-                side.wait_stream(torch.cuda.current_stream(self._device))
-                with torch.cuda.stream(side):  # warm-up at batch 1 on the stream the capture will use
-                    self._states_prediction(self._x0_tensor, self._b1_actions)
-                torch.cuda.current_stream(self._device).wait_stream(side)
-                torch.cuda.synchronize(self._device)
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=side):
-                    self._b1_states = self._states_prediction(self._x0_tensor, self._b1_actions)
-                self._graph_b1 = g
-            except Exception as e:  # noqa: BLE001  not capturable at batch 1: stay eager for this step
-                torch.cuda.synchronize(self._device)
-                self._graph_b1 = False
-                warnings.warn(f"graph_callables: the batch-1 rollout of the solution could not be captured "
-                              f"({type(e).__name__}); it stays on the eager loop")
-        if self._graph_b1 is False:
-            return self._states_prediction(self._x0_tensor, self._action_out.repeat(1, 1, 1))
-        self._b1_actions.copy_(self._action_out)
-        self._graph_b1.replay()
-        return self._b1_states.clone()
-
-    def recapture(self) -> None:
-        """graph_callables: drop the captured loops; the next solve runs eagerly (warm-up) and the one after captures
-        again.  Call it after REBINDING anything the callables read (a new tensor object for a reference path, a
-        changed Python scalar): a replay reads the storage that was captured — update tensors in place (`copy_`) to
-        change what a captured graph sees without recapturing."""
-        if self._graph_callables:
-            self._graph = self._graph_b1 = None
-            self._graph_info_keys = None
-            self._graph_state = "warmup"
-
-    def _capture_callables(self, info: Dict) -> None:
-        """Capture _callable_loops into a hipGraph and run it once; on failure fall back to the eager loops for good."""
-        import warnings
-
-        try:
-            torch.cuda.synchronize(self._device)
-            side = torch.cuda.Stream(device=self._device)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=side):
-                self._callable_loops(info)
-            self._graph = g
-            self._graph_state = "replay"
-            # what the caller's dict held besides the solver's own four keys when the loops were captured: a replay cannot
-            # see later changes of it (see _check_replay_info)
-            self._graph_info_keys = self._info_signature(info)
-            g.replay()
-        except Exception as e:  # not capturable (host sync, data-dependent shapes, ...): stay eager
-            self._graph, self._graph_state = None, "failed"
-            torch.cuda.synchronize(self._device)
-            warnings.warn(f"graph_callables: the dynamics / cost_func loops could not be captured ({type(e).__name__}: "
-                          f"{str(e).splitlines()[0] if str(e) else ''}); staying on the eager loops")
-            self._callable_loops(info)
-
-    @staticmethod
-    def _info_signature(info: Dict) -> Dict:
-        """What a captured graph saw of the CALLER's entries of `info`, by value: a tensor is its storage (address, shape,
-        in-place version counter: a replay reads that storage, so an equal-valued NEW tensor is a change and an in-place
-        update of the captured one is not — but bumps the version, which is allowed), a Python scalar / string / None is
-        its value (a caller may rebuild an equal dict every tick), anything else its identity."""
-        sig = {}
-        for k, v in info.items():
-            if k in ("prev_state", "prev_action", "initial_state", "t"):
-                continue
-            if torch.is_tensor(v):
-                sig[k] = ("tensor", v.data_ptr(), tuple(v.shape), v.dtype)
-            elif isinstance(v, (bool, int, float, str, bytes, type(None))):
-                sig[k] = ("value", v)
-            else:
-                sig[k] = ("object", id(v))
-        return sig
-
-    def _check_replay_info(self, info: Dict) -> None:
-        """A replayed graph ignores the `info` dict it is handed: the solver's own keys are views of the static buffers
-        (filled in below like the eager loop leaves them), but entries the CALLER put there were read at capture time.  If
-        those changed identity since, the replay would silently use the old objects: refuse instead."""
-        now = self._info_signature(info)
-        if now != self._graph_info_keys:
-            raise RuntimeError("graph_callables: the caller's entries of `info` changed since the loops were captured "
-                               f"({sorted(set(now) ^ set(self._graph_info_keys)) or sorted(now)}); update tensors in place "
-                               "or call solver.recapture()")
-        U, S = self._perturbed_action_seqs_buf, self._state_seq_batch_buf  # what the eager loop leaves in the dict
-        info["prev_state"], info["prev_action"] = S[:, -2, :], U[:, max(self._horizon - 2, 0), :]
-        info["initial_state"], info["t"] = S[:, 0, :], self._horizon - 1
-
-    def _states_prediction(self, state: torch.Tensor, action_seqs: torch.Tensor) -> torch.Tensor:
-        """src/pi_mpc/mppi.py:508-524 with the user's dynamics."""
-        out = torch.zeros(action_seqs.shape[0], self._horizon + 1, self._dim_state, device=self._device,
-                          dtype=self._dtype)
-        out[:, 0, :] = state
-        for t in range(self._horizon):
-            out[:, t + 1, :] = self._dynamics(out[:, t, :], action_seqs[:, t, :])
-        return out
-
-    def _softmax_stats(self, lam: float) -> Dict[str, float]:
-        """{cmin, cmax, se, se2, sec} of softmax(-costs/lam) over ALL samples, reduced on the device
-        (one 40-byte read-back per probe; one all_gather of 5 doubles per probe when sharded)."""
-        out = (C.c_double * 5)()
-        self._h.call("mppi_softmax_stats", float(lam), out, self._stream())
-        cmin, cmax, se, se2, sec = (float(v) for v in out)
-        if self._world > 1:
-            import torch.distributed as dist
-
-            mine = torch.tensor([cmin, cmax, se, se2, sec], dtype=torch.float64, device=self._device)
-            allv = torch.empty(self._world * 5, dtype=torch.float64, device=self._device)
-            dist.all_gather_into_tensor(allv, mine, group=self._pg)
-            a = allv.view(self._world, 5).cpu().numpy()
-            lam32 = np.float32(lam)
-            x = ((-a[:, 0].astype(np.float32)) / lam32).astype(np.float64)
-            f = np.exp(x - x.max())
-            cmin, cmax = float(a[:, 0].min()), float(a[:, 1].max())
-            se, se2, sec = float((f * a[:, 2]).sum()), float((f * f * a[:, 3]).sum()), float((f * a[:, 4]).sum())
-        return dict(cmin=cmin, cmax=cmax, se=se, se2=se2, sec=sec)
-
-    def _ess_grid(self, lams) -> np.ndarray:
-        """ESS(lambda) for up to 32 lambdas from ONE pass over the costs on the device
-        (mppi_softmax_stats_multi; shards combined with one all_gather per call)."""
-        lams = np.ascontiguousarray(lams, dtype=np.float32)
-        L = len(lams)
-        out = np.zeros((L, 3), np.float64)
-        self._h.call("mppi_softmax_stats_multi", lams.ctypes.data_as(C.c_void_p), L, out.ctypes.data_as(C.c_void_p),
-                     self._stream())
-        se, se2 = out[:, 0], out[:, 1]
-        if self._world > 1:
-            import torch.distributed as dist
-
-            cmin = self.last_local_cmin()
-            mine = torch.from_numpy(np.concatenate([[cmin], out.ravel()])).to(self._device)
-            allv = torch.empty(self._world * mine.numel(), dtype=torch.float64, device=self._device)
-            dist.all_gather_into_tensor(allv, mine, group=self._pg)
-            a = allv.view(self._world, -1).cpu().numpy()
-            cm, st = a[:, 0], a[:, 1:].reshape(self._world, L, 3)
-            # every shard's sums are relative to ITS minimum, e = exp((cmin_w - c) / lam) (stats_multi_partial_kernel):
-            # rescale by exp((cmin - cmin_w) / lam), difference first, in float64 — rounding the two quotients
-            # separately would put ulp(cmin / lam) into the exponent
-            f = np.exp((cm.min() - cm)[:, None] * (1.0 / lams.astype(np.float64))[None, :])
-            se, se2 = (f * st[:, :, 0]).sum(0), (f * f * st[:, :, 1]).sum(0)
-        return se * se / se2
-
-    def last_local_cmin(self) -> float:
-        out = (C.c_double * 5)()
-        self._h.call("mppi_softmax_stats", 1.0, out, self._stream())
-        return float(out[0])
-
-    def _gather_costs_host(self) -> np.ndarray:
-        """costs[N] on the host for the temperature search (all shards when sharded)."""
-        c = np.empty(self._local_samples, np.float32)
-        self._h.call("mppi_get_costs", c.ctypes.data_as(C.c_void_p), 0, self._stream())
-        if self._world > 1:
-            import torch.distributed as dist
-
-            counts = [shard_range(self._num_samples, self._world, r)[1] for r in range(self._world)]
-            width = max(counts)  # shards may differ by one sample: gather equal-sized rows, then drop the padding
-            row = np.full(width, np.nan, np.float32)
-            row[:len(c)] = c
-            out = torch.empty(self._world * width, device=self._device, dtype=torch.float32)
-            dist.all_gather_into_tensor(out, torch.from_numpy(row).to(self._device), group=self._pg)
-            rows = out.cpu().numpy().reshape(self._world, width)
-            c = np.concatenate([rows[r, :counts[r]] for r in range(self._world)])
-        return c
-
-    # ------------------------------------------------------------------ lazily materialised state
-    @property
-    def _costs(self) -> torch.Tensor:
-        c = torch.empty(self._local_samples, device=self._device, dtype=self._dtype)
-        self._h.call("mppi_get_costs", _ptr(c), 1, self._stream())
-        return c
-
-    @property
-    def _weights(self) -> torch.Tensor:
-        """softmax(-costs/lambda) of the last solve (src/pi_mpc/mppi.py:376), this shard's slice."""
-        w = torch.empty(self._local_samples, device=self._device, dtype=self._dtype)
-        stats = self._stats.cpu().numpy()
-        self._h.call("mppi_weights", float(self._last_lambda), float(stats[0]), float(stats[1]), _ptr(w),
-                     self._stream())
-        return w
-
-    @property
-    def _action_noises(self) -> torch.Tensor:
-        e = torch.empty(self._local_samples, self._horizon, self._dim_control, device=self._device,
-                        dtype=self._dtype)
-        self._h.call("mppi_export_noise", _ptr(e), None, self._stream())
-        return e
-
-    @property
-    def _perturbed_action_seqs(self) -> torch.Tensor:
-        """clamp(mean + eps) of the last solve, [N,T,dc] (src/pi_mpc/mppi.py:266-275): kept by the generic path,
-        rebuilt on demand from the solve's noise and the mean it sampled around for the native models."""
-        if self._model is None:
-            return self._perturbed_action_seqs_buf
-        return self._perturbed_actions_for(self._mean_of_last_solve)
-
-    @property
-    def _state_seq_batch(self) -> torch.Tensor:
-        """All N state trajectories of the last solve, [N,T+1,ds] (src/pi_mpc/mppi.py:280-286).  The native
-        path never stores them (856 MB at N = 2^20, T = 50): they are re-rolled on demand."""
-        if self._model is None:
-            return self._state_seq_batch_buf
-        n = self._local_samples
-        out = torch.empty(n, self._horizon + 1, self._dim_state, device=self._device, dtype=self._dtype)
-        idx = torch.arange(n, device=self._device, dtype=torch.int64)
-        self._h.call("mppi_rollout_samples", _ptr(idx), n, _ptr(out), self._stream())
-        return out
-
-    def _perturbed_actions_for(self, mean: torch.Tensor) -> torch.Tensor:
-        """clamp(mean + eps) for the resident noise with an explicit mean (the mean of the LAST solve
-        has been overwritten by the warm start when store_mean was on)."""
-        u = torch.empty(self._local_samples, self._horizon, self._dim_control, device=self._device,
-                        dtype=self._dtype)
-        cur = torch.empty(self._horizon, self._dim_control, device=self._device, dtype=self._dtype)
-        st = self._stream()
-        self._h.call("mppi_get_mean", _ptr(cur), 1, st)
-        self._h.call("mppi_set_mean", _ptr(mean.contiguous()), 1, st)
-        self._h.call("mppi_export_noise", None, _ptr(u), st)
-        self._h.call("mppi_set_mean", _ptr(cur), 1, st)
-        return u
-
-    # ------------------------------------------------------------------ queries
-    def get_top_samples(self, num_samples: int) -> Tuple[torch.Tensor, torch.Tensor]:
-        """Top-weighted trajectories of the last solve (src/pi_mpc/mppi.py:462-487).  The N state
-        trajectories are not kept in HBM: the k winners are selected on the device (largest weight =
-        smallest cost) and re-rolled from the noise of that solve around the mean it sampled."""
-        assert num_samples <= self._num_samples
-        if self._world > 1:
-            return self._top_samples_sharded(num_samples)
-        if self._model is None:  # the generic path keeps _state_seq_batch like the reference
-            top = torch.topk(self._weights, num_samples)
-            order = torch.argsort(top.values, descending=True)
-            return self._state_seq_batch_buf[top.indices][order], top.values[order]
-        out = torch.empty(num_samples, self._horizon + 1, self._dim_state, device=self._device, dtype=self._dtype)
-        w = torch.empty(num_samples, device=self._device, dtype=self._dtype)
-        # one library call for any k: radix select + sort (one block up to 1024, multi-pass beyond) + re-roll + weights — ONE
-        # launch up to 4096 samples; the weights use the temperature the solve left on the device (no read-back, no wait)
-        self._h.call("mppi_top_samples", num_samples, _capi.LAMBDA_DEVICE, _ptr(out), _ptr(w), self._stream())
-        return out, w
-
-    def _top_samples_sharded(self, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
-        """Sharded get_top_samples: every rank selects its min(k, local) best candidates ((cost key << 32) | global
-        index, padded to k with the largest word), one all_gather merges them, and — the device noise being a function
-        of the global sample index — every rank re-rolls the k global winners itself: all ranks return the same
-        tensors.  Opaque callables keep their state trajectories (like the reference): there the winners' rows are
-        gathered instead of re-rolled."""
-        import torch.distributed as dist
-
-        st = self._stream()
-        kk = min(k, self._local_samples)
-        flip = torch.tensor(-(1 << 63), dtype=torch.int64, device=self._device)  # unsigned order through a signed sort
-        if self._model is None:
-            wl = self._weights  # this shard's slice of the global softmax
-            top = torch.topk(wl, kk)
-            mine_w = torch.full((k,), -1.0, device=self._device, dtype=self._dtype)
-            mine_s = torch.zeros(k, self._horizon + 1, self._dim_state, device=self._device, dtype=self._dtype)
-            mine_w[:kk], mine_s[:kk] = top.values, self._state_seq_batch_buf[top.indices]
-            all_w = torch.empty(self._world * k, device=self._device, dtype=self._dtype)
-            all_s = torch.empty(self._world * k, self._horizon + 1, self._dim_state, device=self._device, dtype=self._dtype)
-            dist.all_gather_into_tensor(all_w, mine_w, group=self._pg)
-            dist.all_gather_into_tensor(all_s, mine_s, group=self._pg)
-            best = torch.sort(all_w, descending=True, stable=True)
-            return all_s[best.indices[:k]], best.values[:k]
-        mine = torch.full((k,), -1, dtype=torch.int64, device=self._device)  # uint64 bit patterns; -1 = the largest word
-        if kk == k:
-            self._h.call("mppi_top_candidates", kk, _ptr(mine), st)
-        else:
-            part = torch.empty(kk, dtype=torch.int64, device=self._device)
-            self._h.call("mppi_top_candidates", kk, _ptr(part), st)
-            mine[:kk] = part
-        allc = torch.empty(self._world * k, dtype=torch.int64, device=self._device)
-        dist.all_gather_into_tensor(allc, mine, group=self._pg)
-        best = (torch.sort(allc ^ flip).values[:k] ^ flip).contiguous()
-        out = torch.empty(k, self._horizon + 1, self._dim_state, device=self._device, dtype=self._dtype)
-        w = torch.empty(k, device=self._device, dtype=self._dtype)
-        self._h.call("mppi_rollout_candidates", _ptr(best), k, _capi.LAMBDA_DEVICE, _ptr(out), _ptr(w), st)
-        return out, w
-
-    def get_samples_from_posterior(self, optimal_solution: torch.Tensor, state: torch.Tensor,
-                                   num_samples: int) -> Tuple[torch.Tensor, torch.Tensor]:
-        """N(optimal_solution, Sigma) samples (unclamped) and their rollouts (src/pi_mpc/mppi.py:489-506).
-
-        The draw comes from the SOLVER'S noise stream, like the reference's MultivariateNormal.sample() on torch's
-        global generator: in "torch_cpu" mode the next [k,T,dc] normals of the solver's CPU generator (so an
-        identically seeded reference run sees the same samples and the same noise in the following solve), otherwise
-        the Philox stream at the next solve index, which this call consumes.  The solver's own state is untouched:
-        a later get_top_samples still describes the last solve."""
-        assert num_samples <= self._num_samples
-        k, T, dc = num_samples, self._horizon, self._dim_control
-        st = self._stream()
-        loc = torch.as_tensor(optimal_solution, dtype=self._dtype).to(self._device).contiguous()
-        assert loc.shape == (T, dc)
-        if self._noise_source == "torch_cpu":
-            eps = torch.randn(k, T, dc, generator=self._cpu_gen, dtype=torch.float32) * self._sigmas.cpu()
-            samples = (loc + eps.to(self._device)).contiguous()
-        else:
-            samples = torch.empty(k, T, dc, device=self._device, dtype=self._dtype)
-            self._h.call("mppi_sample_posterior", self._solve_idx, _ptr(loc), k, _ptr(samples), st)
-            self._solve_idx += 1
-        x0 = torch.as_tensor(np.asarray(state) if not torch.is_tensor(state) else state).to(
-            self._device, self._dtype).contiguous()
-        assert x0.shape == (self._dim_state,)
-        if self._model is None:
-            return samples, self._states_prediction(x0, samples)
-        out = torch.empty(k, T + 1, self._dim_state, device=self._device, dtype=self._dtype)
-        self._h.call("mppi_rollout_actions", _ptr(samples), k, _ptr(x0), _ptr(out), st)
-        self._posterior_keep = (x0, samples)  # alive until the enqueued kernels ran
-        return samples, out
-
-    # ------------------------------------------------------------------ diagnostics
-    def last_stats(self) -> Dict[str, float]:
-        """{min cost, sum e, sum e^2, sum e*c, ess, lambda} of the last solve (synchronises)."""
-        s = self._stats.cpu().numpy().astype(np.float64)
-        return dict(cmin=s[0], sum_e=s[1], sum_e2=s[2], sum_ec=s[3], ess=s[1] * s[1] / s[2],
-                    lambda_=self._last_lambda)
