@@ -3,7 +3,7 @@
 # rocprofv3 kernel trace + separate PMC passes for C3 (regen / tiles) and for the dense-weight configs C2 / C5.
 # Usage: bash scripts/gpu_record.sh [tag]   (writes gpurun_out/prof_<tag>/, default tag r2)
 set -u
-TAG=${1:-r4}
+TAG=${1:-r5}
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -21,6 +21,10 @@ for spec in "2 all" "2 nccl" "8 all"; do
   MPPI_BENCH_ONE_DEVICE=1 MPPI_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus $1 --exchange $2 --steps 20 --warmup 5 > gpurun_out/bench_dry_g$1_$2.log 2>&1
   echo "dry run --gpus $1 --exchange $2: rc=$? $(tail -1 gpurun_out/bench_dry_g$1_$2.log | cut -c1-160)"
 done
+# --preflight of the N > 1 path (process group, every transport's self-test, one sharded solve each) on this one GPU
+MPPI_BENCH_ONE_DEVICE=1 MPPI_BENCH_BACKEND=gloo timeout 300 python bench.py --gpus 2 --preflight > gpurun_out/bench_preflight_g2.log 2>&1
+echo "preflight --gpus 2: rc=$? $(tail -1 gpurun_out/bench_preflight_g2.log | cut -c1-300)"
+timeout 300 python scripts/lazy_state_stress.py 3000 2>&1 | grep -v amdgpu.ids | tail -5 > gpurun_out/lazy_state_stress.txt
 MASTER_PORT=29543 timeout 300 python scripts/nccl_single_rank.py 2>&1 | grep -E "forced exchange|RCCL all_gather" > gpurun_out/nccl_single_rank.txt
 timeout 300 python scripts/fused_timing.py 2>&1 | grep -v amdgpu.ids > gpurun_out/fused_timing.txt
 timeout 300 python scripts/essps_passes.py 2>&1 | grep -v amdgpu.ids > gpurun_out/essps_passes.txt
