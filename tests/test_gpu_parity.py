@@ -1825,6 +1825,106 @@ def test_c4_eight_shards_at_full_size_on_one_device(lam):
     assert abs(st[1] * st[1] / st[2] - st_full["ess"]) <= 1e-4 * st_full["ess"]
 
 
+def test_c4_eight_shards_match_the_reference_at_full_size():
+    """BASELINE configs[3] against the reference ITSELF: the 8 x 2^20 = 8 388 608 racing samples of the sharded run were put
+    through the real reference UNSHARDED in the build container (tests/golden/make_golden.py fullsize c4: seed 42, two
+    closed-loop solves, ~35 GB of RSS; outputs and summaries only).  Here eight shard handles (sample_offset = r * 2^20) on
+    this one device are fed their slices of the same torch-CPU noise stream, and their summaries are combined by
+    mppi_finalize(num_shards = 8) — the sharded solve minus the transport.  Checked per solve: the noise block's checksums,
+    the 32 smallest (index, cost) pairs over all shards in the reference's order, minimum / maximum / float64 sum / order
+    statistics of the 8 M costs, and action_seq / state_seq (arg-min regime: action == U[argmin] of the reference)."""
+    import os
+
+    from helpers import GOLDEN
+    from mppi_playground_amd import _capi
+
+    name = "full_c4_racing_T50_N8388608_lambda1"
+    if not os.path.exists(os.path.join(GOLDEN, name + ".npz")):
+        pytest.skip(f"{name}.npz not generated (make_golden.py fullsize c4: ~1.5 h, 35 GB)")
+    _need_gpu()
+    g = load(name)
+    W, T = 8, int(g["T"])
+    N, K = int(g["N"]), int(g["K"])
+    NL = N // W
+    mc = MODEL_CFG["racing"]
+    sig = torch.tensor(mc["sigmas"])
+    gen = torch.Generator(device="cpu").manual_seed(int(g["seed"]))
+    ctor = torch.randn(N, T, 2, generator=gen)  # the constructor's draw (mppi.py:146-148)
+    assert float((ctor * sig).numpy().astype(np.float64).sum()) == float(g["ctor_eps_sum64"])
+    del ctor
+    shards = []
+    for r in range(W):
+        sol, c2 = make_solver("racing", T, NL, lambda_=1.0)
+        cfg = _capi.MppiConfig()
+        cfg.model, cfg.horizon, cfg.dim_state, cfg.dim_control = 4, T, 4, 2
+        cfg.num_samples, cfg.sample_offset, cfg.inherit_count = NL, r * NL, N
+        for k in range(2):
+            cfg.u_min[k], cfg.u_max[k], cfg.sigmas[k] = (mc[q][k] for q in ("u_min", "u_max", "sigmas"))
+        cfg.seed, cfg.device = 42, 0
+        sol._h.close()
+        sol._h = _capi.Handle(cfg)
+        sol._uploaded, sol._params_set, sol._ref_uploaded = {}, None, None
+        shards.append((sol, c2))
+    env = _envs["racing"]
+    ctrl0 = shards[0][1]
+    state = torch.from_numpy(g["x0_0"])
+    lo, hi = np.float32(mc["u_min"]), np.float32(mc["u_max"])
+    for k in range(K):
+        assert rel_err(state.cpu().numpy(), g[f"x0_{k}"]) <= TOL
+        ref, ctrl0.current_path_index = ctrl0.calc_ref_trajectory(state, env.racing_center_path, ctrl0.current_path_index, T,
+                                                                  DL=0.1, lookahead_distance=3, reference_path_interval=0.85)
+        assert np.array_equal(ref.numpy(), g[f"ref_path_{k}"])
+        eps = torch.randn(N, T, 2, generator=gen) * sig  # this solve's block of the reference's stream
+        e64 = eps.numpy().astype(np.float64)
+        assert float(e64.sum()) == float(g[f"eps_sum64_{k}"]) and float((e64 * e64).sum()) == float(g[f"eps_sumsq64_{k}"])
+        del e64
+        top_i = g[f"top32_idx_{k}"]
+        assert np.array_equal(eps.numpy()[top_i], g[f"top32_eps_{k}"])
+        x0d = state.cuda().contiguous()
+        md = torch.from_numpy(g[f"mean_in_{k}"]).cuda()
+        sums, costs = [], []
+        for r, (sol, c2) in enumerate(shards):
+            c2.set_reference(ref)
+            sol._h.call("mppi_set_state", C.c_void_p(x0d.data_ptr()), 1, sol._stream())
+            sol._refresh_model_inputs()
+            sol._h.call("mppi_set_mean", C.c_void_p(md.data_ptr()), 1, sol._stream())
+            sl = eps[r * NL:(r + 1) * NL].cuda().contiguous()
+            sol._h.call("mppi_inject_noise", C.c_void_p(sl.data_ptr()), sol._stream())
+            sol._h.call("mppi_rollout_cost", sol._stream())
+            costs.append(sol._costs.cpu().numpy())
+            sums.append(_summary(sol, 1.0))
+            torch.cuda.synchronize()
+            del sl
+        c = np.concatenate(costs)
+        scale = float(g[f"cmax_{k}"])
+        assert np.abs(c[top_i] - g[f"top32_cost_{k}"]).max() <= TOL * scale
+        order = np.lexsort((np.arange(N), c))[:32]
+        assert np.array_equal(order, top_i), (order[:8], top_i[:8])  # (no pair of the reference's top 32 is closer than 4 ulps: checked below)
+        assert np.diff(g[f"top32_cost_{k}"].astype(np.float64)).min() >= 4 * EPS32 * float(np.abs(g[f"top32_cost_{k}"]).max())
+        assert abs(float(c.min()) - float(g[f"cmin_{k}"])) <= TOL * scale and abs(float(c.max()) - scale) <= TOL * scale
+        rel_sum = abs(float(c.astype(np.float64).sum()) - float(g[f"costs_sum64_{k}"])) / abs(float(g[f"costs_sum64_{k}"]))
+        parity_report.record("cost_sum_rel_err_vs_reference_full_c4", rel_sum, 1e-6)
+        assert rel_sum <= 1e-6
+        assert np.abs(np.sort(c)[g[f"quantile_ranks_{k}"]] - g[f"quantiles_{k}"]).max() <= TOL * scale
+        allsum = torch.stack(sums).contiguous()
+        a = torch.zeros(T, 2, device="cuda")
+        s = torch.zeros(1, T + 1, 4, device="cuda")
+        stats = torch.zeros(4, device="cuda")
+        h0 = shards[0][0]
+        h0._h.call("mppi_finalize", C.c_void_p(allsum.data_ptr()), W, 1.0, 0, C.c_void_p(a.data_ptr()), C.c_void_p(s.data_ptr()),
+                   C.c_void_p(stats.data_ptr()), h0._stream())
+        h0.join_state_seq()
+        U = np.clip(g[f"mean_in_{k}"] + g[f"top32_eps_{k}"][0], lo, hi)
+        assert float(g[f"top32_weight_{k}"][0]) >= 1.0 - 1e-6 and int(np.argmin(c)) == int(top_i[0])
+        assert np.abs(a.cpu().numpy() - U).max() <= 1e-6 * np.abs(U).max()
+        band = full_size_band(g, k)
+        check_banded("action_seq_vs_reference_fixture_full_c4", a.cpu().numpy(), g[f"action_seq_{k}"], band["action"])
+        check_banded("state_seq_vs_reference_fixture_full_c4", s.cpu().numpy(), g[f"state_seq_{k}"], band["state"])
+        u = torch.clamp(a[0], env.u_min, env.u_max)
+        state = env.dynamics(state.cuda().unsqueeze(0), u.unsqueeze(0)).squeeze(0)
+        del eps
+
+
 def test_generic_path_hipgraph_capture_of_the_callables():
     """graph_callables=True: the reference's two T-step Python loops over opaque callables, captured once into a
     hipGraph (after one eager warm-up solve) and replayed — bit-identical to the eager loops over a closed loop
