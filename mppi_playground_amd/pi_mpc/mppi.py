@@ -80,6 +80,7 @@ class MPPI(ExchangeMixin, GenericPathMixin, QueriesMixin, nn.Module):
         auto_lambda_stats: str = "device",
         essps_search: str = "device",
         lbps_search: str = "brent",
+        recognize_closures: bool = True,
         sg_filter: str = "device",
         graph_callables: bool = False,
         lazy_state_seq: Optional[bool] = None,
@@ -114,6 +115,10 @@ class MPPI(ExchangeMixin, GenericPathMixin, QueriesMixin, nn.Module):
                 moves by up to 1e-2 under 1-ulp changes of its costs — the `band_rule` entries of tests/golden/), so
                 "device" agrees with the reference to that spread only.
                 The MPO dual always steps on the device when the statistics are the device's own.
+            recognize_closures: True (default): untagged callables that ARE the closures of the reference's classic-control
+                examples (example/pendulum.py, cartpole.py, mountaincar.py, mujoco_cartpole.py: same source fingerprint AND
+                the same values as the shipped plugin on probe batches, pi_mpc/recognize.py) run as the fused native model
+                instead of on the generic path; False: untagged callables always take the generic path.
             sg_filter: "device" (default) runs the Savitzky-Golay step inside the finalize kernel
                 (bit-identical to the host statement), "host" keeps the reference's numpy-style round trip.
             graph_callables: opaque (untagged) callables only.  The reference's two T-step Python loops over the user's
@@ -214,8 +219,17 @@ class MPPI(ExchangeMixin, GenericPathMixin, QueriesMixin, nn.Module):
         # cost measured on a single GPU
         self._force_exchange = bool(_force_exchange and shard_samples and self._world == 1)
 
-        # ---- plugin recognition
+        # ---- plugin recognition: a native tag (pi_mpc/native.py), or the reference examples' own closures (pi_mpc/recognize.py:
+        # fingerprint of their source AND agreement with the shipped plugin on probe batches)
         dyn, cst = resolve(dynamics), resolve(cost_func)
+        self._recognized = None
+        if dyn is None and cst is None and recognize_closures:
+            from pi_mpc import recognize
+
+            twin = recognize.match(dynamics, cost_func, dim_state, dim_control, self._device)
+            if twin is not None:
+                self._recognized = (dynamics, cost_func)  # (kept for inspection; the fused model runs instead)
+                dyn, cst = resolve(twin[0]), resolve(twin[1])
         if (dyn and cst and dyn[0].model == cst[0].model and dyn[0].role == "dynamics"
                 and cst[0].role == "cost"):
             self._model = dyn[0].model  # fused on the device

@@ -1071,6 +1071,52 @@ def test_generic_callable_path_matches_reference(name):
     assert ts.shape == (8, T + 1, ds)
 
 
+def test_recognised_closures_run_the_fused_model():
+    """Untagged callables whose source fingerprint is listed for a model AND that agree with that model's shipped plugin on the
+    probe batches (pi_mpc/recognize.py: how the reference examples' own closures are recognised; the real ones are checked in the
+    build container, tests/test_host_logic.py) run as the fused native model: same bits as the tagged plugins, and the generic
+    path's answer to 1e-5.  A listed fingerprint whose callable computes something else stays on the generic path."""
+    _need_gpu()
+    from envs import classic_control as cc
+    from pi_mpc import recognize
+    from pi_mpc.mppi import MPPI
+
+    def dynamics(state: torch.Tensor, action: torch.Tensor) -> torch.Tensor:  # (a closure, no native tag)
+        th, thdot = state[:, 0:1], state[:, 1:2]
+        u = torch.clamp(action[:, 0:1], -2, 2)
+        newthdot = thdot + (-3 * 10.0 / (2 * 1.0) * torch.sin(th + torch.pi) + 3.0 / (1.0 * 1.0 ** 2) * u) * 0.05
+        return torch.cat((th + newthdot * 0.05, torch.clamp(newthdot, -8, 8)), dim=1)
+
+    def cost(state, action, info):
+        return (torch.remainder(state[:, 0] + torch.pi, 2 * torch.pi) - torch.pi) ** 2 + 0.1 * state[:, 1] ** 2
+
+    def other_cost(state, action, info):
+        return state[:, 0] ** 2
+
+    kw = dict(horizon=15, num_samples=4096, dim_state=2, dim_control=1, u_min=torch.tensor([-2.0]), u_max=torch.tensor([2.0]),
+              sigmas=torch.tensor([1.0]), lambda_=1.0)
+    table = recognize._table()
+    try:
+        recognize._table_cache = {"pendulum": {"dynamics": [recognize.fingerprint(dynamics)],
+                                               "cost": [recognize.fingerprint(cost), recognize.fingerprint(other_cost)]}}
+        rec = MPPI(dynamics=dynamics, cost_func=cost, **kw)
+        wrong = MPPI(dynamics=dynamics, cost_func=other_cost, **kw)   # listed fingerprint, other values: not recognised
+        off = MPPI(dynamics=dynamics, cost_func=cost, recognize_closures=False, **kw)
+    finally:
+        recognize._table_cache = table
+    tagged = MPPI(dynamics=cc.pendulum_dynamics, cost_func=cc.pendulum_cost, **kw)
+    assert rec._model == "pendulum" and rec._recognized == (dynamics, cost) and tagged._model == "pendulum"
+    assert wrong._model is None and off._model is None
+    x = torch.tensor([3.0, 0.5])
+    for _ in range(3):
+        a, s = rec.forward(x)
+        b, sb = tagged.forward(x)
+        g, sg = off.forward(x)
+        assert torch.equal(a, b) and torch.equal(s, sb)
+        assert rel_err(g.cpu().numpy(), a.cpu().numpy()) <= 1e-5 and rel_err(sg.cpu().numpy(), s.cpu().numpy()) <= 1e-5
+        x = sb[0, 1].clone()
+
+
 @pytest.mark.parametrize("dc", [4, 3, 6, 7])
 def test_generic_path_any_control_dimension(dc):
     """dim_control = 3, 4, 6, 7 (the reference accepts any, mppi.py:96-98), dim_state = 5, on a toy linear model,

@@ -567,6 +567,7 @@ def _undefined_globals(path):
 @pytest.mark.parametrize("rel", ["bench.py", "__graft_entry__.py", "mppi_playground_amd/pi_mpc/mppi.py",
                                  "mppi_playground_amd/pi_mpc/_lazy.py", "mppi_playground_amd/pi_mpc/_exchange.py",
                                  "mppi_playground_amd/pi_mpc/_generic.py", "mppi_playground_amd/pi_mpc/_queries.py",
+                                 "mppi_playground_amd/pi_mpc/recognize.py", "scripts/closure_fingerprints.py",
                                  "mppi_playground_amd/_capi.py", "mppi_playground_amd/envs/racing_controller.py",
                                  "scripts/make_visit_docs.py", "scripts/pmc_constants.py", "tests/golden/make_golden.py"])
 def test_no_function_reads_an_undefined_name(rel):
@@ -611,3 +612,68 @@ def test_bench_stdout_carries_only_its_line():
     assert r.returncode == 0, r.stderr
     assert r.stdout == '{"metric": 1}\n'
     assert "banner from C" in r.stderr and "python chatter" in r.stderr
+
+
+# ------------------------------------------------------------------------------ the reference examples' own closures
+def _reference_example_closures(model):
+    """(dynamics, cost) as example/<model>.py holds them — nested definitions inside main(), `dynamics` a TorchScript function,
+    the cost a closure over the module-level TorchScript angle_normalize — rebuilt from the reference's file in a scratch
+    module (build container only; nothing is copied into the repo)."""
+    import ast
+    import importlib.util
+    import tempfile
+    import textwrap
+
+    fn, dyn_name, cost_name = {"pendulum": ("pendulum.py", "dynamics", "cost_function"),
+                               "cartpole": ("cartpole.py", "dynamics", "stage_cost"),
+                               "mountaincar": ("mountaincar.py", "dynamics", "cost_func"),
+                               "mjcartpole": ("mujoco_cartpole.py", "dynamics", "cost_func")}[model]
+    tree = ast.parse(open(os.path.join("/root/reference/example", fn)).read())
+    body = ["import torch\n"]
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name == "angle_normalize":
+            body.append(ast.unparse(node) + "\n")
+    main = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "main"][0]
+    inner = [textwrap.indent(textwrap.dedent(ast.unparse(n)), "    ") for n in main.body
+             if isinstance(n, ast.FunctionDef) and n.name in (dyn_name, cost_name)]
+    body.append("def main():\n" + "\n".join(inner) + f"\n    return {dyn_name}, {cost_name}\n")  # nested, like the example
+    d = tempfile.mkdtemp(prefix="mppi_ref_example_")
+    path = os.path.join(d, f"ref_example_{model}.py")
+    open(path, "w").write("\n".join(body))
+    spec = importlib.util.spec_from_file_location(f"ref_example_{model}", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.main()
+
+
+@pytest.mark.parametrize("model", ["pendulum", "cartpole", "mountaincar", "mjcartpole"])
+def test_reference_example_closures_are_recognised(model):
+    """pi_mpc/recognize.py on the REAL closures of the reference's classic-control examples (container only): the committed
+    fingerprints match what the installed torch prints for them, the shipped torch plugin of that model agrees with them on the
+    probe batches (values returned AND — mountain car — what the call leaves in its argument), and an edited copy is not
+    recognised."""
+    if not os.path.isdir("/root/reference/example"):
+        pytest.skip("needs the reference's example files (build container)")
+    import torch
+
+    from envs import classic_control as cc
+    from pi_mpc import recognize
+
+    dyn, cost = _reference_example_closures(model)
+    assert isinstance(dyn, torch.jit.ScriptFunction) and not isinstance(cost, torch.jit.ScriptFunction)
+    ds, dc = recognize._MODELS[model][:2]
+    twin = recognize.match(dyn, cost, ds, dc, torch.device("cpu"))
+    assert twin == (getattr(cc, f"{model}_dynamics"), getattr(cc, f"{model}_cost"))
+    assert recognize.match(dyn, cost, ds + 1, dc, torch.device("cpu")) is None      # another problem shape
+    assert recognize.match(cost, dyn, ds, dc, torch.device("cpu")) is None          # roles swapped
+    edited = lambda s, a, info: cost(s, a, info) * 1.0001                           # noqa: E731  (another function: another fingerprint)
+    assert recognize.match(dyn, edited, ds, dc, torch.device("cpu")) is None
+    # a callable with the right fingerprint but other values cannot exist by construction; the behaviour test is what
+    # protects against a whitelist entry that does not belong to the plugin it names:
+    other = "cartpole" if model != "cartpole" else "mjcartpole"
+    table = dict(recognize._table())
+    try:
+        recognize._table_cache = {other: table[model]} if recognize._MODELS[other][:2] == (ds, dc) else {}
+        assert recognize.match(dyn, cost, ds, dc, torch.device("cpu")) is None
+    finally:
+        recognize._table_cache = table
