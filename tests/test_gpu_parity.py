@@ -283,12 +283,29 @@ def test_identical_seed_closed_loop_matches_reference(name):
     _identical_seed_closed_loop(name)
 
 
-@pytest.mark.parametrize("mode", ["host", "brent", "device"])
-@pytest.mark.parametrize("name", ["pendulum_T50_N1000_essps", "cartpole_T64_N1024_essps_sg", "racing_T25_N1024_essps",
-                                  "nav2d_T30_N4096_essps", "nav2d_T50_N512_essps", "pendulum_T15_N256_lbps",
-                                  "nav2d_T30_N512_lbps", "pendulum_T15_N256_mpo", "nav2d_T30_N512_mpo",
-                                  "nav2d_T30_N4096_lbps", "racing_T25_N4096_lbps", "nav2d_T30_N4096_mpo",
-                                  "racing_T25_N4096_mpo", "nav2d_T30_N512_essps_at_min", "nav2d_T30_N512_essps_at_max"])
+_HOST_TEMPERATURE_CASES = ["pendulum_T50_N1000_essps", "cartpole_T64_N1024_essps_sg", "racing_T25_N1024_essps",
+                           "nav2d_T30_N4096_essps", "nav2d_T50_N512_essps", "pendulum_T15_N256_lbps", "nav2d_T30_N512_lbps",
+                           "pendulum_T15_N256_mpo", "nav2d_T30_N512_mpo", "nav2d_T30_N4096_lbps", "racing_T25_N4096_lbps",
+                           "nav2d_T30_N4096_mpo", "racing_T25_N4096_mpo", "nav2d_T30_N512_essps_at_min",
+                           "nav2d_T30_N512_essps_at_max"]
+
+
+def _host_temperature_params():
+    """(case, mode) pairs that exist: "host" for every rule; "brent" (the library's ports probing device statistics) for
+    the two searches — MPO has no search, its device-statistics step is the default path; "device" for LBPS only — the
+    device-resident ESSPS search is the default and runs in test_identical_seed_closed_loop_matches_reference."""
+    out = []
+    for name in _HOST_TEMPERATURE_CASES:
+        rule = CASES[name]["lambda_"]
+        out.append((name, "host"))
+        if rule != "MPO":
+            out.append((name, "brent"))
+        if rule == "LBPS":
+            out.append((name, "device"))
+    return out
+
+
+@pytest.mark.parametrize("name,mode", _host_temperature_params())
 def test_identical_seed_closed_loop_with_the_temperature_on_the_host(name, mode):
     """The north star's literal split — auto-lambda on the HOST — through the same identical-seed closed loops:
     mode "host": `auto_lambda_stats="host"`: costs[N] copied to the CPU and searched with scipy's brentq / bounded Brent /
@@ -296,10 +313,6 @@ def test_identical_seed_closed_loop_with_the_temperature_on_the_host(name, mode)
     mode "brent": the same root-finders inside the library (csrc/host_search.hpp ports of brentq's bracket rule and of
     scipy's bounded Brent) probing the device-side softmax statistics one temperature at a time (LBPS: the default);
     mode "device": the searches as kernels, the temperature resident in HBM (ESSPS: the default; LBPS: the opt-in fast path)."""
-    if mode != "host" and CASES[name]["lambda_"] == "MPO":
-        pytest.skip("MPO has no search: the device-statistics step is the default path")
-    if mode == "device" and CASES[name]["lambda_"] != "LBPS":
-        pytest.skip("the device-resident ESSPS search is the default: test_identical_seed_closed_loop_matches_reference")
     kw = {"host": dict(auto_lambda_stats="host"), "brent": dict(lbps_search="brent", essps_search="brentq"),
           "device": dict(lbps_search="device")}[mode]
     _identical_seed_closed_loop(name, tag="_" + mode, **kw)
