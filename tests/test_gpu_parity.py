@@ -469,6 +469,15 @@ def test_identical_seed_full_size_matches_reference(which):
             assert np.abs(a.cpu().numpy() - U).max() <= 1e-6 * np.abs(U).max()
         check_banded("action_seq_vs_reference_fixture" + tag, a.cpu().numpy(), g[f"action_seq_{k}"], band["action"])
         check_banded("state_seq_vs_reference_fixture" + tag, s.cpu().numpy(), g[f"state_seq_{k}"], band["state"])
+        # get_top_samples (mppi.py:462-487) at full size: the 32 largest weights are the reference's, in its order
+        ts, tw = solver.get_top_samples(32)
+        w_ref = g[f"top32_weight_{k}"]
+        werr = float(np.abs(tw.cpu().numpy() - w_ref).max() / w_ref.max())
+        parity_report.record("top32_weights_vs_reference" + tag, werr, 1e-4)
+        assert werr <= 1e-4, werr
+        assert ts.shape == (32, T + 1, s.shape[-1]) and torch.equal(ts[:, 0, :], state.to(ts.device).expand(32, -1))
+        if float(w_ref[0]) >= 1.0 - 1e-6:  # arg-min regime: the best sample's trajectory IS the solution's rollout
+            assert rel_err(ts[0].cpu().numpy(), g[f"state_seq_{k}"][0]) <= TOL
         if ctrl is not None:
             env = _envs["racing"]
             u = torch.clamp(a[0], env.u_min, env.u_max)
