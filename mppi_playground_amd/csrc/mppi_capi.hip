@@ -131,7 +131,6 @@ struct MppiSolver {
     int math_fast = 2;
     int reduce_blocks = 512;
     int reduce_chains = 0;             // option "reduce_chains": 0 = by the grid size, 2 / 4 = pinned (A/B)
-    int half_waves = 1;                // option "half_waves": rollout with 32 trajectories per wave: 0 = never, 1 = up to two full waves per SIMD (default), 2 = always
     int timing = 0;
     std::vector<hipEvent_t> ev_pool[5];  // per stage (4 = the deferred state sequence): start0, stop0, start1, stop1, ...
     size_t ev_used[5] = {0, 0, 0, 0, 0};
@@ -943,19 +942,13 @@ int mppi_rollout_cost(mppi_handle_t h, void* stream) {
     // launch: its T dependent steps hide behind the N-sample rollout instead of extending the previous solve's tail
     float* ride = h->pending_state_out;
     if (ride) { if (int rc = order_behind_pending(h, s)) return rc; }
-    // half-filled waves (32 trajectories per wave) while a SIMD would hold at most two full ones: see the kernel
-    const bool half = gen && h->half_waves != 0 && (h->half_waves == 2 || h->d.tiles <= (int64_t)2 * 4 * h->cu_count);
-    const unsigned grid = (unsigned)(half ? (h->d.N + 2 * WAVE - 1) / (2 * WAVE) : (h->d.tiles + 3) / 4) + (ride ? 1u : 0u);
+    const unsigned grid = (unsigned)((h->d.tiles + 3) / 4) + (ride ? 1u : 0u);
 #define CALL_ROLLOUT(MODEL, FASTV)                                                                    \
     do {                                                                                              \
         const size_t shmem = sizeof(float) * std::max((size_t)8 * h->d.R + (size_t)h->d.T * ModelT<MODEL, FASTV>::KROW, \
                                                       (size_t)h->d.row + MPPI_MAX_DIM_STATE);         \
         constexpr bool UCV = FASTV != 0;  /* the FAST kernels exist in the u_in_bounds form only (see use_fast) */ \
-        if (half)                                                                                     \
-            hipLaunchKernelGGL((rollout_cost_kernel<MODEL, FASTV, true, UCV, true>), dim3(grid), dim3(BLOCK), shmem, s, \
-                               h->noise, h->mean, h->x0_cur, h->costs, mk, mk_next, h->mean_used, h->x0_used, h->d, h->gen, h->ctx, \
-                               (const float*)h->b1, ride);                                           \
-        else if (gen)                                                                                 \
+        if (gen)                                                                                      \
             hipLaunchKernelGGL((rollout_cost_kernel<MODEL, FASTV, true, UCV>), dim3(grid), dim3(BLOCK), shmem, s, \
                                h->noise, h->mean, h->x0_cur, h->costs, mk, mk_next, h->mean_used, h->x0_used, h->d, h->gen, h->ctx, \
                                (const float*)h->b1, ride);                                           \
@@ -1941,7 +1934,6 @@ int mppi_set_option(mppi_handle_t h, const char* key, int64_t value) {
         h->essps_prev_host.warm = false;
         return MPPI_OK;
     }
-    if (k == "half_waves") { h->half_waves = value < 0 ? 0 : value > 2 ? 2 : (int)value; return MPPI_OK; }
     if (k == "reduce_chains") { h->reduce_chains = value == 2 ? 2 : value == 4 ? 4 : 0; return MPPI_OK; }
     if (k == "fused_solve") { h->fused_mode = value < 0 ? 0 : value > 2 ? 2 : (int)value; return MPPI_OK; }
     if (k == "fused_timeout_us") {  // poll budget of the single-launch solve (default 20 000 us; 100 MHz ticks inside)

@@ -166,12 +166,7 @@ __device__ __forceinline__ void batch1_rollout(const ModelCtx& ctx, const float*
 #ifndef MPPI_ROLLOUT_ATTR
 #define MPPI_ROLLOUT_ATTR  // e.g. __attribute__((amdgpu_waves_per_eu(8))) for occupancy experiments
 #endif
-// HALF (regenerated noise only, round 5): 32 trajectories per wave instead of 64 (lanes 32..63 idle), i.e. TWICE the waves for
-// the same samples.  For problems that put one or two waves on a SIMD (N <= 131 072: C2) the kernel is bound by the dependent
-// latencies of a wave's own two chains, not by issue slots (0.24 of the VALU issue peak at one wave per SIMD): two half-filled
-// waves interleave on the SIMD's idle slots — 1 190 -> 980 cycles per loop iteration from one to two waves per SIMD
-// (profiles/r04_experiments.md), the same samples in 18 % less time.  The host picks it by the wave count.
-template <int MODEL, int FAST, bool GEN, bool UC, bool HALF = false>
+template <int MODEL, int FAST, bool GEN, bool UC>
 __global__ __launch_bounds__(BLOCK) MPPI_ROLLOUT_ATTR void rollout_cost_kernel(const float4* __restrict__ noise,
                                                              const float* __restrict__ mean,
                                                              const float* __restrict__ x0,
@@ -213,18 +208,13 @@ __global__ __launch_bounds__(BLOCK) MPPI_ROLLOUT_ATTR void rollout_cost_kernel(c
     for (int f = threadIdx.x; f < d.T * M::KROW; f += BLOCK) s_ktab[f] = ctx.ref[f];
     __syncthreads();
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    static_assert(!HALF || GEN, "half-filled waves regenerate their noise (the tiles are laid out for 64 lanes)");
-    constexpr int PER_WAVE = HALF ? 32 : 64;  // trajectories per wave
-    const int64_t tile = (int64_t)blockIdx.x * (BLOCK / WAVE) + wid;  // (HALF: index of the half-tile)
+    const int64_t tile = (int64_t)blockIdx.x * (BLOCK / WAVE) + wid;
     // the minimum key is double-buffered: this launch accumulates into `min_key` (reset by the
     // previous launch) and resets the other slot for the next one -> no memset between solves
     if (blockIdx.x == 0 && threadIdx.x == 0) *next_min_key = 0xFFFFFFFFu;
     float total = INFINITY;
-    bool run;  // (the full-wave test is left exactly as it was: the headline kernel's listing does not change)
-    if constexpr (HALF) run = tile * PER_WAVE < d.N && lane < PER_WAVE;
-    else run = tile < d.tiles;
-    if (run) {
-        const int64_t i = tile * PER_WAVE + lane;
+    if (tile < d.tiles) {
+        const int64_t i = tile * 64 + lane;
         const uint64_t gi = (uint64_t)(d.sample_offset + i);
         const bool inherit = (d.sample_offset + i) < d.inherit_count;
         const float4* np = noise + tile * d.R * 64 + lane;

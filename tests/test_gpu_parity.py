@@ -652,35 +652,6 @@ def test_regenerated_noise_equals_materialised_tiles(model, T, N):
         assert torch.equal(x, y)
 
 
-@pytest.mark.parametrize("model,T,N,lam", [("nav2d", 50, 65536, "ESSPS"), ("racing", 50, 5000, 300.0), ("pendulum", 15, 777, 1.0),
-                                          ("cartpole", 64, 33, 1.0), ("mountaincar", 100, 20000, 0.1)])
-def test_half_filled_waves_give_the_same_bits(model, T, N, lam):
-    """Option half_waves: the rollout kernel with 32 trajectories per wave (twice the waves: the default while a SIMD would hold
-    at most two full ones — C2's size) against 64 per wave.  The arithmetic of a trajectory does not depend on its lane: costs,
-    minimum, temperature, actions and states are bit-identical, also at sample counts that are not a multiple of 32."""
-    a_s, a_c = make_solver(model, T, N, lambda_=lam)
-    b_s, b_c = make_solver(model, T, N, lambda_=lam)
-    a_s.set_option("half_waves", 2)
-    b_s.set_option("half_waves", 0)
-    a_s.set_option("fused_solve", 0)  # (the multi-kernel path is where the rollout kernel runs)
-    b_s.set_option("fused_solve", 0)
-    x0 = {"pendulum": [3.0, 0.1], "cartpole": [0.01, 0.0, 0.02, 0.0], "mountaincar": [-0.5, 0.0], "nav2d": [-9.0, -9.0, 0.785]}.get(model)
-    if model == "racing":
-        env = _envs["racing"]
-        x = env.reset().clone()
-        ref, _ = a_c.calc_ref_trajectory(x, env.racing_center_path, 0, T, DL=0.1, lookahead_distance=3, reference_path_interval=0.85)
-        a_c.set_reference(ref)
-        b_c.set_reference(ref)
-    else:
-        x = torch.tensor(x0).cuda()
-    for _ in range(3):
-        a, s = a_s.forward(x)
-        b, sb = b_s.forward(x)
-        assert torch.equal(a_s._costs, b_s._costs) and a_s._last_lambda == b_s._last_lambda
-        assert torch.equal(a, b) and torch.equal(s, sb)
-        x = sb[0, 1].clone()
-
-
 @pytest.mark.parametrize("model,T,N", [("racing", 50, 3000), ("pendulum", 15, 500), ("mountaincar", 100, 300),
                                        ("nav2d", 30, 777), ("cartpole", 64, 256)])
 def test_wavefront_per_trajectory_variant_agrees(model, T, N):
