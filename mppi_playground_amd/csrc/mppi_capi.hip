@@ -1015,15 +1015,19 @@ int mppi_weights_reduce(mppi_handle_t h, float lambda, float* summary_out_dev, v
     const bool gen = h->noise_regen && !h->injected && !h->wide;
     if (!gen && !h->tiles_valid) return fail(h, MPPI_E_STATE, "no noise: call mppi_sample or mppi_inject_noise first");
     const unsigned* mk = h->min_key + h->min_slot;
-#define CALL_REDUCE(GPWV, GENV, WIDEV, CHAINSV)                                                       \
-    hipLaunchKernelGGL((weights_reduce_kernel<GPWV, GENV, WIDEV, CHAINSV>), grid, dim3(BLOCK), 0, s, h->noise, h->mean, h->costs, mk, \
+#define CALL_REDUCE(GPWV, GENV, WIDEV, CHAINSV, REMV)                                                 \
+    hipLaunchKernelGGL((weights_reduce_kernel<GPWV, GENV, WIDEV, CHAINSV, REMV>), grid, dim3(BLOCK), 0, s, h->noise, h->mean, h->costs, mk, \
                        h->partials, h->heads, h->d, h->gen, lambda, lam_dev, (const float*)h->coltab)
     // regenerated noise: four chains per basic block while a SIMD holds one or two reduction waves, two beyond (see the kernel)
     const bool chains4 = h->reduce_chains == 4 || (h->reduce_chains == 0 && blocks * (int64_t)h->nchunks <= 2 * (int64_t)h->cu_count);
-    if (h->wide) CALL_REDUCE(8, false, true, 2);
-    else if (gen && chains4) CALL_REDUCE(8, true, false, 4);
-    else if (gen) CALL_REDUCE(8, true, false, 2);
-    else CALL_REDUCE(8, false, false, 2);
+    const bool rem = (h->d.R % 4) != 0;  // some chunk of the row leaves groups over (chunks hold 32 groups: R % 32 % 4)
+    if (h->wide) CALL_REDUCE(8, false, true, 2, true);
+    else if (gen && chains4 && rem) CALL_REDUCE(8, true, false, 4, true);
+    else if (gen && chains4) CALL_REDUCE(8, true, false, 4, false);
+    else if (gen && rem) CALL_REDUCE(8, true, false, 2, true);
+    else if (gen) CALL_REDUCE(8, true, false, 2, false);
+    else if (rem) CALL_REDUCE(8, false, false, 2, true);
+    else CALL_REDUCE(8, false, false, 2, false);
 #undef CALL_REDUCE
     HIP_TRY(h, hipGetLastError());
     // Fold the published partial rows into the shard summary.  Sharded use needs the summary before the

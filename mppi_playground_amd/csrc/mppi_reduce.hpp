@@ -30,7 +30,10 @@ constexpr int REDUCE_MAX_BLOCKS = 2048;
 // CHAINS: Philox + Box-Muller chains per basic block of the regenerating reduction.  4: a lone wave per SIMD (grids of a few
 // hundred blocks: C2) hides the chains' latencies inside its own instruction stream, 104 VGPRs; 2: 72 VGPRs = seven waves
 // per SIMD, the interleaving comes from the other waves (C3 / C5 sizes).  The host picks by the tile count.
-template <int GPW, bool GEN, bool WIDE = false, int CHAINS = 2>  // GPW: float4 groups per wave and column chunk (8: the host launches ceil(R / 32) chunks)
+// REM: some chunk of the row has groups left over (R % 4 != 0): without them (cart-pole's 16-group rows, ...) the remainder's
+// accumulators and its loop-carried state are compiled out — they cost the 16-group reduction 66 instructions per tile and wave
+// (a second block of accumulator moves at the loop edge): C5 +2 us.
+template <int GPW, bool GEN, bool WIDE = false, int CHAINS = 2, bool REM = true>  // GPW: float4 groups per wave and column chunk (8: the host launches ceil(R / 32) chunks)
 __global__ __launch_bounds__(BLOCK) MPPI_REDUCE_ATTR void weights_reduce_kernel(const float4* __restrict__ noise,
                                                                const float* __restrict__ mean,
                                                                const float* __restrict__ costs,
@@ -170,22 +173,23 @@ __global__ __launch_bounds__(BLOCK) MPPI_REDUCE_ATTR void weights_reduce_kernel(
                     };
                     const auto single = [&](int m) { accumulate(m, noise_group<true>(np, r0 + wid + NW * m, gi, gen, d)); };
                     static_assert(GPW == 8, "the cases below are written for eight groups per wave");
+                    // (independent `if`s, no else branches: every region updates its accumulators in place or not at all —
+                    // nested if / else chains made the compiler add a second block of 28 accumulator moves per tile)
                     if constexpr (CHAINS == 4) {
-                        if (full >= 8) { quad(0); quad(4); }
-                        else if (full >= 4) {
-                            quad(0);
-                            if (full >= 6) { pair(4); if (full >= 7) single(6); }
-                            else if (full >= 5) single(4);
-                        } else {
-                            if (full >= 2) { pair(0); if (full >= 3) single(2); }
-                            else if (full >= 1) single(0);
-                        }
+                        if (full >= 4) quad(0);
+                        if (full >= 8) quad(4);
+                        if (full == 6 || full == 7) pair(4);
+                        if (full == 7) single(6);
+                        if (full == 5) single(4);
+                        if (full == 2 || full == 3) pair(0);
+                        if (full == 3) single(2);
+                        if (full == 1) single(0);
                     } else {
                         (void)quad;
 #pragma unroll
                         for (int m0 = 0; m0 < GPW; m0 += 2) {
                             if (full >= m0 + 2) pair(m0);
-                            else if (full >= m0 + 1) single(m0);
+                            if (full == m0 + 1) single(m0);
                         }
                     }
                 } else {
@@ -194,7 +198,7 @@ __global__ __launch_bounds__(BLOCK) MPPI_REDUCE_ATTR void weights_reduce_kernel(
                         if (m < full) accumulate(m, noise_group<false>(np, r0 + wid + NW * m, gi, gen, d));
                 }
                 // this wave's share of the remainder groups (see `accx` above)
-                const bool mine = rem == 1 ? ((int)tile & 3) == wid : rem == 2 ? ((int)tile & 1) == (wid >> 1) : wid < rem;
+                const bool mine = REM && (rem == 1 ? ((int)tile & 3) == wid : rem == 2 ? ((int)tile & 1) == (wid >> 1) : wid < rem);
                 if (mine) {  // wave-uniform
                     const int g = NW * full + (rem == 1 ? 0 : rem == 2 ? (wid & 1) : wid);
                     accumulate4(accx, g, noise_group<GEN>(np, r0 + g, gi, gen, d));
@@ -230,7 +234,7 @@ __global__ __launch_bounds__(BLOCK) MPPI_REDUCE_ATTR void weights_reduce_kernel(
             const int a = p * RP + lane;
             if (lane < RP && (a >> 2) < full) partials[(int64_t)blockIdx.x * colsp + 4 * (r0 + wid + NW * (a >> 2)) + (a & 3)] = v;
         }
-        if (rem) {
+        if (REM && rem) {
             float x8[RP];
 #pragma unroll
             for (int j = 0; j < RP; ++j) x8[j] = j < 4 ? accx[j & 3] : 0.0f;

@@ -14,7 +14,7 @@ import bench
 import mppi_playground_amd  # noqa: F401
 
 which = sys.argv[1:] or ["c3_dense", "c3_essps", "c5", "c2_essps", "c2"]
-grids = [(512, 0), (512, 2), (512, 4), (768, 2), (1024, 2), (1024, 4), (1536, 2)]
+grids = [(512, 0), (512, 2), (512, 4), (1024, 2)]
 
 
 def solver_of(key):

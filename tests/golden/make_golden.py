@@ -446,7 +446,7 @@ def run_case_full(name, make_solver, x0, K, next_state, before_solve=None, nv_fi
         e64 = eps.astype(np.float64)
         d[f"eps_sum64_{k}"], d[f"eps_sumsq64_{k}"] = np.float64(e64.sum()), np.float64((e64 * e64).sum())
         d[f"eps_head_{k}"], d[f"eps_tail_{k}"] = eps[:2].copy(), eps[-1:].copy()
-        del e64
+        del e64, eps, w, w64, c
         # ---- per-solve bands (the reference's steps 4-8 on prescribed costs; see run_case)
         post = _snapshot(solver)
         lam_used = pre["lam"] if auto == "MPO" else solver._lambda
@@ -483,7 +483,11 @@ def run_case_full(name, make_solver, x0, K, next_state, before_solve=None, nv_fi
               f"band action {fixed[:, 0].max():.2e}", flush=True)
         del stage, terminal, costs
         state = next_state(state, a, s)
-    # ---- closed-loop bands
+    # ---- closed-loop bands (the first solver is released first: at C4 one solver is 30 GB of the reference's buffers)
+    import gc
+
+    del solver, rec, pre, post
+    gc.collect()
     cl = np.zeros((K, len(vsel_closed), 4))
     for j, v in enumerate(vsel_closed):
         solver2, rec2, _ = make_solver()
@@ -506,7 +510,7 @@ def run_case_full(name, make_solver, x0, K, next_state, before_solve=None, nv_fi
                         abs(float(solver2._lambda) - lam_ref) / lam_ref)
             a2, s2 = torch.from_numpy(av), torch.from_numpy(sv)
             st2 = next_state(st2, a2, s2)
-        del solver2, rec2
+        del solver2, rec2, stage2, term2, costs2
         print(f"  {name}: closed-loop probe {j + 1}/{len(vsel_closed)} at {time.time() - t0:.0f} s", flush=True)
     d["band_closed_loop"] = cl
     path = os.path.join(OUT, name + ".npz")
@@ -517,7 +521,7 @@ def run_case_full(name, make_solver, x0, K, next_state, before_solve=None, nv_fi
 def _spread(n):
     """n of the 256 variant indices, every class represented: the four re-summations always, the rest evenly."""
     n = min(n, len(BAND_VARIANTS))
-    special = [N_ULP, N_ULP + 1, N_ULP + 2, N_ULP + 3]
+    special = [N_ULP, N_ULP + 1, N_ULP + 2, N_ULP + 3][:max(n, 1)]
     rest = [v for v in range(len(BAND_VARIANTS)) if v not in special]
     take = max(n - len(special), 0)
     idx = sorted(set(special + [rest[int(i * len(rest) / max(take, 1))] for i in range(take)]))
@@ -705,6 +709,10 @@ def main():
         ctrl_box = {}
 
         def make():
+            import gc
+
+            ctrl_box.clear()  # (the previous controller and its solver go first: at C4 one solver is 30 GB)
+            gc.collect()
             ctrl = racing_example.racing_controller(env, debug=False, device=cpu)
             ctrl.set_cost_map(env._obstacle_map, env._lane_map)
             rec = Recorder(ctrl.cost_function)
@@ -781,7 +789,7 @@ def main():
             # (~35 GB of RSS, minutes per solve: only on request; the probes are few — the regime is C3's arg-min)
             make, before, nxt = racing_parts(50, 1 << 23, 1.0)
             run_case_full("full_c4_racing_T50_N8388608_lambda1", make, env._robot_state.numpy().copy(), 2, nxt,
-                          before_solve=before, nv_fixed=8, nv_closed=2)
+                          before_solve=before, nv_fixed=8, nv_closed=1)
         return
     if PARTIAL:
         print(f"done ({MODE}):", sorted(ROUND2) if ONLY_ROUND2 else "")
