@@ -49,10 +49,7 @@ __global__ __launch_bounds__(BLOCK) MPPI_REDUCE_ATTR void weights_reduce_kernel(
     constexpr int NW = BLOCK / WAVE;
     constexpr int CHG = NW * GPW;  // float4 groups per column chunk
     constexpr int TPW = 8;
-#ifndef MPPI_REDUCE_RP
-#define MPPI_REDUCE_RP 8  // (A/B knob of scripts/build_variant.sh: 8, 16 or 32)
-#endif
-    constexpr int RP = MPPI_REDUCE_RP;  // accumulators combined per pass of the cross-lane sum (round 5: 8, was 32 — 33 KB of LDS for a
+    constexpr int RP = 8;  // accumulators combined per pass of the cross-lane sum (round 5: 8, was 32 — 33 KB of LDS for a
                            // tile used once after the loop held the kernel at three waves per SIMD)
     __shared__ float s_red[NW][RP][WAVE + 1];
     __shared__ float s_e[NW][TPW][WAVE];
@@ -216,19 +213,16 @@ __global__ __launch_bounds__(BLOCK) MPPI_REDUCE_ATTR void weights_reduce_kernel(
     // w is column 4*(r0 + w + NW*m) + j of the row (m < ng / NW); the remainder groups' accumulators are summed over the
     // waves that took them (fixed order) and are columns 4*(r0 + NW*(ng/NW) + group) + j.
     const int colsp = gridDim.y * CHG * 4;
-    const auto lane_sum8 = [&](const float* a8) {  // lanes 0..RP-1 return the sums over the wave of a8[0..RP-1]
+    const auto lane_sum8 = [&](const float* a8) {  // lanes 0..7 return the sums over the wave of a8[0..7]
 #pragma unroll
         for (int j = 0; j < RP; ++j) s_red[wid][j][lane] = a8[j];
         __builtin_amdgcn_wave_barrier();
-        // lane l sums row l % RP over the RP lanes [RP * (l / RP), +RP) (row stride 65 floats: conflict-free); the 64 / RP
-        // segments are added with shuffles
-        const float* rowp = &s_red[wid][lane & (RP - 1)][(lane / RP) * RP];
-        float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f;
-#pragma unroll
-        for (int k = 0; k < RP; k += 4) { v0 += rowp[k]; v1 += rowp[k + 1]; v2 += rowp[k + 2]; v3 += rowp[k + 3]; }
+        const float* rowp = &s_red[wid][lane & (RP - 1)][(lane >> 3) * 8];
+        float v0 = rowp[0] + rowp[1], v1 = rowp[2] + rowp[3], v2 = rowp[4] + rowp[5], v3 = rowp[6] + rowp[7];
         float v = (v0 + v1) + (v2 + v3);
-#pragma unroll
-        for (int m = RP; m < WAVE; m <<= 1) v += __shfl_xor(v, m);
+        v += __shfl_xor(v, 8);
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
         __builtin_amdgcn_wave_barrier();
         return v;
     };
