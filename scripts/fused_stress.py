@@ -20,8 +20,9 @@ t = torch.tensor
 total = 0
 t0 = time.perf_counter()
 for N, T, rule in ((1000, 30, "ESSPS"), (3000, 30, "ESSPS"), (4096, 50, 1.0), (777, 13, "LBPS"), (16384, 20, "ESSPS"), (65, 7, 1.0)):
-    s = MPPI(T, N, 3, 2, nav.dynamics, nav.cost_function, nav.u_min, nav.u_max, t([0.5, 0.5]), rule)
-    ref = MPPI(T, N, 3, 2, nav.dynamics, nav.cost_function, nav.u_min, nav.u_max, t([0.5, 0.5]), rule)
+    kw = dict(lbps_search="device") if rule == "LBPS" else {}  # (the search as kernels: what the single launch runs; the default is Brent)
+    s = MPPI(T, N, 3, 2, nav.dynamics, nav.cost_function, nav.u_min, nav.u_max, t([0.5, 0.5]), rule, **kw)
+    ref = MPPI(T, N, 3, 2, nav.dynamics, nav.cost_function, nav.u_min, nav.u_max, t([0.5, 0.5]), rule, **kw)
     ref.set_option("fused_solve", 0)
     x = nav.reset().clone()
     per = n_solves // 6
