@@ -155,6 +155,74 @@ def run_with_deadline(cmd, env, timeout_s, on_timeout_line):
         return 124
 
 
+def run_child_transport(mode, index, budget_s):
+    """One transport in its OWN process (this rank's child; the children of all ranks rendezvous on a port of their own): the
+    same script with `--exchange <mode>`, i.e. a complete single-transport run that prints its own contract line on rank 0.
+    Returns (exit code, stdout text, seconds); 124 = killed at the budget."""
+    import signal
+
+    env = dict(os.environ)
+    env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 17 * (index + 1))
+    env["MPPI_BENCH_CHILD"] = mode
+    cmd = [sys.executable, os.path.abspath(__file__), *sys.argv[1:], "--exchange", mode]
+    t0 = time.perf_counter()
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, start_new_session=True)
+    try:
+        out, _ = proc.communicate(timeout=budget_s)
+        rc = proc.returncode
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        out, _ = proc.communicate()
+        rc = 124
+    return rc, (out or b"").decode(errors="replace"), time.perf_counter() - t0
+
+
+def orchestrate_transports(args, world, rank, order, run_child=run_child_transport):
+    """`--exchange all` at N > 1 (round 5): every transport runs in a process of its own, one after the other, on every rank.
+    A transport that hangs — in its communicator's set-up, its self-test or a collective — is killed at its budget and costs
+    only itself: the parents (this function, one per rank; they never touch the GPU or a process group) go on to the next
+    transport.  Rank 0 merges the children's lines: the best complete run is the line, all of them are listed under
+    `transports`; no complete run -> a null line with every transport's error.  Returns the exit code."""
+    entries, lines = [], {}
+    for i, mode in enumerate(order):
+        rc, text, secs = run_child(mode, i, args.first_budget_s)
+        found = [ln for ln in text.splitlines() if ln.startswith("{")]
+        line = None
+        if found:
+            try:
+                line = json.loads(found[-1])
+            except ValueError:
+                line = None
+        e = {"exchange": mode, "requested": mode, "isolated_process": True, "exit_code": rc, "seconds": round(secs, 1)}
+        if line is not None and line.get("value"):
+            lines[mode] = line
+            e.update({"exchange": line.get("config", {}).get("exchange_used", mode), "value": line["value"],
+                      "ms_per_step": line["ms_per_step"], "exchange_us": line.get("exchange_us"),
+                      "rccl_ranks": line.get("rccl_ranks"), "strong": line.get("strong"),
+                      "per_rank_stages_ms": (line.get("transports") or [{}])[0].get("per_rank_stages_ms")})
+        else:
+            why = (line or {}).get("error") if line else None
+            e["error"] = why or ("killed at its %.0f s budget" % args.first_budget_s if rc == 124 else
+                                 "exit code %d, no line" % rc if rank == 0 else "exit code %d" % rc)
+            if line is not None and line.get("transports"):
+                e["detail"] = line["transports"]
+        entries.append(e)
+    if rank != 0:
+        return 0
+    if not lines:
+        print_line(json.dumps(null_line(args, world, "no transport completed a run (each ran in its own process)", entries)))
+        return 1
+    best = max(lines, key=lambda m: lines[m]["value"])
+    out = dict(lines[best])
+    out["transports"] = entries
+    out.setdefault("config", {})["exchange_requested"] = "all (one process per transport)"
+    print_line(json.dumps(out))
+    return 0
+
+
 def launch_ranks(args) -> int:
     """`python bench.py --gpus N` without a launcher: re-run this script under torch.distributed.run, one rank per
     GPU of this node, rendezvous on 127.0.0.1; the ranks' output (rank 0's JSON line) passes through.  The launcher gets a
@@ -194,6 +262,9 @@ def main():
                     help="wall-clock guard of the process-group set-up and of the FIRST transport (armed before either starts)")
     ap.add_argument("--launch-timeout-s", type=float, default=1500.0,
                     help="wall-clock limit of the ranks `python bench.py --gpus N` launches itself (below the driver's)")
+    ap.add_argument("--isolate", type=int, default=1,
+                    help="N > 1 with --exchange all: 1 (default) = every transport in a process of its own (a hang costs that "
+                         "transport only), 0 = all transports in this process under the watchdog")
     ap.add_argument("--preflight", action="store_true",
                     help="N > 1: process-group set-up, every transport's own self-test and ONE sharded solve per transport on a "
                          "small problem, under the watchdog; prints one JSON line of statuses (< 60 s) instead of the bench line")
@@ -220,6 +291,9 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))
     own_stdout()
+    if (args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) == args.gpus and args.exchange == "all" and args.isolate
+            and not args.preflight and args.workload == "c3"):
+        sys.exit(orchestrate_transports(args, args.gpus, int(os.environ.get("RANK", "0")), ["rccl", "nccl", "p2p"]))
 
     import numpy as np
     import torch
@@ -448,7 +522,7 @@ def main():
                        "exchange": {"p2p": "peer-to-peer buffers (xGMI stores, polled)",
                                     "rccl": "ncclAllGather of 4+T*dc floats issued by the library on the solve's stream",
                                     "nccl": "torch.distributed all_gather of 4+T*dc floats", "none": "none"}[used],
-                       "exchange_requested": args.exchange if world > 1 else None,
+                       "exchange_used": used, "exchange_requested": args.exchange if world > 1 else None,
                        "backend": backend, "ranks_share_one_device": one_device and world > 1},
             "solves_per_sec": solves_per_s,
             # the kernel is VALU-issue bound (valu_roofline), not HBM bound: `achieved`/`frac` price its ALGORITHMIC

@@ -427,6 +427,44 @@ def test_bench_watchdog_reports_when_a_transport_blocks_forever(hang_at):
         assert line["transports"][-1]["exchange"] == "transport nccl"
 
 
+def test_bench_runs_every_transport_in_its_own_process(monkeypatch, capsys):
+    """`bench.py --gpus N --exchange all` (the default): one child process per transport on every rank (orchestrate_transports).
+    With a transport that is killed at its budget and one that reports an error, rank 0 still prints the best complete run with
+    all three listed; with none complete it prints a null line and exits 1; other ranks print nothing."""
+    import argparse
+    import importlib
+    import json
+
+    bench = importlib.import_module("bench")
+    args = argparse.Namespace(steps=20, warmup=5, samples=1 << 20, horizon=50, first_budget_s=300.0)
+    printed = []
+    monkeypatch.setattr(bench, "print_line", printed.append)
+
+    def line(mode, value):
+        return json.dumps({"metric": "sample_steps_per_sec", "value": value, "ms_per_step": 0.14, "n_gpus": 8,
+                           "config": {"exchange_used": mode}, "exchange_us": 3.0, "rccl_ranks": None, "strong": {"value": 1.0},
+                           "transports": [{"per_rank_stages_ms": []}]})
+
+    def run_child(mode, index, budget_s):
+        assert budget_s == 300.0
+        if mode == "rccl":
+            return 0, "chatter\n" + line("rccl", 10.0) + "\n", 12.0
+        if mode == "nccl":
+            return 124, "", 300.0                                       # hung: killed at the budget
+        return 1, json.dumps(bench.null_line(args, 8, "MPPI_EXCHANGE=p2p: not usable here")) + "\n", 3.0
+
+    assert bench.orchestrate_transports(args, 8, 0, ["rccl", "nccl", "p2p"], run_child=run_child) == 0
+    out = json.loads(printed[-1])
+    assert out["value"] == 10.0 and out["config"]["exchange_used"] == "rccl" and len(out["transports"]) == 3
+    assert out["transports"][1]["exit_code"] == 124 and "killed at its 300 s budget" in out["transports"][1]["error"]
+    assert "not usable" in out["transports"][2]["error"] and out["transports"][0]["isolated_process"] is True
+    printed.clear()
+    assert bench.orchestrate_transports(args, 8, 3, ["rccl", "nccl", "p2p"], run_child=run_child) == 0 and printed == []
+    assert bench.orchestrate_transports(args, 8, 0, ["nccl", "p2p"], run_child=run_child) == 1
+    out = json.loads(printed[-1])
+    assert out["value"] is None and out["n_gpus"] == 8 and len(out["transports"]) == 2
+
+
 def test_lbps_grid_search_finds_the_brent_minimum_on_random_costs():
     """The grid variant of the LBPS search against scipy's bounded Brent minimiser (the reference's call) on a float64
     evaluation of the objective, over cost vectors of different shapes; where Brent stops in a local minimum the grid may
