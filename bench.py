@@ -155,7 +155,7 @@ def run_with_deadline(cmd, env, timeout_s, on_timeout_line):
         return 124
 
 
-def run_child_transport(mode, index, budget_s):
+def run_child_transport(mode, index, budget_s, script=None):
     """One transport in its OWN process (this rank's child; the children of all ranks rendezvous on a port of their own): the
     same script with `--exchange <mode>`, i.e. a complete single-transport run that prints its own contract line on rank 0.
     Returns (exit code, stdout text, seconds); 124 = killed at the budget."""
@@ -164,7 +164,11 @@ def run_child_transport(mode, index, budget_s):
     env = dict(os.environ)
     env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 17 * (index + 1))
     env["MPPI_BENCH_CHILD"] = mode
-    cmd = [sys.executable, os.path.abspath(__file__), *sys.argv[1:], "--exchange", mode]
+    # a launcher's TORCHELASTIC_USE_AGENT_STORE makes env:// rendezvous a CLIENT of the launcher's store on the original port:
+    # the children host their own store on the shifted port (rank 0), so the launcher's variables must not reach them
+    for k in [k for k in env if k.startswith("TORCHELASTIC_")]:
+        env.pop(k)
+    cmd = [sys.executable, script or os.path.abspath(__file__), *sys.argv[1:], "--exchange", mode]
     t0 = time.perf_counter()
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, start_new_session=True)
     try:

@@ -11,7 +11,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from helpers import CASES, load, oracle_problem, orc, rel_err
+from helpers import CASES, ROOT, load, oracle_problem, orc, rel_err
 
 
 def _free_port():
@@ -81,3 +81,45 @@ def test_shard_range():
         assert max(c for _, c in blocks) - min(c for _, c in blocks) <= 1
     with pytest.raises(ValueError):
         shard_range(3, 4, 0)
+
+
+def test_bench_transport_children_rendezvous_under_a_launcher(tmp_path):
+    """bench.py's per-transport process isolation, end to end on the CPU: two ranks under torch.distributed.run, every rank's
+    parent spawns one child per transport (bench.run_child_transport: shifted MASTER_PORT, the launcher's TORCHELASTIC_*
+    variables removed — with them the children would wait for a store that does not exist), the children of a transport form
+    their own gloo process group; transport "b" hangs on one rank and is killed at its budget on both, "c" runs after it.  Rank 0
+    prints ONE merged line."""
+    import json
+    import subprocess
+    import sys
+
+    child = tmp_path / "child.py"
+    child.write_text(
+        "import json, os, sys, time\n"
+        "import torch.distributed as dist\n"
+        "mode = sys.argv[sys.argv.index('--exchange') + 1]\n"
+        "dist.init_process_group('gloo')\n"
+        "if mode == 'b' and dist.get_rank() == 1:\n"
+        "    time.sleep(600)\n"                      # a rank that never arrives: the other one blocks in the barrier
+        "dist.barrier()\n"
+        "if dist.get_rank() == 0:\n"
+        "    print(json.dumps({'value': {'a': 5.0, 'c': 7.0}.get(mode), 'ms_per_step': 1.0, 'config': {'exchange_used': mode}}), flush=True)\n"
+        "dist.destroy_process_group()\n")
+    driver = tmp_path / "driver.py"
+    driver.write_text(
+        "import argparse, os, sys\n"
+        f"sys.path.insert(0, {str(ROOT)!r})\n"
+        "import bench\n"
+        "bench.own_stdout()\n"
+        "args = argparse.Namespace(steps=20, warmup=5, samples=1 << 20, horizon=50, first_budget_s=12.0)\n"
+        f"run = lambda mode, i, b: bench.run_child_transport(mode, i, b, script={str(child)!r})\n"
+        "sys.exit(bench.orchestrate_transports(args, 2, int(os.environ['RANK']), ['a', 'b', 'c'], run_child=run))\n")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29733", str(driver)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["value"] == 7.0 and d["config"]["exchange_used"] == "c"
+    t = {e["requested"]: e for e in d["transports"]}
+    assert t["a"]["value"] == 5.0 and t["b"]["exit_code"] == 124 and "killed" in t["b"]["error"] and t["c"]["value"] == 7.0
