@@ -209,6 +209,9 @@ def orchestrate_transports(args, world, rank, order, run_child=run_child_transpo
                       "per_rank_stages_ms": (line.get("transports") or [{}])[0].get("per_rank_stages_ms")})
         else:
             why = (line or {}).get("error") if line else None
+            inner = [t.get("error") for t in (line or {}).get("transports") or [] if t.get("error")]
+            if inner:  # (the child's own transport error says more than its "no transport completed")
+                why = inner[0]
             e["error"] = why or ("killed at its %.0f s budget" % args.first_budget_s if rc == 124 else
                                  "exit code %d, no line" % rc if rank == 0 else "exit code %d" % rc)
             if line is not None and line.get("transports"):
