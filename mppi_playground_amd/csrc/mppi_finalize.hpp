@@ -146,6 +146,61 @@ __device__ __forceinline__ bool rollout_states(const float* __restrict__ x0, int
     for (int j = 0; j < DS; ++j) out[T * DS + j] = s[j];
     return bad;
 }
+// The same rollout driven by a sample's NOISE, software-pipelined like the rollout kernel (round 5): LOADG(g) returns float4 group
+// g of the sample's noise row (regenerated or read from the tiles — the caller picks, no branch in here); the group of the NEXT
+// 4 / DC steps is requested at the top of the loop body and the current group's steps follow in the SAME basic block, so that a
+// lone wave overlaps the Philox + Box-Muller chain with the state recurrence (with the action fetched step by step behind an
+// "is this a new group?" branch the two chains ran one after the other: 0.36 us per step in get_top_samples' re-roll).
+// `mp`: the mean row as float4 groups in LDS (zeros past the row; an all-zero copy for samples beyond the exploration split,
+// mppi.py:266-270).  u = clamp(mean + eps) exactly as rollout_cost_kernel forms it; same step functions, same order: the same
+// bits as rollout_states with a per-step GETU.
+template <int MODEL, int FAST, class LOADG>
+__device__ __forceinline__ bool rollout_states_noise(const float* __restrict__ x0, const Dims& d, const ModelCtx& ctx,
+                                                     float* __restrict__ out, const float4* mp, LOADG loadg) {
+    using M = ModelT<MODEL, FAST>;
+    constexpr int DS = M::DS, DC = M::DC, SPG = 4 / DC;  // steps per float4 group
+    static_assert(DC == 1 || DC == 2 || DC == 4, "a step's controls lie inside one float4 group");
+    const int T = d.T;
+    bool bad = false;
+    float s[DS];
+#pragma unroll
+    for (int j = 0; j < DS; ++j) s[j] = x0[j];
+    constexpr bool GENERAL = FAST != 0 && EntryGeneral<M>::value;
+    float raw_heading = 0.0f;
+    if constexpr (GENERAL) { raw_heading = s[2]; M::enter_any(s); }
+    else if (FAST) M::check_state(ctx, s, bad);
+    const auto step = [&](int t, const float4& e, const float4& m, int j) {
+        const float e4[4] = {e.x, e.y, e.z, e.w}, m4[4] = {m.x, m.y, m.z, m.w};
+        float u[DC], sn[DS], ss[DS];
+#pragma unroll
+        for (int kk = 0; kk < DC; ++kk) u[kk] = clampf(m4[j * DC + kk] + e4[j * DC + kk], d.u_min[kk], d.u_max[kk]);
+        if constexpr (GENERAL) {
+            M::step(ctx, s, u, sn, ss, bad, false, true);
+            if (t == 0) ss[2] = raw_heading;
+        } else {
+            M::step(ctx, s, u, sn, ss, bad);
+        }
+#pragma unroll
+        for (int j2 = 0; j2 < DS; ++j2) { out[t * DS + j2] = ss[j2]; s[j2] = sn[j2]; }
+    };
+    float4 nxt = loadg(0);
+    const int gfull = T / SPG;  // groups whose SPG steps all exist
+    for (int g = 0; g < gfull; ++g) {
+        const float4 cur = nxt;
+        nxt = loadg(g + 1 < d.R ? g + 1 : g);  // (the last request repeats a group: nobody reads it)
+        const float4 m = mp[g];
+#pragma unroll
+        for (int j = 0; j < SPG; ++j) step(g * SPG + j, cur, m, j);
+    }
+    if (gfull * SPG < T) {  // the row's last, partial group
+        const float4 m = mp[gfull];
+        for (int j = 0; gfull * SPG + j < T; ++j) step(gfull * SPG + j, nxt, m, j);
+    }
+    if constexpr (GENERAL) { if (T == 0) s[2] = raw_heading; }
+#pragma unroll
+    for (int j = 0; j < DS; ++j) out[T * DS + j] = s[j];
+    return bad;
+}
 template <int MODEL, int FAST, class GETU>
 __device__ __forceinline__ void rollout_states_checked(const float* __restrict__ x0, int T, const ModelCtx& ctx,
                                                        float* __restrict__ out, GETU getu) {

@@ -222,8 +222,16 @@ __global__ __launch_bounds__(TOPK_MAX) void topk_rollout_kernel(const unsigned l
                                                                 unsigned* __restrict__ hist,
                                                                 unsigned* __restrict__ counters, Dims d, GenCtx gen,
                                                                 ModelCtx ctx) {
-    constexpr int DS = ModelT<MODEL, FAST>::DS, DC = ModelT<MODEL, FAST>::DC;
+    constexpr int DS = ModelT<MODEL, FAST>::DS;
     __shared__ unsigned long long s_key[SORTED ? 1 : TOPK_MAX];
+    // [4R] the mean row the solve sampled around (zeros past the row), [4R] zeros (samples beyond the exploration split): the
+    // re-roll reads its mean groups from here (rollout_states_noise)
+    extern __shared__ __attribute__((aligned(16))) float s_mrow[];
+    for (int f = threadIdx.x; f < 4 * d.R; f += blockDim.x) {
+        s_mrow[f] = f < d.row ? mean[f] : 0.0f;
+        s_mrow[4 * d.R + f] = 0.0f;
+    }
+    __syncthreads();
     if (hist && blockIdx.x == 0) {  // leave the select state clean for the next call
         for (int b = threadIdx.x; b < 3 * TOPK_BINS; b += blockDim.x) hist[b] = 0u;
         if (threadIdx.x < 2) counters[threadIdx.x] = 0u;
@@ -322,23 +330,15 @@ __global__ __launch_bounds__(TOPK_MAX) void topk_rollout_kernel(const unsigned l
     const int64_t i = (int64_t)gi - d.sample_offset;  // local index: only meaningful when the tiles are read
     const float4* np = noise + ((i >> 6) * d.R) * 64 + (i & 63);
     float* out = states + (int64_t)q * (d.T + 1) * DS;
-    int have = -1;
-    float grp[4] = {0.f, 0.f, 0.f, 0.f};
-    rollout_states_checked<MODEL, FAST>(x0, d.T, ctx, out, [&](int t, float* u) {
-#pragma unroll
-        for (int kk = 0; kk < DC; ++kk) {
-            const int f = t * DC + kk;
-            if ((f >> 2) != have) {
-                have = f >> 2;
-                const float4 n4 = gen_noise ? gen_noise4(gi, have, gen, d) : np[(int64_t)have * 64];
-                grp[0] = n4.x; grp[1] = n4.y; grp[2] = n4.z; grp[3] = n4.w;
-            }
-            const float m = inherit ? mean[f] : 0.0f;
-            const int c4 = f & 3;
-            const float e = c4 == 0 ? grp[0] : c4 == 1 ? grp[1] : c4 == 2 ? grp[2] : grp[3];
-            u[kk] = clampf(m + e, d.u_min[kk], d.u_max[kk]);
+    const float4* mp = reinterpret_cast<const float4*>(s_mrow) + (inherit ? 0 : d.R);
+    const auto roll = [&](auto loadg) {
+        const bool bad = rollout_states_noise<MODEL, FAST>(x0, d, ctx, out, mp, loadg);
+        if constexpr (FAST != 0 && !EntryGeneral<ModelT<MODEL, FAST>>::value) {  // (a lane that left a fast path: the library-math walk)
+            if (bad) (void)rollout_states_noise<MODEL, 0>(x0, d, ctx, out, mp, loadg);
         }
-    });
+    };
+    if (gen_noise) roll([&](int g) { return gen_noise4(gi, g, gen, d); });
+    else roll([&](int g) { return np[(int64_t)g * 64]; });
 }
 
 // Ascending sort of P = 2^m >= 2048 candidate words in global memory (k > TOPK_MAX; the tail past k holds ~0).  Bitonic:
