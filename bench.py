@@ -797,18 +797,22 @@ def example_loop(torch):
     ctrl.set_cost_map(env._obstacle_map, env._lane_map)
     state = env.reset()
     ticks, warm = 200, 20
-    for tick in range(warm + ticks):
-        if tick == warm:
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-        a, s = ctrl.update(state, env.racing_center_path)
-        state, _ = env.step(a[0, :])
-        env.collision_check(state=s)
-        ctrl.get_top_samples(num_samples=300)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    runs = []
+    for rep in range(3):  # (min of three 200-tick loops: one loop is 12 ms of wall clock, a single host hiccup is 10 % of it)
+        for tick in range((warm if rep == 0 else 0) + ticks):
+            if tick == (warm if rep == 0 else 0):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            a, s = ctrl.update(state, env.racing_center_path)
+            state, _ = env.step(a[0, :])
+            env.collision_check(state=s)
+            ctrl.get_top_samples(num_samples=300)
+        torch.cuda.synchronize()
+        runs.append(time.perf_counter() - t0)
+    dt = min(runs)
     return {"config": "racing T=25 N=4000 lambda=1 (the reference example's own size): update + env.step + collision_check + "
-                      "get_top_samples(300) per tick", "ticks": ticks, "ms_per_tick": dt / ticks * 1e3, "ticks_per_sec": ticks / dt}
+                      "get_top_samples(300) per tick", "ticks": ticks, "ms_per_tick": dt / ticks * 1e3, "ticks_per_sec": ticks / dt,
+            "timing": "min of three 200-tick loops", "ms_per_tick_all": [r / ticks * 1e3 for r in runs]}
 
 
 def _time_solver(torch, solver, x0, n=50, warm=10, repeats=3):
