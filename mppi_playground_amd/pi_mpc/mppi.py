@@ -366,7 +366,8 @@ class MPPI(ExchangeMixin, GenericPathMixin, QueriesMixin, nn.Module):
     def _bind_log_temperature(self) -> None:
         """`log_temperature` of the reference (an nn.Parameter, mppi.py:194-199) as a registered Parameter whose storage IS
         the dual the library steps on the device (zero-copy view through __cuda_array_interface__): always current on the
-        solve's stream, listed by parameters() / state_dict(), never copied.  Read-only in effect — the library derives the
+        solve's stream, listed by parameters() / state_dict(), never copied (valid while this solver is alive: the memory belongs to
+        its handle; `state_dict()` values should be cloned by callers that outlive it).  Read-only in effect — the library derives the
         temperatures it uses when the dual steps; assigning `_lambda` is how a caller overrides a solve's temperature."""
         ptr = C.c_void_p(0)
         self._h.call("mppi_mpo_log_temperature_ptr", C.byref(ptr))

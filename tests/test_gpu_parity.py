@@ -1514,6 +1514,31 @@ def test_info_dict_and_log_temperature_like_the_reference():
     assert lam2 != lam and abs(float(torch.exp(m.log_temperature)) - lam2) <= 1e-6 * lam2
 
 
+def test_log_temperature_follows_load_state_dict_and_module_conversions():
+    """`log_temperature` (MPO, mppi.py:194-199) is a Parameter whose storage IS the library's dual.  load_state_dict() writes
+    into it: the library restarts the dual from the loaded value (temperature of the next solve = exp(loaded), Adam moments
+    zero) instead of keeping a stale derived temperature; module.to() / .float() would replace the Parameter by a detached
+    copy: it is re-bound to the dual afterwards."""
+    a, _ = make_solver("pendulum", 15, 1000, lambda_="MPO")
+    b, _ = make_solver("pendulum", 15, 1000, lambda_="MPO")
+    x = torch.tensor([3.0, 0.0])
+    for _ in range(4):
+        a.forward(x)
+    sd = {k: v.clone() for k, v in a.state_dict().items()}
+    assert "log_temperature" in sd and abs(float(np.exp(float(sd["log_temperature"][0]))) - a._lambda) <= 1e-6 * a._lambda
+    b.load_state_dict(sd)
+    assert abs(b._lambda - a._lambda) <= 1e-6 * a._lambda            # the dual was restarted from the loaded value ...
+    b.forward(x)
+    assert abs(b._last_lambda - a._lambda) <= 1e-6 * a._lambda       # ... and the next solve's weights use exp(loaded)
+    ptr = b.log_temperature.data_ptr()
+    b.float()
+    b.to(torch.device("cuda"))
+    assert b.log_temperature.data_ptr() == ptr                       # still the library's dual, not a detached copy
+    lam_before = b._lambda
+    b.forward(x)
+    assert abs(float(np.exp(float(b.log_temperature.detach().cpu()[0]))) - b._lambda) <= 1e-6 * b._lambda and b._lambda != lam_before
+
+
 def test_device_sg_filter_equals_the_host_statement():
     """Step 7 inside finalize_kernel (sg_filter="device", default) against the host numpy statement of the reference's
     filter (sg_filter="host"): same taps, same accumulation order -> identical actions, states and history, over a
