@@ -201,21 +201,47 @@ __device__ __forceinline__ void block_bitonic_1024(unsigned long long (&v)[NV], 
         }
     }
 }
-// Ascending sort of the n <= 1024 DISTINCT words a block holds (thread t < n: word w) by rank (round 5): every thread counts
-// the words below its own — n broadcast reads of LDS, no barrier inside the loop — and stores its word at that position.
-// Returns the t-th smallest word (~0 for t >= n); the sorted words are left in s_x.  For the k = 300 candidates of the
-// examples' get_top_samples this is 0.9 us against 8.8 us for the 55-stage bitonic network over 1024 padded words (measured
-// with phase stamps in the kernel: load 1.8, radix select 3.6, compaction 0.8, sort 8.8, re-roll 4.9 us).
+// Ascending sort of the n <= 1024 DISTINCT words a block of 1024 threads holds (thread t < n: word w) — round 5, replaces the
+// 55-stage bitonic network over 1024 padded words (10 of its stages through LDS behind 1024-thread barriers: 8.8 us of the
+// examples' 20 us get_top_samples kernel, measured with phase stamps: load 1.8, radix select 3.6, compaction 0.8, sort 8.8,
+// re-roll 4.9 us).  Merge by rank: every wave sorts its own 64 words with shuffles (21 compare-exchange stages, no barrier),
+// leaves the run in LDS, and every thread then finds how many words of each OTHER run lie below its own by a branch-free
+// binary search (7 LDS reads per run, the runs independent of each other): its rank is its position in its run plus those
+// counts, and it stores its word there.  Two barriers in all; only the ceil(n / 64) runs that hold words are searched.
+// Returns the t-th smallest word (~0 for t >= n); the sorted words are left in s_x[0 .. n).
 __device__ __forceinline__ unsigned long long block_rank_sort_1024(unsigned long long w, int n, unsigned long long* s_x, int tid) {
-    s_x[tid] = tid < n ? w : ~0ull;
+    const int lane = tid & 63;
+    if (tid >= n) w = ~0ull;
+    // (1) the wave's 64 words ascending (bitonic over the lanes)
+#pragma unroll
+    for (int size = 2; size <= WAVE; size <<= 1) {
+        const bool up = (lane & size) == 0 || size == WAVE;
+#pragma unroll
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            const unsigned long long o = shfl_xor_u64(w, stride);
+            const bool keep_min = ((lane & stride) == 0) == up;
+            w = keep_min ? (w < o ? w : o) : (w > o ? w : o);
+        }
+    }
+    s_x[tid] = w;
     __syncthreads();
-    int rank = 0;
-    if (tid < n) {
-#pragma unroll 8
-        for (int j = 0; j < n; ++j) rank += s_x[j] < w ? 1 : 0;
+    // (2) rank = position in the own run + the number of smaller words in every other run
+    const int nruns = (n + WAVE - 1) / WAVE, my = tid >> 6;
+    int rank = lane;  // (its smaller words of the own run sit in the lanes below)
+    if (w != ~0ull) {
+        for (int r = 0; r < nruns; ++r) {
+            if (r == my) continue;  // (wave-uniform)
+            const unsigned long long* run = s_x + r * WAVE;
+            int pos = 0;
+#pragma unroll
+            for (int step = 32; step >= 1; step >>= 1) pos += run[pos + step - 1] < w ? step : 0;
+            pos += run[pos] < w ? 1 : 0;  // (pos = 63 here when all of the first 63 are smaller)
+            rank += pos;
+        }
     }
     __syncthreads();
-    if (tid < n) s_x[rank] = w;
+    if (w != ~0ull) s_x[rank] = w;
+    else if (tid >= n) s_x[tid] = ~0ull;
     __syncthreads();
     return s_x[tid];
 }
