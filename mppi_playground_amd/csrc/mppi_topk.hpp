@@ -303,6 +303,57 @@ __global__ __launch_bounds__(TOPK_MAX) void topk_rollout_kernel(const unsigned l
             __shared__ unsigned s_hist[TOPK_BINS];
             __shared__ unsigned s_scan[TOPK_MAX + 2];
             __shared__ unsigned s_cnt[2];
+            __shared__ float s_mm[2][TOPK_MAX / WAVE];
+            // (a) ONE pass over bins of the cost VALUE (round 5): 2048 equal bins over [min, max] of the block's costs — the
+            // top 11 BITS of the keys of one solve fall into a handful of bins (costs of 77 k .. 110 k share their exponent), so
+            // the bitwise select below needs all three passes; a monotone value bin puts ~2 of 4096 keys in the bin of the
+            // k-th smallest.  Every key in a lower bin is smaller than every key of that bin, so {keys in bins <= b*} is a
+            // superset of the k smallest: when it fits one row it is sorted by rank and the first k are the answer (exact).
+            // Costs that are all equal, infinite or NaN, or a crowded boundary bin, take the bitwise passes (b).
+            bool done = false;
+            {
+                float cmn = INFINITY, cmx = -INFINITY, cf[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool valid = r * TOPK_MAX + tid < n_direct;
+                    cf[r] = valid ? key_to_float((unsigned)(v[r] >> 32)) : 0.0f;
+                    if (valid) { cmn = fminf(cmn, cf[r]); cmx = fmaxf(cmx, cf[r]); }
+                }
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1) { cmn = fminf(cmn, __shfl_xor(cmn, m)); cmx = fmaxf(cmx, __shfl_xor(cmx, m)); }
+                if ((tid & 63) == 0) { s_mm[0][tid >> 6] = cmn; s_mm[1][tid >> 6] = cmx; }
+                for (int b = tid; b < TOPK_BINS; b += TOPK_MAX) s_hist[b] = 0u;
+                if (tid < 2) s_cnt[tid] = 0u;
+                __syncthreads();
+#pragma unroll
+                for (int w = 0; w < TOPK_MAX / WAVE; ++w) { cmn = fminf(cmn, s_mm[0][w]); cmx = fmaxf(cmx, s_mm[1][w]); }
+                const float scale = (float)(TOPK_BINS - 1) / (cmx - cmn);
+                const bool usable = cmx > cmn && cmx < INFINITY && cmn > -INFINITY && scale < INFINITY;  // (block-uniform)
+                if (usable) {
+                    int vb[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        vb[r] = (int)fminf((cf[r] - cmn) * scale, (float)(TOPK_BINS - 1));  // monotone in the cost
+                        if (r * TOPK_MAX + tid < n_direct) atomicAdd(&s_hist[vb[r]], 1u);
+                    }
+                    __syncthreads();
+                    unsigned bstar, below;
+                    topk_pick<TOPK_MAX>(s_hist, TOPK_BINS, (unsigned)k, s_scan, bstar, below);
+                    const unsigned total = below + s_hist[bstar];  // keys in bins <= b*  (>= k)
+                    if (total <= (unsigned)TOPK_MAX) {             // (block-uniform)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (r * TOPK_MAX + tid < n_direct && vb[r] <= (int)bstar) s_key[atomicAdd(&s_cnt[0], 1u)] = v[r];
+                        __syncthreads();
+                        const unsigned long long wk = tid < (int)total ? s_key[tid] : ~0ull;
+                        __syncthreads();
+                        v[0] = block_rank_sort_1024(wk, (int)total, s_key, tid);  // the k smallest are its first k
+                        done = true;
+                    }
+                }
+            }
+            if (!done) {
+            // (b) bitwise radix select
             unsigned prefix = 0u, krem = (unsigned)k;
 #pragma unroll
             for (int pass = 0; pass < 3; ++pass) {
@@ -351,6 +402,7 @@ __global__ __launch_bounds__(TOPK_MAX) void topk_rollout_kernel(const unsigned l
             const unsigned long long wk = tid < k ? s_key[tid] : ~0ull;
             __syncthreads();
             v[0] = block_rank_sort_1024(wk, k, s_key, tid);
+            }
         }
         // Every block of the grid has sorted the same words; block b re-rolls candidates 64 b .. 64 b + 63 with ONE wave.
         // (The re-roll is a serial chain of T steps per lane, ~12 us for a lone wave; k = 300 candidates in the first five
