@@ -1,0 +1,42 @@
+"""Output tensors of per-tick calls: rows of one allocation, handed out one by one (host-side plumbing, no arithmetic).
+
+The reference's example loops at their own sizes (racing: T = 25, N = 4000; example/racing.py:221-266) are bound by the HOST
+once every call of the tick is one launch: seven `torch.empty` per tick at ~1.3 us each (scripts/example_tick_host.py,
+profiles/r05_experiments.md).  A RowPool allocates a block of rows at once and splits it with ONE `unbind` (~0.2 us per row).
+Every row is handed out exactly once — a fresh tensor like torch.empty's: nobody else holds it, contents undefined,
+contiguous, 256-byte aligned — and a block goes back to torch's caching allocator when the last of its rows is dropped.
+The visible difference to torch.empty: a row is a view of its block (`torch.save` of one writes the block; `.clone()` first)."""
+from __future__ import annotations
+
+import math
+
+import torch
+
+_ALIGN = 256  # bytes between rows (vector stores of the kernels need 16)
+
+
+class RowPool:
+    __slots__ = ("_shape", "_device", "_dtype", "_pitch", "_per_block", "_strides", "_rows", "_stream")
+
+    def __init__(self, shape, device, dtype, block_bytes: int = 1 << 20, max_rows: int = 256):
+        self._shape, self._device, self._dtype = tuple(int(v) for v in shape), device, dtype
+        item = torch.empty((), dtype=dtype).element_size()
+        numel = math.prod(self._shape)
+        self._pitch = max(1, -(-(numel * item) // _ALIGN)) * _ALIGN // item  # elements from row to row
+        self._per_block = max(1, min(max_rows, block_bytes // (self._pitch * item)))
+        strides, acc = [], 1
+        for s in reversed(self._shape):
+            strides.append(acc)
+            acc *= s
+        self._strides = tuple(reversed(strides))
+        self._rows, self._stream = [], None
+
+    def take(self, stream: int) -> torch.Tensor:
+        """A fresh row for work on raw stream `stream` of the pool's device (the block was allocated under torch's current
+        stream, like a torch.empty at this point would be: a change of stream starts a new block)."""
+        if not self._rows or stream != self._stream:
+            n = self._per_block
+            block = torch.empty(n * self._pitch, device=self._device, dtype=self._dtype)
+            self._rows = list(block.as_strided((n, *self._shape), (self._pitch, *self._strides)).unbind(0))
+            self._stream = stream
+        return self._rows.pop()

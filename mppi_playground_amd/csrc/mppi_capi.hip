@@ -1732,7 +1732,7 @@ static int topk_rollout(mppi_handle_t h, const unsigned long long* cand, int k, 
     unsigned* counters = clean ? h->topk_hist + 3 * TOPK_BINS : nullptr;
     if (k <= TOPK_MAX) {
 #define CALL_TOPK(MODEL, FASTV)                                                                       \
-    hipLaunchKernelGGL((topk_rollout_kernel<MODEL, FASTV, false>), dim3((unsigned)((k + WAVE - 1) / WAVE)), dim3(TOPK_MAX), sizeof(float) * 8 * h->d.R, s, cand, k, \
+    hipLaunchKernelGGL((topk_rollout_kernel<MODEL, FASTV, false>), dim3((unsigned)((k + WAVE - 1) / WAVE)), dim3(TOPK_MAX), topk_rollout_lds(h->d.R, false, gen), s, cand, k, \
                        direct ? (const float*)h->costs : (const float*)nullptr, direct ? (int)h->d.N : 0, h->noise, gen,  \
                        h->mean_used, h->x0_used, h->solve_stats, lambda, states_out, weights_out, hist, counters,  \
                        h->d, h->gen, h->ctx)
@@ -1742,7 +1742,7 @@ static int topk_rollout(mppi_handle_t h, const unsigned long long* cand, int k, 
         if (int rc = topk_sort_large(h, k, s)) return rc;
         const unsigned grid = (unsigned)((k + WAVE - 1) / WAVE);
 #define CALL_TOPK_SORTED(MODEL, FASTV)                                                                \
-    hipLaunchKernelGGL((topk_rollout_kernel<MODEL, FASTV, true>), dim3(grid), dim3(WAVE), sizeof(float) * 8 * h->d.R, s, (const unsigned long long*)h->topk_cand, \
+    hipLaunchKernelGGL((topk_rollout_kernel<MODEL, FASTV, true>), dim3(grid), dim3(WAVE), topk_rollout_lds(h->d.R, true, gen), s, (const unsigned long long*)h->topk_cand, \
                        k, (const float*)nullptr, 0, h->noise, gen, h->mean_used, h->x0_used, h->solve_stats, lambda, states_out,  \
                        weights_out, hist, counters, h->d, h->gen, h->ctx)
         MPPI_DISPATCH(h, CALL_TOPK_SORTED);

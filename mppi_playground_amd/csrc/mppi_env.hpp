@@ -46,6 +46,10 @@ __global__ __launch_bounds__(REFWIN_BLOCK) void ref_window_kernel(RefWindowCtx w
                                                                   float* __restrict__ ref_out /*[rows][8]*/) {
     __shared__ unsigned long long s_best[REFWIN_BLOCK / WAVE];
     __shared__ int s_ind;
+    // everything that does not depend on the search is requested before it (the carried index, this thread's window
+    // offset, the last offset): the kernel is a chain of memory round trips, two instead of four this way
+    const int cind0 = *w.cind;
+    const int dmine = (int)threadIdx.x < w.rows ? w.dind[threadIdx.x] : 0, dlast = w.dind[w.rows - 1];
     const float sx = state[0], sy = state[1];
     unsigned long long best = ~0ull;
     for (int i = threadIdx.x; i < w.n; i += REFWIN_BLOCK) {
@@ -66,15 +70,15 @@ __global__ __launch_bounds__(REFWIN_BLOCK) void ref_window_kernel(RefWindowCtx w
         unsigned long long b = s_best[0];
 #pragma unroll
         for (int q = 1; q < REFWIN_BLOCK / WAVE; ++q) b = s_best[q] < b ? s_best[q] : b;
-        const int ind = max(*w.cind, (int)(unsigned)b);  // "ensure the index is not less than the current index"
+        const int ind = max(cind0, (int)(unsigned)b);  // "ensure the index is not less than the current index"
         *w.cind = ind;
         s_ind = ind;
     }
     __syncthreads();
     const int ind = s_ind;
-    const bool all_inside = ind + w.dind[w.rows - 1] < w.n;  // dind is increasing
+    const bool all_inside = ind + dlast < w.n;  // dind is increasing
     for (int i = threadIdx.x; i < w.rows; i += REFWIN_BLOCK) {
-        const int idx = ind + w.dind[i];
+        const int idx = ind + (i == (int)threadIdx.x ? dmine : w.dind[i]);
         const float4* src = reinterpret_cast<const float4*>(w.path8 + 8 * (int64_t)(idx < w.n ? idx : w.n - 1));
         float4 a = src[0];
         const float4 b = src[1];

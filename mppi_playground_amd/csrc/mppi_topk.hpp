@@ -254,6 +254,11 @@ __device__ __forceinline__ unsigned long long block_rank_sort_1024(unsigned long
 // SORTED = true: `cand` is already ascending (topk_sort_* below: any k) and the grid's threads take one candidate each.
 // lambda <= 0: the temperature the last solve's weights used (stats[4], left by finalize_tail) — no host read-back.
 constexpr int TOPK_DIRECT_MAX = 4096;
+constexpr int TOPK_PREGEN_MAX_R = 32;  // rows of up to 32 float4 groups (T <= 64 at two controls): 32 KiB of LDS
+// dynamic LDS of topk_rollout_kernel: the two mean rows [8R floats] + (unsorted candidates, regen mode) the block's noise
+inline size_t topk_rollout_lds(int R, bool sorted, bool gen_noise) {
+    return sizeof(float) * 8 * (size_t)R + (!sorted && gen_noise && R <= TOPK_PREGEN_MAX_R ? sizeof(float4) * 64 * (size_t)R : 0);
+}
 template <int MODEL, int FAST, bool SORTED>
 __global__ __launch_bounds__(TOPK_MAX) void topk_rollout_kernel(const unsigned long long* __restrict__ cand, int k,
                                                                 const float* __restrict__ costs, int n_direct,
@@ -271,16 +276,26 @@ __global__ __launch_bounds__(TOPK_MAX) void topk_rollout_kernel(const unsigned l
     // [4R] the mean row the solve sampled around (zeros past the row), [4R] zeros (samples beyond the exploration split): the
     // re-roll reads its mean groups from here (rollout_states_noise)
     extern __shared__ __attribute__((aligned(16))) float s_mrow[];
-    for (int f = threadIdx.x; f < 4 * d.R; f += blockDim.x) {
-        s_mrow[f] = f < d.row ? mean[f] : 0.0f;
-        s_mrow[4 * d.R + f] = 0.0f;
-    }
-    __syncthreads();
+    __shared__ float s_x0[DS];
+    // (the unsorted path calls this AFTER it has requested its candidates: one memory round trip for both, and the barrier
+    // that publishes the sorted words publishes these as well)
+    const auto stage_inputs = [&]() {
+        for (int f = threadIdx.x; f < 4 * d.R; f += blockDim.x) {
+            s_mrow[f] = f < d.row ? mean[f] : 0.0f;
+            s_mrow[4 * d.R + f] = 0.0f;
+        }
+        if (threadIdx.x < DS) s_x0[threadIdx.x] = x0[threadIdx.x];
+    };
+    if (SORTED) { stage_inputs(); __syncthreads(); }
+    // (dynamic LDS behind the mean rows: the block's noise, see below; sized by topk_rollout_lds())
+    const bool pregen = !SORTED && gen_noise && d.R <= TOPK_PREGEN_MAX_R;
+    float4* s_noise = reinterpret_cast<float4*>(s_mrow + 8 * d.R);
     if (hist && blockIdx.x == 0) {  // leave the select state clean for the next call
         for (int b = threadIdx.x; b < 3 * TOPK_BINS; b += blockDim.x) hist[b] = 0u;
         if (threadIdx.x < 2) counters[threadIdx.x] = 0u;
     }
     const float lambda = lambda_arg > 0.0f ? lambda_arg : stats[4];
+    const float st_min = stats[0], st_sum = stats[1];  // (requested here: not a round trip of their own before the re-roll)
     int q = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long mine;
     if (!SORTED) {
@@ -294,6 +309,7 @@ __global__ __launch_bounds__(TOPK_MAX) void topk_rollout_kernel(const unsigned l
             if (costs) v[r] = i < n_direct ? ((unsigned long long)float_to_key(costs[i]) << 32) | (unsigned long long)(d.sample_offset + i) : ~0ull;
             else v[r] = (r == 0 && tid < k) ? cand[tid] : ~0ull;
         }
+        stage_inputs();
         if (rows <= 1) {
             v[0] = block_rank_sort_1024(v[0], costs ? n_direct : k, s_key, tid);
         } else {
@@ -410,6 +426,17 @@ __global__ __launch_bounds__(TOPK_MAX) void topk_rollout_kernel(const unsigned l
         s_key[tid] = v[0];
         __syncthreads();
         q = blockIdx.x * WAVE + tid;
+        // The fifteen waves that do not re-roll generate the block's noise first (regen mode, rows of <= TOPK_PREGEN_MAX_R
+        // groups): group g of candidate 64 b + lane by wave g mod 16, into LDS as [g][lane] — the serial chain of the
+        // re-roll is then the model's steps alone (the Philox + Box-Muller of a group is about as long as its two steps).
+        if (pregen) {
+            const int lane = tid & 63, cq = blockIdx.x * WAVE + lane;
+            if (cq < k) {
+                const uint64_t cgi = s_key[cq] & 0xFFFFFFFFull;
+                for (int g = tid >> 6; g < d.R; g += TOPK_MAX / WAVE) s_noise[g * 64 + lane] = gen_noise4(cgi, g, gen, d);
+            }
+            __syncthreads();
+        }
         if (tid >= WAVE || q >= k) return;
         mine = s_key[q];
     } else {
@@ -418,19 +445,20 @@ __global__ __launch_bounds__(TOPK_MAX) void topk_rollout_kernel(const unsigned l
     }
     const uint64_t gi = mine & 0xFFFFFFFFull;            // global sample index
     const float c = key_to_float((unsigned)(mine >> 32));  // its cost
-    weights[q] = expf((-c) / lambda - (-stats[0]) / lambda) / stats[1];  // softmax(-c/lambda)_i (mppi.py:376)
+    weights[q] = expf((-c) / lambda - (-st_min) / lambda) / st_sum;  // softmax(-c/lambda)_i (mppi.py:376)
     const bool inherit = (int64_t)gi < d.inherit_count;
     const int64_t i = (int64_t)gi - d.sample_offset;  // local index: only meaningful when the tiles are read
     const float4* np = noise + ((i >> 6) * d.R) * 64 + (i & 63);
     float* out = states + (int64_t)q * (d.T + 1) * DS;
     const float4* mp = reinterpret_cast<const float4*>(s_mrow) + (inherit ? 0 : d.R);
     const auto roll = [&](auto loadg) {
-        const bool bad = rollout_states_noise<MODEL, FAST>(x0, d, ctx, out, mp, loadg);
+        const bool bad = rollout_states_noise<MODEL, FAST>(s_x0, d, ctx, out, mp, loadg);
         if constexpr (FAST != 0 && !EntryGeneral<ModelT<MODEL, FAST>>::value) {  // (a lane that left a fast path: the library-math walk)
-            if (bad) (void)rollout_states_noise<MODEL, 0>(x0, d, ctx, out, mp, loadg);
+            if (bad) (void)rollout_states_noise<MODEL, 0>(s_x0, d, ctx, out, mp, loadg);
         }
     };
-    if (gen_noise) roll([&](int g) { return gen_noise4(gi, g, gen, d); });
+    if (pregen) roll([&](int g) { return s_noise[g * 64 + (int)(threadIdx.x & 63)]; });
+    else if (gen_noise) roll([&](int g) { return gen_noise4(gi, g, gen, d); });
     else roll([&](int g) { return np[(int64_t)g * 64]; });
 }
 

@@ -1,6 +1,8 @@
 """Shared model math in torch (used by env.step with batch 1 and by any torch caller of the plugins)."""
 import torch
 
+from mppi_playground_amd._pool import RowPool
+
 
 def angle_normalize(x: torch.Tensor) -> torch.Tensor:
     """Wrap to [-pi, pi): ((x + pi) mod 2 pi) - pi with Python-style modulo."""
@@ -23,15 +25,19 @@ class NativeStep:
         self._model = _capi.MODEL_IDS[model]
         self._params, self._lo, self._hi, self._goal = f(params), f(u_min), f(u_max), f(goal_xy)
         self._thr, self._ds, self._device, self._dtype = float(goal_threshold), dim_state, device, dtype
+        self._n_params = len(self._params)
+        self._index = torch.device(device).index or 0
+        # (the tick is bound by the host at the examples' sizes: outputs come from row pools, the stream as a raw handle)
+        self._next_pool = RowPool((dim_state,), device, dtype)
+        self._reached_pool = RowPool((), device, torch.bool)
 
     def __call__(self, state: torch.Tensor, u: torch.Tensor):
         assert u.dtype == torch.float32 and state.dtype == torch.float32 and state.is_contiguous()
         u = u if u.is_contiguous() else u.contiguous()
-        nxt = torch.empty(self._ds, device=self._device, dtype=self._dtype)
-        reached = torch.empty((), device=self._device, dtype=torch.bool)
-        rc = self._lib.mppi_model_step(self._model, self._params, len(self._params), self._lo, self._hi, state.data_ptr(),
-                                       u.data_ptr(), nxt.data_ptr(), self._goal, self._thr, reached.data_ptr(),
-                                       torch.cuda.current_stream(self._device).cuda_stream)
+        st = torch._C._cuda_getCurrentRawStream(self._index)
+        nxt, reached = self._next_pool.take(st), self._reached_pool.take(st)
+        rc = self._lib.mppi_model_step(self._model, self._params, self._n_params, self._lo, self._hi, state.data_ptr(),
+                                       u.data_ptr(), nxt.data_ptr(), self._goal, self._thr, reached.data_ptr(), st)
         if rc != 0:
             raise self._capi.MppiError(f"mppi_model_step failed ({rc})")
         return nxt, reached

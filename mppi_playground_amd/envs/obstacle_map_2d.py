@@ -12,6 +12,8 @@ from typing import List, Sequence, Tuple
 import numpy as np
 import torch
 
+from mppi_playground_amd._pool import RowPool
+
 from pi_mpc.native import GridSpec
 
 
@@ -106,6 +108,9 @@ class ObstacleMap:
 
 
 _native = None  # (binding module, library handle) once a device lookup has been asked for
+_POOLED_POINTS = 4096
+_out_pools = {}  # (shape, device index) -> RowPool of small outputs
+_stride_of_layout = {}  # (shape, strides) -> _uniform_point_stride
 
 
 def _uniform_point_stride(x: torch.Tensor):
@@ -138,13 +143,30 @@ def _grid_lookup_device(grid: torch.Tensor, x: torch.Tensor, cell_size: float, o
         _native = (_capi, _capi.load())
     capi, lib = _native
     o = origin_xy  # host floats owned by the map object (never a cache keyed on device addresses: those get reused)
-    step = _uniform_point_stride(x)
+    layout = (x.shape, x.stride())
+    step = _stride_of_layout.get(layout, 0)
+    if step == 0:  # (a per-tick caller passes the same layout every time)
+        if len(_stride_of_layout) >= 256:
+            _stride_of_layout.clear()
+        step = _stride_of_layout[layout] = _uniform_point_stride(x)
     if step is None:
         x = x.contiguous()
         step = 2
-    out = torch.empty(x.shape[:-1], device=x.device, dtype=torch.float32)
+    st = torch._C._cuda_getCurrentRawStream(x.device.index)
+    shape = x.shape[:-1]
+    n = shape.numel()
+    if n <= _POOLED_POINTS:  # (per-tick callers: env.collision_check of a predicted trajectory; see _pool.py)
+        key = (shape, x.device.index)
+        pool = _out_pools.get(key)
+        if pool is None:
+            if len(_out_pools) >= 64:
+                _out_pools.clear()
+            pool = _out_pools[key] = RowPool(shape, x.device, torch.float32)
+        out = pool.take(st)
+    else:
+        out = torch.empty(shape, device=x.device, dtype=torch.float32)
     rc = lib.mppi_grid_lookup(grid.data_ptr(), grid.shape[0], grid.shape[1], float(cell_size), o[0], o[1], x.data_ptr(),
-                              out.numel(), step, out.data_ptr(), torch._C._cuda_getCurrentRawStream(x.device.index))
+                              n, step, out.data_ptr(), st)
     if rc != 0:
         raise capi.MppiError(f"mppi_grid_lookup failed ({rc})")
     return out

@@ -10,6 +10,7 @@ import numpy as np
 import torch
 
 from mppi_playground_amd import _capi
+from mppi_playground_amd._pool import RowPool
 from pi_mpc._lazy import _ptr
 from pi_mpc.sharding import shard_range
 
@@ -150,11 +151,18 @@ class QueriesMixin:
             top = torch.topk(self._weights, num_samples)
             order = torch.argsort(top.values, descending=True)
             return self._state_seq_batch_buf[top.indices][order], top.values[order]
-        out = torch.empty(num_samples, self._horizon + 1, self._dim_state, device=self._device, dtype=self._dtype)
-        w = torch.empty(num_samples, device=self._device, dtype=self._dtype)
+        st = self._stream()
+        pools = self._top_pools.get(num_samples)
+        if pools is None:  # (the examples ask for the same k every tick: see _pool.py)
+            if len(self._top_pools) >= 16:
+                self._top_pools.clear()
+            pools = self._top_pools[num_samples] = (
+                RowPool((num_samples, self._horizon + 1, self._dim_state), self._device, self._dtype),
+                RowPool((num_samples,), self._device, self._dtype))
+        out, w = pools[0].take(st.value), pools[1].take(st.value)
         # one library call for any k: radix select + sort (one block up to 1024, multi-pass beyond) + re-roll + weights — ONE
         # launch up to 4096 samples; the weights use the temperature the solve left on the device (no read-back, no wait)
-        self._h.call("mppi_top_samples", num_samples, _capi.LAMBDA_DEVICE, _ptr(out), _ptr(w), self._stream())
+        self._h.call("mppi_top_samples", num_samples, _capi.LAMBDA_DEVICE, _ptr(out), _ptr(w), st)
         return out, w
 
     def _top_samples_sharded(self, k: int) -> Tuple[torch.Tensor, torch.Tensor]:

@@ -22,6 +22,7 @@ import torch
 import torch.nn as nn
 
 from mppi_playground_amd import _capi
+from mppi_playground_amd._pool import RowPool
 from pi_mpc import _host
 from pi_mpc.native import resolve
 from pi_mpc.sharding import all_gather_summaries, shard_range
@@ -324,6 +325,10 @@ class MPPI(ExchangeMixin, GenericPathMixin, QueriesMixin, nn.Module):
 
         # ---- RNG stream bookkeeping (src/pi_mpc/mppi.py:93,146-148; SURVEY B-Q1/Q2)
         self._solve_idx = 0
+        # outputs of the per-tick calls (see _pool.py: the example loops are bound by the host at their own sizes)
+        self._action_pool = RowPool((horizon, dim_control), self._device, self._dtype)
+        self._state_pool = RowPool((1, horizon + 1, dim_state), self._device, self._dtype)
+        self._top_pools = {}
         self._cpu_gen = None
         if noise_source == "torch_cpu":
             self._cpu_gen = torch.Generator(device="cpu")
@@ -877,11 +882,12 @@ class MPPI(ExchangeMixin, GenericPathMixin, QueriesMixin, nn.Module):
         """forward() through mppi_solve: the same kernel sequence as _solve_by_steps in one library call (native model,
         device noise, a fixed temperature or a device-resident rule, one GPU or an in-library exchange)."""
         h, st = self._h, self._stream()
+        me = self.__dict__  # (private state is written straight into the instance dict: see __setattr__ above)
         if torch.is_tensor(state) and state.is_cuda:
             if state.dtype is self._dtype and state.device == self._device and state.is_contiguous():
-                self._x0_keep = state  # zero-copy as it is (kept alive until the next solve)
+                me["_x0_keep"] = state  # zero-copy as it is (kept alive until the next solve)
             else:
-                self._x0_keep = state.detach().to(self._device, self._dtype).contiguous()
+                me["_x0_keep"] = state.detach().to(self._device, self._dtype).contiguous()
             x0p = _ptr(self._x0_keep)
         else:
             x0h = np.ascontiguousarray(state.detach().cpu().numpy() if torch.is_tensor(state) else state,
@@ -890,32 +896,31 @@ class MPPI(ExchangeMixin, GenericPathMixin, QueriesMixin, nn.Module):
             x0p = None
         self._refresh_model_inputs()
         if not self._fused_error_seen and h.lib.mppi_fused_error(h.h):
-            self._fused_error_seen = True  # (from now on the library stays on the multi-kernel path)
+            me["_fused_error_seen"] = True  # (from now on the library stays on the multi-kernel path)
             raise _capi.MppiError("a single-launch solve gave up waiting for one of its blocks (default budget 20 ms; is the GPU "
                                   "shared with other work?): that solve returned the previous plan instead of a new one and NaN "
                                   "statistics (last_stats()); later solves use the multi-kernel path.  "
                                   "set_option('fused_timeout_us', ...) widens the budget, set_option('fused_rearm', 1) allows "
                                   "the single launch again")
-        self._mean_of_last_solve = self._previous_action_seq
+        me["_mean_of_last_solve"] = self._previous_action_seq
         if self._auto_lambda is None:
             lam = float(self._lambda_value)
-            self._last_lambda_value, self._used_known = lam, True
+            me["_last_lambda_value"], me["_used_known"] = lam, True
         elif self._lambda_override is not None:  # MPO with a temperature assigned by the caller (the dual still steps)
-            lam = self._last_lambda_value = self._lambda_override
-            self._lambda_pending, self._lambda_stream, self._used_known = True, st, True
-            self._lambda_override = None
+            lam = me["_last_lambda_value"] = self._lambda_override
+            me["_lambda_pending"], me["_lambda_stream"], me["_used_known"] = True, st, True
+            me["_lambda_override"] = None
         else:  # the configured rule runs on the device; the temperature is fetched when somebody asks for it
             if self._rule_on_device != "MPO":
                 self._push_auto_lambda()
             lam = _capi.LAMBDA_DEVICE
-            self._lambda_pending, self._lambda_stream, self._used_known = True, st, False
+            me["_lambda_pending"], me["_lambda_stream"], me["_used_known"] = True, st, False
         # (the previous solve's state tensor stays alive across this launch: with a lazily completed state sequence this
         # solve's rollout launch may still write it)
         prev_state_keep = self._state_out
-        self._action_out = torch.empty(self._horizon, self._dim_control, device=self._device, dtype=self._dtype)
-        self._state_out = torch.empty(1, self._horizon + 1, self._dim_state, device=self._device, dtype=self._dtype)
+        me["_action_out"], me["_state_out"] = self._action_pool.take(st.value), self._state_pool.take(st.value)
         h.call("mppi_solve", x0p, self._solve_idx, lam, _ptr(self._action_out), _ptr(self._state_out), _ptr(self._stats), st)
         del prev_state_keep
-        self._solve_idx += 1
-        self._previous_action_seq = self._action_out
+        me["_solve_idx"] = self._solve_idx + 1
+        me["_previous_action_seq"] = self._action_out
         return self._action_out, self._returned_state_seq()

@@ -607,6 +607,9 @@ def _undefined_globals(path):
                                  "mppi_playground_amd/pi_mpc/_generic.py", "mppi_playground_amd/pi_mpc/_queries.py",
                                  "mppi_playground_amd/pi_mpc/recognize.py", "scripts/closure_fingerprints.py",
                                  "mppi_playground_amd/_capi.py", "mppi_playground_amd/envs/racing_controller.py",
+                                 "mppi_playground_amd/_pool.py", "mppi_playground_amd/envs/common.py",
+                                 "mppi_playground_amd/envs/obstacle_map_2d.py", "mppi_playground_amd/envs/lane_map_2d.py",
+                                 "mppi_playground_amd/envs/racing_env.py", "mppi_playground_amd/envs/navigation_2d.py",
                                  "scripts/make_visit_docs.py", "scripts/pmc_constants.py", "tests/golden/make_golden.py"])
 def test_no_function_reads_an_undefined_name(rel):
     assert _undefined_globals(os.path.join(ROOT, rel)) == []
@@ -715,3 +718,27 @@ def test_reference_example_closures_are_recognised(model):
         assert recognize.match(dyn, cost, ds, dc, torch.device("cpu")) is None
     finally:
         recognize._table_cache = table
+
+
+def test_row_pool_hands_out_fresh_aligned_rows():
+    """mppi_playground_amd/_pool.py: every row is handed out once, contiguous and 256 bytes apart, rows never overlap, a new
+    block starts when the rows run out or the stream changes, and a dropped block's rows stay valid while somebody holds one."""
+    import torch
+    from mppi_playground_amd._pool import RowPool
+
+    pool = RowPool((25, 2), torch.device("cpu"), torch.float32, block_bytes=4096)
+    rows = [pool.take(7) for _ in range(3 * pool._per_block + 1)]
+    assert pool._per_block == 16 and all(r.shape == (25, 2) and r.is_contiguous() and r.data_ptr() % 64 == 0 for r in rows)
+    assert (rows[1].data_ptr() - rows[0].data_ptr()) % 256 == 0  # (blocks of torch's GPU allocator start on 512-byte boundaries)
+    spans = sorted((r.data_ptr(), r.data_ptr() + 200) for r in rows)
+    assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:]))
+    for i, r in enumerate(rows):
+        r.fill_(float(i))
+    assert all(float(r[0, 0]) == float(i) and float(r[-1, -1]) == float(i) for i, r in enumerate(rows))
+    left = len(pool._rows)
+    other = pool.take(8)  # another stream: a new block
+    assert len(pool._rows) == pool._per_block - 1 and left != len(pool._rows) + 1 and other.data_ptr() not in {r.data_ptr() for r in rows}
+    scalar = RowPool((), torch.device("cpu"), torch.bool).take(0)
+    assert scalar.shape == () and scalar.dtype == torch.bool
+    big = RowPool((300, 26, 4), torch.device("cpu"), torch.float32)
+    assert big._per_block == 8 and big.take(0).numel() == 300 * 26 * 4
