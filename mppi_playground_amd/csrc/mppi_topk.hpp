@@ -201,47 +201,112 @@ __device__ __forceinline__ void block_bitonic_1024(unsigned long long (&v)[NV], 
         }
     }
 }
+// Wave-level prefix sums / reductions through DPP (row_shr within the rows of 16 lanes, then row_bcast15 / row_bcast31 across
+// them — CDNA keeps both): six VALU instructions with a DPP operand, against six ds_bpermute round trips (~100 cycles of
+// latency each) for the __shfl forms.  A lane whose source lies outside its row (or whose row is masked off) gets `old`.
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ unsigned dpp_u32(unsigned old, unsigned src) {
+    return (unsigned)__builtin_amdgcn_update_dpp((int)old, (int)src, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ unsigned wave_inclusive_sum_dpp(unsigned x) {
+    x += dpp_u32<0x111>(0u, x);  // row_shr:1
+    x += dpp_u32<0x112>(0u, x);  // row_shr:2
+    x += dpp_u32<0x114>(0u, x);  // row_shr:4
+    x += dpp_u32<0x118>(0u, x);  // row_shr:8  -> inclusive sums inside every row
+    x += dpp_u32<0x142, 0xA>(0u, x);  // row_bcast15 into rows 1 and 3: the total of the row before
+    x += dpp_u32<0x143, 0xC>(0u, x);  // row_bcast31 into rows 2 and 3: the total of lanes 0 .. 31
+    return x;
+}
+// op over the wave's 64 values, the same in every lane (lane 63 holds it after the six steps)
+template <class OP>
+__device__ __forceinline__ float wave_reduce_dpp(float v, OP op) {
+    const auto step = [&](auto ctrl, auto rows) {
+        const unsigned u = __float_as_uint(v);
+        v = op(v, __uint_as_float(dpp_u32<decltype(ctrl)::value, decltype(rows)::value>(u, u)));
+    };
+    using std::integral_constant;
+    step(integral_constant<int, 0x111>{}, integral_constant<int, 0xF>{});
+    step(integral_constant<int, 0x112>{}, integral_constant<int, 0xF>{});
+    step(integral_constant<int, 0x114>{}, integral_constant<int, 0xF>{});
+    step(integral_constant<int, 0x118>{}, integral_constant<int, 0xF>{});
+    step(integral_constant<int, 0x142>{}, integral_constant<int, 0xA>{});
+    step(integral_constant<int, 0x143>{}, integral_constant<int, 0xC>{});
+    return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), 63));
+}
+// topk_pick for 2048 bins and 1024 threads (the in-block select of topk_rollout_kernel): two bins per thread, the wave's prefix
+// sums through DPP, the sixteen wave totals through LDS — two barriers instead of four and no serial tail.
+__device__ __forceinline__ void topk_pick_2048(const unsigned* __restrict__ hist, unsigned krem, unsigned* __restrict__ s_part /*[18]*/,
+                                               int tid, unsigned& bin, unsigned& below) {
+    const uint2 h = *reinterpret_cast<const uint2*>(hist + 2 * tid);
+    const unsigned loc = h.x + h.y, incl = wave_inclusive_sum_dpp(loc);
+    if ((tid & 63) == 63) s_part[tid >> 6] = incl;
+    __syncthreads();
+    unsigned before = 0u;  // the totals of the waves below this one
+#pragma unroll
+    for (int w = 0; w < TOPK_MAX / WAVE; ++w) before += w < (tid >> 6) ? s_part[w] : 0u;
+    const unsigned excl = before + incl - loc;
+    if (excl < krem && krem <= excl + loc) {  // exactly one thread (loc > 0 there)
+        const bool first = krem <= excl + h.x;
+        s_part[16] = (unsigned)(2 * tid) + (first ? 0u : 1u);
+        s_part[17] = first ? excl : excl + h.x;
+    }
+    __syncthreads();
+    bin = s_part[16];
+    below = s_part[17];
+}
 // Ascending sort of the n <= 1024 DISTINCT words a block of 1024 threads holds (thread t < n: word w) — round 5, replaces the
 // 55-stage bitonic network over 1024 padded words (10 of its stages through LDS behind 1024-thread barriers: 8.8 us of the
 // examples' 20 us get_top_samples kernel, measured with phase stamps: load 1.8, radix select 3.6, compaction 0.8, sort 8.8,
-// re-roll 4.9 us).  Merge by rank: every wave sorts its own 64 words with shuffles (21 compare-exchange stages, no barrier),
-// leaves the run in LDS, and every thread then finds how many words of each OTHER run lie below its own by a branch-free
-// binary search (7 LDS reads per run, the runs independent of each other): its rank is its position in its run plus those
-// counts, and it stores its word there.  Two barriers in all; only the ceil(n / 64) runs that hold words are searched.
-// Returns the t-th smallest word (~0 for t >= n); the sorted words are left in s_x[0 .. n).
-__device__ __forceinline__ unsigned long long block_rank_sort_1024(unsigned long long w, int n, unsigned long long* s_x, int tid) {
-    const int lane = tid & 63;
+// re-roll 4.9 us).  Merge by rank in two levels:
+//   (1) inside a run of 64 words (one wave): every thread counts the words of its run below its own — 64 broadcast LDS reads
+//       that do not depend on each other — and stores its word at that position of the run in the second buffer (an in-wave
+//       bitonic network is 21 stages of two cross-lane permutes each, ~100 cycles of latency apiece: 3.3 us of this kernel
+//       under the phase stamps of -DMPPI_TOPK_TRACE, against ~1 us this way);
+//   (2) across runs: how many words of each OTHER (now sorted) run lie below its own, by a branch-free binary search (7 LDS
+//       reads per run, eight runs in flight); rank = position in the run + those counts.
+// Three barriers in all; only the ceil(n / 64) runs that hold words are looked at.  Returns the t-th smallest word (~0 for
+// t >= n); the sorted words are left in s_x[0 .. n).  s_y: a second buffer of 1024 words.
+__device__ __forceinline__ unsigned long long block_rank_sort_1024(unsigned long long w, int n, unsigned long long* s_x,
+                                                                   unsigned long long* s_y, int tid) {
+    const int nruns = (n + WAVE - 1) / WAVE, my = tid >> 6;
     if (tid >= n) w = ~0ull;
-    // (1) the wave's 64 words ascending (bitonic over the lanes)
-#pragma unroll
-    for (int size = 2; size <= WAVE; size <<= 1) {
-        const bool up = (lane & size) == 0 || size == WAVE;
-#pragma unroll
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            const unsigned long long o = shfl_xor_u64(w, stride);
-            const bool keep_min = ((lane & stride) == 0) == up;
-            w = keep_min ? (w < o ? w : o) : (w > o ? w : o);
-        }
-    }
     s_x[tid] = w;
     __syncthreads();
-    // (2) rank = position in the own run + the number of smaller words in every other run
-    const int nruns = (n + WAVE - 1) / WAVE, my = tid >> 6;
-    int rank = lane;  // (its smaller words of the own run sit in the lanes below)
-    if (w != ~0ull) {
-        for (int r = 0; r < nruns; ++r) {
-            if (r == my) continue;  // (wave-uniform)
-            const unsigned long long* run = s_x + r * WAVE;
-            int pos = 0;
+    int rank = 0;
+    if (my < nruns) {  // (wave-uniform)
+        const ulonglong2* own = reinterpret_cast<const ulonglong2*>(s_x + my * WAVE);
 #pragma unroll
-            for (int step = 32; step >= 1; step >>= 1) pos += run[pos + step - 1] < w ? step : 0;
-            pos += run[pos] < w ? 1 : 0;  // (pos = 63 here when all of the first 63 are smaller)
-            rank += pos;
+        for (int j = 0; j < WAVE / 2; ++j) {
+            const ulonglong2 p = own[j];
+            rank += p.x < w ? 1 : 0;
+            rank += p.y < w ? 1 : 0;
         }
+        // (the words of a run's tail that are padding sit in its last lanes: they keep their places)
+        s_y[w != ~0ull ? my * WAVE + rank : tid] = w;
     }
     __syncthreads();
-    if (w != ~0ull) s_x[rank] = w;
-    else if (tid >= n) s_x[tid] = ~0ull;
+    if (w != ~0ull) {
+        // eight runs at a time: the seven reads of one search depend on each other (7 LDS latencies), those of different
+        // runs do not (a run past the last one repeats it and does not count, nor does the thread's own)
+        constexpr int G = 8;
+        for (int r0 = 0; r0 < nruns; r0 += G) {
+            const unsigned long long* run[G];
+            int pos[G];
+#pragma unroll
+            for (int j = 0; j < G; ++j) { run[j] = s_y + min(r0 + j, nruns - 1) * WAVE; pos[j] = 0; }
+#pragma unroll
+            for (int step = 32; step >= 1; step >>= 1) {
+#pragma unroll
+                for (int j = 0; j < G; ++j) pos[j] += run[j][pos[j] + step - 1] < w ? step : 0;
+            }
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+                pos[j] += run[j][pos[j]] < w ? 1 : 0;  // (pos = 63 here when all of the first 63 are smaller)
+                rank += (r0 + j < nruns && r0 + j != my) ? pos[j] : 0;
+            }
+        }
+        s_x[rank] = w;  // (nobody reads s_x any more: its last readers passed the barrier above)
+    }
     __syncthreads();
     return s_x[tid];
 }
@@ -254,6 +319,13 @@ __device__ __forceinline__ unsigned long long block_rank_sort_1024(unsigned long
 // SORTED = true: `cand` is already ascending (topk_sort_* below: any k) and the grid's threads take one candidate each.
 // lambda <= 0: the temperature the last solve's weights used (stats[4], left by finalize_tail) — no host read-back.
 constexpr int TOPK_DIRECT_MAX = 4096;
+// -DMPPI_TOPK_TRACE (experiments only, scripts/build_variant.sh): block 0 stamps the 100 MHz clock at the phase boundaries of
+// topk_rollout_kernel<.., false> and prints the differences (10 ns units) when it is done
+#ifdef MPPI_TOPK_TRACE
+#define TK_TRACE(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) s_tk[i] = (long long)wall_clock64(); } while (0)
+#else
+#define TK_TRACE(i) do { } while (0)
+#endif
 constexpr int TOPK_PREGEN_MAX_R = 32;  // rows of up to 32 float4 groups (T <= 64 at two controls): 32 KiB of LDS
 // dynamic LDS of topk_rollout_kernel: the two mean rows [8R floats] + (unsorted candidates, regen mode) the block's noise
 inline size_t topk_rollout_lds(int R, bool sorted, bool gen_noise) {
@@ -272,11 +344,16 @@ __global__ __launch_bounds__(TOPK_MAX) void topk_rollout_kernel(const unsigned l
                                                                 unsigned* __restrict__ counters, Dims d, GenCtx gen,
                                                                 ModelCtx ctx) {
     constexpr int DS = ModelT<MODEL, FAST>::DS;
-    __shared__ unsigned long long s_key[SORTED ? 1 : TOPK_MAX];
+    __shared__ __attribute__((aligned(16))) unsigned long long s_key[SORTED ? 1 : TOPK_MAX];
+    __shared__ __attribute__((aligned(16))) unsigned long long s_key2[SORTED ? 1 : TOPK_MAX];  // the sort's second buffer; the select's histogram before that
     // [4R] the mean row the solve sampled around (zeros past the row), [4R] zeros (samples beyond the exploration split): the
     // re-roll reads its mean groups from here (rollout_states_noise)
     extern __shared__ __attribute__((aligned(16))) float s_mrow[];
     __shared__ float s_x0[DS];
+#ifdef MPPI_TOPK_TRACE
+    __shared__ long long s_tk[10];
+    TK_TRACE(0);
+#endif
     // (the unsorted path calls this AFTER it has requested its candidates: one memory round trip for both, and the barrier
     // that publishes the sorted words publishes these as well)
     const auto stage_inputs = [&]() {
@@ -311,12 +388,13 @@ __global__ __launch_bounds__(TOPK_MAX) void topk_rollout_kernel(const unsigned l
         }
         stage_inputs();
         if (rows <= 1) {
-            v[0] = block_rank_sort_1024(v[0], costs ? n_direct : k, s_key, tid);
+            v[0] = block_rank_sort_1024(v[0], costs ? n_direct : k, s_key, s_key2, tid);
         } else {
             // 2-4 rows: radix select of the k smallest keys INSIDE the block (three passes of 11 / 11 / 10 bits over the <= 4
             // keys a thread holds, histogram in LDS: the scheme of topk_hist_kernel / topk_collect_kernel without their four
             // launches), then one row to sort.  (Sorting all four rows and pruning was measured at ~25 us: 4x the work.)
-            __shared__ unsigned s_hist[TOPK_BINS];
+            static_assert(sizeof(unsigned) * TOPK_BINS <= sizeof(unsigned long long) * TOPK_MAX, "the histogram lives in s_key2");
+            unsigned* s_hist = reinterpret_cast<unsigned*>(s_key2);
             __shared__ unsigned s_scan[TOPK_MAX + 2];
             __shared__ unsigned s_cnt[2];
             __shared__ float s_mm[2][TOPK_MAX / WAVE];
@@ -335,14 +413,15 @@ __global__ __launch_bounds__(TOPK_MAX) void topk_rollout_kernel(const unsigned l
                     cf[r] = valid ? key_to_float((unsigned)(v[r] >> 32)) : 0.0f;
                     if (valid) { cmn = fminf(cmn, cf[r]); cmx = fmaxf(cmx, cf[r]); }
                 }
-#pragma unroll
-                for (int m = 32; m >= 1; m >>= 1) { cmn = fminf(cmn, __shfl_xor(cmn, m)); cmx = fmaxf(cmx, __shfl_xor(cmx, m)); }
+                cmn = wave_reduce_dpp(cmn, [](float a, float b) { return fminf(a, b); });
+                cmx = wave_reduce_dpp(cmx, [](float a, float b) { return fmaxf(a, b); });
                 if ((tid & 63) == 0) { s_mm[0][tid >> 6] = cmn; s_mm[1][tid >> 6] = cmx; }
                 for (int b = tid; b < TOPK_BINS; b += TOPK_MAX) s_hist[b] = 0u;
                 if (tid < 2) s_cnt[tid] = 0u;
                 __syncthreads();
 #pragma unroll
                 for (int w = 0; w < TOPK_MAX / WAVE; ++w) { cmn = fminf(cmn, s_mm[0][w]); cmx = fmaxf(cmx, s_mm[1][w]); }
+                TK_TRACE(1);  // the candidates' costs have arrived, their range is known
                 const float scale = (float)(TOPK_BINS - 1) / (cmx - cmn);
                 const bool usable = cmx > cmn && cmx < INFINITY && cmn > -INFINITY && scale < INFINITY;  // (block-uniform)
                 if (usable) {
@@ -353,17 +432,38 @@ __global__ __launch_bounds__(TOPK_MAX) void topk_rollout_kernel(const unsigned l
                         if (r * TOPK_MAX + tid < n_direct) atomicAdd(&s_hist[vb[r]], 1u);
                     }
                     __syncthreads();
+                    TK_TRACE(2);  // histogram
                     unsigned bstar, below;
-                    topk_pick<TOPK_MAX>(s_hist, TOPK_BINS, (unsigned)k, s_scan, bstar, below);
+                    static_assert(TOPK_BINS == 2 * TOPK_MAX, "topk_pick_2048: two bins per thread");
+                    topk_pick_2048(s_hist, (unsigned)k, s_scan, tid, bstar, below);
+                    TK_TRACE(3);  // the boundary bin
                     const unsigned total = below + s_hist[bstar];  // keys in bins <= b*  (>= k)
                     if (total <= (unsigned)TOPK_MAX) {             // (block-uniform)
+                        {  // (ONE LDS atomic per wave, not one per key: the order of the words is free)
+                            const int lane = tid & 63;
+                            const unsigned long long below_me = (1ull << lane) - 1ull;
+                            bool take[4];
+                            unsigned at[4], cnt = 0u;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (r * TOPK_MAX + tid < n_direct && vb[r] <= (int)bstar) s_key[atomicAdd(&s_cnt[0], 1u)] = v[r];
+                            for (int r = 0; r < 4; ++r) {
+                                take[r] = r * TOPK_MAX + tid < n_direct && vb[r] <= (int)bstar;
+                                const unsigned long long m = __ballot(take[r]);
+                                at[r] = cnt + (unsigned)__popcll(m & below_me);
+                                cnt += (unsigned)__popcll(m);
+                            }
+                            unsigned base = 0u;
+                            if (lane == 0 && cnt) base = atomicAdd(&s_cnt[0], cnt);
+                            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (take[r]) s_key[base + at[r]] = v[r];
+                        }
                         __syncthreads();
                         const unsigned long long wk = tid < (int)total ? s_key[tid] : ~0ull;
                         __syncthreads();
-                        v[0] = block_rank_sort_1024(wk, (int)total, s_key, tid);  // the k smallest are its first k
+                        TK_TRACE(4);  // compaction
+                        v[0] = block_rank_sort_1024(wk, (int)total, s_key, s_key2, tid);  // the k smallest are its first k
+                        TK_TRACE(5);  // sort
                         done = true;
                     }
                 }
@@ -417,7 +517,7 @@ __global__ __launch_bounds__(TOPK_MAX) void topk_rollout_kernel(const unsigned l
             __syncthreads();
             const unsigned long long wk = tid < k ? s_key[tid] : ~0ull;
             __syncthreads();
-            v[0] = block_rank_sort_1024(wk, k, s_key, tid);
+            v[0] = block_rank_sort_1024(wk, k, s_key, s_key2, tid);
             }
         }
         // Every block of the grid has sorted the same words; block b re-rolls candidates 64 b .. 64 b + 63 with ONE wave.
@@ -437,6 +537,7 @@ __global__ __launch_bounds__(TOPK_MAX) void topk_rollout_kernel(const unsigned l
             }
             __syncthreads();
         }
+        TK_TRACE(6);  // the block's noise
         if (tid >= WAVE || q >= k) return;
         mine = s_key[q];
     } else {
@@ -460,6 +561,14 @@ __global__ __launch_bounds__(TOPK_MAX) void topk_rollout_kernel(const unsigned l
     if (pregen) roll([&](int g) { return s_noise[g * 64 + (int)(threadIdx.x & 63)]; });
     else if (gen_noise) roll([&](int g) { return gen_noise4(gi, g, gen, d); });
     else roll([&](int g) { return np[(int64_t)g * 64]; });
+#ifdef MPPI_TOPK_TRACE
+    if (!SORTED && blockIdx.x == 0 && threadIdx.x == 0) {
+        const long long t7 = (long long)wall_clock64();
+        printf("topk trace (10 ns): costs %lld, histogram %lld, pick %lld, compaction %lld, sort %lld, noise %lld, re-roll %lld, total %lld\n",
+               s_tk[1] - s_tk[0], s_tk[2] - s_tk[1], s_tk[3] - s_tk[2], s_tk[4] - s_tk[3], s_tk[5] - s_tk[4], s_tk[6] - s_tk[5],
+               t7 - s_tk[6], t7 - s_tk[0]);
+    }
+#endif
 }
 
 // Ascending sort of P = 2^m >= 2048 candidate words in global memory (k > TOPK_MAX; the tail past k holds ~0).  Bitonic:

@@ -31,6 +31,8 @@ timeout 300 python scripts/essps_passes.py 2>&1 | grep -v amdgpu.ids > gpurun_ou
 timeout 300 python scripts/top_samples_breakdown.py 2>&1 | grep -v amdgpu.ids > gpurun_out/top_samples_breakdown.txt
 timeout 400 python scripts/fused_crossover.py 2>&1 | grep -v amdgpu.ids > gpurun_out/fused_crossover.txt
 timeout 200 python scripts/host_overhead.py 2>&1 | grep -v amdgpu.ids > gpurun_out/host_overhead.txt
+{ for i in 1 2 3; do python scripts/example_tick.py 400 2>&1 | tail -1; done; python scripts/example_tick_host.py 400 2>&1 | grep -v amdgpu.ids; } > gpurun_out/example_tick.txt
+[ -f mppi_playground_amd/csrc/variants/lib_topktrace.so ] && MPPI_HIP_LIB=mppi_playground_amd/csrc/variants/lib_topktrace.so timeout 300 python scripts/topk_trace.py 2>&1 | grep -v amdgpu.ids > gpurun_out/topk_trace.txt
 [ -f mppi_playground_amd/csrc/variants/lib_trace.so ] && MPPI_HIP_LIB=mppi_playground_amd/csrc/variants/lib_trace.so timeout 300 python scripts/fused_trace.py 2>&1 | grep -v amdgpu.ids > gpurun_out/fused_trace.txt
 scripts/ubench/icache_cold > gpurun_out/ubench_cold_code.txt 2>&1; scripts/ubench/clock_cost > gpurun_out/ubench_clock_cost.txt 2>&1
 cd /tmp

@@ -51,7 +51,8 @@ Un-profiled (`bench.py` `other_configs`): c3_dense {oc.get('c3_dense', {}).get('
     open(out(f"{name}_c3_dense_path.md"), "w").write(hdr3 + c3_dense)
 for src, dst in (("fused_timing.txt", "fused_timing.txt"), ("essps_passes.txt", "essps_passes.txt"), ("nccl_single_rank.txt", "exchange_single_rank.txt"),
                  ("pytest_gpu.log", "pytest_gpu.log"), ("top_samples_breakdown.txt", "top_samples.txt"), ("fused_crossover.txt", "fused_crossover.txt"),
-                 ("host_overhead.txt", "host_overhead.txt"), ("lazy_state_stress.txt", "lazy_state_stress.txt")):
+                 ("host_overhead.txt", "host_overhead.txt"), ("lazy_state_stress.txt", "lazy_state_stress.txt"),
+                 ("example_tick.txt", "example_tick.txt"), ("topk_trace.txt", "top_samples_phase_stamps.txt")):
     f = os.path.join(root, "gpurun_out", src)
     if os.path.exists(f):
         shutil.copy(f, out(f"{name}_{dst}"))
