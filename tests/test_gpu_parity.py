@@ -2568,3 +2568,65 @@ def test_single_launch_solve_at_edge_sizes_against_oracle(model, T, N, expl):
         check_rel("state_seq_vs_oracle_rollout", s.cpu().numpy()[0], P.rollout_single(x0.cpu().numpy(), a.cpu().numpy()), TOL)
         assert abs(solver.last_stats()["ess"] - st["ess"]) <= 1e-4 * st["ess"]
         mean = a.cpu().numpy()  # the warm start of the next solve
+
+
+def test_one_launch_top_k_on_randomised_cost_vectors():
+    """The one-launch get_top_samples (N <= 4096, k <= 1024: value-binned select, compaction, two-level rank sort, re-roll) on
+    cost vectors of awkward shapes — one exponent, a range of e^40, 40 distinct values a few ulps apart, plateaus, mixed signs,
+    all equal, infinite costs, sorted input, duplicates around the boundary — against a host sort of the same costs: the weights
+    in order, and without ties the trajectories bit-equal to the index-driven re-roll of the host's order.  (A short form of
+    scripts/topk_soak.py, whose 4 000 cases are recorded in profiles/r05_topk_soak.txt.)"""
+    _need_gpu()
+    rng = np.random.default_rng(7)
+
+    def draw(N, kind):
+        if kind == 0:
+            c = rng.uniform(77e3, 110e3, N)
+        elif kind == 1:
+            c = np.exp(rng.uniform(-20, 20, N))
+        elif kind == 2:
+            c = 5.0 + rng.integers(0, 40, N) * np.float32(4.8e-7)
+        elif kind == 3:
+            c = rng.integers(0, max(2, N // 50), N).astype(np.float64)
+        elif kind == 4:
+            c = rng.standard_normal(N) * 10.0 ** rng.integers(-3, 6)
+        elif kind == 5:
+            c = np.full(N, float(rng.uniform(-5, 5)))
+        elif kind == 6:
+            c = rng.uniform(0, 100, N)
+            c[rng.random(N) < 0.2] = np.inf
+        elif kind == 7:
+            c = np.sort(rng.uniform(0, 1e4, N))[:: (1 if rng.random() < 0.5 else -1)]
+        else:
+            c = rng.uniform(0, 1, N)
+            c[rng.integers(0, N, max(1, N // 8))] = c[rng.integers(0, N)]
+        return np.ascontiguousarray(c, dtype=np.float32)
+
+    x0 = torch.tensor([1.0, 0.0])
+    for N in (4000, 1024, 1025, 4096, 2731, 77):
+        solver, _ = make_solver("pendulum", 10, N, lambda_=1.0)
+        solver.forward(x0)
+        st = solver._stream()
+        for kind in range(9):
+            for k in sorted({1, min(N, 64), min(N, 300), min(N, 1024), int(rng.integers(1, min(N, 1024) + 1))}):
+                costs = draw(N, kind)
+                fin = costs[np.isfinite(costs)]
+                lam = float(max(1e-3, np.ptp(fin))) if fin.size else 1.0
+                c = torch.from_numpy(costs).cuda()
+                solver._h.call("mppi_set_costs", c.data_ptr(), 1, st)
+                solver._h.call("mppi_weights_reduce", lam, None, st)
+                a = torch.empty(10, 1, device="cuda")
+                solver._h.call("mppi_finalize", None, 1, lam, 0, a.data_ptr(), None, None, st)
+                out, w = torch.empty(k, 11, 2, device="cuda"), torch.empty(k, device="cuda")
+                solver._h.call("mppi_top_samples", k, lam, out.data_ptr(), w.data_ptr(), st)
+                order = np.lexsort((np.arange(N), costs))[:k]
+                x = (-costs) / np.float32(lam)  # (fp32 quotients like the device's)
+                ref = np.exp((x - x.max()).astype(np.float64))
+                ref /= ref.sum()
+                got = w.cpu().numpy()
+                assert np.all(np.isfinite(got)) and np.abs(got - ref[order]).max() <= 2e-5 * ref.max(), (N, kind, k)
+                if len(np.unique(costs[order])) == k and (k == N or costs[order][-1] < np.partition(costs, k)[k]):
+                    out2 = torch.empty_like(out)
+                    idx = torch.from_numpy(order.astype(np.int64)).cuda()
+                    solver._h.call("mppi_rollout_samples", idx.data_ptr(), k, out2.data_ptr(), st)
+                    assert torch.equal(out, out2), (N, kind, k)
