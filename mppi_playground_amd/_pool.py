@@ -16,7 +16,7 @@ _ALIGN = 256  # bytes between rows (vector stores of the kernels need 16)
 
 
 class RowPool:
-    __slots__ = ("_shape", "_device", "_dtype", "_pitch", "_per_block", "_strides", "_rows", "_stream")
+    __slots__ = ("_shape", "_device", "_dtype", "_pitch", "_per_block", "_strides", "_block")
 
     def __init__(self, shape, device, dtype, block_bytes: int = 1 << 20, max_rows: int = 256):
         self._shape, self._device, self._dtype = tuple(int(v) for v in shape), device, dtype
@@ -29,14 +29,25 @@ class RowPool:
             strides.append(acc)
             acc *= s
         self._strides = tuple(reversed(strides))
-        self._rows, self._stream = [], None
+        self._block = (None, [])  # (raw stream the rows were allocated under, rows not handed out yet): replaced as ONE object
 
     def take(self, stream: int) -> torch.Tensor:
         """A fresh row for work on raw stream `stream` of the pool's device (the block was allocated under torch's current
-        stream, like a torch.empty at this point would be: a change of stream starts a new block)."""
-        if not self._rows or stream != self._stream:
-            n = self._per_block
-            block = torch.empty(n * self._pitch, device=self._device, dtype=self._dtype)
-            self._rows = list(block.as_strided((n, *self._shape), (self._pitch, *self._strides)).unbind(0))
-            self._stream = stream
-        return self._rows.pop()
+        stream, like a torch.empty at this point would be: a change of stream starts a new block).  Safe to call from several
+        threads: `list.pop` is atomic, and a thread never pops from a block of another stream."""
+        held, rows = self._block
+        if held == stream:
+            try:
+                return rows.pop()
+            except IndexError:
+                pass
+        n = self._per_block
+        block = torch.empty(n * self._pitch, device=self._device, dtype=self._dtype)
+        rows = list(block.as_strided((n, *self._shape), (self._pitch, *self._strides)).unbind(0))
+        row = rows.pop()
+        self._block = (stream, rows)
+        return row
+
+    @property
+    def rows_left(self) -> int:
+        return len(self._block[1])

@@ -735,9 +735,9 @@ def test_row_pool_hands_out_fresh_aligned_rows():
     for i, r in enumerate(rows):
         r.fill_(float(i))
     assert all(float(r[0, 0]) == float(i) and float(r[-1, -1]) == float(i) for i, r in enumerate(rows))
-    left = len(pool._rows)
+    left = pool.rows_left
     other = pool.take(8)  # another stream: a new block
-    assert len(pool._rows) == pool._per_block - 1 and left != len(pool._rows) + 1 and other.data_ptr() not in {r.data_ptr() for r in rows}
+    assert pool.rows_left == pool._per_block - 1 and left != pool.rows_left + 1 and other.data_ptr() not in {r.data_ptr() for r in rows}
     scalar = RowPool((), torch.device("cpu"), torch.bool).take(0)
     assert scalar.shape == () and scalar.dtype == torch.bool
     big = RowPool((300, 26, 4), torch.device("cpu"), torch.float32)
