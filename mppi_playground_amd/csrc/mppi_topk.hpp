@@ -234,25 +234,34 @@ __device__ __forceinline__ float wave_reduce_dpp(float v, OP op) {
     return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), 63));
 }
 // topk_pick for 2048 bins and 1024 threads (the in-block select of topk_rollout_kernel): two bins per thread, the wave's prefix
-// sums through DPP, the sixteen wave totals through LDS — two barriers instead of four and no serial tail.
-__device__ __forceinline__ void topk_pick_2048(const unsigned* __restrict__ hist, unsigned krem, unsigned* __restrict__ s_part /*[18]*/,
-                                               int tid, unsigned& bin, unsigned& below) {
+// sums through DPP, the sixteen wave totals through LDS — two barriers instead of four and no serial tail.  Also leaves the
+// exclusive prefix sums of ALL bins in s_pref[0 .. 2048] (s_pref[2048] = the number of keys) and reports whether a bin up to
+// the chosen one holds more than `crowd` keys.
+__device__ __forceinline__ void topk_pick_2048(const unsigned* __restrict__ hist, unsigned krem, unsigned* __restrict__ s_part /*[19]*/,
+                                               unsigned* __restrict__ s_pref /*[2049]*/, unsigned crowd, int tid, unsigned& bin,
+                                               unsigned& below, bool& crowded) {
     const uint2 h = *reinterpret_cast<const uint2*>(hist + 2 * tid);
     const unsigned loc = h.x + h.y, incl = wave_inclusive_sum_dpp(loc);
     if ((tid & 63) == 63) s_part[tid >> 6] = incl;
+    if (tid == 0) s_part[18] = 0u;
     __syncthreads();
     unsigned before = 0u;  // the totals of the waves below this one
 #pragma unroll
     for (int w = 0; w < TOPK_MAX / WAVE; ++w) before += w < (tid >> 6) ? s_part[w] : 0u;
     const unsigned excl = before + incl - loc;
+    *reinterpret_cast<uint2*>(s_pref + 2 * tid) = make_uint2(excl, excl + h.x);
+    if (tid == TOPK_MAX - 1) s_pref[2 * TOPK_MAX] = excl + loc;
     if (excl < krem && krem <= excl + loc) {  // exactly one thread (loc > 0 there)
         const bool first = krem <= excl + h.x;
         s_part[16] = (unsigned)(2 * tid) + (first ? 0u : 1u);
         s_part[17] = first ? excl : excl + h.x;
     }
+    // (a bin lies at or below the chosen one exactly when keys of it come before the krem-th: its exclusive prefix < krem)
+    if ((h.x > crowd && excl < krem) || (h.y > crowd && excl + h.x < krem)) s_part[18] = 1u;
     __syncthreads();
     bin = s_part[16];
     below = s_part[17];
+    crowded = s_part[18] != 0u;
 }
 // Ascending sort of the n <= 1024 DISTINCT words a block of 1024 threads holds (thread t < n: word w) — round 5, replaces the
 // 55-stage bitonic network over 1024 padded words (10 of its stages through LDS behind 1024-thread barriers: 8.8 us of the
@@ -396,14 +405,16 @@ __global__ __launch_bounds__(TOPK_MAX) void topk_rollout_kernel(const unsigned l
             static_assert(sizeof(unsigned) * TOPK_BINS <= sizeof(unsigned long long) * TOPK_MAX, "the histogram lives in s_key2");
             unsigned* s_hist = reinterpret_cast<unsigned*>(s_key2);
             __shared__ unsigned s_scan[TOPK_MAX + 2];
+            __shared__ __attribute__((aligned(8))) unsigned s_pref[TOPK_BINS + 2];  // exclusive prefix sums of the value bins
             __shared__ unsigned s_cnt[2];
             __shared__ float s_mm[2][TOPK_MAX / WAVE];
-            // (a) ONE pass over bins of the cost VALUE (round 5): 2048 equal bins over [min, max] of the block's costs — the
-            // top 11 BITS of the keys of one solve fall into a handful of bins (costs of 77 k .. 110 k share their exponent), so
-            // the bitwise select below needs all three passes; a monotone value bin puts ~2 of 4096 keys in the bin of the
-            // k-th smallest.  Every key in a lower bin is smaller than every key of that bin, so {keys in bins <= b*} is a
-            // superset of the k smallest: when it fits one row it is sorted by rank and the first k are the answer (exact).
-            // Costs that are all equal, infinite or NaN, or a crowded boundary bin, take the bitwise passes (b).
+            // (a) ONE pass over bins of the cost VALUE (round 5): 2048 bins, monotone in the cost, between the block's minimum
+            // and maximum (see bin_of below) — the top 11 BITS of the keys of one solve fall into a handful of bins (costs of
+            // 77 k .. 110 k share their exponent), so the bitwise select below needs all three passes; a value bin holds a few
+            // keys around the k-th smallest.  Every key in a lower bin is smaller than every key of that bin, so {keys in bins <= b*} is a
+            // superset of the k smallest: when it fits one row it is sorted — by counting when no bin is crowded, else by the
+            // merge by rank — and the first k are the answer (exact).  Costs that are all equal, infinite or NaN, or more than
+            // one row of keys up to the boundary bin, take the bitwise passes (b).
             bool done = false;
             {
                 float cmn = INFINITY, cmx = -INFINITY, cf[4];
@@ -411,7 +422,7 @@ __global__ __launch_bounds__(TOPK_MAX) void topk_rollout_kernel(const unsigned l
                 for (int r = 0; r < 4; ++r) {
                     const bool valid = r * TOPK_MAX + tid < n_direct;
                     cf[r] = valid ? key_to_float((unsigned)(v[r] >> 32)) : 0.0f;
-                    if (valid) { cmn = fminf(cmn, cf[r]); cmx = fmaxf(cmx, cf[r]); }
+                    if (valid) { cmn = fminf(cmn, cf[r]); cmx = fmaxf(cmx, cf[r]); if (cf[r] != cf[r]) cmx = INFINITY; }  // (a NaN: not usable)
                 }
                 cmn = wave_reduce_dpp(cmn, [](float a, float b) { return fminf(a, b); });
                 cmx = wave_reduce_dpp(cmx, [](float a, float b) { return fmaxf(a, b); });
@@ -422,23 +433,53 @@ __global__ __launch_bounds__(TOPK_MAX) void topk_rollout_kernel(const unsigned l
 #pragma unroll
                 for (int w = 0; w < TOPK_MAX / WAVE; ++w) { cmn = fminf(cmn, s_mm[0][w]); cmx = fmaxf(cmx, s_mm[1][w]); }
                 TK_TRACE(1);  // the candidates' costs have arrived, their range is known
-                const float scale = (float)(TOPK_BINS - 1) / (cmx - cmn);
-                const bool usable = cmx > cmn && cmx < INFINITY && cmn > -INFINITY && scale < INFINITY;  // (block-uniform)
+                // bin = the exponent and the first six mantissa bits of (cost - min), counted down from those of (max - min):
+                // 64 bins per octave over the 32 octaves below the range's top (anything smaller: bin 0) — monotone in the cost
+                // like equal bins, but a handful of collision penalties (+10^4 per step: costs of 300 .. 250 000 in a running
+                // racing loop) no longer push every candidate into bins 0 and 1 (400 .. 1 300 keys there: measured)
+                const bool usable = cmx > cmn && cmx < INFINITY && cmn > -INFINITY && (cmx - cmn) < INFINITY;  // (block-uniform)
+                const int bin_base = (int)(__float_as_uint(cmx - cmn) >> 17) - (TOPK_BINS - 1);
+                const auto bin_of = [&](float c) { return min(max((int)(__float_as_uint(c - cmn) >> 17) - bin_base, 0), TOPK_BINS - 1); };
                 if (usable) {
                     int vb[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        vb[r] = (int)fminf((cf[r] - cmn) * scale, (float)(TOPK_BINS - 1));  // monotone in the cost
+                        vb[r] = bin_of(cf[r]);
                         if (r * TOPK_MAX + tid < n_direct) atomicAdd(&s_hist[vb[r]], 1u);
                     }
                     __syncthreads();
                     TK_TRACE(2);  // histogram
                     unsigned bstar, below;
+                    bool crowded;
                     static_assert(TOPK_BINS == 2 * TOPK_MAX, "topk_pick_2048: two bins per thread");
-                    topk_pick_2048(s_hist, (unsigned)k, s_scan, tid, bstar, below);
+                    topk_pick_2048(s_hist, (unsigned)k, s_scan, s_pref, 64u, tid, bstar, below, crowded);
                     TK_TRACE(3);  // the boundary bin
-                    const unsigned total = below + s_hist[bstar];  // keys in bins <= b*  (>= k)
-                    if (total <= (unsigned)TOPK_MAX) {             // (block-uniform)
+                    const unsigned total = s_pref[bstar + 1];  // keys in bins <= b*  (>= k)
+                    if (total <= (unsigned)TOPK_MAX && !crowded) {  // (block-uniform)
+                        // Counting sort (no bin up to b* holds more than 64 keys; a few at the examples' sizes): the histogram is
+                        // its own set of cursors — a key takes the next free place of its bin's segment [pref[b], pref[b + 1]) —
+                        // and the words, now ordered by bin, find their rank inside their segment by looking at its few words.
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (r * TOPK_MAX + tid < n_direct && vb[r] <= (int)bstar)
+                                s_key[s_pref[vb[r]] + atomicSub(&s_hist[vb[r]], 1u) - 1u] = v[r];
+                        __syncthreads();
+                        TK_TRACE(4);  // scatter by bin
+                        unsigned long long w = ~0ull;
+                        unsigned rank = (unsigned)tid;  // (threads without a word pad their own places)
+                        if (tid < (int)total) {
+                            w = s_key[tid];
+                            const int bin = bin_of(key_to_float((unsigned)(w >> 32)));
+                            const unsigned lo = s_pref[bin], hi = s_pref[bin + 1];
+                            rank = lo;
+                            for (unsigned j = lo; j < hi; ++j) rank += s_key[j] < w ? 1u : 0u;
+                        }
+                        s_key2[rank] = w;  // (the histogram's memory: its cursors were last touched before the barrier above)
+                        __syncthreads();
+                        v[0] = s_key2[tid];  // the k smallest are the first k
+                        TK_TRACE(5);  // ranks inside the bins
+                        done = true;
+                    } else if (total <= (unsigned)TOPK_MAX) {  // a crowded bin: compaction + merge by rank
                         {  // (ONE LDS atomic per wave, not one per key: the order of the words is free)
                             const int lane = tid & 63;
                             const unsigned long long below_me = (1ull << lane) - 1ull;

@@ -20,7 +20,7 @@ rng = np.random.default_rng(20260927)
 
 
 def draw(N):
-    kind = rng.integers(0, 9)
+    kind = rng.integers(0, 10)
     if kind == 0:    # one exponent, like the costs of a racing solve
         c = rng.uniform(77e3, 110e3, N)
     elif kind == 1:  # a huge range: almost everything in the first value bin
@@ -38,15 +38,17 @@ def draw(N):
         c[rng.random(N) < 0.2] = np.inf
     elif kind == 7:  # sorted / reversed input
         c = np.sort(rng.uniform(0, 1e4, N))[:: (1 if rng.random() < 0.5 else -1)]
-    else:            # the k-th value duplicated around the boundary
+    elif kind == 8:  # the k-th value duplicated around the boundary
         c = rng.uniform(0, 1, N)
         c[rng.integers(0, N, max(1, N // 8))] = c[rng.integers(0, N)]
+    else:            # a running racing loop: a few hundred to a few thousand, plus collision penalties of 10^4 per step
+        c = rng.uniform(300, 3000, N) + 1e4 * rng.integers(0, 25, N) * (rng.random(N) < 0.4)
     return np.ascontiguousarray(c, dtype=np.float32), int(kind)
 
 
 solvers = {}
 bad = 0
-by_kind = [0] * 9
+by_kind = [0] * 10
 for case in range(cases):
     N = int(rng.choice([rng.integers(1, 4097), rng.integers(1000, 4097), 1024, 1025, 2048, 4096, 4000]))
     k = int(min(N, rng.choice([rng.integers(1, 1025), 1, 64, 300, 1000, 1024, N])))

@@ -2573,7 +2573,7 @@ def test_single_launch_solve_at_edge_sizes_against_oracle(model, T, N, expl):
 def test_one_launch_top_k_on_randomised_cost_vectors():
     """The one-launch get_top_samples (N <= 4096, k <= 1024: value-binned select, compaction, two-level rank sort, re-roll) on
     cost vectors of awkward shapes — one exponent, a range of e^40, 40 distinct values a few ulps apart, plateaus, mixed signs,
-    all equal, infinite costs, sorted input, duplicates around the boundary — against a host sort of the same costs: the weights
+    all equal, infinite costs, sorted input, duplicates around the boundary, collision penalties on top of a narrow range — against a host sort of the same costs: the weights
     in order, and without ties the trajectories bit-equal to the index-driven re-roll of the host's order.  (A short form of
     scripts/topk_soak.py, whose 4 000 cases are recorded in profiles/r05_topk_soak.txt.)"""
     _need_gpu()
@@ -2597,9 +2597,11 @@ def test_one_launch_top_k_on_randomised_cost_vectors():
             c[rng.random(N) < 0.2] = np.inf
         elif kind == 7:
             c = np.sort(rng.uniform(0, 1e4, N))[:: (1 if rng.random() < 0.5 else -1)]
-        else:
+        elif kind == 8:
             c = rng.uniform(0, 1, N)
             c[rng.integers(0, N, max(1, N // 8))] = c[rng.integers(0, N)]
+        else:  # a running racing loop: collision penalties of 10^4 per step on top of a few thousand
+            c = rng.uniform(300, 3000, N) + 1e4 * rng.integers(0, 25, N) * (rng.random(N) < 0.4)
         return np.ascontiguousarray(c, dtype=np.float32)
 
     x0 = torch.tensor([1.0, 0.0])
@@ -2607,7 +2609,7 @@ def test_one_launch_top_k_on_randomised_cost_vectors():
         solver, _ = make_solver("pendulum", 10, N, lambda_=1.0)
         solver.forward(x0)
         st = solver._stream()
-        for kind in range(9):
+        for kind in range(10):
             for k in sorted({1, min(N, 64), min(N, 300), min(N, 1024), int(rng.integers(1, min(N, 1024) + 1))}):
                 costs = draw(N, kind)
                 fin = costs[np.isfinite(costs)]
