@@ -26,15 +26,18 @@ class NativeStep:
         self._params, self._lo, self._hi, self._goal = f(params), f(u_min), f(u_max), f(goal_xy)
         self._thr, self._ds, self._device, self._dtype = float(goal_threshold), dim_state, device, dtype
         self._n_params = len(self._params)
-        self._index = torch.device(device).index or 0
-        # (the tick is bound by the host at the examples' sizes: outputs come from row pools, the stream as a raw handle)
-        self._next_pool = RowPool((dim_state,), device, dtype)
-        self._reached_pool = RowPool((), device, torch.bool)
+        # (the tick is bound by the host at the examples' sizes: outputs come from row pools, the stream as a raw handle —
+        # both of the device the STATE lives on: the env's device is the reference's unindexed "cuda")
+        self._pool_device, self._next_pool, self._reached_pool = None, None, None
 
     def __call__(self, state: torch.Tensor, u: torch.Tensor):
-        assert u.dtype == torch.float32 and state.dtype == torch.float32 and state.is_contiguous()
+        assert u.dtype == torch.float32 and state.dtype == torch.float32 and state.is_contiguous() and state.is_cuda
         u = u if u.is_contiguous() else u.contiguous()
-        st = torch._C._cuda_getCurrentRawStream(self._index)
+        dev = state.device
+        if dev != self._pool_device:
+            self._pool_device = dev
+            self._next_pool, self._reached_pool = RowPool((self._ds,), dev, self._dtype), RowPool((), dev, torch.bool)
+        st = torch._C._cuda_getCurrentRawStream(dev.index)
         nxt, reached = self._next_pool.take(st), self._reached_pool.take(st)
         rc = self._lib.mppi_model_step(self._model, self._params, self._n_params, self._lo, self._hi, state.data_ptr(),
                                        u.data_ptr(), nxt.data_ptr(), self._goal, self._thr, reached.data_ptr(), st)
