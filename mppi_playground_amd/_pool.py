@@ -5,7 +5,9 @@ once every call of the tick is one launch: seven `torch.empty` per tick at ~1.3 
 profiles/r05_experiments.md).  A RowPool allocates a block of rows at once and splits it with ONE `unbind` (~0.2 us per row).
 Every row is handed out exactly once — a fresh tensor like torch.empty's: nobody else holds it, contents undefined,
 contiguous, 256-byte aligned — and a block goes back to torch's caching allocator when the last of its rows is dropped.
-The visible difference to torch.empty: a row is a view of its block (`torch.save` of one writes the block; `.clone()` first)."""
+The visible difference to torch.empty: a row is a view of its block (`torch.save` of one writes the block; `.clone()` first).
+Under stream capture (torch.cuda.graph: the generic path's `graph_callables`, or a caller's own graph) `take` is a plain
+torch.empty from the graph's private pool, like the code it replaces."""
 from __future__ import annotations
 
 import math
@@ -13,13 +15,20 @@ import math
 import torch
 
 _ALIGN = 256  # bytes between rows (vector stores of the kernels need 16)
+_capturing = torch._C._cuda_isCurrentStreamCapturing if hasattr(torch._C, "_cuda_isCurrentStreamCapturing") else (lambda: False)
+
+
+def capturing() -> bool:
+    """Is torch's current stream of the current GPU being captured into a graph?  (Callers on a GPU path only.)"""
+    return _capturing()
 
 
 class RowPool:
-    __slots__ = ("_shape", "_device", "_dtype", "_pitch", "_per_block", "_strides", "_block")
+    __slots__ = ("_shape", "_device", "_dtype", "_pitch", "_per_block", "_strides", "_block", "_on_gpu")
 
     def __init__(self, shape, device, dtype, block_bytes: int = 1 << 20, max_rows: int = 256):
         self._shape, self._device, self._dtype = tuple(int(v) for v in shape), device, dtype
+        self._on_gpu = torch.device(device).type == "cuda"
         item = torch.empty((), dtype=dtype).element_size()
         numel = math.prod(self._shape)
         self._pitch = max(1, -(-(numel * item) // _ALIGN)) * _ALIGN // item  # elements from row to row
@@ -31,10 +40,14 @@ class RowPool:
         self._strides = tuple(reversed(strides))
         self._block = (None, [])  # (raw stream the rows were allocated under, rows not handed out yet): replaced as ONE object
 
-    def take(self, stream: int) -> torch.Tensor:
+    def take(self, stream: int, captured: bool = None) -> torch.Tensor:
         """A fresh row for work on raw stream `stream` of the pool's device (the block was allocated under torch's current
         stream, like a torch.empty at this point would be: a change of stream starts a new block).  Safe to call from several
         threads: `list.pop` is atomic, and a thread never pops from a block of another stream."""
+        # (a row of ordinary memory must not be baked into a graph: it is freed when its block's rows are dropped.  A caller that
+        # takes several rows passes `captured=capturing()` so that the query — 0.29 us — is made once per call)
+        if (self._on_gpu and _capturing()) if captured is None else captured:
+            return torch.empty(self._shape, device=self._device, dtype=self._dtype)
         held, rows = self._block
         if held == stream:
             try:

@@ -1,7 +1,7 @@
 """Shared model math in torch (used by env.step with batch 1 and by any torch caller of the plugins)."""
 import torch
 
-from mppi_playground_amd._pool import RowPool
+from mppi_playground_amd._pool import RowPool, capturing
 
 
 def angle_normalize(x: torch.Tensor) -> torch.Tensor:
@@ -38,7 +38,8 @@ class NativeStep:
             self._pool_device = dev
             self._next_pool, self._reached_pool = RowPool((self._ds,), dev, self._dtype), RowPool((), dev, torch.bool)
         st = torch._C._cuda_getCurrentRawStream(dev.index)
-        nxt, reached = self._next_pool.take(st), self._reached_pool.take(st)
+        cap = capturing()
+        nxt, reached = self._next_pool.take(st, cap), self._reached_pool.take(st, cap)
         rc = self._lib.mppi_model_step(self._model, self._params, self._n_params, self._lo, self._hi, state.data_ptr(),
                                        u.data_ptr(), nxt.data_ptr(), self._goal, self._thr, reached.data_ptr(), st)
         if rc != 0:

@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from mppi_playground_amd import _capi
-from mppi_playground_amd._pool import RowPool
+from mppi_playground_amd._pool import RowPool, capturing
 from pi_mpc._lazy import _ptr
 from pi_mpc.sharding import shard_range
 
@@ -159,7 +159,8 @@ class QueriesMixin:
             pools = self._top_pools[num_samples] = (
                 RowPool((num_samples, self._horizon + 1, self._dim_state), self._device, self._dtype),
                 RowPool((num_samples,), self._device, self._dtype))
-        out, w = pools[0].take(st.value), pools[1].take(st.value)
+        cap = capturing()
+        out, w = pools[0].take(st.value, cap), pools[1].take(st.value, cap)
         # one library call for any k: radix select + sort (one block up to 1024, multi-pass beyond) + re-roll + weights — ONE
         # launch up to 4096 samples; the weights use the temperature the solve left on the device (no read-back, no wait)
         self._h.call("mppi_top_samples", num_samples, _capi.LAMBDA_DEVICE, _ptr(out), _ptr(w), st)

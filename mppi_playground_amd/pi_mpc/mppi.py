@@ -22,7 +22,7 @@ import torch
 import torch.nn as nn
 
 from mppi_playground_amd import _capi
-from mppi_playground_amd._pool import RowPool
+from mppi_playground_amd._pool import RowPool, capturing
 from pi_mpc import _host
 from pi_mpc.native import resolve
 from pi_mpc.sharding import all_gather_summaries, shard_range
@@ -918,7 +918,8 @@ class MPPI(ExchangeMixin, GenericPathMixin, QueriesMixin, nn.Module):
         # (the previous solve's state tensor stays alive across this launch: with a lazily completed state sequence this
         # solve's rollout launch may still write it)
         prev_state_keep = self._state_out
-        me["_action_out"], me["_state_out"] = self._action_pool.take(st.value), self._state_pool.take(st.value)
+        cap = capturing()
+        me["_action_out"], me["_state_out"] = self._action_pool.take(st.value, cap), self._state_pool.take(st.value, cap)
         h.call("mppi_solve", x0p, self._solve_idx, lam, _ptr(self._action_out), _ptr(self._state_out), _ptr(self._stats), st)
         del prev_state_keep
         me["_solve_idx"] = self._solve_idx + 1

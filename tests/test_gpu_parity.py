@@ -2632,3 +2632,35 @@ def test_one_launch_top_k_on_randomised_cost_vectors():
                     idx = torch.from_numpy(order.astype(np.int64)).cuda()
                     solver._h.call("mppi_rollout_samples", idx.data_ptr(), k, out2.data_ptr(), st)
                     assert torch.equal(out, out2), (N, kind, k)
+
+
+def test_row_pool_steps_aside_under_stream_capture():
+    """mppi_playground_amd/_pool.py: a pooled row is ordinary memory that goes back to the allocator when its block's rows
+    are dropped, so it must never be baked into a graph — under capture `take` is a plain torch.empty (the graph's private
+    pool), and env.collision_check captured in a caller's graph replays correctly after the eager outputs are gone."""
+    _need_gpu()
+    from mppi_playground_amd._pool import RowPool
+
+    dev = torch.device("cuda", torch.cuda.current_device())
+    pool = RowPool((8,), dev, torch.float32)
+    raw = torch._C._cuda_getCurrentRawStream(dev.index)
+    eager = pool.take(raw)
+    assert eager.untyped_storage().nbytes() > 32  # a row of a block
+    make_solver("racing", 5, 64)
+    env = _envs["racing"]
+    pts = torch.zeros(1, 26, 4, device=dev)
+    pts[0, :, 0] = torch.linspace(-3.0, 3.0, 26, device=dev)
+    want = env.collision_check(state=pts).clone()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        inside = pool.take(torch._C._cuda_getCurrentRawStream(dev.index))
+        got = env.collision_check(state=pts)
+    assert inside.untyped_storage().nbytes() == 32 and got.untyped_storage().nbytes() == got.numel() * 4
+    junk = [env.collision_check(state=pts) for _ in range(600)]  # eager rows come and go around the replays
+    del junk
+    pts[0, :, 1] = 0.5
+    want2 = env.collision_check(state=pts).clone()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(got, want2) and want.shape == want2.shape
