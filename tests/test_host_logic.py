@@ -742,3 +742,45 @@ def test_row_pool_hands_out_fresh_aligned_rows():
     assert scalar.shape == () and scalar.dtype == torch.bool
     big = RowPool((300, 26, 4), torch.device("cpu"), torch.float32)
     assert big._per_block == 8 and big.take(0).numel() == 300 * 26 * 4
+
+
+def test_value_bins_of_the_one_launch_top_k_are_monotone_and_exact():
+    """csrc/mppi_topk.hpp `bin_of` (the exponent and six mantissa bits of cost - min, counted down from those of max - min,
+    clamped to 0 .. 2047), restated in numpy: monotone in the cost, hence {keys in bins <= b*} is a superset of the k smallest
+    and ordering that set by (bin, word) is ordering it by word — the property the device select + counting sort rely on
+    (the implementation itself is checked on the GPU: test_one_launch_top_k_on_randomised_cost_vectors, scripts/topk_soak.py)."""
+    rng = np.random.default_rng(11)
+
+    def bins(c):
+        cmn, cmx = c.min(), c.max()
+        base = int(np.float32(cmx - cmn).view(np.uint32) >> 17) - 2047
+        u = ((c - cmn).astype(np.float32).view(np.uint32) >> 17).astype(np.int64)
+        return np.clip(u - base, 0, 2047)
+
+    for trial in range(200):
+        N = int(rng.integers(2, 4097))
+        kind = trial % 4
+        if kind == 0:
+            c = rng.uniform(77e3, 110e3, N)
+        elif kind == 1:
+            c = rng.uniform(300, 3000, N) + 1e4 * rng.integers(0, 25, N) * (rng.random(N) < 0.4)
+        elif kind == 2:
+            c = rng.standard_normal(N) * 10.0 ** rng.integers(-3, 6)
+        else:
+            c = np.exp(rng.uniform(-20, 20, N))
+        c = c.astype(np.float32)
+        if c.max() == c.min():
+            continue
+        b = bins(c)
+        order = np.argsort(c, kind="stable")
+        assert np.all(np.diff(b[order]) >= 0)  # monotone
+        k = int(rng.integers(1, min(N, 1024) + 1))
+        words = (c.view(np.uint32).astype(np.uint64) ^ np.where(c.view(np.int32) < 0, 0xFFFFFFFF, 0x80000000).astype(np.uint64)) << np.uint64(32) \
+            | np.arange(N, dtype=np.uint64)  # (order-preserving key of the float, then the index)
+        bstar = int(np.searchsorted(np.cumsum(np.bincount(b, minlength=2048)), k))
+        chosen = np.flatnonzero(b <= bstar)
+        assert len(chosen) >= k
+        by_bin_then_word = chosen[np.lexsort((words[chosen], b[chosen]))][:k]
+        assert np.array_equal(by_bin_then_word, np.argsort(words, kind="stable")[:k])
+        if kind == 1 and N >= 2000 and k >= 300:  # the running racing loop: the boundary set stays within one row of 1024 words
+            assert len(chosen) <= 1024
