@@ -101,7 +101,7 @@ typedef struct MppiConfig {
 const char* mppi_version(void);
 /* Integer version of THIS header's function signatures; bindings compare it with the constant they were written
  * against and refuse a stale library (a changed argument list would otherwise be called with shifted arguments). */
-#define MPPI_ABI_VERSION 9
+#define MPPI_ABI_VERSION 10
 int mppi_abi_version(void);
 /* Number of visible HIP devices (0 => the product cannot run; callers must fail loudly). */
 int mppi_device_count(void);
@@ -119,6 +119,14 @@ int mppi_destroy(mppi_handle_t h);
 int mppi_set_control_limits(mppi_handle_t h, const float* u_min_host, const float* u_max_host, const float* sigmas_host,
                             int n);
 
+/* copy.deepcopy(solver) (the reference's MPPI is a plain nn.Module, src/pi_mpc/mppi.py:16: every tensor it holds is copied
+ * with it).  `dst` must have been created from the same MppiConfig; after the call it continues exactly like `src`: warm
+ * start (`_previous_action_seq`), noise identity, costs and minimum of the last solve (get_top_samples / weights work on
+ * the copy), Savitzky-Golay taps and history, the temperature with every device-resident search / dual state (ESSPS warm
+ * grid, MPO dual and Adam moments), model parameters, maps, reference window, centre path and path index, options.
+ * A borrowed state (mppi_bind_state) becomes an owned copy; a pending lazily completed state sequence is completed on
+ * both handles first.  Set-up path: synchronises the device. */
+int mppi_clone_state(mppi_handle_t dst, mppi_handle_t src);
 /* Model constants (closures' Python constants / env attributes).  params: MPPI_RP_* or MPPI_NP_*
  * layout; models without parameters accept n == 0. */
 int mppi_set_model_params(mppi_handle_t h, const float* params_host, int n);
@@ -330,6 +338,17 @@ int mppi_get_lambda(mppi_handle_t h, double* lambda_out_host, double* lambda_use
  * on exact statistics; against the reference's own Brent (which stops 6e-5 .. 5e-3 away from it) within 1e-3 relative
  * wherever the objective is not flat to fp32 rounding.  The temperature stays in HBM (MPPI_LAMBDA_DEVICE). */
 int mppi_lbps_lambda_device(mppi_handle_t h, double delta, double lam_min, double lam_max, void* stream);
+/* LBPS exactly as the reference searches it (mppi.py:341-349: scipy.optimize.minimize_scalar(method="bounded"), ported
+ * step for step in csrc/host_search.hpp) with NO host synchronisation: one launch (lbps_brent_kernel) runs all ~22-31
+ * dependent probes; every probe evaluates the statistics of mppi_softmax_stats bit for bit (the same threads add the same
+ * costs in the same order) and every block takes the same double-precision Brent step, so the temperature equals
+ * mppi_lbps_lambda's TO THE BIT — at one hop through memory per probe instead of two launches and a read-back.  The
+ * temperature stays in HBM (MPPI_LAMBDA_DEVICE; mppi_get_lambda reads it back, mppi_search_passes returns the number of
+ * probes).  This is what mppi_solve runs for MPPI_AUTO_LBPS (option "lbps_search" = 1 selects the grid search above).
+ * mppi_search_error: 1 once a poll of that kernel gave up (budget = option "fused_timeout_us"; a block never became
+ * resident because the GPU is shared): the temperature of that solve is NaN; option "search_rearm" clears the flag. */
+int mppi_lbps_brent_device(mppi_handle_t h, double delta, double lam_min, double lam_max, void* stream);
+int mppi_search_error(mppi_handle_t h);
 /* LBPS (mppi.py:341-349,534-557): argmin over [lam_min, lam_max] of -(E_w[-c] - (max c - min c) * sqrt((1-delta)/delta)
  * / sqrt(ESS)), searched on the host with Brent's bounded minimiser (scipy minimize_scalar(method="bounded"): xatol
  * 1e-5, at most 500 evaluations); every probe is one mppi_softmax_stats round trip.  Unsharded handles; synchronises. */
@@ -338,8 +357,10 @@ int mppi_lbps_lambda(mppi_handle_t h, double delta, double lam_min, double lam_m
  *   mppi_mpo_reset  log T = log(lambda0), moments cleared; epsilon = the KL bound (0.1), lr = Adam step (0.2)
  *   mppi_mpo_step   one Adam step on loss = softplus(logT) * (epsilon + logsumexp(-c / softplus(logT))) over the LAST
  *                   solve's costs; *lambda_out_host = exp(logT), the temperature of the NEXT solve.  Synchronises.
- *   mppi_mpo_state  out4_host = {log T, first moment, second moment, step count}. */
+ *   mppi_mpo_state  out4_host = {log T, first moment, second moment, step count}.
+ *   mppi_mpo_set_state  the inverse (restoring a saved solver); the next solve's temperature becomes exp(log T). */
 int mppi_mpo_reset(mppi_handle_t h, double lambda0, double epsilon, double lr);
+int mppi_mpo_set_state(mppi_handle_t h, const double* in4_host);
 int mppi_mpo_step(mppi_handle_t h, double* lambda_out_host, void* stream);
 /* mppi_mpo_step without the read-back (no host synchronisation): the dual, its moments and the resulting temperature
  * stay in device memory; the NEXT solve's weights read it through MPPI_LAMBDA_DEVICE.  Call it after mppi_finalize. */

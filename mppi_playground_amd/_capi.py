@@ -23,7 +23,7 @@ LAMBDA_DEVICE = -1.0  # MPPI_LAMBDA_DEVICE: "the temperature a device-resident r
 AUTO_RULES = {None: 0, "ESSPS": 1, "LBPS": 2, "MPO": 3}  # MPPI_AUTO_*
 
 # every symbol include/mppi_hip.h declares
-ABI_VERSION = 9  # MPPI_ABI_VERSION of the header this binding was written against
+ABI_VERSION = 10  # MPPI_ABI_VERSION of the header this binding was written against
 
 SYMBOLS = [
     "mppi_version", "mppi_abi_version", "mppi_device_count", "mppi_last_error", "mppi_create", "mppi_destroy", "mppi_set_control_limits",
@@ -34,7 +34,7 @@ SYMBOLS = [
     "mppi_p2p_alloc", "mppi_p2p_connect", "mppi_p2p_exchange", "mppi_p2p_error", "mppi_rollout_actions", "mppi_rollout_samples", "mppi_top_samples", "mppi_top_candidates", "mppi_rollout_candidates", "mppi_set_option", "mppi_get_timing",
     "mppi_set_center_path", "mppi_ref_window", "mppi_set_path_index", "mppi_get_path_index", "mppi_get_reference",
     "mppi_model_step", "mppi_comm_unique_id", "mppi_comm_init", "mppi_comm_exchange", "mppi_comm_destroy",
-    "mppi_set_auto_lambda", "mppi_lbps_lambda_device", "mppi_mpo_step_device", "mppi_fused_error",
+    "mppi_set_auto_lambda", "mppi_lbps_lambda_device", "mppi_lbps_brent_device", "mppi_search_error", "mppi_clone_state", "mppi_mpo_set_state", "mppi_mpo_step_device", "mppi_fused_error",
     "mppi_search_passes", "mppi_grid_lookup", "mppi_mpo_log_temperature_ptr", "mppi_join_state_seq", "mppi_state_seq_serial", "mppi_get_state_seq_timing", "mppi_comm_info",
 ]
 
@@ -98,6 +98,10 @@ def load():
     lib.mppi_get_lambda.argtypes = [vp, vp, vp, vp]
     lib.mppi_set_auto_lambda.argtypes = [vp, i32, C.c_double, C.c_double, C.c_double]
     lib.mppi_lbps_lambda_device.argtypes = [vp, C.c_double, C.c_double, C.c_double, vp]
+    lib.mppi_lbps_brent_device.argtypes = [vp, C.c_double, C.c_double, C.c_double, vp]
+    lib.mppi_search_error.argtypes = [vp]
+    lib.mppi_clone_state.argtypes = [vp, vp]
+    lib.mppi_mpo_set_state.argtypes = [vp, vp]
     lib.mppi_mpo_step_device.argtypes = [vp, vp]
     lib.mppi_fused_error.argtypes = [vp]
     lib.mppi_search_passes.argtypes = [vp, vp]

@@ -34,10 +34,13 @@ struct SoftmaxStats {  // of softmax(-c/lambda) over all samples, e_i = exp(-(c_
 // ---------------------------------------------------------------------------------------------------------
 // Brent's bounded minimiser.  f: double -> double (may fail: returns false), minimum of f on [x1, x2].
 // Returns false if an evaluation failed.
+// (Host AND device: lbps_brent_kernel in mppi_search.hpp runs this very function in one wave per block, with the probe
+// f(x) = a pass of the whole grid over the costs.  Only +, -, *, /, sqrt, fabs and compares on doubles, every one
+// correctly rounded on both sides and nothing contracted (-ffp-contract=off): the same x sequence to the bit.)
 template <class F>
-bool fminbound(F&& f, double x1, double x2, double xatol, int maxiter, double& xmin, int* nfev = nullptr) {
-    const double sqrt_eps = std::sqrt(2.2e-16);
-    const double golden_mean = 0.5 * (3.0 - std::sqrt(5.0));
+MPPI_SEARCH_HD bool fminbound(F&& f, double x1, double x2, double xatol, int maxiter, double& xmin, int* nfev = nullptr) {
+    const double sqrt_eps = sqrt(2.2e-16);
+    const double golden_mean = 0.5 * (3.0 - sqrt(5.0));
     double a = x1, b = x2;
     double fulc = a + golden_mean * (b - a);
     double nfc = fulc, xf = fulc;
@@ -48,21 +51,21 @@ bool fminbound(F&& f, double x1, double x2, double xatol, int maxiter, double& x
     double fu = INFINITY;
     double ffulc = fx, fnfc = fx;
     double xm = 0.5 * (a + b);
-    double tol1 = sqrt_eps * std::fabs(xf) + xatol / 3.0;
+    double tol1 = sqrt_eps * fabs(xf) + xatol / 3.0;
     double tol2 = 2.0 * tol1;
-    while (std::fabs(xf - xm) > (tol2 - 0.5 * (b - a))) {
+    while (fabs(xf - xm) > (tol2 - 0.5 * (b - a))) {
         bool golden = true;
-        if (std::fabs(e) > tol1) {  // try a parabolic step through (fulc, nfc, xf)
+        if (fabs(e) > tol1) {  // try a parabolic step through (fulc, nfc, xf)
             golden = false;
             double r = (xf - nfc) * (fx - ffulc);
             double q = (xf - fulc) * (fx - fnfc);
             double p = (xf - fulc) * q - (xf - nfc) * r;
             q = 2.0 * (q - r);
             if (q > 0.0) p = -p;
-            q = std::fabs(q);
+            q = fabs(q);
             r = e;
             e = rat;
-            if (std::fabs(p) < std::fabs(0.5 * q * r) && p > q * (a - xf) && p < q * (b - xf)) {
+            if (fabs(p) < fabs(0.5 * q * r) && p > q * (a - xf) && p < q * (b - xf)) {
                 rat = p / q;
                 x = xf + rat;
                 if ((x - a) < tol2 || (b - x) < tol2) {  // too close to an end point: step tol1 towards the middle
@@ -79,7 +82,7 @@ bool fminbound(F&& f, double x1, double x2, double xatol, int maxiter, double& x
             rat = golden_mean * e;
         }
         const double si = (rat > 0.0 ? 1.0 : (rat < 0.0 ? -1.0 : 0.0)) + (rat == 0.0 ? 1.0 : 0.0);
-        x = xf + si * std::max(std::fabs(rat), tol1);
+        x = xf + si * (fabs(rat) > tol1 ? fabs(rat) : tol1);
         if (!f(x, fu)) return false;
         ++num;
         if (fu <= fx) {
@@ -97,7 +100,7 @@ bool fminbound(F&& f, double x1, double x2, double xatol, int maxiter, double& x
             }
         }
         xm = 0.5 * (a + b);
-        tol1 = sqrt_eps * std::fabs(xf) + xatol / 3.0;
+        tol1 = sqrt_eps * fabs(xf) + xatol / 3.0;
         tol2 = 2.0 * tol1;
         if (num >= maxiter) break;
     }
@@ -116,7 +119,7 @@ MPPI_SEARCH_HD double lbps_objective(const SoftmaxStats& st, double delta) {
 // LBPS temperature (mppi.py:341-349): bounded minimisation of the objective over [lam_min, lam_max].
 // stats(lambda, SoftmaxStats&) -> bool evaluates the softmax sums (one device round trip per probe).
 template <class S>
-bool lbps_lambda(S&& stats, double delta, double lam_min, double lam_max, double& lam, int* nfev = nullptr) {
+MPPI_SEARCH_HD bool lbps_lambda(S&& stats, double delta, double lam_min, double lam_max, double& lam, int* nfev = nullptr) {
     return fminbound(
         [&](double l, double& out) {
             SoftmaxStats st{};

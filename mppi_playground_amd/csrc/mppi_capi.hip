@@ -42,6 +42,13 @@ struct MppiSolver {
     LbpsDev* lbps_dev = nullptr;              // grids of the device-resident LBPS search
     float* stats_max = nullptr;               // [STATS_BLOCKS] per-block maximum cost (LBPS: the cost range)
     double lbps_lo = 0.0, lbps_hi = 0.0;      // [lam_min, lam_max] the preset round-0 grid was built for
+    // device-resident Brent search of LBPS (lbps_brent_kernel): tagged cells, probe-tag base, error flag, the rule's variant
+    unsigned long long* brent_cells = nullptr;  // [2][BRENT_LANES][BRENT_CELLS]
+    unsigned brent_seq = 0;
+    int* search_error = nullptr;               // mapped pinned: a poll of lbps_brent_kernel timed out
+    int* search_error_dev = nullptr;
+    int lbps_grid = 0;                         // option "lbps_search": 0 = Brent on the device (default), 1 = the two-grid search
+    int lds_max = 65536;                       // hipDeviceAttributeMaxSharedMemoryPerBlock
     // single-launch solve (solve_fused_kernel): cells the blocks exchange through, its error flag, the solve counter
     unsigned long long* fused_cells = nullptr;
     int* fused_error = nullptr;        // mapped pinned
@@ -467,6 +474,12 @@ int mppi_create(const MppiConfig* cfg, mppi_handle_t* out) {
     HIP_TRY(h, hipMalloc(&h->mpo_temp_dev, sizeof(float)));
     HIP_TRY(h, hipMalloc(&h->lbps_dev, sizeof(LbpsDev)));
     HIP_TRY(h, hipMalloc(&h->stats_max, sizeof(float) * STATS_BLOCKS));
+    HIP_TRY(h, hipMalloc(&h->brent_cells, sizeof(unsigned long long) * 2 * BRENT_LANES * BRENT_CELLS));
+    HIP_TRY(h, hipMemset(h->brent_cells, 0, sizeof(unsigned long long) * 2 * BRENT_LANES * BRENT_CELLS));
+    HIP_TRY(h, hipHostMalloc((void**)&h->search_error, sizeof(int) * 16, hipHostMallocMapped));
+    *h->search_error = 0;
+    HIP_TRY(h, hipHostGetDevicePointer((void**)&h->search_error_dev, h->search_error, 0));
+    HIP_TRY(h, hipDeviceGetAttribute(&h->lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, cfg->device));
     HIP_TRY(h, hipMalloc(&h->lams_dev, sizeof(float) * 3 * STATS_L));
     HIP_TRY(h, hipMalloc(&h->essps_dev, sizeof(EsspsDev)));
     HIP_TRY(h, hipMalloc(&h->lambda_dev, sizeof(float)));
@@ -519,7 +532,8 @@ int mppi_destroy(mppi_handle_t h) {
     (void)hipFree(h->noise); (void)hipFree(h->costs); (void)hipFree(h->min_key); (void)hipFree(h->x0);
     (void)hipFree(h->x0_used); (void)hipFree(h->coltab); (void)hipFree(h->lams_dev); (void)hipFree(h->essps_dev);
     (void)hipFree(h->lambda_dev); (void)hipFree(h->mpo_dev); (void)hipFree(h->mpo_temp_dev); (void)hipFree(h->lbps_dev);
-    (void)hipFree(h->stats_max);
+    (void)hipFree(h->stats_max); (void)hipFree(h->brent_cells);
+    if (h->search_error) (void)hipHostFree(h->search_error);
     (void)hipFree(h->mean); (void)hipFree(h->mean_used); (void)hipFree(h->solve_stats); (void)hipFree(h->topk_hist);
     (void)hipFree(h->topk_sel); (void)hipFree(h->topk_cand); (void)hipFree(h->sg_coeffs); (void)hipFree(h->sg_history);
     (void)hipFree(h->ref); (void)hipFree(h->partials); (void)hipFree(h->heads);
@@ -543,6 +557,116 @@ int mppi_destroy(mppi_handle_t h) {
     if (h->lazy_ev) (void)hipEventDestroy(h->lazy_ev);
     (void)hipFree(h->b1);
     delete h;
+    return MPPI_OK;
+}
+
+// copy.deepcopy(solver) (the reference is a plain nn.Module, mppi.py:16: every tensor it holds is copied with it): make `dst`
+// — a handle created from the same MppiConfig — continue exactly like `src` from here: warm start, noise identity, costs and
+// minimum of the last solve (queries), Savitzky-Golay history, the temperature and every device-resident search / dual
+// state, model parameters, maps, reference window and path index, options.  Set-up path: synchronises the device.
+static int reserve_ref(mppi_handle_t h, int rows);
+static int clone_buf(mppi_handle_t h, void* dst, const void* src, size_t bytes) {
+    if (!bytes || !src || !dst) return MPPI_OK;
+    HIP_TRY(h, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToDevice));
+    return MPPI_OK;
+}
+int mppi_clone_state(mppi_handle_t dst, mppi_handle_t src) {
+    if (!dst || !src || dst == src) return fail(dst, MPPI_E_INVALID, "clone_state: two distinct handles");
+    const MppiConfig &a = dst->cfg, &b = src->cfg;
+    if (a.model != b.model || a.horizon != b.horizon || a.dim_state != b.dim_state || a.dim_control != b.dim_control ||
+        a.num_samples != b.num_samples || a.sample_offset != b.sample_offset || a.inherit_count != b.inherit_count ||
+        a.device != b.device)
+        return fail(dst, MPPI_E_INVALID, "clone_state: the handles were created from different configurations");
+    if (int rc = settle_state_seq(src)) return rc;
+    if (int rc = settle_state_seq(dst)) return rc;
+    HIP_TRY(dst, hipDeviceSynchronize());
+    const Dims& d = src->d;
+    dst->cfg = src->cfg; dst->d = src->d; dst->wide = src->wide; dst->limits_set = src->limits_set;
+    const size_t x0_floats = (size_t)std::max(src->ds, (int)MPPI_MAX_DIM_STATE);
+#define CLONE(field, bytes) do { if (int rc = clone_buf(dst, dst->field, src->field, (bytes))) return rc; } while (0)
+    if (src->tiles_valid) CLONE(noise, (size_t)d.tiles * d.R * 64 * sizeof(float4));
+    CLONE(costs, sizeof(float) * (size_t)d.N);
+    CLONE(min_key, 2 * sizeof(unsigned));
+    if (int rc = clone_buf(dst, dst->x0, src->x0_cur, sizeof(float) * (size_t)src->ds)) return rc;  // (a borrowed state becomes an owned copy)
+    dst->x0_cur = dst->x0;
+    CLONE(x0_used, sizeof(float) * x0_floats);
+    if (src->coltab && dst->coltab) CLONE(coltab, sizeof(float) * 12 * (size_t)d.R);
+    CLONE(mean, sizeof(float) * (size_t)d.row);
+    CLONE(mean_used, sizeof(float) * (size_t)d.row);
+    CLONE(solve_stats, sizeof(float) * 8);
+    CLONE(summary, sizeof(float) * (size_t)(MPPI_SUMMARY_HEAD + d.row));
+    CLONE(mpo_dev, sizeof(mppi::host::MpoState));
+    CLONE(mpo_temp_dev, sizeof(float));
+    CLONE(lbps_dev, sizeof(LbpsDev));
+    CLONE(lams_dev, sizeof(float) * 3 * STATS_L);
+    CLONE(essps_dev, sizeof(EsspsDev));
+    CLONE(lambda_dev, sizeof(float));
+    if (src->grid0_dev) {
+        if (!dst->grid0_dev) HIP_TRY(dst, hipMalloc(&dst->grid0_dev, sizeof(double) * STATS_L));
+        CLONE(grid0_dev, sizeof(double) * STATS_L);
+    }
+#undef CLONE
+    dst->min_slot = src->min_slot; dst->gen = src->gen; dst->tiles_valid = src->tiles_valid; dst->injected = src->injected;
+    dst->noise_regen = src->noise_regen; dst->mapping = src->mapping; dst->math_fast = src->math_fast;
+    dst->reduce_blocks = src->reduce_blocks; dst->reduce_chains = src->reduce_chains; dst->fold_mode = src->fold_mode;
+    dst->fused_mode = src->fused_mode; dst->fused_timeout_ticks = src->fused_timeout_ticks; dst->lbps_grid = src->lbps_grid;
+    dst->essps_merge0 = src->essps_merge0;
+    dst->auto_rule = src->auto_rule; dst->auto_param = src->auto_param; dst->auto_lo = src->auto_lo; dst->auto_hi = src->auto_hi;
+    dst->lbps_lo = src->lbps_lo; dst->lbps_hi = src->lbps_hi; dst->grid0_lo = src->grid0_lo; dst->grid0_hi = src->grid0_hi;
+    dst->essps_lo = src->essps_lo; dst->essps_hi = src->essps_hi; dst->essps_range = src->essps_range;
+    dst->essps_prev_host = src->essps_prev_host; dst->essps_prev_lo = src->essps_prev_lo; dst->essps_prev_hi = src->essps_prev_hi;
+    dst->lambda_dev_valid = src->lambda_dev_valid;
+    for (int i = 0; i < 3; ++i) dst->stats_host[8 + STATS_L * 3 + i] = src->stats_host[8 + STATS_L * 3 + i];  // the temperature's host mirror
+    dst->last_reduce_blocks = 0;            // the partial rows of src's last reduction are not copied ...
+    dst->summary_valid = src->summary_valid || src->last_reduce_blocks > 0;
+    if (!src->summary_valid && src->last_reduce_blocks > 0) {  // ... so a finalize on dst alone would find nothing: copy them after all
+        if (int rc = clone_buf(dst, dst->partials, src->partials, sizeof(float) * (size_t)2048 * src->colsp)) return rc;
+        if (int rc = clone_buf(dst, dst->heads, src->heads, sizeof(float) * (size_t)2048 * 4)) return rc;
+        dst->last_reduce_blocks = src->last_reduce_blocks; dst->summary_valid = false;
+    }
+    // Savitzky-Golay filter
+    dst->sg_window = 0;
+    if (src->sg_coeffs && src->sg_history) {
+        const size_t hist_floats = (size_t)std::max(d.T - 1, 1) * src->dc;
+        if (!dst->sg_coeffs) HIP_TRY(dst, hipMalloc(&dst->sg_coeffs, sizeof(float) * 256));
+        if (!dst->sg_history) HIP_TRY(dst, hipMalloc(&dst->sg_history, sizeof(float) * hist_floats));
+        if (int rc = clone_buf(dst, dst->sg_coeffs, src->sg_coeffs, sizeof(float) * 256)) return rc;
+        if (int rc = clone_buf(dst, dst->sg_history, src->sg_history, sizeof(float) * hist_floats)) return rc;
+        dst->sg_window = src->sg_window;
+    }
+    // lazily completed state sequences: the option, not a pending rollout (both were settled above)
+    if (src->lazy_state && !dst->b1) HIP_TRY(dst, hipMalloc(&dst->b1, sizeof(float) * ((size_t)d.row + MPPI_MAX_DIM_STATE)));
+    dst->lazy_state = src->lazy_state;
+    // model context: parameters and flags by value, every pointer re-aimed at dst's own copy
+    const ModelCtx old = dst->ctx;
+    dst->ctx = src->ctx;
+    dst->params_set = src->params_set;
+    for (int slot = 0; slot < 2; ++slot) {
+        dst->ctx.maps[slot].cells = old.maps[slot].cells;
+        if (!src->map_cells[slot]) { dst->ctx.maps[slot] = old.maps[slot]; continue; }
+        const MapView& m = src->ctx.maps[slot];
+        if (int rc = prepare_map(dst, slot, m.nx, m.ny, m.cell, m.ox, m.oy)) return rc;
+        if (int rc = clone_buf(dst, dst->map_cells[slot], src->map_cells[slot], (size_t)m.nx * m.ny)) return rc;
+    }
+    dst->ctx.ref = nullptr; dst->ctx.ref_rows = 0;
+    if (src->ref && src->ref_cap > 0) {
+        if (int rc = reserve_ref(dst, src->ref_cap)) return rc;
+        if (int rc = clone_buf(dst, dst->ref, src->ref, sizeof(float) * 8 * (size_t)src->ref_cap)) return rc;
+        if (src->ctx.ref) { dst->ctx.ref = dst->ref; dst->ctx.ref_rows = src->ctx.ref_rows; }
+    }
+    if (src->center_n) {
+        (void)hipFree(dst->center8); (void)hipFree(dst->win_dind);
+        dst->center8 = nullptr; dst->win_dind = nullptr;
+        HIP_TRY(dst, hipMalloc(&dst->center8, sizeof(float) * 8 * (size_t)src->center_n));
+        HIP_TRY(dst, hipMalloc(&dst->win_dind, sizeof(int32_t) * (size_t)src->win_rows));
+        if (!dst->path_index) HIP_TRY(dst, hipMalloc(&dst->path_index, sizeof(int32_t)));
+        if (int rc = clone_buf(dst, dst->center8, src->center8, sizeof(float) * 8 * (size_t)src->center_n)) return rc;
+        if (int rc = clone_buf(dst, dst->win_dind, src->win_dind, sizeof(int32_t) * (size_t)src->win_rows)) return rc;
+        if (int rc = clone_buf(dst, dst->path_index, src->path_index, sizeof(int32_t))) return rc;
+        dst->center_n = src->center_n; dst->win_rows = src->win_rows; dst->win_v = src->win_v;
+    }
+    refresh_pad(dst, nullptr);  // the padded grid of the fast lookups, rebuilt from dst's own maps
+    HIP_TRY(dst, hipDeviceSynchronize());
     return MPPI_OK;
 }
 
@@ -1165,6 +1289,8 @@ static bool fused_applies(mppi_handle_t h, float lambda) {
     // a fixed temperature up to a few thousand samples (27 vs 32 us for racing at N = 1024, 29 vs 32 at 4096, 33 vs 32 at
     // 8192), under a temperature search further (nav2d ESSPS 32 vs 47 us at N = 1024, 48 vs 52 at 16 384, 51 vs 52 at 32 768)
     const bool search = lambda == MPPI_LAMBDA_DEVICE && (h->auto_rule == MPPI_AUTO_ESSPS || h->auto_rule == MPPI_AUTO_LBPS);
+    // (the single launch searches LBPS on 32-temperature grids; the reference's Brent search is a kernel of its own)
+    if (lambda == MPPI_LAMBDA_DEVICE && h->auto_rule == MPPI_AUTO_LBPS && !h->lbps_grid) return false;
     if (h->fused_mode == 1 && h->d.N > (search ? FUSED_AUTO_MAX_SAMPLES_SEARCH : FUSED_AUTO_MAX_SAMPLES)) return false;
     if (!(h->noise_regen && !h->injected && !h->wide)) return false;         // the noise is regenerated in registers
     if (h->p2p_enabled || h->comm_enabled) return false;                      // sharded solves exchange between devices
@@ -1318,7 +1444,8 @@ int mppi_solve(mppi_handle_t h, const float* x0_dev, uint32_t solve_idx, float l
     if (dev && h->auto_rule == MPPI_AUTO_ESSPS) {
         if (int rc = mppi_essps_lambda_device(h, h->auto_param, h->auto_lo, h->auto_hi, stream)) return rc;
     } else if (dev && h->auto_rule == MPPI_AUTO_LBPS) {
-        if (int rc = mppi_lbps_lambda_device(h, h->auto_param, h->auto_lo, h->auto_hi, stream)) return rc;
+        if (int rc = h->lbps_grid ? mppi_lbps_lambda_device(h, h->auto_param, h->auto_lo, h->auto_hi, stream)
+                                  : mppi_lbps_brent_device(h, h->auto_param, h->auto_lo, h->auto_hi, stream)) return rc;
     }
     if (int rc = mppi_weights_reduce(h, lambda, nullptr, stream)) return rc;
     if (int rc = mppi_finalize(h, nullptr, 1, lambda, 1, action_out_dev, state_seq_out_dev, stats_out_dev, stream)) return rc;
@@ -1533,6 +1660,58 @@ int mppi_essps_lambda(mppi_handle_t h, double target_ess, double lam_min, double
     return ok ? MPPI_OK : rc;
 }
 
+// LBPS as the reference searches it (mppi.py:341-349: scipy's bounded Brent, host::fminbound step for step) with NO host
+// synchronisation: ONE launch of lbps_brent_kernel (mppi_search.hpp) runs every probe — the statistics of
+// mppi_softmax_stats bit for bit, gathered by every block through tagged cells — and leaves the temperature in HBM
+// (MPPI_LAMBDA_DEVICE) and in mapped host memory.  The same temperature as mppi_lbps_lambda, to the bit.
+int mppi_lbps_brent_device(mppi_handle_t h, double delta, double lam_min, double lam_max, void* stream) {
+    if (!h || !(lam_min > 0.0) || !(lam_max > lam_min) || !(delta > 0.0) || !(delta < 1.0))
+        return fail(h, MPPI_E_INVALID, "bad lbps arguments");
+    hipStream_t s = (hipStream_t)stream;
+    // the geometry of mppi_softmax_stats (stats_partial_kernel): nvb blocks of 256 threads, grid-stride over the costs;
+    // block l of this launch runs the virtual blocks l, l + 64, ... (lane l's rows of stats_combine_kernel)
+    const int nvb = (int)std::max<int64_t>(1, std::min<int64_t>(STATS_BLOCKS, (h->d.N + BLOCK - 1) / BLOCK));
+    const int64_t per_thread64 = (h->d.N + (int64_t)nvb * BLOCK - 1) / ((int64_t)nvb * BLOCK);
+    const int grid = std::min(nvb, BRENT_LANES);
+    const int threads = BLOCK * ((nvb + BRENT_LANES - 1) / BRENT_LANES);
+    if (grid > h->cu_count) return fail(h, MPPI_E_STATE, "lbps_brent: more blocks than CUs (they must be resident at once)");
+    int per_thread = (int)std::min<int64_t>(per_thread64, BRENT_STAGE_MAX + 1);  // (beyond the staging limit only the flag matters)
+    size_t shmem = per_thread <= BRENT_STAGE_MAX ? sizeof(float) * (size_t)per_thread * threads : 0;
+    if (shmem + sizeof(BrentLds) + 256 > (size_t)h->lds_max) { per_thread = BRENT_STAGE_MAX + 1; shmem = 0; }
+    if (shmem > 48 * 1024) {
+        static size_t granted = 0;  // (per process: the attribute belongs to the kernel, not to a handle)
+        if (shmem > granted) {
+            (void)hipFuncSetAttribute((const void*)lbps_brent_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+            (void)hipGetLastError();
+            granted = shmem;
+        }
+    }
+    if (h->brent_seq > 0xFFFFFFFFu - 2 * BRENT_SEQ_STRIDE) {  // tag space used up (after 8 million searches): start over on clean cells
+        HIP_TRY(h, hipMemsetAsync(h->brent_cells, 0, sizeof(unsigned long long) * 2 * BRENT_LANES * BRENT_CELLS, s));
+        h->brent_seq = 0;
+    }
+    const BrentCtx bx{h->brent_cells, h->search_error_dev, h->brent_seq, h->fused_timeout_ticks};
+    h->brent_seq += BRENT_SEQ_STRIDE;
+    double* host_lam = h->stats_host_dev + 8 + STATS_L * 3;
+    hipLaunchKernelGGL(lbps_brent_kernel, dim3(grid), dim3(threads), shmem, s, (const float*)h->costs, h->d.N,
+                       (const unsigned*)(h->min_key + h->min_slot), nvb, per_thread, delta, lam_min, lam_max, bx, h->lambda_dev,
+                       host_lam);
+    HIP_TRY(h, hipGetLastError());
+    h->lambda_dev_valid = true;
+    return MPPI_OK;
+}
+// 1 once a poll of a device-resident temperature search timed out on this handle (a block of lbps_brent_kernel never became
+// resident: the GPU is shared with other work): that solve's temperature — and with it its outputs — are NaN.
+int mppi_search_error(mppi_handle_t h) { return (h && h->search_error) ? *(volatile int*)h->search_error : 0; }
+#ifdef MPPI_BRENT_TRACE
+extern "C" int mppi_debug_brent_trace(mppi_handle_t h, int* out8) {  // 10 ns ticks of the last search per phase (block 0)
+    if (!h || !h->search_error) return MPPI_E_STATE;
+    (void)hipDeviceSynchronize();
+    for (int k = 0; k < 8; ++k) out8[k] = h->search_error[1 + k];
+    return MPPI_OK;
+}
+#endif
+
 // LBPS temperature (mppi.py:341-349,534-557): scipy's bounded Brent minimiser (host::fminbound, xatol 1e-5) of the
 // lower-bound objective over [lam_min, lam_max]; every probe is one mppi_softmax_stats round trip (two tiny launches
 // + a 40-byte read-back through mapped host memory), with no interpreter in the loop.  Unsharded handles; synchronises.
@@ -1602,6 +1781,23 @@ int mppi_mpo_state(mppi_handle_t h, double* out4_host) {
     HIP_TRY(h, hipDeviceSynchronize());
     HIP_TRY(h, hipMemcpy(&st, h->mpo_dev, sizeof(st), hipMemcpyDeviceToHost));
     out4_host[0] = st.log_temperature; out4_host[1] = st.m; out4_host[2] = st.v; out4_host[3] = st.t;
+    return MPPI_OK;
+}
+
+// The inverse of mppi_mpo_state (restoring a saved solver): {log T, first moment, second moment, step count} -> the dual; the
+// temperature of the next solve becomes exp(log T) (mppi.py:398).  epsilon / lr keep their values.  Synchronises the device.
+int mppi_mpo_set_state(mppi_handle_t h, const double* in4_host) {
+    if (!h || !in4_host) return fail(h, MPPI_E_INVALID, "null");
+    mppi::host::MpoState st;
+    HIP_TRY(h, hipDeviceSynchronize());
+    HIP_TRY(h, hipMemcpy(&st, h->mpo_dev, sizeof(st), hipMemcpyDeviceToHost));
+    st.log_temperature = (float)in4_host[0]; st.m = (float)in4_host[1]; st.v = (float)in4_host[2]; st.t = (int32_t)in4_host[3];
+    const float temp = st.temperature(), lam = (float)exp(st.log_temperature);
+    HIP_TRY(h, hipMemcpy(h->mpo_dev, &st, sizeof(st), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->mpo_temp_dev, &temp, sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->lambda_dev, &lam, sizeof(float), hipMemcpyHostToDevice));
+    h->stats_host[8 + STATS_L * 3] = h->stats_host[8 + STATS_L * 3 + 1] = (double)lam;
+    h->lambda_dev_valid = true;
     return MPPI_OK;
 }
 
@@ -1954,6 +2150,8 @@ int mppi_set_option(mppi_handle_t h, const char* key, int64_t value) {
         h->lazy_state = value ? 1 : 0;
         return MPPI_OK;
     }
+    if (k == "lbps_search") { h->lbps_grid = value ? 1 : 0; return MPPI_OK; }  // what mppi_solve's LBPS rule runs: 0 Brent (default), 1 grids
+    if (k == "search_rearm") { if (h->search_error) *(volatile int*)h->search_error = 0; return MPPI_OK; }
     if (k == "essps_merge0") { h->essps_merge0 = value != 0; return MPPI_OK; }  // A/B: round 0 of the ESSPS chain as one launch
     if (k == "fold_path") { h->fold_mode = (value >= 0 && value <= 2) ? (int)value : 0; return MPPI_OK; }
     if (k == "exchange_p2p") {  // sharded solves: summaries travel through the peer-to-peer buffer, no collective

@@ -11,6 +11,36 @@ namespace mppi {
 // of pulling costs[N] over PCIe and running ~10-40 softmaxes on the CPU.  Two tiny launches
 // (per-block partials, then a fixed-order combine written to mapped host memory): deterministic.
 constexpr int STATS_BLOCKS = 256;
+// One thread's share of the single-temperature statistics: the costs start, start + stride, ... in this order.  `load(i)`
+// fetches costs[i] (global memory, or a copy a block staged once).  stats_partial_kernel AND lbps_brent_kernel: the same
+// arithmetic in the same order, so that the Brent search on the device sees the statistics of mppi_softmax_stats bit for bit.
+template <bool WITH_MAX = true, class Load>
+__device__ __forceinline__ void stats_partial_thread(Load&& load, int64_t N, int64_t start, int64_t stride, float lambda,
+                                                     float xmax, float& se, float& se2, float& sec, float& cmax) {
+    se = 0.f; se2 = 0.f; sec = 0.f; cmax = -INFINITY;
+    int m = 0;
+    for (int64_t i = start; i < N; i += stride, ++m) {
+        const float c = load(i, m);
+        const float e = expf((-c) / lambda - xmax);
+        se += e;
+        se2 = fmaf(e, e, se2);
+        sec = fmaf(e, c, sec);
+        if (WITH_MAX) cmax = fmaxf(cmax, c);  // (the maximum does not depend on the temperature: a search needs it once)
+    }
+}
+template <bool WITH_MAX = true>
+__device__ __forceinline__ void stats_partial_wave(float& se, float& se2, float& sec, float& cmax) {
+    // (the butterflies of wave_sum / __shfl_xor to the bit, through DPP instead of the LDS crossbar: mppi_common.hpp)
+    se = wave_sum_bfly(se); se2 = wave_sum_bfly(se2); sec = wave_sum_bfly(sec);
+    if (WITH_MAX) cmax = wave_max_bfly(cmax);
+}
+// column j (0..2 sums, 3 the maximum) of a 256-thread block's partial row from its four waves' values s_p[w][j]
+__device__ __forceinline__ float stats_partial_fold(const float (*s_p)[4], int j) {
+    float v = s_p[0][j];
+#pragma unroll
+    for (int w = 1; w < BLOCK / WAVE; ++w) v = j == 3 ? fmaxf(v, s_p[w][3]) : v + s_p[w][j];
+    return v;
+}
 __global__ __launch_bounds__(BLOCK) void stats_partial_kernel(const float* __restrict__ costs, int64_t N,
                                                              const unsigned* __restrict__ min_key, float lambda_arg,
                                                              const float* __restrict__ lambda_dev /* nullable */,
@@ -19,42 +49,34 @@ __global__ __launch_bounds__(BLOCK) void stats_partial_kernel(const float* __res
     const float lambda = lambda_dev ? *lambda_dev : lambda_arg;
     const float cmin = key_to_float(*min_key);
     const float xmax = (-cmin) / lambda;
-    float se = 0.f, se2 = 0.f, sec = 0.f, cmax = -INFINITY;
-    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < N; i += (int64_t)gridDim.x * BLOCK) {
-        const float c = costs[i];
-        const float e = expf((-c) / lambda - xmax);
-        se += e;
-        se2 = fmaf(e, e, se2);
-        sec = fmaf(e, c, sec);
-        cmax = fmaxf(cmax, c);
-    }
-    se = wave_sum(se); se2 = wave_sum(se2); sec = wave_sum(sec);
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) cmax = fmaxf(cmax, __shfl_xor(cmax, m));
+    float se, se2, sec, cmax;
+    stats_partial_thread([&](int64_t i, int) { return costs[i]; }, N, (int64_t)blockIdx.x * BLOCK + threadIdx.x,
+                         (int64_t)gridDim.x * BLOCK, lambda, xmax, se, se2, sec, cmax);
+    stats_partial_wave(se, se2, sec, cmax);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     if (lane == 0) { s_p[wid][0] = se; s_p[wid][1] = se2; s_p[wid][2] = sec; s_p[wid][3] = cmax; }
     __syncthreads();
-    if (threadIdx.x < 4) {
-        float v = s_p[0][threadIdx.x];
-#pragma unroll
-        for (int w = 1; w < BLOCK / WAVE; ++w) v = threadIdx.x == 3 ? fmaxf(v, s_p[w][3]) : v + s_p[w][threadIdx.x];
-        part[blockIdx.x * 4 + threadIdx.x] = v;
+    if (threadIdx.x < 4) part[blockIdx.x * 4 + threadIdx.x] = stats_partial_fold(s_p, threadIdx.x);
+}
+// One wave: the partial rows part[b][0..3], b < nblocks, summed in double in a fixed order (lane l takes rows l, l + 64, ...,
+// then a butterfly).  Every lane returns the totals.
+template <class Row>
+__device__ __forceinline__ void stats_combine_wave(Row&& row, int nblocks, int lane, double& se, double& se2, double& sec,
+                                                   float& cmax) {
+    se = 0.0; se2 = 0.0; sec = 0.0; cmax = -INFINITY;
+    for (int b = lane; b < nblocks; b += WAVE) {
+        se += row(b, 0); se2 += row(b, 1); sec += row(b, 2);
+        cmax = fmaxf(cmax, row(b, 3));
     }
+    se = wave_sum_bfly(se); se2 = wave_sum_bfly(se2); sec = wave_sum_bfly(sec);
+    cmax = wave_max_bfly(cmax);
 }
 __global__ __launch_bounds__(WAVE) void stats_combine_kernel(const float* __restrict__ part, int nblocks,
                                                             const unsigned* __restrict__ min_key,
                                                             double* __restrict__ out /*[5] mapped host*/) {
-    double se = 0.0, se2 = 0.0, sec = 0.0;
-    float cmax = -INFINITY;
-    for (int b = threadIdx.x; b < nblocks; b += WAVE) {
-        se += part[b * 4]; se2 += part[b * 4 + 1]; sec += part[b * 4 + 2];
-        cmax = fmaxf(cmax, part[b * 4 + 3]);
-    }
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        se += __shfl_xor(se, m); se2 += __shfl_xor(se2, m); sec += __shfl_xor(sec, m);
-        cmax = fmaxf(cmax, __shfl_xor(cmax, m));
-    }
+    double se, se2, sec;
+    float cmax;
+    stats_combine_wave([&](int b, int j) { return part[b * 4 + j]; }, nblocks, (int)threadIdx.x, se, se2, sec, cmax);
     if (threadIdx.x == 0) {
         out[0] = (double)key_to_float(*min_key); out[1] = (double)cmax; out[2] = se; out[3] = se2; out[4] = sec;
     }
@@ -442,6 +464,223 @@ __global__ __launch_bounds__(1024) void lbps_select_kernel(const float* __restri
         const double gj = mppi::host::essps_grid_point<STATS_L>(s_bracket[0], s_bracket[1], j);
         st->grid[j] = gj;
         lams[j] = (float)gj;
+    }
+}
+
+// LBPS as the REFERENCE searches it — scipy's bounded Brent (mppi.py:341-349; host_search.hpp: fminbound, ported step for
+// step), ~22-31 DEPENDENT probes of the objective — without leaving the device: lbps_brent_kernel.
+//
+// mppi_lbps_lambda runs that search on the host: per probe two launches (stats_partial_kernel, stats_combine_kernel) and a
+// read-back, ~19 us each — 0.58 ms per solve at 65 536 samples, 12x the rest of the solve.  Here the search is ONE
+// launch of G = min(64, nvb) blocks, nvb = the blocks of stats_partial_kernel's grid ("virtual blocks": 256 threads, the
+// same threads own the same costs and add them in the same order), the costs staged once in LDS.  Block l runs the virtual
+// blocks l, l + 64, l + 128, l + 192 — exactly the partial rows LANE l of stats_combine_kernel adds up — so per probe it
+// publishes that lane's three double sums as six 8-byte {half, probe tag} cells (one relaxed agent-scope store each: data
+// and readiness cannot be seen apart, no fence — the protocol of essps_round_kernel / solve_fused_kernel); wave 0 of EVERY
+// block then gathers the G lanes' sums (lane l polls block l's cells: one wave per CU on the memory system, one round of
+// latency), finishes the sum with stats_combine_kernel's butterfly and takes the SAME Brent step in double precision:
+// identical inputs, identical code, so all blocks agree on the next temperature and nothing is broadcast — one dependent
+// hop through memory per probe instead of launch + launch + PCIe.  The temperature is the host search's TO THE BIT
+// (same partial sums, same order, same fp64 steps; tests/test_gpu_parity.py::test_device_brent_*).
+// (First form, measured: every virtual block published its fp32 row and all 1024 threads of every block gathered 8 KB of
+// cells — an all-to-all, 2.2-2.8 us per probe for the hop alone; several polls in flight per thread made it worse.)
+// Cells are double-buffered by probe parity: a block can run at most one probe ahead of the slowest one (it needs that
+// block's sums to finish a probe).  A poll that does not complete within the budget (a block that never became resident)
+// raises *error and leaves NaN — no hang.
+constexpr int BRENT_LANES = WAVE;                    // blocks of the launch = lanes of the combine (at most)
+constexpr int BRENT_GROUPS = STATS_BLOCKS / BRENT_LANES;  // virtual blocks per block (at most): 4
+constexpr int BRENT_THREADS = BLOCK * BRENT_GROUPS;  // 1024
+constexpr int BRENT_STAGE_MAX = 32;                  // costs per thread staged in LDS (128 KB); beyond that they are re-read (L2)
+constexpr int BRENT_MAXITER = 500;                   // scipy's maxiter: a search takes at most this many probes
+constexpr unsigned BRENT_SEQ_STRIDE = 512;           // probe tags of one launch: seq0 + 1 .. seq0 + BRENT_MAXITER
+constexpr int BRENT_CELLS = 8;                       // per (parity, block): 3 doubles as halves, the block's maximum cost, one spare
+struct BrentCtx {
+    unsigned long long* cells;  // [2][BRENT_LANES][BRENT_CELLS]
+    int* error;                 // mapped host flag
+    unsigned seq0;              // tags of this launch start above it (a multiple of BRENT_SEQ_STRIDE)
+    long long timeout_ticks;    // poll budget (100 MHz)
+};
+// -DMPPI_BRENT_TRACE (experiments only): block 0's lane 0 adds up the 100 MHz clock per phase of a probe into bx.error[1..8]
+#ifdef MPPI_BRENT_TRACE
+#define BRENT_TRACE(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const long long now_ = wall_clock64(); L.trace[k] += (int)(now_ - L.tlast); L.tlast = now_; } } while (0)
+#else
+#define BRENT_TRACE(k) do { } while (0)
+#endif
+struct BrentLds {
+    float p[BRENT_THREADS / WAVE][4];  // per-wave partial sums of the probe
+    float lam, xmax;                   // the temperature of the probe in flight (fp32: what the host search hands the device), (-cmin) / it
+    int go;
+#ifdef MPPI_BRENT_TRACE
+    long long tlast;
+    int trace[8];
+#endif
+};
+// (polls: one round of loads in flight per lane and a short sleep between rounds — more loads in flight per lane were
+// measured SLOWER: the polls of 64 CUs queue up behind each other in the memory system)
+#ifndef BRENT_POLL_SLEEP
+#define BRENT_POLL_SLEEP 1
+#endif
+__device__ __forceinline__ void brent_publish_wave(int nvb, const BrentCtx& bx, unsigned probe, const BrentLds& L, int lane);
+// The block's share of one probe, by every thread: the partial sums of its virtual blocks, per wave, into L.p (ends with
+// the barrier that publishes them to wave 0).
+__device__ __forceinline__ void brent_partials_block(const float* __restrict__ costs, const float* s_cost, bool staged, int64_t N,
+                                                     int nvb, const BrentCtx& bx, unsigned probe, BrentLds& L) {
+    const int tid = threadIdx.x, g = tid >> 8, t = tid & (BLOCK - 1);
+    const int vb = (int)blockIdx.x + BRENT_LANES * g;
+    const float lambda = L.lam;
+    const float xmax = L.xmax;  // (-cmin) / lambda, divided once per block instead of once per thread (the same bits)
+    float se, se2, sec, cmax;
+    const int64_t n_eff = vb < nvb ? N : 0, start = (int64_t)vb * BLOCK + t, stride = (int64_t)nvb * BLOCK;
+    const auto from_lds = [&](int64_t, int m) { return s_cost[m * (int)blockDim.x + tid]; };
+    const auto from_mem = [&](int64_t i, int) { return costs[i]; };
+    // (the maximum cost — the objective's range term — does not depend on the temperature: the first probe computes and
+    // publishes it, the later ones skip its share of the loop, its butterfly and its cell: ~25 of ~100 instructions per wave)
+    if (probe == 1) {
+        if (staged) stats_partial_thread<true>(from_lds, n_eff, start, stride, lambda, xmax, se, se2, sec, cmax);
+        else stats_partial_thread<true>(from_mem, n_eff, start, stride, lambda, xmax, se, se2, sec, cmax);
+        BRENT_TRACE(1);  // exp + sums of the thread
+        stats_partial_wave<true>(se, se2, sec, cmax);
+    } else {
+        if (staged) stats_partial_thread<false>(from_lds, n_eff, start, stride, lambda, xmax, se, se2, sec, cmax);
+        else stats_partial_thread<false>(from_mem, n_eff, start, stride, lambda, xmax, se, se2, sec, cmax);
+        BRENT_TRACE(1);
+        stats_partial_wave<false>(se, se2, sec, cmax);
+    }
+    const int lane = tid & 63, wid = tid >> 6;
+    if (lane == 0) { L.p[wid][0] = se; L.p[wid][1] = se2; L.p[wid][2] = sec; L.p[wid][3] = cmax; }
+    BRENT_TRACE(2);  // wave reduction
+    __syncthreads();  // (B)
+    // wave 1 publishes (wave 0 gathers meanwhile: a wave that stores waits for the store's acknowledgement — a trip to
+    // memory for a write-through store — before it can look at a load issued after it: one counter, in order)
+    if (wid == 1) brent_publish_wave(nvb, bx, probe, L, lane);
+}
+// Wave 1 after (B): this block's lane sums (stats_combine_wave's loop over its rows: blockIdx.x, + 64, ... ascending, like
+// lane blockIdx.x of the combine) and its maximum, published as seven tagged cells.
+__device__ __forceinline__ void brent_publish_wave(int nvb, const BrentCtx& bx, unsigned probe, const BrentLds& L, int lane) {
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    float mx = -INFINITY;
+    for (int g = 0; g < BRENT_GROUPS; ++g)
+        if ((int)blockIdx.x + BRENT_LANES * g < nvb) {
+            const float (*wp)[4] = L.p + g * (BLOCK / WAVE);
+            a0 += stats_partial_fold(wp, 0); a1 += stats_partial_fold(wp, 1); a2 += stats_partial_fold(wp, 2);
+            mx = fmaxf(mx, stats_partial_fold(wp, 3));
+        }
+    const unsigned tag = bx.seq0 + probe;
+    unsigned long long* mine = bx.cells + ((size_t)(probe & 1u) * BRENT_LANES + blockIdx.x) * BRENT_CELLS;
+    if (lane < (probe == 1 ? 7 : 6)) {
+        const unsigned long long b0 = (unsigned long long)__double_as_longlong(a0), b1 = (unsigned long long)__double_as_longlong(a1),
+                                 b2 = (unsigned long long)__double_as_longlong(a2);
+        const unsigned half = lane == 0 ? (unsigned)b0 : lane == 1 ? (unsigned)(b0 >> 32) : lane == 2 ? (unsigned)b1
+                            : lane == 3 ? (unsigned)(b1 >> 32) : lane == 4 ? (unsigned)b2 : lane == 5 ? (unsigned)(b2 >> 32)
+                            : __float_as_uint(mx);
+        __hip_atomic_store(mine + lane, ((unsigned long long)tag << 32) | (unsigned long long)half, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+// Wave 0 after (B): every lane's sums gathered (lane l polls block l's cells), then the butterfly.  Every lane returns the
+// totals; false = a poll timed out.
+__device__ __forceinline__ bool brent_gather_wave(int nvb, const BrentCtx& bx, unsigned probe, BrentLds& L, long long t0,
+                                                  double& se, double& se2, double& sec, float& cmax) {
+    const int lane = threadIdx.x;  // (wave 0)
+    const int G = nvb < BRENT_LANES ? nvb : BRENT_LANES;
+    const unsigned tag = bx.seq0 + probe;
+    bool timed_out = false;
+    se = 0.0; se2 = 0.0; sec = 0.0; cmax = -INFINITY;
+    if (lane < G) {
+        const unsigned long long* theirs = bx.cells + ((size_t)(probe & 1u) * BRENT_LANES + lane) * BRENT_CELLS;
+        const int ncell = probe == 1 ? 7 : 6;  // (the maximum travels with the first probe only)
+        unsigned long long c[7];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) c[j] = j < ncell ? __hip_atomic_load(theirs + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        for (;;) {
+            bool all = true;
+#pragma unroll
+            for (int j = 0; j < 7; ++j) all = all && (j >= ncell || (unsigned)(c[j] >> 32) == tag);
+            if (all) break;
+            if (wall_clock64() - t0 > bx.timeout_ticks) { timed_out = true; break; }
+            __builtin_amdgcn_s_sleep(BRENT_POLL_SLEEP);
+#pragma unroll
+            for (int j = 0; j < 7; ++j)
+                if (j < ncell) c[j] = __hip_atomic_load(theirs + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        se = __longlong_as_double((long long)((c[1] << 32) | (c[0] & 0xFFFFFFFFull)));
+        se2 = __longlong_as_double((long long)((c[3] << 32) | (c[2] & 0xFFFFFFFFull)));
+        sec = __longlong_as_double((long long)((c[5] << 32) | (c[4] & 0xFFFFFFFFull)));
+        if (probe == 1) cmax = __uint_as_float((unsigned)c[6]);
+    }
+    BRENT_TRACE(4);  // gather
+    se = wave_sum_bfly(se); se2 = wave_sum_bfly(se2); sec = wave_sum_bfly(sec);
+    if (probe == 1) cmax = wave_max_bfly(cmax);
+    BRENT_TRACE(5);  // butterfly
+    return !__any(timed_out);
+}
+__global__ __launch_bounds__(BRENT_THREADS) void lbps_brent_kernel(const float* __restrict__ costs, int64_t N,
+                                                                   const unsigned* __restrict__ min_key, int nvb, int per_thread,
+                                                                   double delta, double lam_min, double lam_max, BrentCtx bx,
+                                                                   float* __restrict__ lambda_out,
+                                                                   double* __restrict__ lambda_host /*[3]: next, used, probes*/) {
+    extern __shared__ float s_cost[];  // [per_thread][blockDim.x] when staged
+    __shared__ BrentLds L;
+    const int tid = threadIdx.x;
+    const bool staged = per_thread <= BRENT_STAGE_MAX;
+    const long long t0 = wall_clock64();
+    if (staged) {
+        const int vb = (int)blockIdx.x + BRENT_LANES * (tid >> 8);
+        int m = 0;
+        if (vb < nvb)
+            for (int64_t i = (int64_t)vb * BLOCK + (tid & (BLOCK - 1)); i < N; i += (int64_t)nvb * BLOCK, ++m)
+                s_cost[m * (int)blockDim.x + tid] = costs[i];  // (read back by the same thread only: no barrier needed)
+    }
+    if (tid == 0) {
+        L.go = 0;
+#ifdef MPPI_BRENT_TRACE
+        L.tlast = wall_clock64();
+        for (int k = 0; k < 8; ++k) L.trace[k] = 0;
+#endif
+    }
+    const float cmin = key_to_float(*min_key);
+    __syncthreads();
+    if (tid < WAVE) {  // wave 0: the search itself (every lane the same scalars); the probe's barriers pair with the loop below
+        unsigned probe = 0;
+        double lam = 0.0;
+        int nfev = 0;
+        float cmax_all = -INFINITY;  // (gathered with the first probe)
+        const bool ok = mppi::host::lbps_lambda(
+            [&](double x, mppi::host::SoftmaxStats& st) {
+                if (tid == 0) { L.lam = (float)x; L.xmax = (-cmin) / (float)x; L.go = 1; }
+                ++probe;
+                BRENT_TRACE(6);  // objective + Brent step
+                __syncthreads();  // (A) the other waves pick the temperature up
+                BRENT_TRACE(0);  // barrier A
+                brent_partials_block(costs, s_cost, staged, N, nvb, bx, probe, L);
+                BRENT_TRACE(3);  // barrier B
+                double se, se2, sec;
+                float cmax;
+                if (!brent_gather_wave(nvb, bx, probe, L, t0, se, se2, sec, cmax)) return false;
+                if (probe == 1) cmax_all = cmax;
+                st = mppi::host::SoftmaxStats{(double)cmin, (double)cmax_all, se, se2, sec};
+                return true;
+            },
+            delta, lam_min, lam_max, lam, &nfev);
+        if (tid == 0) L.go = 0;
+        __syncthreads();  // (A) releases the other waves for good
+        if (blockIdx.x == 0 && tid == 0) {
+            if (!ok) { lam = NAN; *bx.error = 1; }
+            *lambda_out = (float)lam;
+            lambda_host[0] = lam; lambda_host[1] = lam; lambda_host[2] = (double)nfev;
+#ifdef MPPI_BRENT_TRACE
+            BRENT_TRACE(7);
+            for (int k = 0; k < 8; ++k) bx.error[1 + k] = L.trace[k];
+#endif
+        }
+    } else {
+        unsigned probe = 0;
+        for (;;) {
+            __syncthreads();  // (A)
+            if (!L.go) break;
+            ++probe;
+            brent_partials_block(costs, s_cost, staged, N, nvb, bx, probe, L);
+        }
     }
 }
 

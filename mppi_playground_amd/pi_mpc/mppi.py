@@ -31,13 +31,14 @@ from pi_mpc.sharding import all_gather_summaries, shard_range
 from pi_mpc._exchange import ExchangeMixin
 from pi_mpc._generic import GenericPathMixin
 from pi_mpc._lazy import _DeferredStateSeq, _LazyInfoTensor, _ptr  # noqa: F401  (re-exported: tests, callers)
+from pi_mpc._module import ModuleProtocolMixin
 from pi_mpc._queries import QueriesMixin
 
 
 _NO_INFO: Dict = {}  # forward()'s default `info` (the reference's shared mutable default, mppi.py:224): nobody can read it back
 
 
-class MPPI(ExchangeMixin, GenericPathMixin, QueriesMixin, nn.Module):
+class MPPI(ModuleProtocolMixin, ExchangeMixin, GenericPathMixin, QueriesMixin, nn.Module):
     """Model Predictive Path Integral control (Williams et al., T-RO 2017) — MI355X-native."""
 
     # Private state ("_name") never holds Parameters, sub-modules or buffers, so it skips nn.Module's attribute
@@ -104,17 +105,17 @@ class MPPI(ExchangeMixin, GenericPathMixin, QueriesMixin, nn.Module):
                 statistics back after each pass; "brentq" probes one lambda at a time like the reference's scipy
                 call.  All return the same root (to ~1e-6 relative).  Sharded solvers combine the shards'
                 statistics on the host ("device" behaves like "grid" there).
-            lbps_search: with device statistics on one GPU.  "brent" (default since round 5) is the reference's own
-                algorithm (mppi.py:341-349: scipy's bounded Brent, ported step for step in csrc/host_search.hpp) inside
-                the library, one read-back of the device's softmax statistics per probe — the north star's split (auto-lambda
-                on the host) and the rule that lands where the reference lands: within its own measured spread on every
-                LBPS fixture (2.7e-5 .. 2.8e-3 against bands of 5.8e-5 .. 1.4e-2).  "device" is the opt-in fast path:
-                two 32-temperature grids + the minimiser of the quartic through the five grid points around the minimum,
-                all as kernels (no host wait; C2: 64 us per solve instead of ~1 ms).  On exact statistics it returns the
-                float64 minimiser to 3e-7 — the REFERENCE's Brent stops 6e-5..5e-3 away from that (xatol = 1e-5 absolute,
-                short of a bound it never evaluates, on an objective that is flat to fp32 noise for nav2d: its temperature
-                moves by up to 1e-2 under 1-ulp changes of its costs — the `band_rule` entries of tests/golden/), so
-                "device" agrees with the reference to that spread only.
+            lbps_search: with device statistics on one GPU.  "brent" (default) is the reference's own algorithm
+                (mppi.py:341-349: scipy's bounded Brent, ported step for step in csrc/host_search.hpp) run ON THE DEVICE
+                (round 6, mppi_lbps_brent_device: one launch for all ~22-31 dependent probes, the temperature stays in HBM,
+                no host wait, capturable) — the rule that lands where the reference lands: within its own measured spread on
+                every LBPS fixture.  "brent_host" is the same search as a host loop inside the library (mppi_lbps_lambda:
+                one read-back of the device's statistics per probe, ~0.5 ms per solve; round 5's default) — the two return
+                the same temperature TO THE BIT (same partial sums, same fp64 steps), which is what the GPU tests hold the
+                device search to.  "grid" (round 3-5: "device", still accepted) is the two-grid search + quartic
+                (mppi_lbps_lambda_device): on exact statistics the float64 minimiser to 3e-7, but the REFERENCE's Brent
+                stops 6e-5..5e-3 away from that (xatol = 1e-5 absolute on an objective that is flat to fp32 noise for
+                nav2d), so "grid" agrees with the reference to that spread only; kept for comparison.
                 The MPO dual always steps on the device when the statistics are the device's own.
             recognize_closures: True (default): untagged callables that ARE the closures of the reference's classic-control
                 examples (example/pendulum.py, cartpole.py, mountaincar.py, mujoco_cartpole.py: same source fingerprint AND
@@ -149,6 +150,15 @@ class MPPI(ExchangeMixin, GenericPathMixin, QueriesMixin, nn.Module):
         CPU device is refused; "cuda" / "cuda:i" must name the process's current device (one process per GPU).
         """
         super().__init__()
+        # (what copy.deepcopy constructs the copy from: pi_mpc/_module.py)
+        self._ctor = dict(horizon=horizon, num_samples=num_samples, dim_state=dim_state, dim_control=dim_control, dynamics=dynamics,
+                          cost_func=cost_func, u_min=u_min, u_max=u_max, sigmas=sigmas, lambda_=lambda_, lbps_delta=lbps_delta,
+                          essps_target_ess=essps_target_ess, lambda_min=lambda_min, lambda_max=lambda_max, exploration=exploration,
+                          use_sg_filter=use_sg_filter, sg_window_size=sg_window_size, sg_poly_order=sg_poly_order, device=device,
+                          dtype=dtype, seed=seed, noise_source=noise_source, shard_samples=shard_samples,
+                          process_group=process_group, auto_lambda_stats=auto_lambda_stats, essps_search=essps_search,
+                          lbps_search=lbps_search, recognize_closures=recognize_closures, sg_filter=sg_filter,
+                          graph_callables=graph_callables, lazy_state_seq=lazy_state_seq, _force_exchange=_force_exchange)
         assert u_min.shape == (dim_control,)
         assert u_max.shape == (dim_control,)
         assert sigmas.shape == (dim_control,)
@@ -195,8 +205,10 @@ class MPPI(ExchangeMixin, GenericPathMixin, QueriesMixin, nn.Module):
         if essps_search not in ("device", "grid", "brentq"):
             raise ValueError("essps_search must be 'device', 'grid' or 'brentq'")
         self._essps_search = essps_search
-        if lbps_search not in ("device", "brent"):
-            raise ValueError("lbps_search must be 'device' or 'brent'")
+        if lbps_search == "device":  # rounds 3-5 name of the grid search
+            lbps_search = "grid"
+        if lbps_search not in ("brent", "brent_host", "grid"):
+            raise ValueError("lbps_search must be 'brent', 'brent_host' or 'grid'")
         self._lbps_search = lbps_search
         assert sg_filter in ("device", "host")
         self._sg_on_device = sg_filter == "device"
@@ -308,8 +320,9 @@ class MPPI(ExchangeMixin, GenericPathMixin, QueriesMixin, nn.Module):
             if self._auto_lambda == "ESSPS" and essps_search == "device":
                 self._rule_on_device = "ESSPS"
                 self._push_auto_lambda()
-            elif self._auto_lambda == "LBPS" and lbps_search == "device":
+            elif self._auto_lambda == "LBPS" and lbps_search in ("brent", "grid"):
                 self._rule_on_device = "LBPS"
+                self._h.call("mppi_set_option", b"lbps_search", 1 if lbps_search == "grid" else 0)
                 self._push_auto_lambda()
             elif self._auto_lambda == "MPO":
                 self._rule_on_device = "MPO"
@@ -397,6 +410,9 @@ class MPPI(ExchangeMixin, GenericPathMixin, QueriesMixin, nn.Module):
         the next solve uses and the Adam moments are derived state the library keeps next to it: restart the dual from the
         loaded value (mppi_mpo_reset: lambda = exp(log T), moments zero, like a freshly constructed reference solver whose
         parameter was loaded before its optimizer state) instead of leaving them stale."""
+        if module.__dict__.pop("_mpo_restored", False):  # `_extra_state` carried the whole dual (moments included): nothing to restart
+            module._bind_log_temperature()
+            return
         if module.__dict__.get("_auto_lambda") == "MPO" and module._rule_on_device == "MPO":
             v = float(module.log_temperature.detach().cpu()[0])
             module._h.call("mppi_mpo_reset", float(np.exp(v)), 0.1, 0.2)
@@ -739,9 +755,21 @@ class MPPI(ExchangeMixin, GenericPathMixin, QueriesMixin, nn.Module):
     def _lam_fixed(self, st) -> None:
         pass
 
-    def _lam_lbps_device(self, st) -> None:  # grid rounds as kernels: nothing is read back
-        self._h.call("mppi_lbps_lambda_device", float(self._lbps_delta), float(self._lambda_min), float(self._lambda_max), st)
+    def _lam_lbps_device(self, st) -> None:  # the Brent search (or the grid rounds) as kernels: nothing is read back
+        self._check_search_error()
+        self._h.call("mppi_lbps_lambda_device" if self._lbps_search == "grid" else "mppi_lbps_brent_device",
+                     float(self._lbps_delta), float(self._lambda_min), float(self._lambda_max), st)
         self._lambda_pending, self._lambda_stream = True, st
+
+    def _check_search_error(self) -> None:
+        """A poll of the device-resident Brent search gave up on an EARLIER solve (one of its blocks never became resident: the
+        GPU is shared with other work) — that solve's temperature and outputs are NaN.  Raised once per occurrence."""
+        h = self._h
+        if self._rule_on_device == "LBPS" and self._lbps_search == "brent" and h.lib.mppi_search_error(h.h):
+            h.call("mppi_set_option", b"search_rearm", 1)
+            raise _capi.MppiError("the device-resident LBPS search gave up waiting for one of its blocks on an earlier solve "
+                                  "(budget: set_option('fused_timeout_us', ...), default 20 ms; is the GPU shared with other "
+                                  "work?): that solve returned NaN.  lbps_search='brent_host' searches with a host loop instead")
 
     def _lam_mpo_device(self, st) -> None:  # this solve uses the temperature the dual left in HBM (or the caller's)
         self._lambda_pending, self._lambda_stream = self._lambda_override is None, st
@@ -913,6 +941,8 @@ class MPPI(ExchangeMixin, GenericPathMixin, QueriesMixin, nn.Module):
         else:  # the configured rule runs on the device; the temperature is fetched when somebody asks for it
             if self._rule_on_device != "MPO":
                 self._push_auto_lambda()
+                if self._rule_on_device == "LBPS":
+                    self._check_search_error()
             lam = _capi.LAMBDA_DEVICE
             me["_lambda_pending"], me["_lambda_stream"], me["_used_known"] = True, st, False
         # (the previous solve's state tensor stays alive across this launch: with a lazily completed state sequence this

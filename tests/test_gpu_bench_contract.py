@@ -38,3 +38,10 @@ def test_bench_line_at_one_gpu():
     assert rf["kernel_ms"] <= d["ms_per_step"]
     assert rf["traffic"] is None or rf["traffic"] > 0
     assert isinstance(rf["traffic_stale"], bool)
+    # the headline is the product out of the box: no extension keyword, state_seq completed inside the solve
+    assert d["config"]["solver_kwargs"] == {} and d["config"]["state_seq"].startswith("default")
+    # ... and a longer region on the same solver does not contradict it: a timed region only ever ADDS a fixed cost, so the
+    # best of three 200-step regions must not be slower per step than the contract's K-step one (1 % for the box's jitter)
+    lr = d["long_run"]
+    assert lr["same_solver_and_timing_as_headline"] and len(lr["repetitions"]) == 3
+    assert lr["ms_per_step"] <= d["ms_per_step"] * 1.01, (lr, d["ms_per_step"])

@@ -121,7 +121,7 @@ def check_rel(quantity, got, want, tol):
 # sample maximum): a measurement of the reference's own spread, held at 1.0x.  The parity report also counts the checks
 # beyond 1e-5 and gives each band's 99th percentile.
 BAND_MARGIN = 1.0
-# ... except for the OPT-IN device-resident LBPS search (lbps_search="device"): it returns the float64 minimiser of the
+# ... except for the OPT-IN grid search of LBPS (lbps_search="grid"): it returns the float64 minimiser of the
 # objective, which is not where the reference's Brent stops (MPPI's docstring); end to end it is held to 1.5x the band
 BAND_MARGIN_FAST_LBPS = 1.5
 
@@ -168,15 +168,20 @@ def check_end_to_end(a, s, c_gpu, g, k, cfg, band_a, band_s, tag="", margin=None
 # the library's own search tolerances (the reference-side spread of the temperature comes from the fixture bands):
 # ESSPS: grid + inverse interpolation, checked to 1e-5 against brentq (test_host_logic); LBPS: scipy's bounded Brent stops
 # within xatol = 1e-5 ABSOLUTE + sqrt(eps) of a minimum of the reference's fp32 objective, short of a bound it never
-# evaluates (pendulum: lambda_max = 10 -> 9.9994..9.9998), while the library's opt-in grid search (lbps_search="device")
-# returns the float64 minimiser to 1e-7: 1e-3 for that one; the default — the port of scipy's Brent — is held to 1e-4
+# evaluates (pendulum: lambda_max = 10 -> 9.9994..9.9998), while the library's opt-in grid search (lbps_search="grid")
+# returns the float64 minimiser to 1e-7: 1e-3 for that one; the default — the port of scipy's Brent, on the device since
+# round 6, or as a host loop (lbps_search="brent_host") — is held to 1e-4
 LBPS_TOL = 1e-3
 LBPS_TOL_BRENT = 1e-4
 LAMBDA_TOL = {"ESSPS": 1e-4}
 
 
+def grid_lbps(solver):
+    return getattr(solver, "_rule_on_device", None) == "LBPS" and solver._lbps_search == "grid"
+
+
 def lbps_floor(solver):
-    return LBPS_TOL if getattr(solver, "_rule_on_device", None) == "LBPS" else LBPS_TOL_BRENT
+    return LBPS_TOL if grid_lbps(solver) else LBPS_TOL_BRENT
 
 
 # ------------------------------------------------------------------------------ whole solve vs oracle / golden
@@ -296,7 +301,7 @@ _HOST_TEMPERATURE_CASES = ["pendulum_T50_N1000_essps", "cartpole_T64_N1024_essps
 
 def _host_temperature_params():
     """(case, mode) pairs that exist: "host" for every rule; "brent" (the library's ports probing device statistics) for
-    the two searches — MPO has no search, its device-statistics step is the default path; "device" for LBPS only — the
+    the two searches — MPO has no search, its device-statistics step is the default path; "grid" for LBPS only — the
     device-resident ESSPS search is the default and runs in test_identical_seed_closed_loop_matches_reference."""
     out = []
     for name in _HOST_TEMPERATURE_CASES:
@@ -305,7 +310,7 @@ def _host_temperature_params():
         if rule != "MPO":
             out.append((name, "brent"))
         if rule == "LBPS":
-            out.append((name, "device"))
+            out.append((name, "grid"))
     return out
 
 
@@ -315,10 +320,12 @@ def test_identical_seed_closed_loop_with_the_temperature_on_the_host(name, mode)
     mode "host": `auto_lambda_stats="host"`: costs[N] copied to the CPU and searched with scipy's brentq / bounded Brent /
     the Adam step in numpy fp32, the reference's own calls (mppi.py:341-370,387-398; pi_mpc/_host.py);
     mode "brent": the same root-finders inside the library (csrc/host_search.hpp ports of brentq's bracket rule and of
-    scipy's bounded Brent) probing the device-side softmax statistics one temperature at a time (LBPS: the default);
-    mode "device": the searches as kernels, the temperature resident in HBM (ESSPS: the default; LBPS: the opt-in fast path)."""
-    kw = {"host": dict(auto_lambda_stats="host"), "brent": dict(lbps_search="brent", essps_search="brentq"),
-          "device": dict(lbps_search="device")}[mode]
+    scipy's bounded Brent) probing the device-side softmax statistics one temperature at a time, as host loops (LBPS: the
+    DEFAULT runs this very search on the device — test_identical_seed_closed_loop_matches_reference — and must return the
+    host loop's temperature to the bit: test_device_brent_*);
+    mode "grid": LBPS's opt-in grid search as kernels."""
+    kw = {"host": dict(auto_lambda_stats="host"), "brent": dict(lbps_search="brent_host", essps_search="brentq"),
+          "grid": dict(lbps_search="grid")}[mode]
     _identical_seed_closed_loop(name, tag="_" + mode, **kw)
 
 
@@ -354,7 +361,7 @@ def _identical_seed_closed_loop(name, tag="", **solver_kw):
         else:
             assert lam == lam_ref
         check_end_to_end(a.cpu().numpy(), s.cpu().numpy(), c, g, k, cfg, band["action"], band["state"], tag=tag,
-                         margin=BAND_MARGIN_FAST_LBPS if solver._rule_on_device == "LBPS" else None)
+                         margin=BAND_MARGIN_FAST_LBPS if grid_lbps(solver) else None)
         if "posterior_after" in g.files and int(g["posterior_after"]) == k:
             ps, pst = solver.get_samples_from_posterior(a, state, g["posterior_samples"].shape[0])
             assert rel_err(ps.cpu().numpy(), g["posterior_samples"]) <= max(TOL, BAND_MARGIN * band["action"])
@@ -958,6 +965,124 @@ def test_baseline_configs_against_oracle(model, T, N, lam):
     check_rel("state_seq_vs_oracle_rollout", s.cpu().numpy()[0], P.rollout_single(x0, a.cpu().numpy()), TOL)
 
 
+def brent_cost_vector(rng, N, kind):
+    """Cost vectors for the LBPS search: the shapes of the shipped models' costs and awkward ones."""
+    if kind == 0:    # nav2d-like: distances + collision penalties
+        c = rng.uniform(10, 40, N) + 1e4 * rng.integers(0, 30, N) * (rng.random(N) < 0.5)
+    elif kind == 1:  # racing-like
+        c = rng.uniform(300, 3000, N) + 1e4 * rng.integers(0, 25, N) * (rng.random(N) < 0.4)
+    elif kind == 2:  # pendulum / cartpole-like: a smooth, narrow range
+        c = rng.gamma(2.0, rng.uniform(0.5, 50.0), N) + rng.uniform(0, 100)
+    elif kind == 3:  # a range of e^40
+        c = np.exp(rng.uniform(-20, 20, N))
+    elif kind == 4:  # mixed signs, any scale
+        c = rng.standard_normal(N) * 10.0 ** rng.integers(-3, 6)
+    elif kind == 5:  # all equal: the objective has no range term
+        c = np.full(N, float(rng.uniform(-5, 5)))
+    elif kind == 6:  # few distinct values
+        c = rng.integers(0, max(2, N // 50), N).astype(np.float64)
+    else:            # one clear winner
+        c = rng.uniform(100, 200, N)
+        c[int(rng.integers(0, N))] = 1.0
+    return np.ascontiguousarray(c, dtype=np.float32)
+
+
+def brent_both(solver, costs, delta=0.01, lo=0.01, hi=10.0):
+    """(host loop's temperature, device search's temperature, probes of either) on the same uploaded cost vector."""
+    st = solver._stream()
+    c = torch.from_numpy(costs).cuda()
+    solver._h.call("mppi_set_costs", c.data_ptr(), 1, st)
+    lam_host = C.c_double(0.0)
+    solver._h.call("mppi_lbps_lambda", delta, lo, hi, C.byref(lam_host), st)
+    solver._h.call("mppi_lbps_brent_device", delta, lo, hi, st)
+    lam_dev, used = C.c_double(0.0), C.c_double(0.0)
+    solver._h.call("mppi_get_lambda", C.byref(lam_dev), C.byref(used), st)
+    assert not solver._h.lib.mppi_search_error(solver._h.h)
+    return lam_host.value, lam_dev.value, solver._h.lib.mppi_search_passes(solver._h.h, st)
+
+
+@pytest.mark.parametrize("N", [1, 63, 256, 257, 1000, 4096, 65536, 65537, 262144, 1048576, 3000001])
+def test_device_brent_equals_the_host_loop_to_the_bit(N):
+    """LBPS's bounded Brent search as ONE kernel (mppi_lbps_brent_device, the default of lambda_="LBPS") against the same
+    search as a host loop over mppi_softmax_stats (mppi_lbps_lambda; csrc/host_search.hpp::fminbound on both sides): the
+    temperature must be IDENTICAL, float64 bit for bit — same partial sums in the same order, same double-precision steps —
+    for sample counts on every side of the kernel's geometry (one virtual block, ragged tails, 256 virtual blocks with 1,
+    4, 16 costs per thread staged in LDS, and beyond the staging limit), for every shape of cost vector, other deltas and
+    ranges.  (A short form of scripts/brent_soak.py, whose 4 000 cases are recorded in profiles/r06_brent_soak.txt.)"""
+    _need_gpu()
+    rng = np.random.default_rng(N)
+    solver, _ = make_solver("pendulum", 5, N, lambda_=1.0)
+    solver.forward(torch.tensor([1.0, 0.0]))
+    reps = 3 if N <= 65537 else 1
+    for kind in range(8):
+        for _ in range(reps):
+            costs = brent_cost_vector(rng, N, kind)
+            lh, ld, probes = brent_both(solver, costs)
+            assert lh == ld and 3 <= probes <= 500, (N, kind, lh, ld, probes)
+    costs = brent_cost_vector(rng, N, 0)
+    for delta, lo, hi in ((0.1, 0.01, 10.0), (0.01, 0.5, 2.0), (0.001, 1e-3, 1e3), (0.5, 5.0, 5.5)):
+        lh, ld, probes = brent_both(solver, costs, delta, lo, hi)
+        assert lh == ld, (N, delta, lo, hi, lh, ld, probes)
+
+
+@pytest.mark.parametrize("name", ["pendulum_T15_N256_lbps", "nav2d_T30_N512_lbps", "nav2d_T30_N4096_lbps", "racing_T25_N4096_lbps"])
+def test_device_brent_on_the_reference_fixtures(name):
+    """The same on the cost vectors of the reference's own LBPS solves (tests/golden/): device search == host loop to the bit,
+    and both within the fixture's band of the temperature the reference found."""
+    _need_gpu()
+    cfg, g = CASES[name], load(name)
+    solver, _ = make_solver("pendulum", 5, cfg["N"], lambda_=1.0)
+    solver.forward(torch.tensor([1.0, 0.0]))
+    for k in range(int(g["K"])):
+        lh, ld, probes = brent_both(solver, np.ascontiguousarray(g[f"costs_{k}"], np.float32))
+        assert lh == ld, (name, k, lh, ld)
+        assert same_lbps_minimum(g[f"costs_{k}"], ld, float(g[f"lambda_{k}"])), (name, k, ld, float(g[f"lambda_{k}"]))
+        parity_report.record("device_brent_probes", probes, 500)
+
+
+def test_device_brent_in_a_captured_graph_and_back_to_back():
+    """The search is one launch with no host wait: 200 searches enqueued back to back on alternating cost vectors (the
+    probe tags and the double-buffered cells carry over from launch to launch) return the host loop's temperatures, and a
+    whole LBPS solve can be captured into a hipGraph and replayed."""
+    _need_gpu()
+    N = 65536
+    rng = np.random.default_rng(3)
+    solver, _ = make_solver("pendulum", 5, N, lambda_=1.0)
+    solver.forward(torch.tensor([1.0, 0.0]))
+    vecs = [brent_cost_vector(rng, N, kind) for kind in (0, 2, 3)]
+    want = [brent_both(solver, v)[0] for v in vecs]
+    st = solver._stream()
+    dev = [torch.from_numpy(v).cuda() for v in vecs]
+    got = torch.empty(200, device="cuda")
+    lam_ptr = C.c_void_p(0)
+    for i in range(200):
+        solver._h.call("mppi_set_costs", dev[i % 3].data_ptr(), 1, st)
+        solver._h.call("mppi_lbps_brent_device", 0.01, 0.01, 10.0, st)
+        lam, used = C.c_double(0.0), C.c_double(0.0)
+        if i % 50 == 49:  # (most of the searches are never waited for individually)
+            solver._h.call("mppi_get_lambda", C.byref(lam), C.byref(used), st)
+            assert lam.value == want[i % 3], (i, lam.value, want[i % 3])
+    torch.cuda.synchronize()
+    assert not solver._h.lib.mppi_search_error(solver._h.h)
+    lbps, _ = make_solver("nav2d", 30, 32768, lambda_="LBPS")
+    twin, _ = make_solver("nav2d", 30, 32768, lambda_="LBPS")
+    x0 = torch.tensor([-9.0, -9.0, 0.785], device="cuda")
+    for _ in range(3):
+        lbps.forward(x0)
+        twin.forward(x0)
+    a_t, s_t = twin.forward(x0)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            a, s = lbps.forward(x0)
+        g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(a, a_t) and torch.equal(torch.as_tensor(s), torch.as_tensor(s_t))
+    assert lbps._last_lambda == twin._last_lambda and 0.01 <= twin._last_lambda <= 10.0
+
+
 @pytest.mark.parametrize("lam_mode", ["ESSPS", "LBPS", "MPO"])
 def test_device_softmax_stats_drive_the_same_temperature(lam_mode):
     """auto_lambda_stats='device' (sums on the GPU) and 'host' (costs copied to numpy) find the same lambda
@@ -1005,13 +1130,21 @@ def test_device_softmax_stats_drive_the_same_temperature(lam_mode):
     assert rel_err(outs[0][1], outs[1][1]) < 20 * tol
     x0 = torch.tensor([-9.0, -9.0, 0.785])
     if lam_mode == "LBPS":
-        # the default (round 5) is the reference's own algorithm — scipy's bounded Brent inside the library, one read-back
-        # per probe (north star: auto-lambda stays on the host); lbps_search="device" runs the search as kernels (two
-        # 32-temperature grids + a quartic, no host wait) and lands on the same minimum
+        # the default is the reference's own algorithm — scipy's bounded Brent — as ONE kernel (round 6; no host wait);
+        # lbps_search="brent_host" runs the same search as a host loop with one read-back per probe (round 5's default):
+        # the same temperature and the same action TO THE BIT; lbps_search="grid" (two 32-temperature grids + a quartic)
+        # lands on the same minimum
         sb = outs[0][3]
-        assert sb._rule_on_device is None and sb._lbps_search == "brent"
+        assert sb._rule_on_device == "LBPS" and sb._lbps_search == "brent" and sb._one_call
         c = sb._costs.cpu().numpy()
-        sd, _ = make_solver("nav2d", T, N, lambda_="LBPS", lbps_search="device")
+        sh, _ = make_solver("nav2d", T, N, lambda_="LBPS", lbps_search="brent_host")
+        assert sh._rule_on_device is None and not sh._one_call
+        sh.forward(x0)
+        ah, _ = sh.forward(x0)
+        assert sh._last_lambda == sb._last_lambda and torch.equal(ah, torch.from_numpy(outs[0][2]).cuda())
+        probes = sb._h.lib.mppi_search_passes(sb._h.h, None)
+        assert 10 <= probes <= 60, probes
+        sd, _ = make_solver("nav2d", T, N, lambda_="LBPS", lbps_search="grid")
         assert sd._rule_on_device == "LBPS" and sd._one_call
         sd.forward(x0)
         ad, _ = sd.forward(x0)
@@ -1524,9 +1657,11 @@ def test_log_temperature_follows_load_state_dict_and_module_conversions():
     x = torch.tensor([3.0, 0.0])
     for _ in range(4):
         a.forward(x)
-    sd = {k: v.clone() for k, v in a.state_dict().items()}
-    assert "log_temperature" in sd and abs(float(np.exp(float(sd["log_temperature"][0]))) - a._lambda) <= 1e-6 * a._lambda
-    b.load_state_dict(sd)
+    # (a state dict as the REFERENCE's solver writes it: `log_temperature` only — this build's own also carries `_extra_state`,
+    # see test_state_dict_round_trip_continues_bit_identically)
+    sd = {k: v.clone() for k, v in a.state_dict().items() if torch.is_tensor(v)}
+    assert list(sd) == ["log_temperature"] and abs(float(np.exp(float(sd["log_temperature"][0]))) - a._lambda) <= 1e-6 * a._lambda
+    b.load_state_dict(sd)  # (strict: the missing `_extra_state` of a reference checkpoint is not an error)
     assert abs(b._lambda - a._lambda) <= 1e-6 * a._lambda            # the dual was restarted from the loaded value ...
     b.forward(x)
     assert abs(b._last_lambda - a._lambda) <= 1e-6 * a._lambda       # ... and the next solve's weights use exp(loaded)
@@ -1537,6 +1672,119 @@ def test_log_temperature_follows_load_state_dict_and_module_conversions():
     lam_before = b._lambda
     b.forward(x)
     assert abs(float(np.exp(float(b.log_temperature.detach().cpu()[0]))) - b._lambda) <= 1e-6 * b._lambda and b._lambda != lam_before
+
+
+def _protocol_cases():
+    return [("pendulum", 15, 1000, dict(lambda_="ESSPS")), ("nav2d", 30, 8192, dict(lambda_="LBPS")),
+            ("nav2d", 30, 20000, dict(lambda_="MPO")), ("cartpole", 32, 4096, dict(lambda_="ESSPS", use_sg_filter=True)),
+            ("nav2d", 20, 4096, dict(lambda_=1.0, noise_source="torch_cpu", exploration=0.1)),
+            ("racing", 25, 4000, dict(lambda_=1.0)), ("goalzone", 20, 2000, dict(lambda_=5.0)),
+            ("cartpole", 32, 70000, dict(lambda_="ESSPS", use_sg_filter=True, lazy_state_seq=True))]
+
+
+def _x0_for(model):
+    if model == "racing":
+        return _envs["racing"].reset().clone().cuda()
+    if model == "goalzone":
+        from helpers import goalzone_env_fixture
+        return torch.from_numpy(np.asarray(goalzone_env_fixture()["x0"], np.float32)).cuda()
+    return {"pendulum": torch.tensor([3.0, 0.0]), "nav2d": torch.tensor([-9.0, -9.0, 0.785]),
+            "cartpole": torch.tensor([0.01, 0.0, 0.02, 0.0])}[model].cuda()
+
+
+@pytest.mark.parametrize("model,T,N,kw", _protocol_cases())
+def test_deepcopy_mid_loop_continues_bit_identically(model, T, N, kw):
+    """copy.deepcopy(solver) — for the reference a plain nn.Module copy (mppi.py:16), here a second handle with the device
+    state cloned (mppi_clone_state) — in the middle of a closed loop: original and copy continue with IDENTICAL actions,
+    state sequences and temperatures (warm start, RNG stream position, Savitzky-Golay history, ESSPS warm grid, the MPO dual
+    with its Adam moments, the racing window's path index all travel), the copy answers queries about the solve it never
+    ran (get_top_samples), and the two are independent afterwards.  For racing the CONTROLLER is deep-copied (the solver is
+    copied with it and its cost plugin re-bound to the controller's copy)."""
+    import copy
+
+    solver, ctrl = make_solver(model, T, N, **kw)
+    env = _envs.get("racing")
+    x = _x0_for(model)
+
+    def tick(s, c, x):
+        if c is not None:
+            a, st = c.update(x, env.racing_center_path)
+        else:
+            a, st = s.forward(x)
+        return a, st, torch.as_tensor(st)[0, 1].clone()
+
+    for _ in range(3):
+        a, st, x = tick(solver, ctrl, x)
+    if ctrl is not None:
+        ctrl2 = copy.deepcopy(ctrl)
+        twin = ctrl2.solver
+        assert twin is not solver and twin._cost_owner is ctrl2 and ctrl2.env is not ctrl.env
+    else:
+        ctrl2 = None
+        twin = copy.deepcopy(solver)
+    assert twin._h.h.value != solver._h.h.value and twin._solve_idx == solver._solve_idx
+    assert twin._lambda == solver._lambda and twin._last_lambda == solver._last_lambda
+    assert torch.equal(twin._previous_action_seq, solver._previous_action_seq)
+    t1, w1 = solver.get_top_samples(16)
+    t2, w2 = twin.get_top_samples(16)  # (the copy never ran that solve: costs, noise identity and start state were cloned)
+    assert torch.equal(t1, t2) and torch.equal(w1, w2)
+    x2 = x.clone()
+    for k in range(3):
+        a1, s1, x = tick(solver, ctrl, x)
+        a2, s2, x2 = tick(twin, ctrl2, x2)
+        assert torch.equal(a1, a2) and torch.equal(torch.as_tensor(s1), torch.as_tensor(s2)), (model, k)
+        assert solver._last_lambda == twin._last_lambda and solver._lambda == twin._lambda
+    if kw.get("use_sg_filter"):
+        assert np.array_equal(solver._actions_history_for_sg, twin._actions_history_for_sg)
+    # independent from here on: another solve on the copy alone moves the copy only
+    before = solver._previous_action_seq.clone()
+    tick(twin, ctrl2, x2)
+    assert torch.equal(solver._previous_action_seq, before) and twin._solve_idx == solver._solve_idx + 1
+
+
+def test_pickling_a_solver_raises_a_message_that_names_the_handle():
+    """pickle.dumps(solver) / torch.save(solver) cannot work (the buffers live behind mppi_handle_t): a TypeError that says so
+    and names the two supported routes, not ctypes' "objects containing pointers cannot be pickled"."""
+    import io
+    import pickle
+
+    solver, _ = make_solver("pendulum", 10, 256, lambda_=1.0)
+    for dump in (lambda: pickle.dumps(solver), lambda: torch.save(solver, io.BytesIO())):
+        with pytest.raises(TypeError) as e:
+            dump()
+        assert "mppi_handle_t" in str(e.value) and "deepcopy" in str(e.value) and "state_dict" in str(e.value)
+    import copy
+    with pytest.raises(TypeError):
+        copy.copy(solver)  # (a shallow copy would share the handle)
+
+
+@pytest.mark.parametrize("model,T,N,kw", [("pendulum", 15, 1000, dict(lambda_=0.5)), ("nav2d", 30, 20000, dict(lambda_="MPO")),
+                                          ("cartpole", 32, 4096, dict(lambda_=2.0, use_sg_filter=True)),
+                                          ("nav2d", 20, 4096, dict(lambda_=1.0, noise_source="torch_cpu"))])
+def test_state_dict_round_trip_continues_bit_identically(model, T, N, kw):
+    """torch.save(solver.state_dict()) -> a freshly constructed solver -> load_state_dict(): the loaded solver continues like
+    the saved one — warm start, Savitzky-Golay history, RNG stream position (Philox index / torch-CPU generator) and the MPO
+    dual WITH its Adam moments travel in `_extra_state` (the reference keeps them as plain attributes its state_dict drops)."""
+    import io
+
+    a, _ = make_solver(model, T, N, **kw)
+    x = _x0_for(model)
+    for _ in range(3):
+        _, st = a.forward(x)
+        x = torch.as_tensor(st)[0, 1].clone()
+    buf = io.BytesIO()
+    torch.save(a.state_dict(), buf)
+    buf.seek(0)
+    b, _ = make_solver(model, T, N, **kw)
+    b.load_state_dict(torch.load(buf, weights_only=False))
+    assert b._solve_idx == a._solve_idx and b._lambda == a._lambda
+    xb = x.clone()
+    for k in range(3):
+        a1, s1 = a.forward(x)
+        a2, s2 = b.forward(xb)
+        assert torch.equal(a1, a2) and torch.equal(torch.as_tensor(s1), torch.as_tensor(s2)), (model, k)
+        assert a._last_lambda == b._last_lambda
+        x, xb = torch.as_tensor(s1)[0, 1].clone(), torch.as_tensor(s2)[0, 1].clone()
 
 
 def test_device_sg_filter_equals_the_host_statement():
@@ -2479,7 +2727,7 @@ def test_single_launch_solve_equals_the_multi_kernel_path(model, T, N, lam, kw):
     minimum and the searched temperature bit-identical, action and state sequences equal to the rounding of the two
     summation orders; the queries that read the solve's state afterwards (top samples, weights) agree as well."""
     if lam == "LBPS":
-        kw = dict(kw, lbps_search="device")  # (the search as kernels; the default — Brent — reads statistics back per probe)
+        kw = dict(kw, lbps_search="grid")  # (the single launch searches on grids; the default — Brent — is a kernel of its own)
     fused, cf = make_solver(model, T, N, lambda_=lam, **kw)
     fused.set_option("fused_solve", 2)  # (1, the default, takes the single launch up to 4096 samples only)
     multi, cm = make_solver(model, T, N, lambda_=lam, **kw)
