@@ -155,6 +155,30 @@ def load():
     return lib
 
 
+# Handles whose owner was dropped while a stream of this process was being captured into a graph (torch.cuda.graph): freeing
+# device memory there is not permitted (hipFree inside a capture invalidates it — a garbage collection that happened to run
+# inside another solver's capture took the process down), so the destruction waits for the next handle operation outside a capture.
+_deferred_destroy = []
+
+
+def _capturing() -> bool:
+    try:
+        import torch
+
+        return bool(torch.cuda.is_available() and torch._C._cuda_isCurrentStreamCapturing())
+    except Exception:  # noqa: BLE001  (interpreter shutdown, a torch build without the query)
+        return False
+
+
+def _flush_deferred() -> None:
+    if _deferred_destroy and not _capturing():
+        lib = _lib
+        while _deferred_destroy:
+            h = _deferred_destroy.pop()
+            if lib is not None:
+                lib.mppi_destroy(h)
+
+
 class Handle:
     """RAII wrapper of mppi_handle_t; every call checks the return code and raises MppiError."""
 
@@ -163,6 +187,7 @@ class Handle:
         if self.lib.mppi_device_count() <= 0:
             raise MppiError("no HIP device visible: the MPPI hot path needs an MI355X (gfx950); "
                             "there is no CPU fallback")
+        _flush_deferred()
         self.h = C.c_void_p()
         rc = self.lib.mppi_create(C.byref(cfg), C.byref(self.h))
         if rc != 0:
@@ -179,8 +204,12 @@ class Handle:
 
     def close(self):
         if getattr(self, "h", None):
-            self.lib.mppi_destroy(self.h)
-            self.h = C.c_void_p()
+            h, self.h = self.h, C.c_void_p()
+            if _capturing():  # (dropped — typically by the garbage collector — inside somebody's graph capture: not now)
+                _deferred_destroy.append(h)
+                return
+            self.lib.mppi_destroy(h)
+            _flush_deferred()
 
     def __del__(self):
         try:

@@ -1916,6 +1916,20 @@ static int topk_sort_large(mppi_handle_t h, int k, hipStream_t s) {
     return MPPI_OK;
 }
 
+// A launch whose dynamic LDS grows with the length of a control row (T * dim_control): beyond 32 KiB it is held against the
+// kernel's own static LDS and the 64 KiB a block gets without opting in, so that a horizon too long for the staging fails
+// with a message instead of a bare launch error.  Queried only in that rare case.
+static int check_row_lds(mppi_handle_t h, const void* kernel, size_t dyn, const char* what) {
+    if (dyn <= 32 * 1024) return MPPI_OK;
+    hipFuncAttributes fa{};
+    if (hipFuncGetAttributes(&fa, kernel) != hipSuccess) { (void)hipGetLastError(); return MPPI_OK; }
+    if (fa.sharedSizeBytes + dyn > 64 * 1024)
+        return fail(h, MPPI_E_INVALID, std::string(what) + ": control rows of T * dim_control = " + std::to_string(h->d.row) +
+                    " floats need " + std::to_string((fa.sharedSizeBytes + dyn + 1023) / 1024) + " KiB of LDS per block (limit 64 KiB): "
+                    "horizon x dim_control too long for this query");
+    return MPPI_OK;
+}
+
 // sort k candidates, weigh and re-roll them; `clean` also resets the select state (after topk_select).  `cand` is
 // h->topk_cand when k > TOPK_MAX (sorted in place).
 static int topk_rollout(mppi_handle_t h, const unsigned long long* cand, int k, float lambda, float* states_out,
@@ -1928,6 +1942,7 @@ static int topk_rollout(mppi_handle_t h, const unsigned long long* cand, int k, 
     unsigned* counters = clean ? h->topk_hist + 3 * TOPK_BINS : nullptr;
     if (k <= TOPK_MAX) {
 #define CALL_TOPK(MODEL, FASTV)                                                                       \
+    if (int rc = check_row_lds(h, (const void*)topk_rollout_kernel<MODEL, FASTV, false>, topk_rollout_lds(h->d.R, false, gen), "get_top_samples")) return rc; \
     hipLaunchKernelGGL((topk_rollout_kernel<MODEL, FASTV, false>), dim3((unsigned)((k + WAVE - 1) / WAVE)), dim3(TOPK_MAX), topk_rollout_lds(h->d.R, false, gen), s, cand, k, \
                        direct ? (const float*)h->costs : (const float*)nullptr, direct ? (int)h->d.N : 0, h->noise, gen,  \
                        h->mean_used, h->x0_used, h->solve_stats, lambda, states_out, weights_out, hist, counters,  \
@@ -1938,6 +1953,7 @@ static int topk_rollout(mppi_handle_t h, const unsigned long long* cand, int k, 
         if (int rc = topk_sort_large(h, k, s)) return rc;
         const unsigned grid = (unsigned)((k + WAVE - 1) / WAVE);
 #define CALL_TOPK_SORTED(MODEL, FASTV)                                                                \
+    if (int rc = check_row_lds(h, (const void*)topk_rollout_kernel<MODEL, FASTV, true>, topk_rollout_lds(h->d.R, true, gen), "get_top_samples")) return rc; \
     hipLaunchKernelGGL((topk_rollout_kernel<MODEL, FASTV, true>), dim3(grid), dim3(WAVE), topk_rollout_lds(h->d.R, true, gen), s, (const unsigned long long*)h->topk_cand, \
                        k, (const float*)nullptr, 0, h->noise, gen, h->mean_used, h->x0_used, h->solve_stats, lambda, states_out,  \
                        weights_out, hist, counters, h->d, h->gen, h->ctx)

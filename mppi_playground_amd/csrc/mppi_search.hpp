@@ -592,12 +592,13 @@ __device__ __forceinline__ bool brent_gather_wave(int nvb, const BrentCtx& bx, u
         unsigned long long c[7];
 #pragma unroll
         for (int j = 0; j < 7; ++j) c[j] = j < ncell ? __hip_atomic_load(theirs + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-        for (;;) {
+        for (unsigned spins = 1;; ++spins) {
             bool all = true;
 #pragma unroll
             for (int j = 0; j < 7; ++j) all = all && (j >= ncell || (unsigned)(c[j] >> 32) == tag);
             if (all) break;
-            if (wall_clock64() - t0 > bx.timeout_ticks) { timed_out = true; break; }
+            // (the clock is a trip to the memory clock domain: looked at once in 64 rounds, not in every one)
+            if ((spins & 63u) == 0u && wall_clock64() - t0 > bx.timeout_ticks) { timed_out = true; break; }
             __builtin_amdgcn_s_sleep(BRENT_POLL_SLEEP);
 #pragma unroll
             for (int j = 0; j < 7; ++j)

@@ -170,37 +170,6 @@ __global__ __launch_bounds__(BLOCK) void topk_collect_kernel(const float* __rest
     }
 }
 
-// Ascending bitonic sort of one 64-bit word per thread across the block's 1024 threads, NV independent sorts in lockstep
-// (v[r] of thread t = element t of row r).  Strides below 64 are wave shuffles (no barrier); only the 10 stages with a
-// stride >= 64 go through LDS (s_x [NV][1024]) — a plain LDS bitonic sort pays a 1024-thread barrier for each of its 55
-// stages.  first_size = 2: full sort; = 1024: the final merge only (rows that are bitonic already).
-__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int m) {
-    const unsigned lo = __shfl_xor((unsigned)v, m), hi = __shfl_xor((unsigned)(v >> 32), m);
-    return ((unsigned long long)hi << 32) | lo;
-}
-template <int NV>
-__device__ __forceinline__ void block_bitonic_1024(unsigned long long (&v)[NV], unsigned long long* s_x, int tid, int first_size) {
-    for (int size = first_size; size <= TOPK_MAX; size <<= 1) {
-        const bool up = (tid & size) == 0;  // (size = 1024: every thread)
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            unsigned long long o[NV];
-            if (stride >= WAVE) {
-#pragma unroll
-                for (int r = 0; r < NV; ++r) s_x[r * TOPK_MAX + tid] = v[r];
-                __syncthreads();
-#pragma unroll
-                for (int r = 0; r < NV; ++r) o[r] = s_x[r * TOPK_MAX + (tid ^ stride)];
-                __syncthreads();
-            } else {
-#pragma unroll
-                for (int r = 0; r < NV; ++r) o[r] = shfl_xor_u64(v[r], stride);
-            }
-            const bool keep_min = ((tid & stride) == 0) == up;
-#pragma unroll
-            for (int r = 0; r < NV; ++r) v[r] = keep_min ? (v[r] < o[r] ? v[r] : o[r]) : (v[r] > o[r] ? v[r] : o[r]);
-        }
-    }
-}
 // Wave-level prefix sums / reductions through DPP (row_shr within the rows of 16 lanes, then row_bcast15 / row_bcast31 across
 // them — CDNA keeps both): six VALU instructions with a DPP operand, against six ds_bpermute round trips (~100 cycles of
 // latency each) for the __shfl forms.  A lane whose source lies outside its row (or whose row is masked off) gets `old`.
@@ -605,7 +574,9 @@ __global__ __launch_bounds__(TOPK_MAX) void topk_rollout_kernel(const unsigned l
 #ifdef MPPI_TOPK_TRACE
     if (!SORTED && blockIdx.x == 0 && threadIdx.x == 0) {
         const long long t7 = (long long)wall_clock64();
-        printf("topk trace (10 ns): costs %lld, histogram %lld, pick %lld, compaction %lld, sort %lld, noise %lld, re-roll %lld, total %lld\n",
+        // (phases 4 / 5 are "scatter by bin" / "ranks inside the bins" of the counting sort, or "compaction" / "sort" of the
+        // crowded-bin fallback: the two paths stamp the same slots)
+        printf("topk trace (10 ns): costs %lld, histogram %lld, boundary bin %lld, scatter | compaction %lld, ranks | sort %lld, noise %lld, re-roll %lld, total %lld\n",
                s_tk[1] - s_tk[0], s_tk[2] - s_tk[1], s_tk[3] - s_tk[2], s_tk[4] - s_tk[3], s_tk[5] - s_tk[4], s_tk[6] - s_tk[5],
                t7 - s_tk[6], t7 - s_tk[0]);
     }

@@ -30,6 +30,15 @@ class NativeStep:
         # both of the device the STATE lives on: the env's device is the reference's unindexed "cuda")
         self._pool_device, self._next_pool, self._reached_pool = None, None, None
 
+    def __deepcopy__(self, memo):
+        """copy.deepcopy(env) (e.g. as part of copy.deepcopy(controller), pi_mpc/_module.py): the constants are immutable and
+        shared, the library module / handle are process-wide, the output pools start empty."""
+        new = type(self).__new__(type(self))
+        new.__dict__.update(self.__dict__)
+        new._pool_device, new._next_pool, new._reached_pool = None, None, None
+        memo[id(self)] = new
+        return new
+
     def __call__(self, state: torch.Tensor, u: torch.Tensor):
         assert u.dtype == torch.float32 and state.dtype == torch.float32 and state.is_contiguous() and state.is_cuda
         u = u if u.is_contiguous() else u.contiguous()

@@ -236,10 +236,12 @@ class MPPI(ModuleProtocolMixin, ExchangeMixin, GenericPathMixin, QueriesMixin, n
         # fingerprint of their source AND agreement with the shipped plugin on probe batches)
         dyn, cst = resolve(dynamics), resolve(cost_func)
         self._recognized = None
+        self._recognition = None
         if dyn is None and cst is None and recognize_closures:
             from pi_mpc import recognize
 
             twin = recognize.match(dynamics, cost_func, dim_state, dim_control, self._device)
+            self._recognition = dict(recognize.last_report)  # what was decided and why (inspection; a disagreement warns once)
             if twin is not None:
                 self._recognized = (dynamics, cost_func)  # (kept for inspection; the fused model runs instead)
                 dyn, cst = resolve(twin[0]), resolve(twin[1])

@@ -180,16 +180,53 @@ def oracle_problem(model, N, T, exploration=0.0, ref_path=None):
 
 
 # ---- the reference's own measured sensitivity (tests/golden/make_golden.py: BAND_VARIANTS; 256 probes per solve)
-class Band(float):
-    """A band: the sample MAXIMUM over the probes (its float value, what the tests compare with) that also carries the 99th
-    percentile of the same probes for the parity report."""
+# the probes by row of every band array (make_golden.py: BAND_VARIANTS): what a coinciding probe is called in the report
+N_ULP, N_STAGE_ULP = 160, 92
+BAND_VARIANTS = (tuple(f"ulp_{i}" for i in range(N_ULP)) + ("f64sum", "seqsum", "revsum", "pairsum")
+                 + tuple(f"stage_ulp_{i}" for i in range(N_STAGE_ULP)))
 
-    def __new__(cls, values):
+
+class Band(float):
+    """A band: the sample MAXIMUM over the probes (its float value, what the tests compare with) that also carries the probes
+    themselves — every probe's error, sorted, with the probe's name — so that a check can say WHERE in the reference's own
+    spread the device's error falls (`rank`) and whether it IS one of the probes bit for bit (`coincides`: the device then
+    computes exactly that equally valid fp32 evaluation of the costs — e.g. "f64sum", the exactly rounded sum — and its
+    distance to the reference's fixture is that probe's, to the last digit)."""
+
+    def __new__(cls, values, names=None):
         v = np.asarray(values, np.float64).ravel()
         b = super().__new__(cls, float(v.max()) if v.size else 0.0)
         b.p99 = float(np.percentile(v, 99)) if v.size else 0.0
         b.probes = int(v.size)
+        order = np.argsort(v, kind="stable")
+        b.sorted = v[order]
+        nm = list(names) if names is not None else [f"probe_{i}" for i in range(v.size)]
+        b.names = [nm[i] for i in order]
         return b
+
+    def rank(self, err: float) -> int:
+        """How many of the reference's probes moved its output by no more than `err` (0 .. probes)."""
+        return int(np.searchsorted(self.sorted, err, side="right"))
+
+    def coincides(self, err: float, limit: int = 4):
+        """Names of the probes whose error equals `err` (both are max|a - b| / max|b| in float64 of fp32 arrays against the same
+        fixture: equal outputs give equal numbers)."""
+        if not self.probes or err == 0.0:
+            return []
+        hit = np.nonzero(np.abs(self.sorted - err) <= 1e-12 * max(err, 1e-300))[0]
+        return [self.names[i] for i in hit[:limit]]
+
+    @staticmethod
+    def merge(*bands):
+        vals = np.concatenate([b.sorted for b in bands]) if bands else np.zeros(0)
+        names = [n for b in bands for n in b.names]
+        return Band(vals, names)
+
+
+def _probe_names(g, key, prefix):
+    sel = g[key] if key in g.files else None  # (full-size fixtures record a subset of the probes)
+    names = BAND_VARIANTS if sel is None else [BAND_VARIANTS[int(i)] for i in sel]
+    return [prefix + n for n in names]
 
 
 def band_fixed(g, k):
@@ -197,19 +234,31 @@ def band_fixed(g, k):
     by equally valid fp32 evaluations of the same sums (1-ulp changes, other summation orders), inputs and temperature
     held fixed.  Maximum over the recorded probes."""
     b = g[f"band_fixed_{k}"]
-    return Band(b[:, 0]), Band(b[:, 1])
+    nm = _probe_names(g, "band_variants_fixed", "fixed:")
+    return Band(b[:, 0], nm), Band(b[:, 1], nm)
+
+
+def band_rule(g, k):
+    """(action, state, lambda) of the same probes with the reference's temperature rule re-run, or None for a fixed temperature."""
+    if f"band_rule_{k}" not in g.files:
+        return None
+    b = g[f"band_rule_{k}"]
+    nm = _probe_names(g, "band_variants_fixed", "rule:")
+    return Band(b[:, 0], nm), Band(b[:, 1], nm), Band(b[:, 2], nm)
 
 
 def band_rule_lambda(g, k):
     """The same probes with the reference's temperature rule re-run: relative spread of the temperature of solve k."""
-    return Band(g[f"band_rule_{k}"][:, 2]) if f"band_rule_{k}" in g.files else Band([0.0])
+    r = band_rule(g, k)
+    return r[2] if r is not None else Band([0.0])
 
 
 def band_closed_loop(g, k):
     """dict(x0, action, state, lam): the reference's whole K-solve closed loop re-run per probe (states, warm start, SG
     history and the rule's memory evolve on their own), relative distance of solve k to the unperturbed loop."""
     b = g["band_closed_loop"][k]
-    return dict(x0=Band(b[:, 0]), action=Band(b[:, 1]), state=Band(b[:, 2]), lam=Band(b[:, 3]))
+    nm = _probe_names(g, "band_variants_closed", "closed:")
+    return dict(x0=Band(b[:, 0], nm), action=Band(b[:, 1], nm), state=Band(b[:, 2], nm), lam=Band(b[:, 3], nm))
 
 
 def rel_err(a, b):

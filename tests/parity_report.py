@@ -9,23 +9,30 @@ import os
 
 current_test = "?"
 entries = []
+strict = False  # pytest --strict-parity (tests/conftest.py): full-size configurations are held to the plain 1e-5
 
 
 def record(quantity: str, value: float, limit: float, **extra) -> None:
-    """`value` was checked against `limit` (value <= limit) in the test that is running."""
-    entries.append(dict(test=current_test, quantity=quantity, value=float(value), limit=float(limit), **extra))
+    """`value` was checked against `limit` (value <= limit) in the test that is running.  `ordinal` numbers the checks of one
+    quantity inside one test: (test, quantity, ordinal) identifies a check from one session to the next."""
+    ordinal = sum(1 for e in entries if e["test"] == current_test and e["quantity"] == quantity)
+    entries.append(dict(test=current_test, quantity=quantity, ordinal=ordinal, value=float(value), limit=float(limit), **extra))
 
 
 def summary() -> dict:
     out = {}
     for e in entries:
-        q = out.setdefault(e["quantity"], dict(count=0, worst_fraction_of_limit=0.0, worst=None, limit_reached=0))
+        q = out.setdefault(e["quantity"], dict(count=0, worst_fraction_of_limit=0.0, worst=None, limit_reached=0, on_the_band=0,
+                                               on_the_band_explained_by_a_probe=0))
         q["count"] += 1
         frac = e["value"] / e["limit"] if e["limit"] > 0 else (0.0 if e["value"] == 0 else float("inf"))
         if frac >= q["worst_fraction_of_limit"]:
             q["worst_fraction_of_limit"], q["worst"] = frac, e
         if frac > 0.5:
             q["limit_reached"] += 1
+        if "reference_band" in e and frac >= 0.999 and e["value"] > 1e-5:  # sits ON the reference's sample maximum
+            q["on_the_band"] += 1
+            q["on_the_band_explained_by_a_probe"] += 1 if e.get("coincides_with") else 0
     return out
 
 

@@ -720,6 +720,81 @@ def test_reference_example_closures_are_recognised(model):
         recognize._table_cache = table
 
 
+def test_transcribed_pendulum_closure_is_recognised_through_the_version_independent_fingerprints():
+    """tests/closure_transcription.py — the pendulum example's closures written anew with other names — against the SHIPPED
+    table: only the "g2" forms match (operator sequence + sorted constants of the scripted graph; structure of the cost's AST
+    with identifiers numbered), the torch printer's text ("v1") does not; together with the behaviour on the probe batches that
+    is a recognition.  The two tests disagreeing warns once: a TorchScript dynamics that behaves like the shipped model but
+    is not listed (here: the shipped plugin itself, scripted — other operators), and a listed fingerprint whose callable
+    computes something else."""
+    import warnings
+
+    import torch
+
+    import closure_transcription as ct
+    from envs import classic_control as cc
+    from pi_mpc import recognize
+
+    step, cost = ct.build()
+    table = recognize._table()
+    fd, fc = recognize.fingerprints(step), recognize.fingerprints(cost)
+    assert fd & set(table["pendulum"]["dynamics"]) == {table["pendulum"]["dynamics"][1]}   # g2 only
+    assert fc & set(table["pendulum"]["cost"]) == {table["pendulum"]["cost"][1]}
+    assert recognize.fingerprint(step) not in table["pendulum"]["dynamics"]                  # (v1: the printer's text differs)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", recognize.RecognitionWarning)
+        assert recognize.match(step, cost, 2, 1, torch.device("cpu")) == (cc.pendulum_dynamics, cc.pendulum_cost)
+        assert recognize.last_report["model"] == "pendulum" and recognize.last_report["fingerprint"] and recognize.last_report["behaviour"]
+
+        # another constant: another fingerprint, other values -> simply not one of the examples (no warning)
+        @torch.jit.script
+        def other_step(x: torch.Tensor, u: torch.Tensor) -> torch.Tensor:
+            return torch.cat((x[:, 0:1] + 0.07 * x[:, 1:2], torch.clamp(x[:, 1:2] + u[:, 0:1], -8, 8)), dim=1)
+
+        assert recognize.match(other_step, cost, 2, 1, torch.device("cpu")) is None
+    # behaves like the model, not listed: the generic path, and a warning that says what it costs
+    recognize._warned.clear()
+    scripted_plugin = torch.jit.script(lambda_free(cc.pendulum_dynamics))
+    with pytest.warns(recognize.RecognitionWarning, match="GENERIC path"):
+        assert recognize.match(scripted_plugin, cost, 2, 1, torch.device("cpu")) is None
+    assert recognize.last_report == {**recognize.last_report, "model": "pendulum", "fingerprint": False, "behaviour": True}
+    with warnings.catch_warnings():  # ... once per process
+        warnings.simplefilter("error", recognize.RecognitionWarning)
+        assert recognize.match(scripted_plugin, cost, 2, 1, torch.device("cpu")) is None
+    # listed, but other values
+    try:
+        recognize._table_cache = {"_torch": "x", "pendulum": {"dynamics": sorted(recognize.fingerprints(other_step)), "cost": sorted(fc)}}
+        with pytest.warns(recognize.RecognitionWarning, match="values\s+differ"):
+            assert recognize.match(other_step, cost, 2, 1, torch.device("cpu")) is None
+    finally:
+        recognize._table_cache = table
+        recognize._warned.clear()
+
+
+def lambda_free(fn):
+    """The undecorated Python function behind a tagged plugin (torch.jit.script wants a plain function)."""
+    return getattr(fn, "__wrapped__", fn)
+
+
+def test_probe_comparison_is_relative_per_column():
+    """recognize._same: 1e-6 of EACH column's scale: an error of 1e-6 x the position scale in the velocity column
+    of a mountain-car-like state (velocity ~ 0.07, position ~ 1.4) is 20x that column's tolerance and must fail."""
+    import torch
+
+    from pi_mpc import recognize
+
+    g = torch.Generator().manual_seed(1)
+    y = torch.stack([1.4 * (2 * torch.rand(256, generator=g) - 1), 0.07 * (2 * torch.rand(256, generator=g) - 1)], dim=1)
+    assert recognize._same(y.clone(), y)
+    x = y.clone()
+    x[17, 1] += 1.0e-6 * float(y[:, 0].abs().max())
+    assert not recognize._same(x, y)
+    x = y.clone()
+    x[17, 0] += 0.5e-6 * float(y[:, 0].abs().max())
+    assert recognize._same(x, y)
+    assert not recognize._same(y[:, :1], y)
+
+
 def test_row_pool_hands_out_fresh_aligned_rows():
     """mppi_playground_amd/_pool.py: every row is handed out once, contiguous and 256 bytes apart, rows never overlap, a new
     block starts when the rows run out or the stream changes, and a dropped block's rows stay valid while somebody holds one."""
