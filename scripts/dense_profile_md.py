@@ -10,6 +10,8 @@ import sys
 
 d = sys.argv[1]
 CFG = {"c2": dict(label="C2 nav2d N=65 536 T=50 dc=2, lambda = ESSPS", N=65536, T=50, dc=2),
+       "c2_lbps": dict(label="C2 nav2d N=65 536 T=50 dc=2, lambda = LBPS (the default: scipy's bounded Brent as ONE kernel, lbps_brent_kernel)",
+                       N=65536, T=50, dc=2),
        "c5": dict(label="C5 cartpole N=262 144 T=64 dc=1, lambda = ESSPS + Savitzky-Golay", N=262144, T=64, dc=1),
        "c3_dense": dict(label="C3 racing N=1 048 576 T=50 dc=2, lambda = 5000 (dense softmax: every tile carries weight)", N=1 << 20, T=50, dc=2)}
 if len(sys.argv) > 2:  # restrict to the named workloads

@@ -3,7 +3,7 @@
 # rocprofv3 kernel trace + separate PMC passes for C3 (regen / tiles) and for the dense-weight configs C2 / C5.
 # Usage: bash scripts/gpu_record.sh [tag]   (writes gpurun_out/prof_<tag>/, default tag r2)
 set -u
-TAG=${1:-r5}
+TAG=${1:-r6}
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -25,6 +25,9 @@ done
 MPPI_BENCH_ONE_DEVICE=1 MPPI_BENCH_BACKEND=gloo timeout 300 python bench.py --gpus 2 --preflight > gpurun_out/bench_preflight_g2.log 2>&1
 echo "preflight --gpus 2: rc=$? $(tail -1 gpurun_out/bench_preflight_g2.log | cut -c1-300)"
 timeout 300 python scripts/lazy_state_stress.py 3000 2>&1 | grep -v amdgpu.ids | tail -5 > gpurun_out/lazy_state_stress.txt
+timeout 500 python scripts/brent_soak.py 4000 2>&1 | grep -v amdgpu.ids > gpurun_out/brent_soak.txt
+[ -f mppi_playground_amd/csrc/variants/lib_brenttrace.so ] && MPPI_HIP_LIB=mppi_playground_amd/csrc/variants/lib_brenttrace.so timeout 200 python scripts/brent_trace.py 2>&1 | grep "^N=" > gpurun_out/brent_trace.txt
+scripts/ubench/bfly_check > gpurun_out/bfly_check.txt 2>&1
 MASTER_PORT=29543 timeout 300 python scripts/nccl_single_rank.py 2>&1 | grep -E "forced exchange|RCCL all_gather" > gpurun_out/nccl_single_rank.txt
 timeout 300 python scripts/fused_timing.py 2>&1 | grep -v amdgpu.ids > gpurun_out/fused_timing.txt
 timeout 300 python scripts/essps_passes.py 2>&1 | grep -v amdgpu.ids > gpurun_out/essps_passes.txt
@@ -42,10 +45,10 @@ B="python $R/bench.py --no-cpu-baseline --no-extras"
 # otherwise be a fifth of the 265 launches --stats averages over, and the summary would disagree with the live HIP-event time)
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $P -o kt -- $B --steps 1000 --warmup 50 > $R/gpurun_out/rocprof_kt.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $P -o kt_tiles -- $B --steps 300 --warmup 20 --noise-regen 0 > /dev/null 2>&1
-for wl in c2 c5 c3_dense; do
+for wl in c2 c2_lbps c5 c3_dense; do
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $P -o kt_$wl -- $B --workload $wl --steps 200 --warmup 20 > $R/gpurun_out/rocprof_kt_$wl.log 2>&1
 done
-for mode in regen tiles c2 c5 c3_dense; do
+for mode in regen tiles c2 c2_lbps c5 c3_dense; do
   case $mode in
     regen) extra="--steps 6 --warmup 2";;
     tiles) extra="--steps 6 --warmup 2 --noise-regen 0";;

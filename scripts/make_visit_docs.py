@@ -16,7 +16,7 @@ out = lambda f: os.path.join(root, "profiles", f)  # noqa: E731
 run = lambda *a: subprocess.run([sys.executable, *a], capture_output=True, text=True, check=True, cwd=root).stdout  # noqa: E731
 d = json.loads([l for l in open(os.path.join(root, "gpurun_out", "bench.log")) if l.startswith("{")][-1])
 c3 = run("scripts/pmc_summary.py", P)
-dense = run("scripts/dense_profile_md.py", P, "c2", "c5")
+dense = run("scripts/dense_profile_md.py", P, "c2", "c2_lbps", "c5")
 c3_dense = run("scripts/dense_profile_md.py", P, "c3_dense")
 open(out("pmc_constants.json"), "w").write(run("scripts/pmc_constants.py", P, f"profiles/{name}_c3_kernel_stats_pmc.md"))
 rl, vr = d["roofline"], d["valu_roofline"]
@@ -52,7 +52,8 @@ Un-profiled (`bench.py` `other_configs`): c3_dense {oc.get('c3_dense', {}).get('
 for src, dst in (("fused_timing.txt", "fused_timing.txt"), ("essps_passes.txt", "essps_passes.txt"), ("nccl_single_rank.txt", "exchange_single_rank.txt"),
                  ("pytest_gpu.log", "pytest_gpu.log"), ("top_samples_breakdown.txt", "top_samples.txt"), ("fused_crossover.txt", "fused_crossover.txt"),
                  ("host_overhead.txt", "host_overhead.txt"), ("lazy_state_stress.txt", "lazy_state_stress.txt"),
-                 ("example_tick.txt", "example_tick.txt"), ("topk_trace.txt", "top_samples_phase_stamps.txt")):
+                 ("example_tick.txt", "example_tick.txt"), ("topk_trace.txt", "top_samples_phase_stamps.txt"),
+                 ("brent_soak.txt", "brent_soak.txt"), ("brent_trace.txt", "brent_trace.txt")):
     f = os.path.join(root, "gpurun_out", src)
     if os.path.exists(f):
         shutil.copy(f, out(f"{name}_{dst}"))
