@@ -60,4 +60,9 @@ for mode in regen tiles c2 c2_lbps c5 c3_dense; do
     timeout 300 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $P -o pmc_${mode}_$tag -- $B $extra > /dev/null 2>&1
   done
 done
-cd $R; ls $P | wc -l
+cd $R
+# gpurun copies at most 64 MiB back: keep what the summaries are made from (kernel stats and counter collections)
+find $P -type f ! -name "*kernel_stats.csv" ! -name "*counter_collection.csv" ! -name "csrc_sha256.txt" -delete
+find $P -type d -empty -delete
+du -sh gpurun_out $P 2>/dev/null; du -s gpurun_out/* 2>/dev/null | sort -n | tail -5
+ls $P | wc -l

@@ -1026,7 +1026,7 @@ def test_device_brent_equals_the_host_loop_to_the_bit(N):
     temperature must be IDENTICAL, float64 bit for bit — same partial sums in the same order, same double-precision steps —
     for sample counts on every side of the kernel's geometry (one virtual block, ragged tails, 256 virtual blocks with 1,
     4, 16 costs per thread staged in LDS, and beyond the staging limit), for every shape of cost vector, other deltas and
-    ranges.  (A short form of scripts/brent_soak.py, whose 4 000 cases are recorded in profiles/r06_brent_soak.txt.)"""
+    ranges.  (A short form of scripts/brent_soak.py, whose 4 000 cases are recorded in profiles/r06_visitA_brent_soak.txt.)"""
     _need_gpu()
     rng = np.random.default_rng(N)
     solver, _ = make_solver("pendulum", 5, N, lambda_=1.0)

@@ -764,7 +764,7 @@ def test_transcribed_pendulum_closure_is_recognised_through_the_version_independ
     # listed, but other values
     try:
         recognize._table_cache = {"_torch": "x", "pendulum": {"dynamics": sorted(recognize.fingerprints(other_step)), "cost": sorted(fc)}}
-        with pytest.warns(recognize.RecognitionWarning, match="values\s+differ"):
+        with pytest.warns(recognize.RecognitionWarning, match=r"values\s+differ"):
             assert recognize.match(other_step, cost, 2, 1, torch.device("cpu")) is None
     finally:
         recognize._table_cache = table
@@ -793,6 +793,43 @@ def test_probe_comparison_is_relative_per_column():
     x[17, 0] += 0.5e-6 * float(y[:, 0].abs().max())
     assert recognize._same(x, y)
     assert not recognize._same(y[:, :1], y)
+
+
+def test_predicted_scaling_curve_is_self_consistent():
+    """bench.py's predicted 1 -> 8 GPU curve (no multi-GPU node has been available to any round): one row per
+    W and transport, efficiencies in (0, 1], monotone in W, the assumed collective latency's range brackets the central value,
+    the strong-scaling solve never beats its measured one-GPU solve of 2^20 / W samples, live inputs override the committed
+    ones, and every file its inputs cite exists."""
+    import importlib.util
+    import re
+
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    p = bench.predict_scaling()
+    n, T = 1 << 20, 50
+    for tr in ("rccl", "nccl", "p2p"):
+        rows = p["transports"][tr]
+        assert list(rows) == ["1", "2", "4", "8"]
+        t_prev, eff_prev = 0.0, 1.0 + 1e-12
+        for W in (1, 2, 4, 8):
+            r = rows[str(W)]
+            assert r["value"] == pytest.approx(W * n * T / (r["ms_per_step"] * 1e-3))
+            assert 0.0 < r["efficiency"] <= 1.0 and r["efficiency"] <= eff_prev and r["ms_per_step"] >= t_prev
+            t_prev, eff_prev = r["ms_per_step"], r["efficiency"]
+            if W > 1:
+                assert r["ms_per_step_high"] <= r["ms_per_step"] <= r["ms_per_step_low"]
+                assert r["value_low"] <= r["value"] <= r["value_high"]
+                local = bench.SCALING_INPUTS["solve_ms_by_local_samples"][n // W]
+                assert r["strong_ms_per_step"] > local and 0.0 < r["strong_efficiency"] < 1.0
+    assert p["transports"]["p2p"]["8"]["ms_per_step"] < p["transports"]["rccl"]["8"]["ms_per_step"] < p["transports"]["nccl"]["8"]["ms_per_step"]
+    q = bench.predict_scaling(solve_ms_1gpu=0.2)
+    assert q["inputs"]["solve_ms_1gpu"] == 0.2 and q["transports"]["rccl"]["1"]["ms_per_step"] == 0.2
+    assert q["transports"]["rccl"]["8"]["ms_per_step"] == pytest.approx(0.2 + p["transports"]["rccl"]["8"]["ms_per_step"] - p["transports"]["rccl"]["1"]["ms_per_step"])
+    cited = set()
+    for v in bench.SCALING_INPUTS.values():
+        cited |= set(re.findall(r"(?:profiles/[A-Za-z0-9_.]+|BENCH_r\d+\.json)", v.get("source", "")))
+    assert cited and all(os.path.exists(os.path.join(ROOT, f)) for f in cited), cited
 
 
 def test_row_pool_hands_out_fresh_aligned_rows():
