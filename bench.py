@@ -674,7 +674,9 @@ def main():
                 pred["vs_measured"] = {"n_gpus": world, "transport": tr, "predicted_ms_per_step": row["ms_per_step"],
                                        "predicted_range_ms": [row["ms_per_step_high"], row["ms_per_step_low"]],
                                        "measured_ms_per_step": ms_per_step, "measured_over_predicted": ms_per_step / row["ms_per_step"],
-                                       "inside_predicted_range": bool(row["ms_per_step_high"] <= ms_per_step <= row["ms_per_step_low"])}
+                                       "inside_predicted_range": bool(row["ms_per_step_high"] <= ms_per_step <= row["ms_per_step_low"]),
+                                       # (a dry run — all ranks time-sharing ONE device — measures the time slicing, not the exchange)
+                                       "ranks_share_one_device": bool(os.environ.get("MPPI_BENCH_ONE_DEVICE"))}
         out["predicted"] = pred
         out.update(extras)
         return out

@@ -48,12 +48,17 @@ __device__ __forceinline__ void p2p_collect(const P2pCtx& x, int len, float* __r
         unsigned long long cell = p2p_load(cellp);
         unsigned spins = 0;
         while ((unsigned)(cell >> 32) != x.seq) {
-            if ((++spins & 1023u) == 0u && wall_clock64() - t0 > 2000000000ll) {
+            if ((++spins & 255u) == 0u && wall_clock64() - t0 > 2000000000ll) {
                 *x.error = 1;
                 if (s_timed_out) *s_timed_out = 1;  // (LDS) the block voids this solve's outputs
                 break;
             }
-            __builtin_amdgcn_s_sleep(2);
+            // back-off: a peer's summary normally lands within a few microseconds (a handful of polls); a poll that is still
+            // waiting after that is waiting for a straggler or — ranks time-sharing one device in the dry runs — for the
+            // peer's kernel to get the device at all, and should leave the memory system and the issue slots alone
+            if (spins < 64u) __builtin_amdgcn_s_sleep(2);
+            else if (spins < 1024u) __builtin_amdgcn_s_sleep(32);
+            else __builtin_amdgcn_s_sleep(127);
             cell = p2p_load(cellp);
         }
         out[w * stride + j] = __uint_as_float((unsigned)cell);

@@ -1026,7 +1026,7 @@ def test_device_brent_equals_the_host_loop_to_the_bit(N):
     temperature must be IDENTICAL, float64 bit for bit — same partial sums in the same order, same double-precision steps —
     for sample counts on every side of the kernel's geometry (one virtual block, ragged tails, 256 virtual blocks with 1,
     4, 16 costs per thread staged in LDS, and beyond the staging limit), for every shape of cost vector, other deltas and
-    ranges.  (A short form of scripts/brent_soak.py, whose 4 000 cases are recorded in profiles/r06_visitA_brent_soak.txt.)"""
+    ranges.  (A short form of scripts/brent_soak.py, whose 4 000 cases are recorded in profiles/r06_visitB_brent_soak.txt.)"""
     _need_gpu()
     rng = np.random.default_rng(N)
     solver, _ = make_solver("pendulum", 5, N, lambda_=1.0)
@@ -1795,6 +1795,37 @@ def test_deepcopy_mid_loop_continues_bit_identically(model, T, N, kw):
     before = solver._previous_action_seq.clone()
     tick(twin, ctrl2, x2)
     assert torch.equal(solver._previous_action_seq, before) and twin._solve_idx == solver._solve_idx + 1
+
+
+def test_deepcopy_of_a_generic_path_solver():
+    """The same for OPAQUE callables (untagged, not recognised: the generic path keeps its costs from the user's torch loops):
+    the copy continues identically — the functions themselves are shared, like copy.deepcopy shares any function."""
+    import copy
+
+    from envs import classic_control as cc
+    from pi_mpc.mppi import MPPI
+
+    def dyn(s, a):
+        return cc.pendulum_dynamics(s, a)
+
+    def cost(s, a, info):
+        return cc.pendulum_cost(s, a, info)
+
+    solver = MPPI(horizon=12, num_samples=2048, dim_state=2, dim_control=1, dynamics=dyn, cost_func=cost, u_min=torch.tensor([-2.0]),
+                  u_max=torch.tensor([2.0]), sigmas=torch.tensor([1.0]), lambda_="ESSPS", recognize_closures=False)
+    assert solver._model is None
+    x = torch.tensor([3.0, 0.2]).cuda()
+    for _ in range(2):
+        _, st = solver.forward(x)
+        x = st[0, 1].clone()
+    twin = copy.deepcopy(solver)
+    assert twin._model is None and twin._dynamics is dyn and twin._h.h.value != solver._h.h.value
+    x2 = x.clone()
+    for k in range(3):
+        a1, s1 = solver.forward(x)
+        a2, s2 = twin.forward(x2)
+        assert torch.equal(a1, a2) and torch.equal(s1, s2) and solver._last_lambda == twin._last_lambda, k
+        x, x2 = s1[0, 1].clone(), s2[0, 1].clone()
 
 
 def test_pickling_a_solver_raises_a_message_that_names_the_handle():
