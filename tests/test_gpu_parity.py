@@ -1828,6 +1828,24 @@ def test_deepcopy_of_a_generic_path_solver():
         x, x2 = s1[0, 1].clone(), s2[0, 1].clone()
 
 
+def test_top_samples_of_a_very_long_horizon_fail_with_a_message():
+    """get_top_samples stages the mean rows in LDS (32 bytes per float4 group of a control row): a horizon whose rows no
+    longer fit next to the kernel's static LDS must fail with a message that says so, not with a bare launch error
+    (ADVICE r5).  The solve itself still works at that length."""
+    from mppi_playground_amd import _capi
+
+    T, N = 5000, 256  # rows of 5 000 floats: 40 KB of staging + ~28 KB static > 64 KB
+    solver, _ = make_solver("pendulum", T, N, lambda_=1.0)
+    a, s = solver.forward(torch.tensor([3.0, 0.0]))
+    assert a.shape == (T, 1) and torch.isfinite(a).all() and torch.isfinite(s).all()
+    with pytest.raises(_capi.MppiError, match="LDS"):
+        solver.get_top_samples(8)
+    short, _ = make_solver("pendulum", 1000, N, lambda_=1.0)  # (8 KB of staging: fine)
+    short.forward(torch.tensor([3.0, 0.0]))
+    ts, tw = short.get_top_samples(8)
+    assert ts.shape == (8, 1001, 2) and abs(float(tw.sum())) > 0
+
+
 def test_pickling_a_solver_raises_a_message_that_names_the_handle():
     """pickle.dumps(solver) / torch.save(solver) cannot work (the buffers live behind mppi_handle_t): a TypeError that says so
     and names the two supported routes, not ctypes' "objects containing pointers cannot be pickled"."""
