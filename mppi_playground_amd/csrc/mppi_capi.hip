@@ -48,6 +48,7 @@ struct MppiSolver {
     int* search_error = nullptr;               // mapped pinned: a poll of lbps_brent_kernel timed out
     int* search_error_dev = nullptr;
     int lbps_grid = 0;                         // option "lbps_search": 0 = Brent on the device (default), 1 = the two-grid search
+    int brent_drop_block = 0;                  // test hook (option "search_test_drop_block"): launch one block too few
     int lds_max = 65536;                       // hipDeviceAttributeMaxSharedMemoryPerBlock
     // single-launch solve (solve_fused_kernel): cells the blocks exchange through, its error flag, the solve counter
     unsigned long long* fused_cells = nullptr;
@@ -1693,7 +1694,9 @@ int mppi_lbps_brent_device(mppi_handle_t h, double delta, double lam_min, double
     const BrentCtx bx{h->brent_cells, h->search_error_dev, h->brent_seq, h->fused_timeout_ticks};
     h->brent_seq += BRENT_SEQ_STRIDE;
     double* host_lam = h->stats_host_dev + 8 + STATS_L * 3;
-    hipLaunchKernelGGL(lbps_brent_kernel, dim3(grid), dim3(threads), shmem, s, (const float*)h->costs, h->d.N,
+    // (test hook: with the last block missing, its lane's sums never arrive — what a block that is not resident looks like to
+    // the others: every poll runs into the budget, the flag is raised and the temperature is NaN)
+    hipLaunchKernelGGL(lbps_brent_kernel, dim3(grid - (h->brent_drop_block && grid > 1 ? 1 : 0)), dim3(threads), shmem, s, (const float*)h->costs, h->d.N,
                        (const unsigned*)(h->min_key + h->min_slot), nvb, per_thread, delta, lam_min, lam_max, bx, h->lambda_dev,
                        host_lam);
     HIP_TRY(h, hipGetLastError());
@@ -2167,6 +2170,7 @@ int mppi_set_option(mppi_handle_t h, const char* key, int64_t value) {
         return MPPI_OK;
     }
     if (k == "lbps_search") { h->lbps_grid = value ? 1 : 0; return MPPI_OK; }  // what mppi_solve's LBPS rule runs: 0 Brent (default), 1 grids
+    if (k == "search_test_drop_block") { h->brent_drop_block = value ? 1 : 0; return MPPI_OK; }
     if (k == "search_rearm") { if (h->search_error) *(volatile int*)h->search_error = 0; return MPPI_OK; }
     if (k == "essps_merge0") { h->essps_merge0 = value != 0; return MPPI_OK; }  // A/B: round 0 of the ESSPS chain as one launch
     if (k == "fold_path") { h->fold_mode = (value >= 0 && value <= 2) ? (int)value : 0; return MPPI_OK; }

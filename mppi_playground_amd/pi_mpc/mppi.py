@@ -769,9 +769,11 @@ class MPPI(ModuleProtocolMixin, ExchangeMixin, GenericPathMixin, QueriesMixin, n
         h = self._h
         if self._rule_on_device == "LBPS" and self._lbps_search == "brent" and h.lib.mppi_search_error(h.h):
             h.call("mppi_set_option", b"search_rearm", 1)
+            self.reset()  # (that solve's NaN plan was stored as the warm start: start over from zeros, like reset())
             raise _capi.MppiError("the device-resident LBPS search gave up waiting for one of its blocks on an earlier solve "
                                   "(budget: set_option('fused_timeout_us', ...), default 20 ms; is the GPU shared with other "
-                                  "work?): that solve returned NaN.  lbps_search='brent_host' searches with a host loop instead")
+                                  "work?): that solve returned NaN and the warm start has been reset to zeros.  "
+                                  "lbps_search='brent_host' searches with a host loop instead")
 
     def _lam_mpo_device(self, st) -> None:  # this solve uses the temperature the dual left in HBM (or the caller's)
         self._lambda_pending, self._lambda_stream = self._lambda_override is None, st

@@ -1058,6 +1058,37 @@ def test_device_brent_on_the_reference_fixtures(name):
         parity_report.record("device_brent_probes", probes, 500)
 
 
+def test_device_brent_gives_up_instead_of_hanging():
+    """A block of the search that never becomes resident (here: one block too few is launched — test hook
+    `search_test_drop_block`) cannot be waited for: every poll runs into the budget (`fused_timeout_us`), the kernel ends, the
+    temperature of that solve is NaN (never a stale or partial value), `mppi_search_error` is raised and the NEXT solve of the
+    Python class raises a message that names the remedy; after that the solver works again."""
+    _need_gpu()
+    import time
+
+    from mppi_playground_amd import _capi
+
+    solver, _ = make_solver("nav2d", 20, 65536, lambda_="LBPS")
+    x0 = torch.tensor([-9.0, -9.0, 0.785])
+    a0, _ = solver.forward(x0)
+    lam0 = solver._last_lambda
+    assert np.isfinite(lam0) and torch.isfinite(a0).all()
+    solver.set_option("fused_timeout_us", 2000)
+    solver.set_option("search_test_drop_block", 1)
+    t0 = time.perf_counter()
+    a1, s1 = solver.forward(x0)
+    torch.cuda.synchronize()
+    assert time.perf_counter() - t0 < 1.0  # (gave up after ~2 ms, did not hang)
+    assert solver._h.lib.mppi_search_error(solver._h.h) == 1
+    assert np.isnan(solver._last_lambda) and torch.isnan(a1).all()
+    solver.set_option("search_test_drop_block", 0)
+    with pytest.raises(_capi.MppiError, match="brent_host"):
+        solver.forward(x0)
+    assert not torch.isnan(solver._previous_action_seq).any()  # (the NaN plan is gone: the raise reset the warm start)
+    a2, _ = solver.forward(x0)
+    assert torch.isfinite(a2).all() and np.isfinite(solver._last_lambda) and not solver._h.lib.mppi_search_error(solver._h.h)
+
+
 def test_device_brent_in_a_captured_graph_and_back_to_back():
     """The search is one launch with no host wait: 200 searches enqueued back to back on alternating cost vectors (the
     probe tags and the double-buffered cells carry over from launch to launch) return the host loop's temperatures, and a
