@@ -777,6 +777,9 @@ def main():
         if "c2" in want:  # BASELINE configs[1]
             run_case_full("full_c2_nav2d_T50_N65536_essps", nav(horizon=50, num_samples=65536, lambda_="ESSPS"), x0_nav, 2,
                           pred_next, nv_fixed=256, nv_closed=64)
+        if "c2_lbps" in sys.argv[2:]:  # configs[1]'s size under the reference's OTHER search rule (round 6: LBPS's default moved onto the device)
+            run_case_full("full_c2_nav2d_T50_N65536_lbps", nav(horizon=50, num_samples=65536, lambda_="LBPS"), x0_nav, 2,
+                          pred_next, nv_fixed=256, nv_closed=64)
         if "c5" in want:  # BASELINE configs[4]
             run_case_full("full_c5_cartpole_T64_N262144_essps_sg",
                           classic("cartpole", "dynamics", "stage_cost", horizon=64, num_samples=262144, lambda_="ESSPS",

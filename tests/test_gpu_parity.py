@@ -397,6 +397,8 @@ FULL_SIZE = {
     "c2": ("full_c2_nav2d_T50_N65536_essps", "nav2d", dict(lambda_="ESSPS")),
     "c5": ("full_c5_cartpole_T64_N262144_essps_sg", "cartpole", dict(lambda_="ESSPS", use_sg_filter=True)),
     "c3": ("full_c3_racing_T50_N1048576_lambda1", "racing", dict(lambda_=1.0)),
+    # configs[1]'s size under the reference's other search rule (round 6: the default LBPS search is the device-resident Brent)
+    "c2_lbps": ("full_c2_nav2d_T50_N65536_lbps", "nav2d", dict(lambda_="LBPS")),
 }
 
 
@@ -412,7 +414,7 @@ def full_size_band(g, k):
                 lam=Band.merge(cl["lam"], rl[2] if rl else zero))
 
 
-@pytest.mark.parametrize("which", ["c2", "c5", "c3"])
+@pytest.mark.parametrize("which", ["c2", "c5", "c3", "c2_lbps"])
 def test_identical_seed_full_size_matches_reference(which):
     """North star: "action_seq / state_seq match the PyTorch reference on identical RNG seeds within 1e-5" at the sizes the
     metric is quoted on (/root/reference/src/pi_mpc/mppi.py:255-460 run in the build container, outputs only).  Checked per
@@ -474,7 +476,7 @@ def test_identical_seed_full_size_matches_reference(which):
         # ---- temperature and effective sample size
         lam, lam_ref = solver._last_lambda, float(g[f"lambda_{k}"])
         if isinstance(kw["lambda_"], str):
-            lim = max(LAMBDA_TOL[kw["lambda_"]], band["lam"])
+            lim = max(LAMBDA_TOL.get(kw["lambda_"], LBPS_TOL_BRENT), band["lam"])
             parity_report.record("lambda_rel_err_" + kw["lambda_"] + tag, abs(lam - lam_ref) / lam_ref, lim,
                                  reference_band=float(band["lam"]), **_band_position(band["lam"], abs(lam - lam_ref) / lam_ref))
             assert abs(lam - lam_ref) <= lim * lam_ref, (lam, lam_ref)
@@ -485,21 +487,30 @@ def test_identical_seed_full_size_matches_reference(which):
         ess_own = 1.0 / float(np.sum(w64.astype(np.float64) ** 2))
         assert abs(ess - ess_own) <= 1e-4 * ess_own  # the device's statistic against a float64 evaluation of its own costs
         if isinstance(kw["lambda_"], str):
-            assert abs(ess - ess_ref) <= 1e-3 * ess_ref
+            # (ESSPS pins the ESS itself; LBPS's temperature moves by its band under 1-ulp changes of the reference's costs
+            # — 5e-3 at this size — and the ESS follows it with a logarithmic slope of a few)
+            ess_tol = 1e-3 if kw["lambda_"] == "ESSPS" else max(1e-3, 4.0 * float(band["lam"]))
+            assert abs(ess - ess_ref) <= ess_tol * ess_ref, (ess, ess_ref, ess_tol)
         # ---- action_seq / state_seq
         if float(g[f"top32_weight_{k}"][0]) >= 1.0 - 1e-6 and need >= 1:  # arg-min regime: an exact statement exists
             U = np.clip(g[f"mean_in_{k}"] + g[f"top32_eps_{k}"][0], np.float32(mc["u_min"]), np.float32(mc["u_max"]))
             assert int(np.argmin(c)) == int(top_i[0])
             assert np.abs(a.cpu().numpy() - U).max() <= 1e-6 * np.abs(U).max()
-        # (--strict-parity: the full-size configurations are held to the north star's plain 1e-5, without the band)
-        check_banded("action_seq_vs_reference_fixture" + tag, a.cpu().numpy(), g[f"action_seq_{k}"], band["action"], strict_ok=True)
-        check_banded("state_seq_vs_reference_fixture" + tag, s.cpu().numpy(), g[f"state_seq_{k}"], band["state"], strict_ok=True)
+        # (--strict-parity: BASELINE's configurations are held to the north star's plain 1e-5, without the band.  Not the LBPS
+        # twin of C2: there the REFERENCE's own temperature moves by 5e-3 under 1-ulp changes of its costs — its objective is
+        # flat to fp32 noise — and its action_seq with it, by 2.3e-3; the device's distance is 6e-5)
+        strict = kw["lambda_"] != "LBPS"
+        check_banded("action_seq_vs_reference_fixture" + tag, a.cpu().numpy(), g[f"action_seq_{k}"], band["action"], strict_ok=strict)
+        check_banded("state_seq_vs_reference_fixture" + tag, s.cpu().numpy(), g[f"state_seq_{k}"], band["state"], strict_ok=strict)
         # get_top_samples (mppi.py:462-487) at full size: the 32 largest weights are the reference's, in its order
         ts, tw = solver.get_top_samples(32)
         w_ref = g[f"top32_weight_{k}"]
         werr = float(np.abs(tw.cpu().numpy() - w_ref).max() / w_ref.max())
-        parity_report.record("top32_weights_vs_reference" + tag, werr, 1e-4)
-        assert werr <= 1e-4, werr
+        # (under LBPS the reference's own temperature moves by band["lam"] — 5e-3 at this size — when its costs move by one ulp,
+        # and a weight follows the temperature with a logarithmic slope of (c_i - E_w[c]) / lambda = O(1) for the best samples)
+        wtol = 1e-4 if kw["lambda_"] != "LBPS" else max(1e-4, float(band["lam"]))
+        parity_report.record("top32_weights_vs_reference" + tag, werr, wtol)
+        assert werr <= wtol, (werr, wtol)
         assert ts.shape == (32, T + 1, s.shape[-1]) and torch.equal(ts[:, 0, :], state.to(ts.device).expand(32, -1))
         if float(w_ref[0]) >= 1.0 - 1e-6:  # arg-min regime: the best sample's trajectory IS the solution's rollout
             assert rel_err(ts[0].cpu().numpy(), g[f"state_seq_{k}"][0]) <= TOL

@@ -179,10 +179,11 @@ FULL_SIZE = {
     "c2": ("full_c2_nav2d_T50_N65536_essps", "nav2d", {}),
     "c5": ("full_c5_cartpole_T64_N262144_essps_sg", "cartpole", dict(use_sg_filter=True)),
     "c3": ("full_c3_racing_T50_N1048576_lambda1", "racing", {}),
+    "c2_lbps": ("full_c2_nav2d_T50_N65536_lbps", "nav2d", {}),
 }
 
 
-@pytest.mark.parametrize("which", ["c2", "c5", "c3"])
+@pytest.mark.parametrize("which", ["c2", "c5", "c3", "c2_lbps"])
 def test_oracle_at_full_size_against_the_reference(which):
     """The oracle at BASELINE.json's sizes against the real reference (tests/golden/make_golden.py fullsize: outputs and
     summaries only).  The noise is drawn again with torch's CPU generator from the fixture's seed — the reference's own
