@@ -33,6 +33,7 @@ class ModuleProtocolMixin:
         dyn, cst = copy.deepcopy(self._dynamics, memo), copy.deepcopy(self._cost_func, memo)
         me, it = self.__dict__, new.__dict__
         it["_dynamics"], it["_cost_func"] = dyn, cst
+        it["_ctor"] = dict(self._ctor, dynamics=dyn, cost_func=cst)  # (a copy of the copy starts from ITS callables, and the originals are not kept alive)
         if self._model is not None and self._recognized is None:
             d, c = resolve(dyn), resolve(cst)
             if d and c:

@@ -1925,7 +1925,7 @@ def test_state_dict_round_trip_continues_bit_identically(model, T, N, kw):
     torch.save(a.state_dict(), buf)
     buf.seek(0)
     b, _ = make_solver(model, T, N, **kw)
-    b.load_state_dict(torch.load(buf, weights_only=False))
+    b.load_state_dict(torch.load(buf))  # (torch's default weights_only=True: the state is tensors, numbers, lists and None only)
     assert b._solve_idx == a._solve_idx and b._lambda == a._lambda
     xb = x.clone()
     for k in range(3):
